@@ -1,0 +1,287 @@
+/*
+ * mi355pt.h -- C ABI of the MI355X wavefront path-tracing back end.
+ *
+ * This is the drop-in boundary for ONE path of alexmeli100/pbrt-rust: the call
+ *     integ.render(&scene)                                   src/core/api.rs:1746
+ * i.e. `trait Integrator { fn render(&mut self, scene: &Scene); }`
+ *                                                            src/core/integrator.rs:249-252
+ * as implemented by SamplerIntegrator::render                src/core/integrator.rs:263-403
+ * and PathIntegrator::li                                     src/integrators/path.rs:79-222.
+ *
+ * A Rust `Integrators::GpuPath` variant flattens the
+ * already-built `Scene` (lights, BVHAccel nodes + ordered primitives, triangle
+ * meshes, materials), the `PerspectiveCamera`, `SobolSampler` and `Film`
+ * parameters into the POD structs below and calls pt_scene_create / pt_render.
+ * Nothing here is a torch type; all pointers are plain host pointers unless a
+ * comment says "device".  No function unwinds or aborts across the boundary:
+ * every entry point returns a PtStatus.
+ *
+ * Ownership: the caller owns every input array for the duration of the call
+ * (the library copies to HBM).  Output buffers are caller allocated.  Opaque
+ * handles are released with pt_scene_destroy.
+ * Threading: pt_render is blocking and not re-entrant for one pt_scene.
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,       /* null pointer / inconsistent sizes                      */
+    PT_ERR_NO_DEVICE = 2,         /* HIP runtime reports no usable gfx950 device            */
+    PT_ERR_HIP = 3,               /* a HIP call failed; see pt_last_error()                  */
+    PT_ERR_UNSUPPORTED = 4,       /* scene uses a feature outside the implemented rows      */
+    PT_ERR_SOBOL_DIMENSIONS = 5,  /* a path consumed >= 1024 Sobol' dimensions
+                                     (the reference panics: samplers/sobol.rs:69-73)         */
+    PT_ERR_STACK_OVERFLOW = 6,    /* BVH traversal stack deeper than 64 entries
+                                     (the reference has no check: accelerators/bvh.rs:722)   */
+    PT_ERR_OUT_OF_MEMORY = 7
+} PtStatus;
+
+/* ---- scene description -------------------------------------------------------------- */
+
+/* Triangle flag bits (per triangle; replaces fields of shapes/triangle.rs:76-84 and the
+ * per-mesh `n/s/uv.is_empty()` tests of shapes/triangle.rs:303-392). */
+enum {
+    PT_TRI_REVERSE_ORIENTATION = 1u << 0,
+    PT_TRI_SWAPS_HANDEDNESS    = 1u << 1,
+    PT_TRI_HAS_N               = 1u << 2,
+    PT_TRI_HAS_S               = 1u << 3,
+    PT_TRI_HAS_UV              = 1u << 4
+};
+
+/* Primitive shape reference: kind in the top 2 bits, index below. */
+#define PT_SHAPE_TRIANGLE 0u
+#define PT_SHAPE_SPHERE   1u
+#define PT_SHAPE_REF(kind, index) (((uint32_t)(kind) << 30) | (uint32_t)(index))
+#define PT_NONE 0xffffffffu
+
+/* shapes/sphere.rs:27-57 (fields of Sphere after Sphere::new). Matrices are row major
+ * `m.m[row][col]` exactly as core/transform.rs stores them. */
+typedef struct PtSphere {
+    float object_to_world[16];
+    float world_to_object[16];
+    float radius, z_min, z_max, theta_min, theta_max, phi_max;
+    uint32_t reverse_orientation;
+    uint32_t transform_swaps_handedness;
+} PtSphere;
+
+typedef enum PtMaterialType {
+    PT_MAT_MATTE = 0,      /* materials/matte.rs      */
+    PT_MAT_MIRROR = 1,     /* materials/mirror.rs     */
+    PT_MAT_GLASS = 2,      /* materials/glass.rs      */
+    PT_MAT_PLASTIC = 3,    /* materials/plastic.rs    */
+    PT_MAT_METAL = 4,      /* materials/metal.rs      */
+    PT_MAT_UBER = 5,       /* materials/uber.rs       */
+    PT_MAT_SUBSTRATE = 6   /* materials/substrate.rs  */
+} PtMaterialType;
+
+/* Constant-texture material parameters (texture evaluation is a "next" row). Field use
+ * per type follows the reference's create_*_material parameter names. */
+typedef struct PtMaterial {
+    uint32_t type;
+    float kd[3];
+    float ks[3];
+    float kr[3];
+    float kt[3];
+    float opacity[3];
+    float eta_rgb[3];       /* metal: eta        */
+    float k_rgb[3];         /* metal: k          */
+    float sigma;            /* matte             */
+    float eta;              /* glass/uber index  */
+    float roughness;        /* plastic/metal/uber "roughness" */
+    float u_roughness;      /* 0 => use roughness (uber/metal/glass/substrate)  */
+    float v_roughness;
+    uint32_t remap_roughness;
+} PtMaterial;
+
+typedef enum PtLightType {
+    PT_LIGHT_DIFFUSE_AREA = 0, /* lights/diffuse.rs  */
+    PT_LIGHT_DISTANT = 1,      /* lights/distant.rs  */
+    PT_LIGHT_POINT = 2,        /* lights/point.rs    */
+    PT_LIGHT_INFINITE = 3,     /* lights/infinite.rs */
+    PT_LIGHT_SPOT = 4          /* lights/spot.rs     */
+} PtLightType;
+
+typedef struct PtLight {
+    uint32_t type;
+    float L[3];              /* Lemit (area) | L (distant, world-space radiance) | I (point/spot) | unused (infinite: texels) */
+    uint32_t two_sided;      /* area                                                            */
+    uint32_t prim;           /* area: index of the primitive carrying this light (api.rs:1535-1546) */
+    float pos[3];            /* point/spot: plight (world)                                      */
+    float dir[3];            /* distant: w_light (world, normalised by the host, distant.rs:29)  */
+    float cos_total_width;   /* spot                                                            */
+    float cos_falloff_start; /* spot                                                            */
+    float light_to_world[16];
+    float world_to_light[16];
+} PtLight;
+
+/* accelerators/bvh.rs:89-95 LinearBVHNode: left child at index+1, right child at `offset`
+ * for interior nodes (n_prims == 0); leaves index `ordered_prims[offset .. offset+n_prims]`. */
+typedef struct PtBVHNode {
+    float bmin[3];
+    float bmax[3];
+    uint32_t offset;
+    uint16_t n_prims;
+    uint8_t axis;
+    uint8_t pad;
+} PtBVHNode;
+
+typedef struct PtSceneDesc {
+    /* All triangle meshes concatenated; P is world space (shapes/triangle.rs:39-41). */
+    uint32_t n_vertices;
+    const float *P;          /* 3*n_vertices                      */
+    const float *N;          /* 3*n_vertices or NULL              */
+    const float *S;          /* 3*n_vertices or NULL              */
+    const float *UV;         /* 2*n_vertices or NULL              */
+    uint32_t n_triangles;
+    const uint32_t *indices; /* 3*n_triangles                     */
+    const uint8_t *tri_flags;/* n_triangles or NULL (=0)          */
+
+    uint32_t n_spheres;
+    const PtSphere *spheres;
+
+    /* Scene primitives in api.rs creation order (one GeometricPrimitive per shape,
+     * core/api.rs:1544-1545). */
+    uint32_t n_prims;
+    const uint32_t *prim_shape;    /* PT_SHAPE_REF(kind, index)                   */
+    const uint32_t *prim_material; /* index into materials or PT_NONE             */
+    const uint32_t *prim_light;    /* index into lights (area light) or PT_NONE   */
+
+    uint32_t n_materials;
+    const PtMaterial *materials;
+
+    uint32_t n_lights;             /* scene.lights order (core/scene.rs:24-27)    */
+    const PtLight *lights;
+
+    /* InfiniteAreaLight data (at most one infinite light carries a map):
+     * level-0 texels of the MIPMap after the host's resampling (RGB, row major,
+     * power-of-two resolution; core/mipmap.rs:93-150) and the 2w x 2h scalar importance
+     * image (lights/infinite.rs:62-81). NULL texels => no infinite light data. */
+    uint32_t env_width, env_height;
+    const float *env_texels;       /* 3*env_width*env_height       */
+    const float *env_importance;   /* (2*env_width)*(2*env_height) */
+
+    /* Accelerator: either prebuilt by the caller (reference order) or NULL => the
+     * library builds the same SAH tree (accelerators/bvh.rs:200-375,662-693). */
+    uint32_t max_node_prims;       /* bvh "maxnodeprims", default 4 */
+    uint32_t n_nodes;
+    const PtBVHNode *nodes;
+    const uint32_t *ordered_prims; /* n_prims entries, indices into prims */
+} PtSceneDesc;
+
+/* ---- render parameters ---------------------------------------------------------------- */
+
+typedef enum PtLightStrategy { PT_LS_UNIFORM = 0, PT_LS_POWER = 1, PT_LS_SPATIAL = 2 } PtLightStrategy;
+
+typedef struct PtRenderParams {
+    /* Film (core/film.rs:55-100). */
+    int32_t full_resolution[2];
+    int32_t cropped_pixel_bounds[4];  /* xmin, ymin, xmax, ymax */
+    float filter_radius[2];
+    float filter_table[256];          /* 16x16, film.rs:76-89 */
+    float max_sample_luminance;
+    float scale;
+    /* Sampler (samplers/sobol.rs:34-57). sample_bounds = Film::get_sample_bounds(). */
+    uint32_t spp;
+    int32_t sample_bounds[4];         /* xmin, ymin, xmax, ymax */
+    /* Camera (cameras/perspective.rs:40-86). */
+    float raster_to_camera[16];
+    float camera_to_world[16];
+    float lens_radius;
+    float focal_distance;
+    float shutter_open, shutter_close;
+    /* Integrator (integrators/path.rs:225-253). */
+    uint32_t max_depth;
+    float rr_threshold;
+    int32_t pixel_bounds[4];          /* xmin, ymin, xmax, ymax */
+    uint32_t light_strategy;          /* PtLightStrategy */
+    /* Sharding of the 16x16 sample tiles of integrator.rs:276-283: this call renders the
+     * tiles with (tile_index % tile_world) == tile_rank. (1 GPU: rank 0 of 1.) */
+    uint32_t tile_rank, tile_world;
+    /* Samples per pixel traced per wavefront pass (0 => library default). */
+    uint32_t spp_per_pass;
+    /* Non-zero => record per-kernel HIP-event timings (see pt_get_kernel_stats). */
+    uint32_t profile;
+} PtRenderParams;
+
+/* Device-side work counters: mirrors of the reference's stat counters
+ * (integrator.rs:36, scene.rs:14-15, path.rs:24-25) plus the roofline denominators. */
+typedef struct PtCounters {
+    uint64_t camera_rays;
+    uint64_t intersect_tests;        /* Scene::intersect calls            */
+    uint64_t shadow_tests;           /* Scene::intersect_p calls          */
+    uint64_t bvh_nodes_visited;      /* Bounds3f::intersect_p2 executed   */
+    uint64_t triangle_tests;         /* Triangle::intersect(_p) entered via the BVH */
+    uint64_t sphere_tests;
+    uint64_t zero_radiance_paths_num, zero_radiance_paths_den;
+    uint64_t path_length_hist[16];   /* bounces at termination, clamped to 15 */
+    uint64_t sanitized_nan, sanitized_negative, sanitized_infinite; /* integrator.rs:350-368 */
+    uint64_t film_splats;            /* film pixels touched by add_sample */
+    uint64_t wavefront_stages;       /* sum over stages of lanes processed */
+} PtCounters;
+
+typedef struct PtKernelStat {
+    char name[32];
+    uint64_t launches;
+    double total_ms;                 /* HIP-event time on the render stream */
+    uint64_t items;                  /* rays / path vertices processed       */
+} PtKernelStat;
+
+typedef struct pt_scene pt_scene;
+
+/* ---- entry points ------------------------------------------------------------------- */
+
+/* Select the HIP device used by this process (one process per GPU). */
+int pt_init(int device_ordinal);
+const char *pt_last_error(void);
+
+int pt_scene_create(const PtSceneDesc *desc, pt_scene **out_scene);
+void pt_scene_destroy(pt_scene *scene);
+
+/* Size and contents of the accelerator actually used (built or adopted). */
+int pt_scene_bvh_info(const pt_scene *scene, uint32_t *n_nodes, uint32_t *n_prims);
+int pt_scene_bvh_read(const pt_scene *scene, PtBVHNode *nodes, uint32_t *ordered_prims);
+
+/* Replaces `integ.render(&scene)` (core/api.rs:1746). Accumulates the un-normalised film:
+ * film_xyzw[4*(y*W+x)+{0,1,2}] = sum of XYZ contributions (film.rs:153-157) and [+3] = filter
+ * weight sum, over the cropped pixel bounds, W = xmax-xmin. `film_xyzw` is ADDED to (the
+ * caller zeroes it), so shards from several ranks can be summed. If film_is_device != 0 the
+ * pointer is a HIP device pointer on the selected device. */
+int pt_render(pt_scene *scene, const PtRenderParams *params, float *film_xyzw, int film_is_device);
+
+/* Film::write_image normalisation (film.rs:217-258): rgb = max(0, xyz_to_rgb(xyz)/w) * scale.
+ * Pure host arithmetic on a host buffer. */
+int pt_film_resolve(const float *film_xyzw, uint32_t n_pixels, float scale, float *rgb_out);
+
+int pt_get_counters(const pt_scene *scene, PtCounters *out);
+/* Per-kernel statistics of the last pt_render with params->profile != 0. Returns the number
+ * of entries written (<= max_entries) through *n_out. */
+int pt_get_kernel_stats(const pt_scene *scene, PtKernelStat *out, uint32_t max_entries, uint32_t *n_out);
+
+/* Parity / unit entry points (the kernels behind them are the ones pt_render launches). */
+/* BVHAccel::intersect for n rays: out_prim = primitive index (into prims) or PT_NONE,
+ * out_t, out_b = hit t and barycentrics (b0,b1,b2) exactly as shapes/triangle.rs:209-213. */
+int pt_trace_closest(pt_scene *scene, uint32_t n, const float *origins, const float *dirs,
+                     const float *tmax, uint32_t *out_prim, float *out_t, float *out_b);
+/* BVHAccel::intersect_p: out_hit[i] = 1 if occluded. */
+int pt_trace_any(pt_scene *scene, uint32_t n, const float *origins, const float *dirs,
+                 const float *tmax, uint8_t *out_hit);
+/* SobolSampler: for each of n (pixel x, pixel y, sample number) triples produce `n_dims`
+ * consecutive sample_dimension() values starting at dimension 0 (samplers/sobol.rs:68-86). */
+int pt_sobol_samples(const int32_t sample_bounds[4], uint32_t n, const int32_t *pixel_xy,
+                     const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index);
+/* PerspectiveCamera::generate_ray_differential main ray for n camera samples
+ * (pfilm.xy, time, plens.xy) -> origin, direction (cameras/perspective.rs:120-179). */
+int pt_camera_rays(const PtRenderParams *params, uint32_t n, const float *camera_samples,
+                   float *out_origins, float *out_dirs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PT_H */

@@ -1,0 +1,576 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see ref_math.h header).
+// ref_render.cpp: materials -> BSDF, one-light MIS, PathIntegrator::li, perspective camera, film,
+// the tile render loop, and the oracle's C ABI (driven from tests/ and bench.py's cpu_baseline leg).
+//   materials/{matte,mirror,glass,plastic,metal,uber,substrate}.rs; core/integrator.rs:81-237,263-403;
+//   integrators/path.rs:79-222; cameras/perspective.rs:120-179; core/film.rs:104-161,217-258,292-331.
+#include "ref_shading.h"
+#include <thread>
+#include <atomic>
+#include <chrono>
+
+namespace ref {
+
+// ---- materials ------------------------------------------------------------------------------
+static RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
+static TRDist make_dist(Float ax, Float ay) { TRDist d; d.ax = fmax_(ax, 0.001f); d.ay = fmax_(ay, 0.001f); return d; }  // microfacet.rs:325-331
+
+// Returns false when the material leaves `si.bsdf == None` (null surface, path.rs:124-129).
+static bool compute_scattering_functions(const Scene &scene, const SurfaceInteraction &si, BSDF &bsdf) {
+    uint32_t mi = scene.prim_material[si.prim];
+    if (mi == PT_NONE) return false;  // primitive.rs:168-170: no material => no bsdf
+    const PtMaterial &m = scene.materials[mi];
+    switch (m.type) {
+    case PT_MAT_MATTE: {  // matte.rs:28-53
+        bsdf.init(si, 1.0f);
+        RGB r = rgb3(m.kd).clamps(0.0f, INF);
+        Float sig = clampv(m.sigma, 0.0f, 90.0f);
+        if (!r.is_black()) {
+            Bxdf b; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = r;
+            if (sig == 0.0f) b.kind = BX_LAMBERT_R;
+            else {  // reflection.rs:909-921
+                b.kind = BX_OREN_NAYAR;
+                Float sigma = (PI / 180.0f) * sig;
+                Float sigma2 = sigma * sigma;
+                b.A = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+                b.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+            }
+            bsdf.add(b);
+        }
+        return true;
+    }
+    case PT_MAT_MIRROR: {  // mirror.rs:23-42
+        bsdf.init(si, 1.0f);
+        RGB R = rgb3(m.kr).clamps(0.0f, INF);
+        if (!R.is_black()) { Bxdf b; b.kind = BX_SPEC_R; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.r = R; b.fresnel.kind = FR_NOOP; bsdf.add(b); }
+        return true;
+    }
+    case PT_MAT_GLASS: {  // glass.rs:35-92 (allow_multiple_lobes = true, mode = Radiance)
+        Float eta = m.eta, urough = m.u_roughness, vrough = m.v_roughness;
+        RGB R = rgb3(m.kr).clamps(0.0f, INF), T = rgb3(m.kt).clamps(0.0f, INF);
+        bsdf.init(si, eta);
+        if (R.is_black() && T.is_black()) return false;  // App. A #14
+        bool is_specular = urough == 0.0f && vrough == 0.0f;
+        if (is_specular) {
+            Bxdf b; b.kind = BX_FRESNEL_SPEC; b.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+            b.r = R; b.t = T; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+        } else {
+            if (m.remap_roughness) { urough = TRDist::roughness_to_alpha(urough); vrough = TRDist::roughness_to_alpha(vrough); }
+            TRDist d = make_dist(urough, vrough);
+            if (!R.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = R; b.dist = d;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+            if (!T.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_T; b.type = BSDF_TRANSMISSION | BSDF_GLOSSY; b.t = T; b.dist = d; b.etaa = 1.0f; b.etab = eta;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+        }
+        return true;
+    }
+    case PT_MAT_PLASTIC: {  // plastic.rs:34-70
+        bsdf.init(si, 1.0f);
+        RGB kd = rgb3(m.kd).clamps(0.0f, INF);
+        if (!kd.is_black()) { Bxdf b; b.kind = BX_LAMBERT_R; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = kd; bsdf.add(b); }
+        RGB ks = rgb3(m.ks).clamps(0.0f, INF);
+        if (!ks.is_black()) {
+            Float rough = m.roughness;
+            if (m.remap_roughness) rough = TRDist::roughness_to_alpha(rough);
+            Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = ks; b.dist = make_dist(rough, rough);
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.5f; b.fresnel.etat = 1.0f; bsdf.add(b);
+        }
+        return true;
+    }
+    case PT_MAT_METAL: {  // metal.rs:78-112
+        bsdf.init(si, 1.0f);
+        Float urough = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
+        Float vrough = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+        if (m.remap_roughness) { urough = TRDist::roughness_to_alpha(urough); vrough = TRDist::roughness_to_alpha(vrough); }
+        Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = RGB(1.0f); b.dist = make_dist(urough, vrough);
+        b.fresnel.kind = FR_CONDUCTOR; b.fresnel.ci = RGB(1.0f); b.fresnel.ct = rgb3(m.eta_rgb); b.fresnel.k = rgb3(m.k_rgb);
+        bsdf.add(b);
+        return true;
+    }
+    case PT_MAT_UBER: {  // uber.rs:40-106
+        Float e = m.eta;
+        RGB op = rgb3(m.opacity).clamps(0.0f, INF);
+        RGB t = RGB(-op.c[0] + 1.0f, -op.c[1] + 1.0f, -op.c[2] + 1.0f).clamps(0.0f, INF);
+        if (!t.is_black()) {
+            bsdf.init(si, 1.0f);
+            Bxdf b; b.kind = BX_SPEC_T; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.t = t; b.etaa = 1.0f; b.etab = 1.0f;
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = 1.0f; bsdf.add(b);
+        } else bsdf.init(si, e);
+        RGB kd = op * rgb3(m.kd).clamps(0.0f, INF);
+        if (!kd.is_black()) { Bxdf b; b.kind = BX_LAMBERT_R; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = kd; bsdf.add(b); }
+        RGB ks = op * rgb3(m.ks).clamps(0.0f, INF);
+        if (!ks.is_black()) {
+            Float ru = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
+            Float rv = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+            if (m.remap_roughness) { ru = TRDist::roughness_to_alpha(ru); rv = TRDist::roughness_to_alpha(rv); }
+            Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = ks; b.dist = make_dist(ru, rv);
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
+        }
+        RGB kr = op * rgb3(m.kr).clamps(0.0f, INF);
+        if (!kr.is_black()) {
+            Bxdf b; b.kind = BX_SPEC_R; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.r = kr;
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
+        }
+        RGB kt = op * rgb3(m.kt).clamps(0.0f, INF);
+        if (!kt.is_black()) {
+            Bxdf b; b.kind = BX_SPEC_T; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.t = kt; b.etaa = 1.0f; b.etab = e;
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
+        }
+        return true;
+    }
+    case PT_MAT_SUBSTRATE: {  // substrate.rs:34-60
+        bsdf.init(si, 1.0f);
+        RGB d = rgb3(m.kd).clamps(0.0f, INF), s = rgb3(m.ks).clamps(0.0f, INF);
+        Float ru = m.u_roughness, rv = m.v_roughness;
+        if (!d.is_black() || !s.is_black()) {
+            if (m.remap_roughness) { ru = TRDist::roughness_to_alpha(ru); rv = TRDist::roughness_to_alpha(rv); }
+            Bxdf b; b.kind = BX_FRESNEL_BLEND; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = d; b.rs = s; b.dist = make_dist(ru, rv);
+            bsdf.add(b);
+            return true;
+        }
+        return false;  // App. A #14
+    }
+    }
+    return false;
+}
+
+// ---- direct lighting (core/integrator.rs:81-237) ---------------------------------------------------
+struct RenderCtx {
+    const Scene *scene;
+    const LightSampler *lights;
+    Counters *c;
+};
+
+static RGB isect_le(const RenderCtx &ctx, const SurfaceInteraction &si, V3 w) {  // interaction.rs:344-349
+    uint32_t li = ctx.scene->prim_light[si.prim];
+    if (li == PT_NONE) return RGB(0.0f);
+    return ctx.lights->area_l(li, si.n, w);
+}
+
+static RGB estimate_direct(const RenderCtx &ctx, const SurfaceInteraction &si, const BSDF &bsdf, P2 uscatt, uint32_t li, P2 ulight) {
+    const int flags = BSDF_ALL & ~BSDF_SPECULAR;
+    RGB Ld(0.0f);
+    IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n; it.wo = si.wo;
+    V3 wi; Float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+    RGB Li = ctx.lights->sample_li(li, it, ulight, wi, lightpdf, p1);
+    bool delta = ctx.lights->is_delta(li);
+    if (lightpdf > 0.0f && !Li.is_black()) {
+        RGB f = bsdf.f(si.wo, wi, flags) * abs_dot(wi, si.sh_n);
+        scattpdf = bsdf.pdf(si.wo, wi, flags);
+        if (!f.is_black()) {
+            Ray sr = spawn_ray_to(it, p1);  // VisibilityTester::unoccluded (light.rs:120-123)
+            if (ctx.scene->intersect_p(sr, *ctx.c)) Li = RGB(0.0f);
+            if (!Li.is_black()) {
+                if (delta) Ld += f * Li / lightpdf;
+                else {
+                    Float weight = power_heuristic(1, lightpdf, 1, scattpdf);
+                    Ld += f * Li * weight / lightpdf;
+                }
+            }
+        }
+    }
+    if (!delta) {
+        int sampled_type = 0;
+        RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, flags, sampled_type);
+        f = f * abs_dot(wi, si.sh_n);
+        bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+        if (!f.is_black() && scattpdf > 0.0f) {
+            Float weight = 1.0f;
+            if (!sampled_specular) {
+                lightpdf = ctx.lights->pdf_li(li, it, wi);
+                if (lightpdf == 0.0f) return Ld;
+                weight = power_heuristic(1, scattpdf, 1, lightpdf);
+            }
+            SurfaceInteraction lisect;
+            Ray ray = spawn_ray(it, wi);
+            bool found = ctx.scene->intersect(ray, lisect, *ctx.c);
+            RGB li_(0.0f);
+            if (found) {
+                if (ctx.scene->prim_light[lisect.prim] == li) li_ = isect_le(ctx, lisect, -wi);
+            } else li_ = ctx.lights->light_le(li, ray);
+            if (!li_.is_black()) Ld += f * li_ * RGB(1.0f) * weight / scattpdf;
+        }
+    }
+    return Ld;
+}
+
+static RGB uniform_sample_onelight(const RenderCtx &ctx, const SurfaceInteraction &si, const BSDF &bsdf, SobolSampler &sampler,
+                                   const Distribution1D *distrib) {
+    size_t nlights = ctx.scene->lights.size();
+    if (nlights == 0) return RGB(0.0f);
+    Float lightpdf = 0.0f;
+    size_t lightnum = distrib->sample_discrete(sampler.get_1d(), &lightpdf);
+    if (lightpdf == 0.0f) return RGB(0.0f);
+    P2 ulight = sampler.get_2d();
+    P2 uscatt = sampler.get_2d();
+    return estimate_direct(ctx, si, bsdf, uscatt, (uint32_t)lightnum, ulight) / lightpdf;
+}
+
+// ---- PathIntegrator::li (integrators/path.rs:79-222) ------------------------------------------------
+struct PathParams { uint32_t max_depth; Float rr_threshold; };
+
+static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSampler &sampler) {
+    RGB L(0.0f), beta(1.0f);
+    bool specular_bounce = false;
+    uint32_t bounces = 0;
+    Float etascale = 1.0f;
+    for (;;) {
+        SurfaceInteraction isect;
+        bool found = ctx.scene->intersect(ray, isect, *ctx.c);
+        if (bounces == 0 || specular_bounce) {
+            if (found) L += isect_le(ctx, isect, -ray.d) * beta;
+            else for (uint32_t li : ctx.scene->infinite_lights) L += ctx.lights->light_le(li, ray) * beta;
+        }
+        if (!found || bounces >= pp.max_depth) break;
+        BSDF bsdf;
+        if (!compute_scattering_functions(*ctx.scene, isect, bsdf)) {
+            IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
+            ray = spawn_ray(it, ray.d);
+            continue;
+        }
+        const Distribution1D *distrib = ctx.lights->lookup(isect.p);
+        if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+            ctx.c->zero_den++;
+            RGB Ld = beta * uniform_sample_onelight(ctx, isect, bsdf, sampler, distrib);
+            if (Ld.is_black()) ctx.c->zero_num++;
+            L += Ld;
+        }
+        V3 wo = -ray.d, wi;
+        Float pdf = 0.0f; int flags = 0;
+        RGB f = bsdf.sample_f(wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
+        if (f.is_black() || pdf == 0.0f) break;
+        beta *= f * abs_dot(wi, isect.sh_n) / pdf;
+        specular_bounce = (flags & BSDF_SPECULAR) != 0;
+        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+            Float eta = bsdf.eta;
+            etascale *= (dot(wo, isect.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
+        }
+        IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
+        ray = spawn_ray(it, wi);
+        // (BSSRDF branch path.rs:177-204: no subsurface material in the implemented rows)
+        RGB rrbeta = beta * etascale;
+        if (rrbeta.max_component_value() < pp.rr_threshold && bounces > 3) {
+            Float q = fmax_(1.0f - rrbeta.max_component_value(), 0.05f);
+            if (sampler.get_1d() < q) break;
+            beta = beta / (1.0f - q);
+        }
+        bounces += 1;
+    }
+    ctx.c->path_len[std::min<uint32_t>(bounces, 15)]++;
+    return L;
+}
+
+// ---- camera (cameras/perspective.rs:120-179, main ray only) ----------------------------------------
+struct Camera { M4 raster_to_camera, camera_to_world; Float lens_radius, focal_distance, shutter_open, shutter_close; };
+static Ray generate_ray(const Camera &cam, const CameraSample &cs) {
+    V3 pcamera = xf_point(cam.raster_to_camera, V3(cs.pfilm.x, cs.pfilm.y, 0.0f));
+    Ray r(V3(0, 0, 0), normalize(pcamera), INF, 0.0f);
+    if (cam.lens_radius > 0.0f) {
+        P2 d = concentric_sample_disk(cs.plens);
+        P2 plens(d.x * cam.lens_radius, d.y * cam.lens_radius);
+        Float ft = cam.focal_distance / r.d.z;
+        V3 pfocus = r.o + r.d * ft;
+        r.o = V3(plens.x, plens.y, 0.0f);
+        r.d = normalize(pfocus - r.o);
+    }
+    r.time = lerp(cs.time, cam.shutter_open, cam.shutter_close);
+    return xf_ray(cam.camera_to_world, r);
+}
+
+// ---- film (core/film.rs) -------------------------------------------------------------------------
+struct FilmParams {
+    int32_t crop[4]; Float radius[2]; Float table[256]; Float max_lum; Float scale;
+};
+struct FilmTile {
+    int64_t b[4];  // pixel bounds xmin ymin xmax ymax
+    std::vector<Float> rgbw;  // 4 per pixel: contrib_sum rgb + filter_weight_sum
+    const FilmParams *fp;
+    FilmTile(const FilmParams &f, const int64_t sb[4]) : fp(&f) {  // get_film_tile, film.rs:125-140
+        Float p0x = std::ceil((Float)sb[0] - 0.5f - f.radius[0]), p0y = std::ceil((Float)sb[1] - 0.5f - f.radius[1]);
+        Float p1x = std::floor((Float)sb[2] - 0.5f + f.radius[0]), p1y = std::floor((Float)sb[3] - 0.5f + f.radius[1]);
+        b[0] = std::max<int64_t>(f2i_sat(p0x), f.crop[0]); b[1] = std::max<int64_t>(f2i_sat(p0y), f.crop[1]);
+        b[2] = std::min<int64_t>(f2i_sat(p1x) + 1, f.crop[2]); b[3] = std::min<int64_t>(f2i_sat(p1y) + 1, f.crop[3]);
+        int64_t w = std::max<int64_t>(0, b[2] - b[0]), h = std::max<int64_t>(0, b[3] - b[1]);
+        rgbw.assign((size_t)(w * h * 4), 0.0f);
+    }
+    void add_sample(P2 pfilm, RGB L, Float sample_weight, Counters &c) {  // film.rs:292-331
+        if (L.y() > fp->max_lum) L *= RGB(fp->max_lum / L.y());
+        Float dx = pfilm.x - 0.5f, dy = pfilm.y - 0.5f;
+        int64_t p0x = f2i_sat(std::ceil(dx - fp->radius[0])), p0y = f2i_sat(std::ceil(dy - fp->radius[1]));
+        int64_t p1x = f2i_sat(std::floor(dx + fp->radius[0])) + 1, p1y = f2i_sat(std::floor(dy + fp->radius[1])) + 1;
+        p0x = std::max(p0x, b[0]); p0y = std::max(p0y, b[1]); p1x = std::min(p1x, b[2]); p1y = std::min(p1y, b[3]);
+        Float invrx = 1.0f / fp->radius[0], invry = 1.0f / fp->radius[1];
+        int64_t w = b[2] - b[0];
+        for (int64_t y = p0y; y < p1y; ++y) {
+            Float fy = std::fabs(((Float)y - dy) * invry * 16.0f);
+            uint64_t iy = std::min<uint64_t>(f2u_sat(std::floor(fy)), 15);
+            for (int64_t x = p0x; x < p1x; ++x) {
+                Float fx = std::fabs(((Float)x - dx) * invrx * 16.0f);
+                uint64_t ix = std::min<uint64_t>(f2u_sat(std::floor(fx)), 15);
+                Float fw = fp->table[iy * 16 + ix];
+                Float *px = &rgbw[(size_t)(((y - b[1]) * w + (x - b[0])) * 4)];
+                RGB contrib = L * RGB(sample_weight) * RGB(fw);
+                px[0] += contrib.c[0]; px[1] += contrib.c[1]; px[2] += contrib.c[2]; px[3] += fw;
+                c.splats++;
+            }
+        }
+    }
+};
+
+struct RenderJob {
+    const Scene *scene; LightSampler lights; PtRenderParams rp; Camera cam; FilmParams fp;
+};
+
+static void render_tiles(const RenderJob &job, float *film_xyzw, int nthreads, Counters &total, std::atomic<bool> &dim_overflow) {
+    const PtRenderParams &rp = job.rp;
+    const int32_t *sb = rp.sample_bounds;
+    int64_t ntx = (sb[2] - sb[0] + 15) / 16, nty = (sb[3] - sb[1] + 15) / 16;
+    int64_t ntiles = ntx * nty;
+    std::atomic<int64_t> next(0);
+    std::mutex film_mu;
+    int64_t fw = rp.cropped_pixel_bounds[2] - rp.cropped_pixel_bounds[0];
+    PathParams pp{rp.max_depth, rp.rr_threshold};
+    auto worker = [&]() {
+        Counters c;
+        RenderCtx ctx{job.scene, &job.lights, &c};
+        for (;;) {
+            int64_t t = next.fetch_add(1);
+            if (t >= ntiles) break;
+            if (rp.tile_world > 1 && (uint64_t)t % rp.tile_world != rp.tile_rank) continue;
+            int64_t tx = t % ntx, ty = t / ntx;
+            int64_t tb[4] = {sb[0] + tx * 16, sb[1] + ty * 16, 0, 0};
+            tb[2] = std::min<int64_t>(tb[0] + 16, sb[2]); tb[3] = std::min<int64_t>(tb[1] + 16, sb[3]);
+            SobolSampler sampler(rp.spp, rp.sample_bounds);
+            FilmTile tile(job.fp, tb);
+            for (int64_t y = tb[1]; y < tb[3]; ++y)
+                for (int64_t x = tb[0]; x < tb[2]; ++x) {
+                    sampler.start_pixel(x, y);
+                    if (!(x >= rp.pixel_bounds[0] && x < rp.pixel_bounds[2] && y >= rp.pixel_bounds[1] && y < rp.pixel_bounds[3])) continue;
+                    for (;;) {
+                        CameraSample cs = sampler.get_camera_sample(x, y);
+                        Ray ray = generate_ray(job.cam, cs);
+                        c.camera_rays++;
+                        RGB L = path_li(ctx, pp, ray, sampler);
+                        if (L.has_nans()) { L = RGB(0.0f); c.san_nan++; }
+                        else if (L.y() < -1.0e-5f) { L = RGB(0.0f); c.san_neg++; }
+                        else if (std::isinf(L.y())) { L = RGB(0.0f); c.san_inf++; }
+                        tile.add_sample(cs.pfilm, L, 1.0f, c);
+                        if (!sampler.start_next_sample()) break;
+                    }
+                }
+            if (sampler.dim_overflow) dim_overflow = true;
+            // merge_film_tile, film.rs:142-161
+            std::lock_guard<std::mutex> g(film_mu);
+            int64_t w = tile.b[2] - tile.b[0];
+            for (int64_t y = tile.b[1]; y < tile.b[3]; ++y)
+                for (int64_t x = tile.b[0]; x < tile.b[2]; ++x) {
+                    const Float *px = &tile.rgbw[(size_t)(((y - tile.b[1]) * w + (x - tile.b[0])) * 4)];
+                    Float xyz[3]; rgb_to_xyz(px, xyz);
+                    float *out = film_xyzw + ((y - rp.cropped_pixel_bounds[1]) * fw + (x - rp.cropped_pixel_bounds[0])) * 4;
+                    out[0] += xyz[0]; out[1] += xyz[1]; out[2] += xyz[2]; out[3] += px[3];
+                }
+        }
+        std::lock_guard<std::mutex> g(film_mu);
+        total.add(c);
+    };
+    if (nthreads <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nthreads; ++i) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+}
+
+}  // namespace ref
+
+// ---- oracle C ABI (ctypes) -----------------------------------------------------------------------
+using namespace ref;
+
+struct orc_scene { Scene scene; Counters counters; double last_render_seconds = 0; };
+
+extern "C" {
+
+int orc_load_tables(const char *path) { return sobol_tables().load(path) ? 0 : 1; }
+
+int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
+    if (!d || !out) return PT_ERR_INVALID_ARG;
+    orc_scene *h = new orc_scene();
+    Scene &s = h->scene;
+    s.P.resize(d->n_vertices);
+    for (uint32_t i = 0; i < d->n_vertices; ++i) s.P[i] = V3(d->P[3 * i], d->P[3 * i + 1], d->P[3 * i + 2]);
+    if (d->N) { s.N.resize(d->n_vertices); for (uint32_t i = 0; i < d->n_vertices; ++i) s.N[i] = V3(d->N[3 * i], d->N[3 * i + 1], d->N[3 * i + 2]); }
+    if (d->S) { s.S.resize(d->n_vertices); for (uint32_t i = 0; i < d->n_vertices; ++i) s.S[i] = V3(d->S[3 * i], d->S[3 * i + 1], d->S[3 * i + 2]); }
+    if (d->UV) { s.UV.resize(d->n_vertices); for (uint32_t i = 0; i < d->n_vertices; ++i) s.UV[i] = P2(d->UV[2 * i], d->UV[2 * i + 1]); }
+    s.idx.assign(d->indices, d->indices + 3 * (size_t)d->n_triangles);
+    if (d->tri_flags) s.tri_flags.assign(d->tri_flags, d->tri_flags + d->n_triangles); else s.tri_flags.assign(d->n_triangles, 0);
+    if (d->n_spheres) s.spheres.assign(d->spheres, d->spheres + d->n_spheres);
+    s.prim_shape.assign(d->prim_shape, d->prim_shape + d->n_prims);
+    s.prim_material.assign(d->prim_material, d->prim_material + d->n_prims);
+    s.prim_light.assign(d->prim_light, d->prim_light + d->n_prims);
+    if (d->n_materials) s.materials.assign(d->materials, d->materials + d->n_materials);
+    if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) if (s.lights[i].type == PT_LIGHT_INFINITE) s.infinite_lights.push_back(i);
+    if (d->env_texels) {
+        s.env_w = d->env_width; s.env_h = d->env_height;
+        s.env_texels.resize((size_t)s.env_w * s.env_h);
+        for (size_t i = 0; i < s.env_texels.size(); ++i) s.env_texels[i] = RGB(d->env_texels[3 * i], d->env_texels[3 * i + 1], d->env_texels[3 * i + 2]);
+        s.env_importance.assign(d->env_importance, d->env_importance + (size_t)4 * s.env_w * s.env_h);
+    }
+    s.max_node_prims = d->max_node_prims ? d->max_node_prims : 4;
+    if (d->nodes && d->n_nodes) {
+        s.nodes.assign(d->nodes, d->nodes + d->n_nodes);
+        s.ordered.assign(d->ordered_prims, d->ordered_prims + d->n_prims);
+    } else s.build_bvh();
+    if (!s.nodes.empty()) {
+        s.wb.pmin = V3(s.nodes[0].bmin[0], s.nodes[0].bmin[1], s.nodes[0].bmin[2]);
+        s.wb.pmax = V3(s.nodes[0].bmax[0], s.nodes[0].bmax[1], s.nodes[0].bmax[2]);
+    }
+    *out = h;
+    return PT_OK;
+}
+void orc_scene_destroy(orc_scene *h) { delete h; }
+
+int orc_scene_bvh_info(const orc_scene *h, uint32_t *n_nodes, uint32_t *n_prims) {
+    *n_nodes = (uint32_t)h->scene.nodes.size(); *n_prims = (uint32_t)h->scene.ordered.size(); return PT_OK;
+}
+int orc_scene_bvh_read(const orc_scene *h, PtBVHNode *nodes, uint32_t *ordered) {
+    std::memcpy(nodes, h->scene.nodes.data(), h->scene.nodes.size() * sizeof(PtBVHNode));
+    std::memcpy(ordered, h->scene.ordered.data(), h->scene.ordered.size() * 4);
+    return PT_OK;
+}
+
+int orc_render(orc_scene *h, const PtRenderParams *rp, float *film_xyzw, int nthreads) {
+    RenderJob job;
+    job.scene = &h->scene; job.rp = *rp;
+    job.lights.init(h->scene, (int)rp->light_strategy);
+    job.cam.raster_to_camera = m4_from(rp->raster_to_camera); job.cam.camera_to_world = m4_from(rp->camera_to_world);
+    job.cam.lens_radius = rp->lens_radius; job.cam.focal_distance = rp->focal_distance;
+    job.cam.shutter_open = rp->shutter_open; job.cam.shutter_close = rp->shutter_close;
+    std::memcpy(job.fp.crop, rp->cropped_pixel_bounds, 16);
+    job.fp.radius[0] = rp->filter_radius[0]; job.fp.radius[1] = rp->filter_radius[1];
+    std::memcpy(job.fp.table, rp->filter_table, sizeof job.fp.table);
+    job.fp.max_lum = rp->max_sample_luminance; job.fp.scale = rp->scale;
+    h->counters = Counters();
+    std::atomic<bool> overflow(false);
+    auto t0 = std::chrono::steady_clock::now();
+    render_tiles(job, film_xyzw, nthreads, h->counters, overflow);
+    h->last_render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return overflow ? PT_ERR_SOBOL_DIMENSIONS : PT_OK;
+}
+double orc_last_render_seconds(const orc_scene *h) { return h->last_render_seconds; }
+
+int orc_get_counters(const orc_scene *h, PtCounters *o) {
+    std::memset(o, 0, sizeof *o);
+    const Counters &c = h->counters;
+    o->camera_rays = c.camera_rays; o->intersect_tests = c.intersect_tests; o->shadow_tests = c.shadow_tests;
+    o->bvh_nodes_visited = c.nodes; o->triangle_tests = c.tri_tests; o->sphere_tests = c.sphere_tests;
+    o->zero_radiance_paths_num = c.zero_num; o->zero_radiance_paths_den = c.zero_den;
+    for (int i = 0; i < 16; ++i) o->path_length_hist[i] = c.path_len[i];
+    o->sanitized_nan = c.san_nan; o->sanitized_negative = c.san_neg; o->sanitized_infinite = c.san_inf;
+    o->film_splats = c.splats;
+    return PT_OK;
+}
+
+// Film::write_image normalisation (film.rs:217-258)
+int orc_film_resolve(const float *xyzw, uint32_t npix, float scale, float *rgb) {
+    for (uint32_t i = 0; i < npix; ++i) {
+        Float c[3]; xyz_to_rgb(xyzw + 4 * i, c);
+        Float w = xyzw[4 * i + 3];
+        if (w != 0.0f) { Float inv = 1.0f / w; for (int k = 0; k < 3; ++k) c[k] = fmax_(c[k] * inv, 0.0f); }
+        for (int k = 0; k < 3; ++k) rgb[3 * i + k] = c[k] * scale;
+    }
+    return PT_OK;
+}
+
+int orc_trace_closest(orc_scene *h, uint32_t n, const float *o, const float *d, const float *tmax, uint32_t *prim, float *t, float *b) {
+    Counters c;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        SurfaceInteraction si;
+        if (h->scene.intersect(r, si, c)) { prim[i] = si.prim; t[i] = si.t; b[3 * i] = si.b[0]; b[3 * i + 1] = si.b[1]; b[3 * i + 2] = si.b[2]; }
+        else { prim[i] = PT_NONE; t[i] = 0; b[3 * i] = b[3 * i + 1] = b[3 * i + 2] = 0; }
+    }
+    h->counters = c;
+    return PT_OK;
+}
+int orc_trace_any(orc_scene *h, uint32_t n, const float *o, const float *d, const float *tmax, uint8_t *hit) {
+    Counters c;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r(V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]);
+        hit[i] = h->scene.intersect_p(r, c) ? 1 : 0;
+    }
+    h->counters = c;
+    return PT_OK;
+}
+int orc_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    SobolSampler s(1u << 30, sb);
+    for (uint32_t i = 0; i < n; ++i) {
+        s.start_pixel(pixel_xy[2 * i], pixel_xy[2 * i + 1]);
+        s.set_sample_number(sample_num[i]);
+        if (out_index) out_index[i] = s.interval_sample_index;
+        for (uint32_t k = 0; k < n_dims; ++k) out[(size_t)i * n_dims + k] = s.sample_dimension(s.interval_sample_index, (int)k);
+    }
+    return PT_OK;
+}
+int orc_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float *out_o, float *out_d) {
+    Camera cam;
+    cam.raster_to_camera = m4_from(rp->raster_to_camera); cam.camera_to_world = m4_from(rp->camera_to_world);
+    cam.lens_radius = rp->lens_radius; cam.focal_distance = rp->focal_distance; cam.shutter_open = rp->shutter_open; cam.shutter_close = rp->shutter_close;
+    for (uint32_t i = 0; i < n; ++i) {
+        CameraSample c; c.pfilm = P2(cs[5 * i], cs[5 * i + 1]); c.time = cs[5 * i + 2]; c.plens = P2(cs[5 * i + 3], cs[5 * i + 4]);
+        Ray r = generate_ray(cam, c);
+        out_o[3 * i] = r.o.x; out_o[3 * i + 1] = r.o.y; out_o[3 * i + 2] = r.o.z;
+        out_d[3 * i] = r.d.x; out_d[3 * i + 1] = r.d.y; out_d[3 * i + 2] = r.d.z;
+    }
+    return PT_OK;
+}
+
+// ---- known-answer-test hooks (reference tests/*.rs) ------------------------------------------------
+float orc_sobol_sample_float(uint64_t index, int dim, uint32_t scramble) { return sobol_sample_float(index, dim, scramble); }
+float orc_radical_inverse(int base_index, uint64_t n) { return radical_inverse(base_index, n); }
+float orc_next_float_up(float v) { return next_float_up(v); }
+float orc_next_float_down(float v) { return next_float_down(v); }
+int orc_find_interval(int size, const float *a, float x) { return find_interval(size, [&](int i) { return a[i] <= x; }); }
+uint32_t orc_rng_u32_stream(uint64_t seq, int use_default, uint32_t n, uint32_t *out, float *outf) {
+    RNG r = use_default ? RNG() : RNG(seq);
+    for (uint32_t i = 0; i < n; ++i) { if (out) out[i] = r.uniform_u32(); else outf[i] = r.uniform_float(); }
+    return n;
+}
+// Distribution1D (tests/sampling.rs:202-257)
+int orc_dist1d_sample_discrete(const float *func, int n, float u, float *pdf, float *uremapped) {
+    Distribution1D d(std::vector<Float>(func, func + n));
+    return (int)d.sample_discrete(u, pdf, uremapped);
+}
+float orc_dist1d_discrete_pdf(const float *func, int n, int index) { return Distribution1D(std::vector<Float>(func, func + n)).discrete_pdf((size_t)index); }
+float orc_dist1d_sample_continuous(const float *func, int n, float u, float *pdf) { return Distribution1D(std::vector<Float>(func, func + n)).sample_continuous(u, pdf, nullptr); }
+// deterministic math
+float orc_dm_sin(float x) { return dm_sinf(x); }
+float orc_dm_cos(float x) { return dm_cosf(x); }
+float orc_dm_acos(float x) { return dm_acosf(x); }
+float orc_dm_atan2(float y, float x) { return dm_atan2f(y, x); }
+float orc_dm_log(float x) { return dm_logf(x); }
+// single-triangle tests (tests/shapes.rs): a 1-triangle scene is created by the caller.
+int orc_tri_intersect(orc_scene *h, uint32_t tri, const float *o, const float *d, float tmax, float *t, float *b, float *p, float *perr, float *n) {
+    Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmax);
+    Float tt, bb[3];
+    if (!h->scene.tri_intersect(tri, r, tt, bb)) return 0;
+    SurfaceInteraction si; h->scene.tri_fill_interaction(tri, r, tt, bb, true, si);
+    *t = tt; b[0] = bb[0]; b[1] = bb[1]; b[2] = bb[2];
+    p[0] = si.p.x; p[1] = si.p.y; p[2] = si.p.z; perr[0] = si.p_error.x; perr[1] = si.p_error.y; perr[2] = si.p_error.z;
+    n[0] = si.n.x; n[1] = si.n.y; n[2] = si.n.z;
+    return 1;
+}
+int orc_tri_intersect_p(orc_scene *h, uint32_t tri, const float *o, const float *d, float tmax) {
+    Ray r(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmax);
+    Float tt, bb[3];
+    return h->scene.tri_hit_params(tri, r, tt, bb) ? 1 : 0;
+}
+void orc_offset_ray_origin(const float *p, const float *perr, const float *n, const float *w, float *out) {
+    V3 r = offset_ray_origin(V3(p[0], p[1], p[2]), V3(perr[0], perr[1], perr[2]), V3(n[0], n[1], n[2]), V3(w[0], w[1], w[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+}  // extern "C"

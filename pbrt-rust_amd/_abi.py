@@ -1,0 +1,122 @@
+"""ctypes mirror of include/mi355pt.h (the C-ABI drop-in boundary).
+
+Only plain structs, enums and argtypes live here; no compute.  The same structs are
+accepted by the product library (csrc -> libmi355pt.so) and, in tests only, by the CPU oracle.
+"""
+import ctypes as C
+
+PT_OK = 0
+PT_ERR_INVALID_ARG, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_UNSUPPORTED = 1, 2, 3, 4
+PT_ERR_SOBOL_DIMENSIONS, PT_ERR_STACK_OVERFLOW, PT_ERR_OUT_OF_MEMORY = 5, 6, 7
+
+PT_TRI_REVERSE_ORIENTATION = 1
+PT_TRI_SWAPS_HANDEDNESS = 2
+PT_TRI_HAS_N = 4
+PT_TRI_HAS_S = 8
+PT_TRI_HAS_UV = 16
+
+PT_SHAPE_TRIANGLE, PT_SHAPE_SPHERE = 0, 1
+PT_NONE = 0xFFFFFFFF
+
+PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE = range(7)
+PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
+PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
+
+
+def shape_ref(kind, index):
+    return (kind << 30) | index
+
+
+f32, u32, i32, u8, u16, u64 = C.c_float, C.c_uint32, C.c_int32, C.c_uint8, C.c_uint16, C.c_uint64
+fp, u32p, u8p, i32p, u64p = C.POINTER(f32), C.POINTER(u32), C.POINTER(u8), C.POINTER(i32), C.POINTER(u64)
+
+
+class PtSphere(C.Structure):
+    _fields_ = [("object_to_world", f32 * 16), ("world_to_object", f32 * 16),
+                ("radius", f32), ("z_min", f32), ("z_max", f32), ("theta_min", f32), ("theta_max", f32),
+                ("phi_max", f32), ("reverse_orientation", u32), ("transform_swaps_handedness", u32)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
+                ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
+                ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32)]
+
+
+class PtLight(C.Structure):
+    _fields_ = [("type", u32), ("L", f32 * 3), ("two_sided", u32), ("prim", u32), ("pos", f32 * 3),
+                ("dir", f32 * 3), ("cos_total_width", f32), ("cos_falloff_start", f32),
+                ("light_to_world", f32 * 16), ("world_to_light", f32 * 16)]
+
+
+class PtBVHNode(C.Structure):
+    _fields_ = [("bmin", f32 * 3), ("bmax", f32 * 3), ("offset", u32), ("n_prims", u16), ("axis", u8), ("pad", u8)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("n_vertices", u32), ("P", fp), ("N", fp), ("S", fp), ("UV", fp),
+                ("n_triangles", u32), ("indices", u32p), ("tri_flags", u8p),
+                ("n_spheres", u32), ("spheres", C.POINTER(PtSphere)),
+                ("n_prims", u32), ("prim_shape", u32p), ("prim_material", u32p), ("prim_light", u32p),
+                ("n_materials", u32), ("materials", C.POINTER(PtMaterial)),
+                ("n_lights", u32), ("lights", C.POINTER(PtLight)),
+                ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp),
+                ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p)]
+
+
+class PtRenderParams(C.Structure):
+    _fields_ = [("full_resolution", i32 * 2), ("cropped_pixel_bounds", i32 * 4), ("filter_radius", f32 * 2),
+                ("filter_table", f32 * 256), ("max_sample_luminance", f32), ("scale", f32),
+                ("spp", u32), ("sample_bounds", i32 * 4),
+                ("raster_to_camera", f32 * 16), ("camera_to_world", f32 * 16), ("lens_radius", f32),
+                ("focal_distance", f32), ("shutter_open", f32), ("shutter_close", f32),
+                ("max_depth", u32), ("rr_threshold", f32), ("pixel_bounds", i32 * 4), ("light_strategy", u32),
+                ("tile_rank", u32), ("tile_world", u32), ("spp_per_pass", u32), ("profile", u32)]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("camera_rays", u64), ("intersect_tests", u64), ("shadow_tests", u64), ("bvh_nodes_visited", u64),
+                ("triangle_tests", u64), ("sphere_tests", u64), ("zero_radiance_paths_num", u64),
+                ("zero_radiance_paths_den", u64), ("path_length_hist", u64 * 16), ("sanitized_nan", u64),
+                ("sanitized_negative", u64), ("sanitized_infinite", u64), ("film_splats", u64),
+                ("wavefront_stages", u64)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else int(v)
+        return d
+
+
+class PtKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", u64), ("total_ms", C.c_double), ("items", u64)]
+
+
+# Every symbol include/mi355pt.h declares, with its signature (restype, argtypes).
+VP = C.c_void_p
+ENTRY_POINTS = {
+    "pt_init": (C.c_int, [C.c_int]),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(VP)]),
+    "pt_scene_destroy": (None, [VP]),
+    "pt_scene_bvh_info": (C.c_int, [VP, u32p, u32p]),
+    "pt_scene_bvh_read": (C.c_int, [VP, C.POINTER(PtBVHNode), u32p]),
+    "pt_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),
+    "pt_film_resolve": (C.c_int, [fp, u32, f32, fp]),
+    "pt_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
+    "pt_get_kernel_stats": (C.c_int, [VP, C.POINTER(PtKernelStat), u32, u32p]),
+    "pt_trace_closest": (C.c_int, [VP, u32, fp, fp, fp, u32p, fp, fp]),
+    "pt_trace_any": (C.c_int, [VP, u32, fp, fp, fp, u8p]),
+    "pt_sobol_samples": (C.c_int, [i32p, u32, i32p, u32p, u32, fp, u64p]),
+    "pt_camera_rays": (C.c_int, [C.POINTER(PtRenderParams), u32, fp, fp, fp]),
+}
+
+
+def bind(lib, table=ENTRY_POINTS, prefix_from="pt_", prefix_to="pt_"):
+    """Attach restype/argtypes; raises AttributeError if a declared symbol is missing."""
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name.replace(prefix_from, prefix_to, 1))
+        fn.restype = res
+        fn.argtypes = args
+    return lib

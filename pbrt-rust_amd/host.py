@@ -1,0 +1,384 @@
+"""Host-side scene assembly: a Python mirror of the reference's scene API for the hot path.
+
+Plays the role the Rust host plays in front of the C ABI: it keeps the graphics state
+(CTM, current material, area light, reverse-orientation) exactly like core/api.rs:941-1327,1493-1619
+and flattens everything into the POD structs of include/mi355pt.h.  There is no compute here
+that the render path depends on besides the parameter set-up the reference also does on the host
+(camera matrices cameras/perspective.rs:40-86, film bounds film.rs:55-112, filter table film.rs:76-89).
+"""
+import ctypes as C
+import math
+import numpy as np
+from . import _abi as A
+
+F = np.float32
+
+
+class Transform:
+    """core/transform.rs Transform {m, m_inv}, row major, f32."""
+
+    def __init__(self, m=None, m_inv=None):
+        self.m = np.eye(4, dtype=F) if m is None else np.asarray(m, dtype=F)
+        if m_inv is None:
+            m_inv = np.linalg.inv(self.m.astype(np.float64)).astype(F)
+        self.m_inv = np.asarray(m_inv, dtype=F)
+
+    def __mul__(self, o):  # transform.rs Mul: (m1*m2, m2_inv*m1_inv)
+        return Transform(_matmul(self.m, o.m), _matmul(o.m_inv, self.m_inv))
+
+    def inverse(self):
+        return Transform(self.m_inv, self.m)
+
+    def swaps_handedness(self):  # transform.rs swaps_handedness: det of upper 3x3 < 0
+        m = self.m
+        det = (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0]) +
+               m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+        return bool(det < 0)
+
+    def point(self, p):
+        p = np.asarray(p, dtype=F)
+        if p.ndim == 1:
+            x, y, z = F(p[0]), F(p[1]), F(p[2])
+            m = self.m
+            r = np.array([x * m[i, 0] + y * m[i, 1] + z * m[i, 2] + m[i, 3] for i in range(4)], dtype=F)
+            return r[:3] if r[3] == F(1) else (r[:3] * (F(1) / r[3])).astype(F)
+        # batched, same op order as transform.rs:413-432
+        m = self.m
+        x, y, z = p[:, 0], p[:, 1], p[:, 2]
+        out = np.stack([x * m[i, 0] + y * m[i, 1] + z * m[i, 2] + m[i, 3] for i in range(3)], axis=1).astype(F)
+        return out
+
+    def vector(self, v):
+        v = np.asarray(v, dtype=F)
+        m = self.m
+        if v.ndim == 1:
+            return np.array([v[0] * m[i, 0] + v[1] * m[i, 1] + v[2] * m[i, 2] for i in range(3)], dtype=F)
+        return np.stack([v[:, 0] * m[i, 0] + v[:, 1] * m[i, 1] + v[:, 2] * m[i, 2] for i in range(3)], axis=1).astype(F)
+
+    def normal(self, n):  # transform.rs:529-541
+        n = np.asarray(n, dtype=F)
+        mi = self.m_inv
+        if n.ndim == 1:
+            return np.array([n[0] * mi[0, i] + n[1] * mi[1, i] + n[2] * mi[2, i] for i in range(3)], dtype=F)
+        return np.stack([n[:, 0] * mi[0, i] + n[:, 1] * mi[1, i] + n[:, 2] * mi[2, i] for i in range(3)], axis=1).astype(F)
+
+    @staticmethod
+    def translate(d):
+        m = np.eye(4, dtype=F); mi = np.eye(4, dtype=F)
+        m[:3, 3] = np.asarray(d, dtype=F); mi[:3, 3] = -np.asarray(d, dtype=F)
+        return Transform(m, mi)
+
+    @staticmethod
+    def scale(x, y, z):
+        m = np.diag(np.array([x, y, z, 1], dtype=F)); mi = np.diag(np.array([F(1) / F(x), F(1) / F(y), F(1) / F(z), 1], dtype=F))
+        return Transform(m, mi)
+
+    @staticmethod
+    def rotate(theta, axis):  # transform.rs:329-355
+        a = np.asarray(axis, dtype=F); a = a / np.sqrt((a * a).sum(dtype=F))
+        r = F(math.pi / 180.0) * F(theta)
+        s, c = F(math.sin(r)), F(math.cos(r))
+        m = np.eye(4, dtype=F)
+        m[0, 0] = a[0] * a[0] + (1 - a[0] * a[0]) * c; m[0, 1] = a[0] * a[1] * (1 - c) - a[2] * s; m[0, 2] = a[0] * a[2] * (1 - c) + a[1] * s
+        m[1, 0] = a[0] * a[1] * (1 - c) + a[2] * s; m[1, 1] = a[1] * a[1] + (1 - a[1] * a[1]) * c; m[1, 2] = a[1] * a[2] * (1 - c) - a[0] * s
+        m[2, 0] = a[0] * a[2] * (1 - c) - a[1] * s; m[2, 1] = a[1] * a[2] * (1 - c) + a[0] * s; m[2, 2] = a[2] * a[2] + (1 - a[2] * a[2]) * c
+        return Transform(m, m.T.copy())
+
+    @staticmethod
+    def look_at(pos, look, up):  # transform.rs:357-393
+        pos, look, up = (np.asarray(v, dtype=F) for v in (pos, look, up))
+        d = look - pos; d = d / np.sqrt((d * d).sum(dtype=F))
+        un = up / np.sqrt((up * up).sum(dtype=F))
+        right = np.cross(un.astype(np.float64), d.astype(np.float64)).astype(F)
+        right = right / np.sqrt((right * right).sum(dtype=F))
+        new_up = np.cross(d.astype(np.float64), right.astype(np.float64)).astype(F)
+        c2w = np.eye(4, dtype=F)
+        c2w[:3, 0] = right; c2w[:3, 1] = new_up; c2w[:3, 2] = d; c2w[:3, 3] = pos
+        return Transform(np.linalg.inv(c2w.astype(np.float64)).astype(F), c2w)
+
+    @staticmethod
+    def perspective(fov, n, f):  # transform.rs:399-411
+        n, f = F(n), F(f)
+        persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], dtype=F)
+        inv_tan = F(1) / F(math.tan(F(math.pi / 180.0) * F(fov) / F(2)))
+        return Transform.scale(inv_tan, inv_tan, 1) * Transform(persp)
+
+
+def _matmul(a, b):
+    return (a.astype(F) @ b.astype(F)).astype(F)
+
+
+def box_filter_table(radius=(0.5, 0.5)):
+    return np.ones(256, dtype=F)  # filters/boxfilter.rs:19-21
+
+
+def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs:15-36 + film.rs:76-89
+    t = np.zeros(256, dtype=F)
+    a = F(alpha)
+    ex, ey = F(math.exp(-a * F(radius[0]) * F(radius[0]))), F(math.exp(-a * F(radius[1]) * F(radius[1])))
+    for y in range(16):
+        for x in range(16):
+            px = (F(x) + F(0.5)) * F(radius[0]) / F(16)
+            py = (F(y) + F(0.5)) * F(radius[1]) / F(16)
+            gx = max(F(0), F(math.exp(-a * px * px)) - ex)
+            gy = max(F(0), F(math.exp(-a * py * py)) - ey)
+            t[y * 16 + x] = F(gx) * F(gy)
+    return t
+
+
+class SceneBuilder:
+    """Directive-level mirror of core/api.rs for the rows in scope (no parser: SURVEY 8f-2)."""
+
+    def __init__(self):
+        self.ctm = Transform()
+        self._stack = []
+        self.reverse_orientation = False
+        self.material_id = None
+        self.area_light = None
+        self.materials = []
+        self.lights = []
+        self.P, self.N, self.UV, self.S, self.idx, self.tri_flags = [], [], [], [], [], []
+        self.nverts = 0
+        self.ntris = 0
+        self.spheres = []
+        self.prim_shape, self.prim_material, self.prim_light = [], [], []
+        self.nprims = 0
+        self.env = None
+        # options block defaults (api.rs:215-241, film.rs:364-398, sobol.rs:120, path.rs:228-249)
+        self.film = dict(xres=1280, yres=720, crop=(0.0, 1.0, 0.0, 1.0), scale=1.0, max_lum=float("inf"))
+        self.filter = dict(kind="box", radius=(0.5, 0.5), alpha=2.0)
+        self.cam = dict(fov=90.0, lensradius=0.0, focaldistance=1e6, shutteropen=0.0, shutterclose=1.0, c2w=Transform())
+        self.spp = 16
+        self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None)
+        self.max_node_prims = 4
+        self.material("matte")  # api.rs:345-361 default material matte Kd .5
+
+    # -- transforms / attributes (api.rs:941-1010,1268-1327)
+    def identity(self): self.ctm = Transform()
+    def translate(self, x, y, z): self.ctm = self.ctm * Transform.translate((x, y, z))
+    def scale(self, x, y, z): self.ctm = self.ctm * Transform.scale(x, y, z)
+    def rotate(self, deg, x, y, z): self.ctm = self.ctm * Transform.rotate(deg, (x, y, z))
+    def look_at(self, e, l, u): self.ctm = self.ctm * Transform.look_at(e, l, u)
+    def attribute_begin(self): self._stack.append((self.ctm, self.reverse_orientation, self.material_id, self.area_light))
+    def attribute_end(self): self.ctm, self.reverse_orientation, self.material_id, self.area_light = self._stack.pop()
+
+    # -- options
+    def camera(self, fov=90.0, lensradius=0.0, focaldistance=1e6):
+        self.cam.update(fov=fov, lensradius=lensradius, focaldistance=focaldistance, c2w=self.ctm.inverse())  # api.rs:1208
+
+    def world_begin(self): self.ctm = Transform()
+
+    # -- world block
+    def material(self, kind, **kw):
+        m = A.PtMaterial()
+        kinds = dict(matte=A.PT_MAT_MATTE, mirror=A.PT_MAT_MIRROR, glass=A.PT_MAT_GLASS, plastic=A.PT_MAT_PLASTIC,
+                     metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE)
+        m.type = kinds[kind]
+        d = dict(  # create_*_material defaults
+            matte=dict(Kd=0.5, sigma=0.0), mirror=dict(Kr=0.9), glass=dict(Kr=1.0, Kt=1.0, eta=1.5, uroughness=0.0, vroughness=0.0),
+            plastic=dict(Kd=0.25, Ks=0.25, roughness=0.1), metal=dict(roughness=0.01, uroughness=-1.0, vroughness=-1.0),
+            uber=dict(Kd=0.25, Ks=0.25, Kr=0.0, Kt=0.0, roughness=0.1, uroughness=-1.0, vroughness=-1.0, opacity=1.0, eta=1.5),
+            substrate=dict(Kd=0.5, Ks=0.5, uroughness=0.1, vroughness=0.1))[kind]
+        d.update(kw)
+        three = lambda v: (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
+        m.kd = three(d.get("Kd", 0)); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", 0)); m.kt = three(d.get("Kt", 0))
+        m.opacity = three(d.get("opacity", 1)); m.eta_rgb = three(d.get("eta_rgb", (0.2, 0.92, 1.1))); m.k_rgb = three(d.get("k", (3.9, 2.45, 2.14)))
+        m.sigma = d.get("sigma", 0.0); m.eta = d.get("eta", 1.5); m.roughness = d.get("roughness", 0.1)
+        m.u_roughness = d.get("uroughness", -1.0); m.v_roughness = d.get("vroughness", -1.0)
+        m.remap_roughness = 1 if d.get("remaproughness", True) else 0
+        self.materials.append(m)
+        self.material_id = len(self.materials) - 1
+
+    def area_light_source(self, L=(1, 1, 1), twosided=False):
+        self.area_light = dict(L=tuple(float(x) for x in L), twosided=twosided)
+
+    def light_source(self, kind, **kw):
+        l = A.PtLight()
+        l2w = self.ctm
+        l.light_to_world = (C.c_float * 16)(*l2w.m.flatten()); l.world_to_light = (C.c_float * 16)(*l2w.m_inv.flatten())
+        l.prim = A.PT_NONE
+        sc = kw.get("scale", 1.0)
+        if kind == "distant":  # distant.rs:124-132
+            L = np.asarray(kw.get("L", (1, 1, 1)), dtype=F) * F(sc)
+            frm, to = np.asarray(kw.get("from_", (0, 0, 0)), dtype=F), np.asarray(kw.get("to", (0, 0, 1)), dtype=F)
+            w = l2w.vector(frm - to); w = w / np.sqrt((w * w).sum(dtype=F))
+            l.type = A.PT_LIGHT_DISTANT; l.L = (C.c_float * 3)(*L); l.dir = (C.c_float * 3)(*w)
+        elif kind == "point":  # point.rs:99-106 (translation quirk P.x,P.y,P.x -- App. A #15)
+            I = np.asarray(kw.get("I", (1, 1, 1)), dtype=F) * F(sc)
+            p = np.asarray(kw.get("from_", (0, 0, 0)), dtype=F)
+            t = l2w * Transform.translate((p[0], p[1], p[0]))
+            l.type = A.PT_LIGHT_POINT; l.L = (C.c_float * 3)(*I); l.pos = (C.c_float * 3)(*t.point((0, 0, 0)))
+        elif kind == "infinite":  # infinite.rs:243-259, constant-L map = 1x1 texel
+            L = np.asarray(kw.get("L", (1, 1, 1)), dtype=F) * F(sc)
+            l.type = A.PT_LIGHT_INFINITE
+            tex = kw.get("texels")
+            if tex is None:
+                tex = L.reshape(1, 1, 3)
+            tex = np.ascontiguousarray(tex, dtype=F)
+            self.env = dict(texels=tex, importance=_env_importance(tex))
+        else:
+            raise ValueError(kind)
+        self.lights.append(l)
+
+    def _new_area_light(self, prim_index):  # api.rs:1531-1546: one DiffuseAreaLight per shape
+        l = A.PtLight(); l.type = A.PT_LIGHT_DIFFUSE_AREA
+        l.L = (C.c_float * 3)(*self.area_light["L"]); l.two_sided = 1 if self.area_light["twosided"] else 0
+        l.prim = prim_index
+        l.light_to_world = (C.c_float * 16)(*self.ctm.m.flatten()); l.world_to_light = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def trianglemesh(self, P, indices, N=None, UV=None, S=None):
+        """shapes/triangle.rs:21-73: vertices pre-transformed to world space, one primitive per triangle."""
+        P = np.asarray(P, dtype=F).reshape(-1, 3); idx = np.asarray(indices, dtype=np.uint32).reshape(-1, 3)
+        nv, nt = len(P), len(idx)
+        self.P.append(self.ctm.point(P))
+        self.N.append(None if N is None else self.ctm.normal(np.asarray(N, dtype=F).reshape(-1, 3)))
+        self.S.append(None if S is None else self.ctm.vector(np.asarray(S, dtype=F).reshape(-1, 3)))
+        self.UV.append(None if UV is None else np.asarray(UV, dtype=F).reshape(-1, 2))
+        self.idx.append(idx + np.uint32(self.nverts))
+        fl = (A.PT_TRI_REVERSE_ORIENTATION if self.reverse_orientation else 0) | (A.PT_TRI_SWAPS_HANDEDNESS if self.ctm.swaps_handedness() else 0)
+        fl |= (A.PT_TRI_HAS_N if N is not None else 0) | (A.PT_TRI_HAS_S if S is not None else 0) | (A.PT_TRI_HAS_UV if UV is not None else 0)
+        self.tri_flags.append(np.full(nt, fl, dtype=np.uint8))
+        first_prim = self.nprims
+        self.prim_shape.append((np.uint32(A.PT_SHAPE_TRIANGLE << 30) | (np.arange(nt, dtype=np.uint32) + np.uint32(self.ntris))).astype(np.uint32))
+        mid = A.PT_NONE if self.material_id is None else self.material_id
+        self.prim_material.append(np.full(nt, mid, dtype=np.uint32))
+        if self.area_light is None:
+            self.prim_light.append(np.full(nt, A.PT_NONE, dtype=np.uint32))
+        else:
+            self.prim_light.append(np.array([self._new_area_light(first_prim + t) for t in range(nt)], dtype=np.uint32))
+        self.nverts += nv; self.ntris += nt; self.nprims += nt
+        return first_prim
+
+    def sphere(self, radius=1.0, zmin=None, zmax=None, phimax=360.0):
+        """shapes/sphere.rs:31-50,424-431."""
+        r = F(radius)
+        zmin = -r if zmin is None else F(zmin); zmax = r if zmax is None else F(zmax)
+        clampf = lambda v, lo, hi: lo if v < lo else (hi if v > hi else v)
+        s = A.PtSphere()
+        s.object_to_world = (C.c_float * 16)(*self.ctm.m.flatten()); s.world_to_object = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+        s.radius = r
+        s.z_min = clampf(min(zmin, zmax), -r, r); s.z_max = clampf(max(zmin, zmax), -r, r)
+        s.theta_min = math.acos(clampf(min(zmin, zmax) / r, F(-1), F(1))); s.theta_max = math.acos(clampf(max(zmin, zmax) / r, F(-1), F(1)))
+        s.phi_max = F(math.pi / 180.0) * F(clampf(F(phimax), F(0), F(360)))
+        s.reverse_orientation = 1 if self.reverse_orientation else 0
+        s.transform_swaps_handedness = 1 if self.ctm.swaps_handedness() else 0
+        self.spheres.append(s)
+        first_prim = self.nprims
+        self.prim_shape.append(np.array([(A.PT_SHAPE_SPHERE << 30) | (len(self.spheres) - 1)], dtype=np.uint32))
+        self.prim_material.append(np.array([A.PT_NONE if self.material_id is None else self.material_id], dtype=np.uint32))
+        self.prim_light.append(np.array([A.PT_NONE if self.area_light is None else self._new_area_light(first_prim)], dtype=np.uint32))
+        self.nprims += 1
+        return first_prim
+
+    # -- WorldEnd (api.rs:1715-1748): flatten to the C ABI structs
+    def world_end(self):
+        return SceneData(self), self.render_params()
+
+    def render_params(self):
+        rp = A.PtRenderParams()
+        xres, yres = self.film["xres"], self.film["yres"]
+        cw = self.film["crop"]
+        rp.full_resolution = (C.c_int32 * 2)(xres, yres)
+        crop = [math.ceil(F(xres) * F(cw[0])), math.ceil(F(yres) * F(cw[2])), math.ceil(F(xres) * F(cw[1])), math.ceil(F(yres) * F(cw[3]))]  # film.rs:57-66
+        rp.cropped_pixel_bounds = (C.c_int32 * 4)(*crop)
+        rx, ry = self.filter["radius"]
+        rp.filter_radius = (C.c_float * 2)(rx, ry)
+        table = box_filter_table() if self.filter["kind"] == "box" else gaussian_filter_table((rx, ry), self.filter["alpha"])
+        rp.filter_table = (C.c_float * 256)(*table)
+        rp.max_sample_luminance = self.film["max_lum"]; rp.scale = self.film["scale"]
+        rp.spp = self.spp
+        sb = [math.floor(F(crop[0]) + F(0.5) - F(rx)), math.floor(F(crop[1]) + F(0.5) - F(ry)),
+              math.ceil(F(crop[2]) - F(0.5) + F(rx)), math.ceil(F(crop[3]) - F(0.5) + F(ry))]  # film.rs:104-112
+        rp.sample_bounds = (C.c_int32 * 4)(*sb)
+        # PerspectiveCamera::new, perspective.rs:40-86 + create_perspective_camera :298-356
+        frame = F(xres) / F(yres)
+        if frame > 1: sw = (-frame, frame, F(-1), F(1))
+        else: sw = (F(-1), F(1), F(-1) / frame, F(1) / frame)
+        c2s = Transform.perspective(self.cam["fov"], 1e-2, 1000.0)
+        s2r = (Transform.scale(xres, yres, 1) * Transform.scale(F(1) / (sw[1] - sw[0]), F(1) / (sw[2] - sw[3]), 1) *
+               Transform.translate((-sw[0], -sw[3], 0)))
+        r2c = c2s.inverse() * s2r.inverse()
+        rp.raster_to_camera = (C.c_float * 16)(*r2c.m.flatten())
+        rp.camera_to_world = (C.c_float * 16)(*self.cam["c2w"].m.flatten())
+        rp.lens_radius = self.cam["lensradius"]; rp.focal_distance = self.cam["focaldistance"]
+        rp.shutter_open = self.cam["shutteropen"]; rp.shutter_close = self.cam["shutterclose"]
+        rp.max_depth = self.integ["maxdepth"]; rp.rr_threshold = self.integ["rrthreshold"]
+        pb = self.integ["pixelbounds"]
+        if pb is None: pb = sb
+        else: pb = [max(pb[0], sb[0]), max(pb[2], sb[1]), min(pb[1], sb[2]), min(pb[3], sb[3])]  # path.rs:233-246
+        rp.pixel_bounds = (C.c_int32 * 4)(*pb)
+        rp.light_strategy = dict(uniform=A.PT_LS_UNIFORM, power=A.PT_LS_POWER, spatial=A.PT_LS_SPATIAL)[self.integ["strategy"]]
+        rp.tile_rank, rp.tile_world, rp.spp_per_pass, rp.profile = 0, 1, 0, 0
+        return rp
+
+
+def _env_importance(tex):
+    """lights/infinite.rs:62-81 importance image (2w x 2h) for a level-0 map; bilinear lookups
+    (MIPMap::lookup with width fwidth resolves to `triangle` on a 1-level pyramid only for 1x1 maps;
+    general maps go through the trilinear path -> restated for 1x1 here, the only case in scope)."""
+    h, w, _ = tex.shape
+    if (w, h) != (1, 1):
+        raise NotImplementedError("env maps other than constant-L (1x1) are a 'next' row (SURVEY 8f-1)")
+    W, H = 2 * w, 2 * h
+    img = np.zeros((H, W), dtype=F)
+    y_w = np.array([0.212671, 0.715160, 0.072169], dtype=F)
+    texel = tex[0, 0]
+    lum = F(y_w[0] * texel[0] + y_w[1] * texel[1] + y_w[2] * texel[2])
+    for v in range(H):
+        sin_theta = F(math.sin(F(math.pi) * (F(v) + F(0.5)) / F(H)))
+        for u in range(W):
+            img[v, u] = lum * sin_theta  # levels()==1: lookup returns texel(0,0,0) (mipmap.rs:210-211)
+    return img
+
+
+class SceneData:
+    """Owns the numpy arrays behind a PtSceneDesc (keeps them alive for the C call)."""
+
+    def __init__(self, b):
+        cat = lambda parts, width, dt: (np.ascontiguousarray(np.concatenate(parts), dtype=dt) if parts else np.zeros((0, width), dtype=dt))
+        self.P = cat(b.P, 3, F)
+        self.idx = cat(b.idx, 3, np.uint32)
+        self.tri_flags = np.ascontiguousarray(np.concatenate(b.tri_flags), dtype=np.uint8) if b.tri_flags else np.zeros(0, np.uint8)
+
+        def opt(parts, width):
+            if all(p is None for p in parts): return None
+            out = np.zeros((b.nverts, width), dtype=F); o = 0
+            for p, pp in zip(parts, b.P):
+                if p is not None: out[o:o + len(pp)] = p
+                o += len(pp)
+            return np.ascontiguousarray(out)
+        self.N, self.S, self.UV = opt(b.N, 3), opt(b.S, 3), opt(b.UV, 2)
+        c1 = lambda parts: np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32) if parts else np.zeros(0, np.uint32)
+        self.prim_shape, self.prim_material, self.prim_light = c1(b.prim_shape), c1(b.prim_material), c1(b.prim_light)
+        self.materials = (A.PtMaterial * max(1, len(b.materials)))(*b.materials)
+        self.lights = (A.PtLight * max(1, len(b.lights)))(*b.lights)
+        self.spheres = (A.PtSphere * max(1, len(b.spheres)))(*b.spheres)
+        self.n_materials, self.n_lights, self.n_spheres = len(b.materials), len(b.lights), len(b.spheres)
+        self.env = b.env
+        self.max_node_prims = b.max_node_prims
+        self.nodes = None; self.ordered = None
+
+    def set_bvh(self, nodes, ordered):
+        """Adopt a prebuilt accelerator (what a Rust host would pass: BVHAccel.nodes / ordered prims)."""
+        self.nodes, self.ordered = nodes, np.ascontiguousarray(ordered, dtype=np.uint32)
+
+    def desc(self):
+        d = A.PtSceneDesc()
+        ptr = lambda a, t: None if a is None or a.size == 0 else a.ctypes.data_as(t)
+        d.n_vertices = len(self.P); d.P = ptr(self.P, A.fp); d.N = ptr(self.N, A.fp); d.S = ptr(self.S, A.fp); d.UV = ptr(self.UV, A.fp)
+        d.n_triangles = len(self.idx); d.indices = ptr(self.idx, A.u32p); d.tri_flags = ptr(self.tri_flags, A.u8p)
+        d.n_spheres = self.n_spheres; d.spheres = self.spheres
+        d.n_prims = len(self.prim_shape)
+        d.prim_shape = ptr(self.prim_shape, A.u32p); d.prim_material = ptr(self.prim_material, A.u32p); d.prim_light = ptr(self.prim_light, A.u32p)
+        d.n_materials = self.n_materials; d.materials = self.materials
+        d.n_lights = self.n_lights; d.lights = self.lights
+        if self.env is not None:
+            t = self.env["texels"]
+            d.env_height, d.env_width = t.shape[0], t.shape[1]
+            d.env_texels = ptr(t, A.fp); d.env_importance = ptr(self.env["importance"], A.fp)
+        d.max_node_prims = self.max_node_prims
+        if self.nodes is not None:
+            d.n_nodes = len(self.nodes); d.nodes = self.nodes; d.ordered_prims = ptr(self.ordered, A.u32p)
+        return d

@@ -1,0 +1,124 @@
+"""ctypes binding of libmi355pt.so (the HIP product library).  Fails loudly when the
+extension is missing: there is NO CPU fallback behind this module."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355pt.so")
+TABLES_PATH = os.path.join(_HERE, "data", "sobol_tables.bin")
+
+
+def build_library(verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:]); print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libmi355pt.so failed")
+    return LIB_PATH
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise PtError(f"{path} not found: build it with __graft_entry__.build() (no CPU fallback exists)")
+        self.lib = A.bind(C.CDLL(path))
+        self.lib.pt_set_tables_path.argtypes = [C.c_char_p]
+        self.lib.pt_set_tables_path(TABLES_PATH.encode())
+
+    def check(self, st, what=""):
+        if st != A.PT_OK:
+            raise PtError(f"{what} failed: status {st}: {self.lib.pt_last_error().decode(errors='replace')}")
+
+    def init(self, device=0):
+        self.check(self.lib.pt_init(device), "pt_init")
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        _lib = Library()
+    return _lib
+
+
+def _fptr(a):
+    return a.ctypes.data_as(A.fp)
+
+
+class Scene:
+    """pt_scene handle + the render / parity entry points."""
+
+    def __init__(self, lib, scene_data):
+        self.L = lib
+        self.data = scene_data
+        self.h = C.c_void_p()
+        d = scene_data.desc()
+        lib.check(lib.lib.pt_scene_create(C.byref(d), C.byref(self.h)), "pt_scene_create")
+
+    def close(self):
+        if self.h:
+            self.L.lib.pt_scene_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def bvh(self):
+        nn, npr = C.c_uint32(), C.c_uint32()
+        self.L.check(self.L.lib.pt_scene_bvh_info(self.h, C.byref(nn), C.byref(npr)))
+        nodes = (A.PtBVHNode * nn.value)(); ordered = np.zeros(npr.value, dtype=np.uint32)
+        self.L.check(self.L.lib.pt_scene_bvh_read(self.h, nodes, ordered.ctypes.data_as(A.u32p)))
+        return nodes, ordered
+
+    def render(self, rp, film=None, device_ptr=None):
+        """Returns the un-normalised film (H, W, 4) = XYZ sums + weight sum."""
+        cb = rp.cropped_pixel_bounds
+        w, h = cb[2] - cb[0], cb[3] - cb[1]
+        if device_ptr is not None:
+            st = self.L.lib.pt_render(self.h, C.byref(rp), C.c_void_p(device_ptr), 1)
+            self.L.check(st, "pt_render"); return None
+        if film is None:
+            film = np.zeros((h, w, 4), dtype=np.float32)
+        st = self.L.lib.pt_render(self.h, C.byref(rp), film.ctypes.data_as(C.c_void_p), 0)
+        self.L.check(st, "pt_render")
+        return film
+
+    def resolve(self, film, scale=1.0):
+        film = np.ascontiguousarray(film, dtype=np.float32)
+        out = np.zeros(film.shape[:-1] + (3,), dtype=np.float32)
+        self.L.check(self.L.lib.pt_film_resolve(_fptr(film), film.size // 4, scale, _fptr(out)))
+        return out
+
+    def counters(self):
+        c = A.PtCounters()
+        self.L.check(self.L.lib.pt_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def kernel_stats(self):
+        arr = (A.PtKernelStat * 32)(); n = C.c_uint32()
+        self.L.check(self.L.lib.pt_get_kernel_stats(self.h, arr, 32, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, items=arr[i].items) for i in range(n.value)]
+
+    def trace_closest(self, o, d, tmax):
+        o, d, tmax = (np.ascontiguousarray(x, dtype=np.float32) for x in (o, d, tmax))
+        n = len(tmax)
+        prim = np.zeros(n, np.uint32); t = np.zeros(n, np.float32); b = np.zeros((n, 3), np.float32)
+        self.L.check(self.L.lib.pt_trace_closest(self.h, n, _fptr(o), _fptr(d), _fptr(tmax), prim.ctypes.data_as(A.u32p), _fptr(t), _fptr(b)))
+        return prim, t, b
+
+    def trace_any(self, o, d, tmax):
+        o, d, tmax = (np.ascontiguousarray(x, dtype=np.float32) for x in (o, d, tmax))
+        n = len(tmax)
+        hit = np.zeros(n, np.uint8)
+        self.L.check(self.L.lib.pt_trace_any(self.h, n, _fptr(o), _fptr(d), _fptr(tmax), hit.ctypes.data_as(A.u8p)))
+        return hit

@@ -1,0 +1,119 @@
+"""Synthetic config scenes: the real Ganesha / Kitchen / ... assets are not
+available (no network), so the builder authors deterministic stand-ins of the same scale."""
+import numpy as np
+from .host import SceneBuilder, F
+
+
+def _hash3(ix, iy, iz, seed):
+    """Integer lattice hash -> [0,1) (uint32 arithmetic, seed 0x9E3779B9 by default)."""
+    h = (ix.astype(np.uint32) * np.uint32(0x8DA6B343)) ^ (iy.astype(np.uint32) * np.uint32(0xD8163841)) ^ \
+        (iz.astype(np.uint32) * np.uint32(0xCB1AB31F)) ^ np.uint32(seed)
+    h ^= h >> np.uint32(16); h = h * np.uint32(0x7FEB352D); h ^= h >> np.uint32(15); h = h * np.uint32(0x846CA68B); h ^= h >> np.uint32(16)
+    return (h >> np.uint32(8)).astype(np.float64) * (1.0 / (1 << 24))
+
+
+def _value_noise(p, seed):
+    pf = np.floor(p); f = p - pf
+    i = pf.astype(np.int64)
+    w = f * f * (3.0 - 2.0 * f)
+    acc = 0.0
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                c = _hash3(i[:, 0] + dx, i[:, 1] + dy, i[:, 2] + dz, seed)
+                wx = w[:, 0] if dx else 1.0 - w[:, 0]
+                wy = w[:, 1] if dy else 1.0 - w[:, 1]
+                wz = w[:, 2] if dz else 1.0 - w[:, 2]
+                acc = acc + c * wx * wy * wz
+    return acc
+
+
+def fbm(p, octaves=6, seed=0x9E3779B9):
+    amp, freq, total = 0.5, 1.0, 0.0
+    for o in range(octaves):
+        total = total + amp * (2.0 * _value_noise(p * freq, (seed + o * 0x632BE5AB) & 0xFFFFFFFF) - 1.0)
+        amp *= 0.5; freq *= 2.0
+    return total
+
+
+def displaced_sphere(n, with_normals=False):
+    """UV sphere, n x n quads -> 2*n*n triangles; radius 1 + 0.15*fbm(4p, 6 octaves)."""
+    u = np.linspace(0.0, 1.0, n + 1); v = np.linspace(0.0, 1.0, n + 1)
+    uu, vv = np.meshgrid(u, v, indexing="xy")
+    theta = vv.ravel() * np.pi; phi = uu.ravel() * 2.0 * np.pi
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], axis=1)
+    r = 1.0 + 0.15 * fbm(4.0 * d + 100.0, 6)
+    P = (d * r[:, None]).astype(F)
+    i0 = (np.arange(n)[None, :] + (n + 1) * np.arange(n)[:, None]).ravel().astype(np.uint32)
+    tris = np.stack([np.stack([i0, i0 + n + 1, i0 + 1], axis=1), np.stack([i0 + 1, i0 + n + 1, i0 + n + 2], axis=1)], axis=1).reshape(-1, 3)
+    N = d.astype(F) if with_normals else None
+    return P, tris.astype(np.uint32), N
+
+
+def quad(p0, p1, p2, p3):
+    return np.array([p0, p1, p2, p3], dtype=F), np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+
+
+def ganesha_scale(n=1466, xres=1920, yres=1080, spp=256, maxdepth=5, env=True, with_normals=False, strategy="spatial"):
+    """S2 / config C2: 2*n*n-triangle displaced sphere (n=1466 -> 4,298,312 tris), matte Kd .5, ground quad
+    20x20, one-sided quad area light 2x2 at y=4 L=(17,12,4), constant env L=.1, camera (0,1.5,5) fov 35,
+    sobol, path maxdepth 5, rrthreshold 1, spatial light sampling, bvh sah maxnodeprims 4, box filter."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres)
+    b.spp = spp
+    b.integ.update(maxdepth=maxdepth, strategy=strategy)
+    b.look_at((0.0, 1.5, 5.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0))
+    b.camera(fov=35.0)
+    b.world_begin()
+    if env:
+        b.light_source("infinite", L=(0.1, 0.1, 0.1))
+    b.attribute_begin()
+    b.area_light_source(L=(17.0, 12.0, 4.0))
+    P, I = quad((-1.0, 4.0, -1.0), (1.0, 4.0, -1.0), (1.0, 4.0, 1.0), (-1.0, 4.0, 1.0))  # normal faces -y
+    b.trianglemesh(P, I)
+    b.attribute_end()
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-10.0, -1.2, -10.0), (-10.0, -1.2, 10.0), (10.0, -1.2, 10.0), (10.0, -1.2, -10.0))
+    b.trianglemesh(P, I)
+    P, I, N = displaced_sphere(n, with_normals)
+    b.trianglemesh(P, I, N=N)
+    return b
+
+
+def material_zoo(n=24, xres=96, yres=64, spp=16, maxdepth=5):
+    """S3-style mixed-BSDF test scene: a row of small displaced spheres, one per material class, in a lit room."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres)
+    b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.0, 9.0), (0.0, 0.6, 0.0), (0.0, 1.0, 0.0))
+    b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.2, 0.25, 0.3))
+    b.attribute_begin()
+    b.area_light_source(L=(20.0, 18.0, 15.0))
+    P, I = quad((-2.0, 5.0, -2.0), (2.0, 5.0, -2.0), (2.0, 5.0, 2.0), (-2.0, 5.0, 2.0))
+    b.trianglemesh(P, I)
+    b.attribute_end()
+    b.attribute_begin()
+    b.area_light_source(L=(4.0, 6.0, 9.0), twosided=True)
+    P, I = quad((-6.0, 0.5, -3.0), (-6.0, 3.0, -3.0), (-6.0, 3.0, 1.0), (-6.0, 0.5, 1.0))
+    b.trianglemesh(P, I)
+    b.attribute_end()
+    b.material("matte", Kd=(0.6, 0.6, 0.55), sigma=20.0)
+    P, I = quad((-12.0, -0.5, -12.0), (-12.0, -0.5, 12.0), (12.0, -0.5, 12.0), (12.0, -0.5, -12.0))
+    b.trianglemesh(P, I)
+    mats = [("matte", dict(Kd=(0.7, 0.2, 0.2))), ("plastic", dict(Kd=(0.1, 0.3, 0.6), Ks=(0.4, 0.4, 0.4), roughness=0.1)),
+            ("metal", dict(eta_rgb=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.05)), ("glass", dict(eta=1.5)),
+            ("mirror", dict(Kr=(0.9, 0.9, 0.9))), ("uber", dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), Kr=(0.1, 0.1, 0.1), roughness=0.2)),
+            ("substrate", dict(Kd=(0.5, 0.3, 0.1), Ks=(0.2, 0.2, 0.2), uroughness=0.1, vroughness=0.2)),
+            ("glass", dict(eta=1.4, uroughness=0.2, vroughness=0.2))]
+    for k, (kind, kw) in enumerate(mats):
+        b.attribute_begin()
+        b.material(kind, **kw)
+        b.translate(-5.25 + 1.5 * k, 0.35, 0.5 * ((k % 3) - 1))
+        b.scale(0.6, 0.6, 0.6)
+        P, I, N = displaced_sphere(n, with_normals=(k % 2 == 1))
+        b.trianglemesh(P, I, N=N)
+        b.attribute_end()
+    return b
