@@ -1,0 +1,695 @@
+// capi.hip -- host driver behind include/mi355pt.h: scene upload, wavefront scheduling on one HIP stream,
+// film hand-off, counters and per-kernel HIP-event timing. One process drives one GPU (pt_init).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "kernels.hip"  // single translation unit: kernels + host driver
+#include "host_bvh.h"
+
+extern "C" const unsigned char pt_sobol_blob[];   // tables_blob.cpp (.incbin of data/sobol_tables.bin)
+extern "C" const unsigned int pt_sobol_blob_size;
+
+namespace {
+
+std::string g_error;
+int g_device = -1;
+int g_num_cus = 256;
+SobolTables g_tabs = {nullptr, nullptr, nullptr};
+
+int fail(int code, const std::string &msg) { g_error = msg; return code; }
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+
+int ensure_device() {
+    if (g_device >= 0) return PT_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    return pt_init(0);
+}
+
+int upload_tables() {
+    if (g_tabs.m32) return PT_OK;
+    if (pt_sobol_blob_size != 8 + 1024 * 52 * 4 + (25 + 26) * 52 * 8 || std::memcmp(pt_sobol_blob, "PTSOBOL1", 8) != 0)
+        return fail(PT_ERR_INVALID_ARG, "embedded Sobol table blob is corrupt");
+    const unsigned char *p = pt_sobol_blob + 8;
+    void *d = nullptr;
+    size_t bytes = pt_sobol_blob_size - 8;
+    HIP_TRY(hipMalloc(&d, bytes));
+    HIP_TRY(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice));
+    g_tabs.m32 = (const uint32_t *)d;
+    g_tabs.vdc = (const uint64_t *)((const char *)d + 1024 * 52 * 4);
+    g_tabs.vdc_inv = g_tabs.vdc + 25 * 52;
+    return PT_OK;
+}
+
+struct Stat { std::string name; uint64_t launches = 0; double ms = 0; uint64_t items = 0; };
+struct TimedLaunch { int stat; hipEvent_t a, b; };
+
+}  // namespace
+
+struct pt_scene {
+    std::vector<void *> allocs;
+    DeviceScene ds{};
+    std::vector<PtBVHNode> nodes;
+    std::vector<uint32_t> ordered;
+    bool class_used[kNumClasses] = {true, false, false, false};
+    uint32_t n_lights = 0;
+    // light grids (lazy, per effective strategy)
+    LightGrid grid[3]{}; bool grid_ready[3] = {false, false, false};
+    // render workspace
+    hipStream_t stream = nullptr;
+    void *slab = nullptr; size_t capacity = 0; PathSoA ps{};
+    uint32_t *qbuf = nullptr; QueueSet q{};
+    QCounters *qc = nullptr; DevCounters *dc = nullptr;
+    uint32_t *spill = nullptr; uint32_t spill_waves = 0;
+    float *film_rgbw = nullptr; size_t film_px = 0;
+    float *d_filter = nullptr;
+    PtCounters counters{};
+    std::vector<Stat> stats;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    bool profile = false;
+
+    template <class T> int dalloc(T **out, size_t count) {
+        void *p = nullptr;
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(&p, count * sizeof(T));
+        if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocs.push_back(p);
+        *out = (T *)p;
+        return PT_OK;
+    }
+    template <class T> int upload(const T **out, const T *src, size_t count) {
+        T *d = nullptr;
+        int st = dalloc(&d, count);
+        if (st) return st;
+        if (count && src) HIP_TRY(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+        *out = d;
+        return PT_OK;
+    }
+    int stat_id(const char *name) {
+        for (size_t i = 0; i < stats.size(); ++i) if (stats[i].name == name) return (int)i;
+        stats.push_back(Stat{name}); return (int)stats.size() - 1;
+    }
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
+    // bracket a launch with HIP events on the render stream when profiling
+    void begin(const char *name, uint64_t items) {
+        int id = stat_id(name);
+        stats[id].launches++; stats[id].items += items;
+        if (profile) { TimedLaunch t{id, get_event(), get_event()}; hipEventRecord(t.a, stream); timed.push_back(t); }
+    }
+    void end() { if (profile) hipEventRecord(timed.back().b, stream); }
+    void resolve_timings() {
+        for (auto &t : timed) { float ms = 0; hipEventElapsedTime(&ms, t.a, t.b); stats[t.stat].ms += ms; event_pool.push_back(t.a); event_pool.push_back(t.b); }
+        timed.clear();
+    }
+};
+
+namespace {
+
+uint8_t material_class(const PtMaterial &m) {
+    switch (m.type) {
+    case PT_MAT_MATTE: return 0;
+    case PT_MAT_MIRROR: case PT_MAT_METAL: case PT_MAT_SUBSTRATE: return 1;
+    case PT_MAT_GLASS: return (m.u_roughness == 0.0f && m.v_roughness == 0.0f) ? 1 : 2;
+    case PT_MAT_PLASTIC: return 2;
+    default: return 3;
+    }
+}
+
+// Distribution1D::new on the host (sampling.rs:12-34) for the uniform / power strategies and the env map.
+void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func_int) {
+    size_t n = func.size();
+    cdf.assign(n + 1, 0.0f);
+    for (size_t i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)n;
+    func_int = cdf[n];
+    if (func_int == 0.0f) { for (size_t i = 1; i < n + 1; ++i) cdf[i] = (float)i / (float)n; }
+    else { for (size_t i = 1; i < n + 1; ++i) cdf[i] /= func_int; }
+}
+
+int launch_trace(pt_scene *sc, bool any, const TraceJob &job, uint32_t n_upper) {
+    if (n_upper == 0) return PT_OK;
+    uint32_t waves = (n_upper + 63) / 64;
+    uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
+    if (any) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
+    if (!sc->stream) HIP_TRY(hipStreamCreate(&sc->stream));
+    if (!sc->qc) {
+        int st;
+        if ((st = sc->dalloc(&sc->qc, 1))) return st;
+        if ((st = sc->dalloc(&sc->dc, 1))) return st;
+        sc->spill_waves = (uint32_t)g_num_cus * 16u;  // 16 waves per CU resident at most (LDS: 6 KB per wave)
+        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * (kMaxStack - kLdsStack)))) return st;
+        if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
+    }
+    if (capacity > sc->capacity) {
+        if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
+        size_t bytes = capacity * (size_t)(kPathSoAFloatArrays * 4 + 8 + 1) + 4096;
+        hipError_t e = hipMalloc(&sc->slab, bytes);
+        if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "path-state slab: " + std::string(hipGetErrorString(e)));
+        char *p = (char *)sc->slab;
+        PathSoA &ps = sc->ps;
+        ps.sobol_index = (uint64_t *)p; p += capacity * 8;
+        float **fa[] = {&ps.pfilm_x, &ps.pfilm_y, &ps.ox, &ps.oy, &ps.oz, &ps.dx, &ps.dy, &ps.dz, &ps.hit_b0, &ps.hit_b1, &ps.hit_b2,
+                        &ps.beta_r, &ps.beta_g, &ps.beta_b, &ps.L_r, &ps.L_g, &ps.L_b, &ps.etascale,
+                        &ps.sh_ox, &ps.sh_oy, &ps.sh_oz, &ps.sh_dx, &ps.sh_dy, &ps.sh_dz, &ps.A_r, &ps.A_g, &ps.A_b,
+                        &ps.mis_ox, &ps.mis_oy, &ps.mis_oz, &ps.mis_dx, &ps.mis_dy, &ps.mis_dz, &ps.mis_f_r, &ps.mis_f_g, &ps.mis_f_b,
+                        &ps.mis_w, &ps.mis_spdf, &ps.nee_choice_pdf, &ps.nb_r, &ps.nb_g, &ps.nb_b, &ps.mis_b0, &ps.mis_b1, &ps.mis_b2};
+        for (float **f : fa) { *f = (float *)p; p += capacity * 4; }
+        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim};
+        for (uint32_t **u : ua) { *u = (uint32_t *)p; p += capacity * 4; }
+        ps.occluded = (uint8_t *)p;
+        static_assert(sizeof(fa) / sizeof(fa[0]) + sizeof(ua) / sizeof(ua[0]) <= kPathSoAFloatArrays, "slab too small");
+        // queues: ext[2] + shade[2][classes] + shadow + mis
+        size_t nq = 2 + 2 * kNumClasses + 2;
+        e = hipMalloc((void **)&sc->qbuf, nq * capacity * 4);
+        if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "queues: " + std::string(hipGetErrorString(e)));
+        uint32_t *qp = sc->qbuf;
+        for (int i = 0; i < 2; ++i) { sc->q.ext[i] = qp; qp += capacity; }
+        for (int i = 0; i < 2; ++i) for (int c = 0; c < kNumClasses; ++c) { sc->q.shade[i][c] = qp; qp += capacity; }
+        sc->q.shadow = qp; qp += capacity; sc->q.mis = qp;
+        sc->capacity = capacity;
+    }
+    if (film_px > sc->film_px) {
+        if (sc->film_rgbw) hipFree(sc->film_rgbw);
+        HIP_TRY(hipMalloc((void **)&sc->film_rgbw, film_px * 16));
+        sc->film_px = film_px;
+    }
+    return PT_OK;
+}
+
+int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
+    effective = requested;
+    if (requested == PT_LS_UNIFORM || sc->n_lights == 1) effective = PT_LS_UNIFORM;  // lightdistrib.rs:21
+    if (requested > PT_LS_SPATIAL) effective = PT_LS_SPATIAL;
+    LightGrid &g = sc->grid[effective];
+    if (sc->grid_ready[effective]) return PT_OK;
+    g.strategy = effective; g.n_lights = sc->n_lights; g.nvox[0] = g.nvox[1] = g.nvox[2] = 1;
+    const uint32_t nl = sc->n_lights;
+    if (nl == 0) { g.func = g.cdf = g.func_int = nullptr; sc->grid_ready[effective] = true; return PT_OK; }
+    if (effective == PT_LS_POWER) return fail(PT_ERR_UNSUPPORTED, "lightsamplestrategy \"power\" is not implemented on device yet");
+    if (effective == PT_LS_UNIFORM) {
+        std::vector<float> func(nl, 1.0f), cdf; float fi;
+        dist1d(func, cdf, fi);
+        int st;
+        if ((st = sc->upload(&g.func, func.data(), nl))) return st;
+        if ((st = sc->upload(&g.cdf, cdf.data(), nl + 1))) return st;
+        if ((st = sc->upload(&g.func_int, &fi, 1))) return st;
+    } else {  // SpatialLightDistribution::new (lightdistrib.rs:112-128), every voxel precomputed on device
+        float diag[3] = {sc->ds.wb_max[0] - sc->ds.wb_min[0], sc->ds.wb_max[1] - sc->ds.wb_min[1], sc->ds.wb_max[2] - sc->ds.wb_min[2]};
+        int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
+        float bmax = diag[me];
+        for (int i = 0; i < 3; ++i) {
+            float v = std::round(diag[i] / bmax * 64.0f);
+            uint32_t nv = (v > 0.0f) ? (uint32_t)v : 0u;  // `as usize` saturates, NaN -> 0
+            g.nvox[i] = std::max<uint32_t>(1u, nv);
+        }
+        size_t ncell = (size_t)g.nvox[0] * g.nvox[1] * g.nvox[2];
+        if (ncell * nl > ((size_t)1 << 31)) return fail(PT_ERR_UNSUPPORTED, "spatial light grid too large to precompute (voxels x lights > 2^31)");
+        float *func, *cdf, *fint; int st;
+        if ((st = sc->dalloc(&func, ncell * nl))) return st;
+        if ((st = sc->dalloc(&cdf, ncell * (nl + 1)))) return st;
+        if ((st = sc->dalloc(&fint, ncell))) return st;
+        size_t total = ncell * nl;
+        sc->begin("light_grid", total);
+        hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, g.nvox[0], g.nvox[1], g.nvox[2], func);
+        hipLaunchKernelGGL(k_light_grid_finish, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, sc->stream, nl, ncell, func, cdf, fint);
+        sc->end();
+        HIP_TRY(hipGetLastError());
+        g.func = func; g.cdf = cdf; g.func_int = fint;
+    }
+    sc->grid_ready[effective] = true;
+    return PT_OK;
+}
+
+void fill_render_const(const PtRenderParams *rp, RenderConst &rc) {
+    std::memset(&rc, 0, sizeof rc);
+    std::memcpy(rc.sample_bounds, rp->sample_bounds, 16);
+    std::memcpy(rc.pixel_bounds, rp->pixel_bounds, 16);
+    std::memcpy(rc.crop, rp->cropped_pixel_bounds, 16);
+    int32_t dx = rp->sample_bounds[2] - rp->sample_bounds[0], dy = rp->sample_bounds[3] - rp->sample_bounds[1];
+    rc.ntx = (uint32_t)((dx + 15) / 16); rc.nty = (uint32_t)((dy + 15) / 16);
+    // SobolSampler::new (sobol.rs:42-44)
+    int32_t v = std::max(dx, dy); v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+    rc.sobol.resolution = v; rc.sobol.log2_resolution = 31 - __builtin_clz((uint32_t)v);
+    rc.sobol.sb_min[0] = rp->sample_bounds[0]; rc.sobol.sb_min[1] = rp->sample_bounds[1];
+    std::memcpy(rc.raster_to_camera.m, rp->raster_to_camera, 64);
+    std::memcpy(rc.camera_to_world.m, rp->camera_to_world, 64);
+    rc.lens_radius = rp->lens_radius; rc.focal_distance = rp->focal_distance;
+    rc.shutter_open = rp->shutter_open; rc.shutter_close = rp->shutter_close;
+    rc.max_depth = rp->max_depth; rc.rr_threshold = rp->rr_threshold;
+    rc.filter_radius[0] = rp->filter_radius[0]; rc.filter_radius[1] = rp->filter_radius[1];
+    rc.max_sample_luminance = rp->max_sample_luminance;
+    rc.film_w = (uint32_t)(rp->cropped_pixel_bounds[2] - rp->cropped_pixel_bounds[0]);
+    rc.film_h = (uint32_t)(rp->cropped_pixel_bounds[3] - rp->cropped_pixel_bounds[1]);
+    rc.spp = rp->spp;
+    rc.tile_world = rp->tile_world ? rp->tile_world : 1; rc.tile_rank = rp->tile_rank;
+}
+
+__global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
+    // mask bit0: next ext + next shade queues; bit1: shadow + mis; bit2: trace heads; bit3: current ext + shade
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int nxt = 1 - cur;
+    if (mask & 1u) { qc->ext[nxt] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[nxt][c] = 0; }
+    if (mask & 2u) { qc->shadow = 0; qc->mis = 0; }
+    if (mask & 4u) { for (int i = 0; i < 4; ++i) qc->head[i] = 0; }
+    if (mask & 8u) { qc->ext[cur] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[cur][c] = 0; }
+}
+
+template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
+    hipLaunchKernelGGL(k_shade<MAXL>, dim3((upper + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+}
+
+int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
+    const uint32_t total = rc.n_pix_slots * rc.s_count;
+    QCounters *qc = sc->qc;
+    HIP_TRY(hipMemsetAsync(qc, 0, offsetof(QCounters, error), sc->stream));
+    sc->begin("generate", total);
+    hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
+    sc->end();
+    int cur = 0;
+    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber"};
+    for (int iter = 0; iter < 4096; ++iter) {
+        QCounters h;
+        HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : "Sobol dimension overflow (>= 1024)");
+        const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][0], n_shadow = h.shadow, n_mis = h.mis;
+        if (n_ext == 0 && n_resolve == 0) break;
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
+        TraceJob tj{};
+        tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.scalar_tmax = INFINITY;
+        PathSoA &ps = sc->ps;
+        // continuation rays -> hit record + material-class routing
+        tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
+        tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
+        tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2;
+        tj.class_count = &qc->shade[cur][0];
+        for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
+        sc->begin("extend", n_ext);
+        int st = launch_trace(sc, false, tj, n_ext);
+        sc->end();
+        if (st) return st;
+        // MIS rays of the previous vertex (closest hit, integrator.rs:215)
+        tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
+        tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;
+        tj.out_prim = ps.mis_prim; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2;
+        tj.class_count = nullptr;
+        sc->begin("extend_mis", n_mis);
+        st = launch_trace(sc, false, tj, n_mis);
+        sc->end();
+        if (st) return st;
+        // shadow rays (any hit, light.rs:120-123)
+        tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
+        tj.ox = ps.sh_ox; tj.oy = ps.sh_oy; tj.oz = ps.sh_oz; tj.dx = ps.sh_dx; tj.dy = ps.sh_dy; tj.dz = ps.sh_dz;
+        tj.out_occluded = ps.occluded;
+        sc->begin("shadow", n_shadow);
+        st = launch_trace(sc, true, tj, n_shadow);
+        sc->end();
+        if (st) return st;
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
+        uint32_t class_n[kNumClasses];
+        const uint32_t upper = n_ext + n_resolve;
+        if (sc->profile) {  // exact per-class item counts for the statistics (costs one extra sync per iteration)
+            QCounters h2;
+            HIP_TRY(hipMemcpyAsync(&h2, qc, sizeof h2, hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+            for (int c = 0; c < kNumClasses; ++c) class_n[c] = h2.shade[cur][c];
+        } else for (int c = 0; c < kNumClasses; ++c) class_n[c] = upper;
+        for (int c = 0; c < kNumClasses; ++c) {
+            if (!sc->class_used[c] || class_n[c] == 0) continue;
+            ShadeJob sj{};
+            sj.queue = sc->q.shade[cur][c]; sj.count = &qc->shade[cur][c];
+            sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
+            sj.shade_next0 = sc->q.shade[1 - cur][0]; sj.shade_next0_count = &qc->shade[1 - cur][0];
+            sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
+            sj.error = &qc->error; sj.counters = sc->dc;
+            sc->begin(shade_names[c], sc->profile ? class_n[c] : 0);
+            if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
+            else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
+            sc->end();
+        }
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 8u, cur);
+        cur = 1 - cur;
+    }
+    sc->begin("film", total);
+    hipLaunchKernelGGL(k_film, dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    sc->end();
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+void read_counters(pt_scene *sc) {
+    DevCounters d;
+    hipMemcpy(&d, sc->dc, sizeof d, hipMemcpyDeviceToHost);
+    PtCounters &c = sc->counters;
+    std::memset(&c, 0, sizeof c);
+    c.camera_rays = d.camera_rays; c.intersect_tests = d.intersect_tests; c.shadow_tests = d.shadow_tests;
+    c.bvh_nodes_visited = d.nodes; c.triangle_tests = d.tri_tests; c.sphere_tests = d.sphere_tests;
+    c.zero_radiance_paths_num = d.zero_num; c.zero_radiance_paths_den = d.zero_den;
+    for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
+    c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
+    c.film_splats = d.splats; c.wavefront_stages = d.stages;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_init(int device_ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(PT_ERR_INVALID_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr}; }
+    g_device = device_ordinal;
+    return upload_tables();
+}
+
+const char *pt_last_error(void) { return g_error.c_str(); }
+
+int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
+    if (!d || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (d->n_prims == 0 || !d->prim_shape || !d->prim_material || !d->prim_light) return fail(PT_ERR_INVALID_ARG, "scene has no primitives");
+    if (d->n_triangles && (!d->P || !d->indices)) return fail(PT_ERR_INVALID_ARG, "triangle arrays missing");
+    if (d->n_spheres) return fail(PT_ERR_UNSUPPORTED, "spheres (SURVEY row a14) are not implemented on device yet");
+    for (uint32_t i = 0; i < 3 * d->n_triangles; ++i) if (d->indices[i] >= d->n_vertices) return fail(PT_ERR_INVALID_ARG, "vertex index out of range");
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        uint32_t s = d->prim_shape[i];
+        if ((s >> 30) != PT_SHAPE_TRIANGLE || (s & 0x3fffffffu) >= d->n_triangles) return fail(PT_ERR_INVALID_ARG, "primitive shape reference out of range");
+        if (d->prim_material[i] != PT_NONE && d->prim_material[i] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "material index out of range");
+        if (d->prim_light[i] != PT_NONE && d->prim_light[i] >= d->n_lights) return fail(PT_ERR_INVALID_ARG, "light index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        const PtLight &L = d->lights[i];
+        if (L.type == PT_LIGHT_DIFFUSE_AREA && L.prim >= d->n_prims) return fail(PT_ERR_INVALID_ARG, "area light primitive out of range");
+        if (L.type == PT_LIGHT_SPOT) return fail(PT_ERR_UNSUPPORTED, "spot lights are not implemented on device yet");
+        if (L.type == PT_LIGHT_INFINITE && !d->env_texels) return fail(PT_ERR_INVALID_ARG, "infinite light without env_texels");
+    }
+    int st = ensure_device();
+    if (st) return st;
+    pt_scene *sc = new pt_scene();
+    auto bail = [&](int code) { pt_scene_destroy(sc); return code; };
+    DeviceScene &ds = sc->ds;
+    // accelerator: adopt or build
+    if (d->nodes && d->n_nodes && d->ordered_prims) {
+        sc->nodes.assign(d->nodes, d->nodes + d->n_nodes);
+        sc->ordered.assign(d->ordered_prims, d->ordered_prims + d->n_prims);
+        for (uint32_t i = 0; i < d->n_prims; ++i) if (sc->ordered[i] >= d->n_prims) return bail(fail(PT_ERR_INVALID_ARG, "ordered_prims entry out of range"));
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            const PtBVHNode &n = sc->nodes[i];
+            bool ok = n.n_prims ? ((uint64_t)n.offset + n.n_prims <= d->n_prims) : (n.offset < d->n_nodes && i + 1 < d->n_nodes && n.axis < 3);
+            if (!ok) return bail(fail(PT_ERR_INVALID_ARG, "malformed BVH node"));
+        }
+    } else {
+        std::vector<pth::PrimBound> pb(d->n_prims);
+        for (uint32_t i = 0; i < d->n_prims; ++i) {  // Triangle::world_bound (triangle.rs:130-134)
+            uint32_t tri = d->prim_shape[i] & 0x3fffffffu;
+            const float *a = d->P + 3 * (size_t)d->indices[3 * tri], *b = d->P + 3 * (size_t)d->indices[3 * tri + 1], *c = d->P + 3 * (size_t)d->indices[3 * tri + 2];
+            for (int k = 0; k < 3; ++k) { pb[i].lo[k] = std::fmin(std::fmin(a[k], b[k]), c[k]); pb[i].hi[k] = std::fmax(std::fmax(a[k], b[k]), c[k]); }
+        }
+        pth::build_sah_bvh(pb, d->max_node_prims ? d->max_node_prims : 4, sc->nodes, sc->ordered);
+    }
+    // uploads
+#define UP(field, src, count) if ((st = sc->upload(&ds.field, src, (size_t)(count)))) return bail(st)
+    UP(nodes, sc->nodes.data(), sc->nodes.size()); ds.n_nodes = (uint32_t)sc->nodes.size();
+    UP(P, d->P, 3 * (size_t)d->n_vertices);
+    if (d->N) UP(N, d->N, 3 * (size_t)d->n_vertices);
+    if (d->S) UP(S, d->S, 3 * (size_t)d->n_vertices);
+    if (d->UV) UP(UV, d->UV, 2 * (size_t)d->n_vertices);
+    UP(indices, d->indices, 3 * (size_t)d->n_triangles); ds.n_triangles = d->n_triangles;
+    {
+        std::vector<uint8_t> fl(d->n_triangles, 0);
+        if (d->tri_flags) fl.assign(d->tri_flags, d->tri_flags + d->n_triangles);
+        for (auto &f : fl) { if (!d->N) f &= ~PT_TRI_HAS_N; if (!d->S) f &= ~PT_TRI_HAS_S; if (!d->UV) f &= ~PT_TRI_HAS_UV; }
+        UP(tri_flags, fl.data(), fl.size());
+    }
+    UP(prim_shape, d->prim_shape, d->n_prims); UP(prim_material, d->prim_material, d->n_prims); UP(prim_light, d->prim_light, d->n_prims);
+    ds.n_prims = d->n_prims;
+    UP(materials, d->materials, d->n_materials); ds.n_materials = d->n_materials;
+    UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
+    {
+        std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
+        for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }
+        UP(mat_class, mc.data(), mc.size());
+        std::vector<uint32_t> inf;
+        for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == PT_LIGHT_INFINITE) inf.push_back(i);
+        UP(infinite_lights, inf.data(), inf.size()); ds.n_infinite = (uint32_t)inf.size();
+    }
+    if (d->env_texels) {  // Distribution2D::new (sampling.rs:100-117) over the importance image
+        ds.env_w = d->env_width; ds.env_h = d->env_height;
+        UP(env_texels, d->env_texels, 3 * (size_t)ds.env_w * ds.env_h);
+        size_t nu = 2 * (size_t)ds.env_w, nv = 2 * (size_t)ds.env_h;
+        std::vector<float> func(d->env_importance, d->env_importance + nu * nv), cdf(nv * (nu + 1)), fint(nv), mcdf; float mint;
+        for (size_t v = 0; v < nv; ++v) {
+            std::vector<float> row(func.begin() + v * nu, func.begin() + (v + 1) * nu), c; float fi;
+            dist1d(row, c, fi);
+            std::copy(c.begin(), c.end(), cdf.begin() + v * (nu + 1)); fint[v] = fi;
+        }
+        dist1d(fint, mcdf, mint);
+        UP(env_func, func.data(), func.size()); UP(env_cdf, cdf.data(), cdf.size()); UP(env_func_int, fint.data(), fint.size());
+        UP(env_marg_func, fint.data(), fint.size()); UP(env_marg_cdf, mcdf.data(), mcdf.size()); ds.env_marg_int = mint;
+    }
+#undef UP
+    // world bound = root node bounds (bvh.rs:697-703); Light::preprocess -> bounding sphere (bounds.rs:516-524)
+    for (int k = 0; k < 3; ++k) { ds.wb_min[k] = sc->nodes[0].bmin[k]; ds.wb_max[k] = sc->nodes[0].bmax[k]; }
+    {
+        float c[3]; bool inside = true;
+        for (int k = 0; k < 3; ++k) { c[k] = (ds.wb_min[k] + ds.wb_max[k]) * (1.0f / 2.0f); inside = inside && c[k] >= ds.wb_min[k] && c[k] <= ds.wb_max[k]; }
+        float dx = ds.wb_max[0] - c[0], dy = ds.wb_max[1] - c[1], dz = ds.wb_max[2] - c[2];
+        ds.world_radius = inside ? std::sqrt(dx * dx + dy * dy + dz * dz) : 0.0f;
+        for (int k = 0; k < 3; ++k) ds.world_center[k] = c[k];
+    }
+    // leaf triangle packets + light areas (device)
+    {
+        const uint32_t *d_ordered = nullptr;
+        if ((st = sc->upload(&d_ordered, sc->ordered.data(), sc->ordered.size()))) return bail(st);
+        TriPacket *leaf = nullptr; float *area = nullptr;
+        if ((st = sc->dalloc(&leaf, d->n_prims))) return bail(st);
+        if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
+        hipLaunchKernelGGL(k_build_packets, dim3((d->n_prims + 255) / 256), dim3(256), 0, 0, ds, d_ordered, leaf);
+        ds.leaf = leaf;
+        if (d->n_lights) hipLaunchKernelGGL(k_light_area, dim3((d->n_lights + 255) / 256), dim3(256), 0, 0, ds, area);
+        ds.light_area = area;
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return bail(fail(PT_ERR_HIP, "scene preparation kernels failed"));
+    }
+    *out = sc;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *sc) {
+    if (!sc) return;
+    for (void *p : sc->allocs) hipFree(p);
+    if (sc->slab) hipFree(sc->slab);
+    if (sc->qbuf) hipFree(sc->qbuf);
+    if (sc->film_rgbw) hipFree(sc->film_rgbw);
+    for (auto e : sc->event_pool) hipEventDestroy(e);
+    if (sc->stream) hipStreamDestroy(sc->stream);
+    delete sc;
+}
+
+int pt_scene_bvh_info(const pt_scene *sc, uint32_t *n_nodes, uint32_t *n_prims) {
+    if (!sc || !n_nodes || !n_prims) return fail(PT_ERR_INVALID_ARG, "null argument");
+    *n_nodes = (uint32_t)sc->nodes.size(); *n_prims = (uint32_t)sc->ordered.size();
+    return PT_OK;
+}
+int pt_scene_bvh_read(const pt_scene *sc, PtBVHNode *nodes, uint32_t *ordered) {
+    if (!sc || !nodes || !ordered) return fail(PT_ERR_INVALID_ARG, "null argument");
+    std::memcpy(nodes, sc->nodes.data(), sc->nodes.size() * sizeof(PtBVHNode));
+    std::memcpy(ordered, sc->ordered.data(), sc->ordered.size() * 4);
+    return PT_OK;
+}
+
+int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film_is_device) {
+    if (!sc || !rp || !film_xyzw) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (rp->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
+    if (!(rp->filter_radius[0] > 0.0f) || !(rp->filter_radius[1] > 0.0f)) return fail(PT_ERR_INVALID_ARG, "filter radius must be > 0");
+    if (rp->tile_world > 1 && rp->tile_rank >= rp->tile_world) return fail(PT_ERR_INVALID_ARG, "tile_rank >= tile_world");
+    RenderConst rc;
+    fill_render_const(rp, rc);
+    if (rc.film_w == 0 || rc.film_h == 0 || rc.ntx == 0 || rc.nty == 0) return fail(PT_ERR_INVALID_ARG, "empty film or sample bounds");
+    if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
+    const uint32_t ntiles = rc.ntx * rc.nty;
+    rc.n_tile_slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world : 0;
+    rc.n_pix_slots = rc.n_tile_slots * 256u;
+    const size_t film_px = (size_t)rc.film_w * rc.film_h;
+    sc->profile = rp->profile != 0;
+    sc->stats.clear();
+    int st = PT_OK;
+    if (rc.n_pix_slots > 0) {
+        uint32_t S = rp->spp_per_pass;
+        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 23) / rc.n_pix_slots);
+        S = std::min(S, rp->spp);
+        if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
+        if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
+        int eff;
+        if ((st = ensure_light_grid(sc, (int)rp->light_strategy, eff))) return st;
+        HIP_TRY(hipMemcpyAsync(sc->d_filter, rp->filter_table, 256 * 4, hipMemcpyHostToDevice, sc->stream));
+        HIP_TRY(hipMemsetAsync(sc->film_rgbw, 0, film_px * 16, sc->stream));
+        HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
+        HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
+        for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
+            rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
+            if ((st = run_pass(sc, rc, sc->grid[eff]))) return st;
+        }
+        float *dst = film_xyzw, *tmp = nullptr;
+        std::vector<float> host;
+        if (!film_is_device) {
+            HIP_TRY(hipMalloc((void **)&tmp, film_px * 16));
+            HIP_TRY(hipMemsetAsync(tmp, 0, film_px * 16, sc->stream));
+            dst = tmp;
+        }
+        sc->begin("film_finish", film_px);
+        hipLaunchKernelGGL(k_film_finish, dim3((unsigned)((film_px + 255) / 256)), dim3(256), 0, sc->stream, sc->film_rgbw, dst, (uint32_t)film_px);
+        sc->end();
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (!film_is_device) {
+            host.resize(film_px * 4);
+            HIP_TRY(hipMemcpy(host.data(), tmp, film_px * 16, hipMemcpyDeviceToHost));
+            hipFree(tmp);
+            for (size_t i = 0; i < film_px * 4; ++i) film_xyzw[i] += host[i];
+        }
+        sc->resolve_timings();
+        read_counters(sc);
+    }
+    return PT_OK;
+}
+
+int pt_film_resolve(const float *xyzw, uint32_t n, float scale, float *rgb) {  // film.rs:217-258 (host arithmetic)
+    if (!xyzw || !rgb) return fail(PT_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        float c[3]; xyz_to_rgb(xyzw + 4 * (size_t)i, c);
+        float w = xyzw[4 * (size_t)i + 3];
+        if (w != 0.0f) { float inv = 1.0f / w; for (int k = 0; k < 3; ++k) c[k] = std::fmax(c[k] * inv, 0.0f); }
+        for (int k = 0; k < 3; ++k) rgb[3 * (size_t)i + k] = c[k] * scale;
+    }
+    return PT_OK;
+}
+
+int pt_get_counters(const pt_scene *sc, PtCounters *out) {
+    if (!sc || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    *out = sc->counters;
+    return PT_OK;
+}
+int pt_get_kernel_stats(const pt_scene *sc, PtKernelStat *out, uint32_t max_entries, uint32_t *n_out) {
+    if (!sc || !out || !n_out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    uint32_t n = (uint32_t)std::min<size_t>(max_entries, sc->stats.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        std::snprintf(out[i].name, sizeof out[i].name, "%s", sc->stats[i].name.c_str());
+        out[i].launches = sc->stats[i].launches; out[i].total_ms = sc->stats[i].ms; out[i].items = sc->stats[i].items;
+    }
+    *n_out = n;
+    return PT_OK;
+}
+
+static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const float *d, const float *tmax, uint32_t *prim, float *t, float *b, uint8_t *hit) {
+    if (!sc || !o || !d || !tmax) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return PT_OK;
+    int st = ensure_workspace(sc, 0, 0);
+    if (st) return st;
+    std::vector<float> soa(7 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { soa[(size_t)k * n + i] = o[3 * (size_t)i + k]; soa[(size_t)(3 + k) * n + i] = d[3 * (size_t)i + k]; }
+        soa[(size_t)6 * n + i] = tmax[i];
+    }
+    float *din = nullptr, *dout = nullptr; uint32_t *dprim = nullptr; uint8_t *docc = nullptr; uint32_t *dcount = nullptr;
+    HIP_TRY(hipMalloc((void **)&din, soa.size() * 4));
+    HIP_TRY(hipMalloc((void **)&dout, 4 * (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dprim, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&docc, n));
+    HIP_TRY(hipMalloc((void **)&dcount, 4));
+    HIP_TRY(hipMemcpy(din, soa.data(), soa.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dcount, &n, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
+    HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
+    TraceJob tj{};
+    tj.queue = nullptr; tj.count = dcount; tj.head = &sc->qc->head[0];
+    tj.ox = din; tj.oy = din + n; tj.oz = din + 2 * (size_t)n; tj.dx = din + 3 * (size_t)n; tj.dy = din + 4 * (size_t)n; tj.dz = din + 5 * (size_t)n;
+    tj.tmax = din + 6 * (size_t)n;
+    tj.out_prim = dprim; tj.out_t = dout; tj.out_b0 = dout + n; tj.out_b1 = dout + 2 * (size_t)n; tj.out_b2 = dout + 3 * (size_t)n;
+    tj.out_occluded = docc; tj.class_count = nullptr; tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
+    st = launch_trace(sc, any, tj, n);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    QCounters h;
+    HIP_TRY(hipMemcpy(&h, sc->qc, sizeof h, hipMemcpyDeviceToHost));
+    if (any) HIP_TRY(hipMemcpy(hit, docc, n, hipMemcpyDeviceToHost));
+    else {
+        std::vector<float> res(4 * (size_t)n);
+        HIP_TRY(hipMemcpy(res.data(), dout, res.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(prim, dprim, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) { t[i] = res[i]; for (int k = 0; k < 3; ++k) b[3 * (size_t)i + k] = res[(size_t)(1 + k) * n + i]; }
+    }
+    hipFree(din); hipFree(dout); hipFree(dprim); hipFree(docc); hipFree(dcount);
+    read_counters(sc);
+    if (h.error) return fail((int)h.error, "traversal error raised on device");
+    return PT_OK;
+}
+
+int pt_trace_closest(pt_scene *sc, uint32_t n, const float *o, const float *d, const float *tmax, uint32_t *prim, float *t, float *b) {
+    if (!prim || !t || !b) return fail(PT_ERR_INVALID_ARG, "null output");
+    return trace_api(sc, false, n, o, d, tmax, prim, t, b, nullptr);
+}
+int pt_trace_any(pt_scene *sc, uint32_t n, const float *o, const float *d, const float *tmax, uint8_t *hit) {
+    if (!hit) return fail(PT_ERR_INVALID_ARG, "null output");
+    return trace_api(sc, true, n, o, d, tmax, nullptr, nullptr, nullptr, hit);
+}
+
+int pt_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    if (!sb || !pixel_xy || !sample_num || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (n_dims > 1024) return fail(PT_ERR_SOBOL_DIMENSIONS, "SobolSampler can only sample up to 1024 dimensions");
+    int st = ensure_device();
+    if (st || n == 0) return st;
+    PtRenderParams rp{}; std::memcpy(rp.sample_bounds, sb, 16);
+    RenderConst rc; fill_render_const(&rp, rc);
+    int32_t *dxy; uint32_t *dsn; float *dout; uint64_t *didx;
+    HIP_TRY(hipMalloc((void **)&dxy, (size_t)n * 8)); HIP_TRY(hipMalloc((void **)&dsn, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(hipMalloc((void **)&didx, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dxy, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsn, sample_num, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sobol_samples, dim3((n + 255) / 256), dim3(256), 0, 0, g_tabs, rc.sobol, n, dxy, dsn, n_dims, dout, didx);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * n_dims * 4, hipMemcpyDeviceToHost));
+    if (out_index) HIP_TRY(hipMemcpy(out_index, didx, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipFree(dxy); hipFree(dsn); hipFree(dout); hipFree(didx);
+    return PT_OK;
+}
+
+int pt_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float *out_o, float *out_d) {
+    if (!rp || !cs || !out_o || !out_d) return fail(PT_ERR_INVALID_ARG, "null argument");
+    int st = ensure_device();
+    if (st || n == 0) return st;
+    RenderConst rc; fill_render_const(rp, rc);
+    float *dcs, *dout;
+    HIP_TRY(hipMalloc((void **)&dcs, (size_t)n * 20)); HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 24));
+    HIP_TRY(hipMemcpy(dcs, cs, (size_t)n * 20, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_camera_rays, dim3((n + 255) / 256), dim3(256), 0, 0, rc, n, dcs, dout, dout + 3 * (size_t)n);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_o, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_d, dout + 3 * (size_t)n, (size_t)n * 12, hipMemcpyDeviceToHost));
+    hipFree(dcs); hipFree(dout);
+    return PT_OK;
+}
+
+}  // extern "C"

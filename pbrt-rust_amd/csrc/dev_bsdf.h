@@ -1,0 +1,517 @@
+// dev_bsdf.h -- BxDF lobes, BSDF frame/evaluation/sampling and material -> BSDF assembly on device.
+//   core/reflection.rs:29-190 (Fresnel, refract, trig helpers), :384-446 (BxDF defaults),
+//   :612-1222 (lobes), :1506-1689 (BSDF); core/microfacet.rs:249-406 (Trowbridge-Reitz, visible-normal
+//   sampling); core/sampling.rs:153-193; materials/{matte,mirror,glass,plastic,metal,uber,substrate}.rs.
+#pragma once
+#include "dev_scene.h"
+
+namespace ptd {
+
+enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
+enum LobeKind : uint8_t { LB_LAMBERT_R, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_MICRO_R, LB_MICRO_T, LB_FRESNEL_BLEND };
+enum FresnelKind : uint8_t { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR };
+
+// sampling.rs:153-176
+PT_DEV P2 concentric_sample_disk(P2 u) {
+    float ox = u.x * 2.0f - 1.0f, oy = u.y * 2.0f - 1.0f;
+    if (ox == 0.0f && oy == 0.0f) return P2(0.0f, 0.0f);
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
+    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
+    float s, c; dm_sincosf(theta, s, c);
+    return P2(c * r, s * r);
+}
+PT_DEV V3 cosine_sample_hemisphere(P2 u) {  // sampling.rs:188-193
+    P2 d = concentric_sample_disk(u);
+    float z = sqrtf(maxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return V3(d.x, d.y, z);
+}
+PT_DEV float power_heuristic(float fpdf, float gpdf) {  // sampling.rs:328-333 with nf = ng = 1
+    float f = 1.0f * fpdf, g = 1.0f * gpdf;
+    return (f * f) / (f * f + g * g);
+}
+
+PT_DEV float cos_theta(V3 w) { return w.z; }
+PT_DEV float cos2_theta(V3 w) { return w.z * w.z; }
+PT_DEV float abs_cos_theta(V3 w) { return fabsf(w.z); }
+PT_DEV float sin2_theta(V3 w) { return maxf(1.0f - cos2_theta(w), 0.0f); }
+PT_DEV float sin_theta(V3 w) { return sqrtf(sin2_theta(w)); }
+PT_DEV float tan_theta(V3 w) { return sin_theta(w) / cos_theta(w); }
+PT_DEV float tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+PT_DEV float cos_phi(V3 w) { float s = sin_theta(w); return (s == 0.0f) ? 1.0f : clampf(w.x / s, -1.0f, 1.0f); }
+PT_DEV float sin_phi(V3 w) { float s = sin_theta(w); return (s == 0.0f) ? 0.0f : clampf(w.y / s, -1.0f, 1.0f); }
+PT_DEV float cos2_phi(V3 w) { float c = cos_phi(w); return c * c; }
+PT_DEV float sin2_phi(V3 w) { float s = sin_phi(w); return s * s; }
+PT_DEV bool same_hemisphere(V3 w, V3 wp) { return w.z * wp.z > 0.0f; }
+PT_DEV V3 reflect(V3 wo, V3 n) { return -wo + n * 2.0f * dot(wo, n); }
+PT_DEV bool refract(V3 wi, V3 n, float eta, V3 &wt) {  // reflection.rs:160-174
+    float cos_i = dot(n, wi);
+    float sin2_i = maxf(1.0f - cos_i * cos_i, 0.0f);
+    float sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1.0f) return false;
+    float cos_t = sqrtf(1.0f - sin2_t);
+    wt = n * (eta * cos_i - cos_t) + (-wi) * eta;
+    return true;
+}
+PT_DEV float fr_dielectric(float cos_i, float etai, float etat) {  // reflection.rs:29-52
+    cos_i = clampf(cos_i, -1.0f, 1.0f);
+    if (!(cos_i > 0.0f)) { float t = etai; etai = etat; etat = t; cos_i = fabsf(cos_i); }
+    float sin_i = sqrtf(maxf(0.0f, 1.0f - cos_i * cos_i));
+    float sin_t = etai / etat * sin_i;
+    if (sin_t >= 1.0f) return 1.0f;
+    float cos_t = sqrtf(maxf(0.0f, 1.0f - sin_t * sin_t));
+    float rparl = ((etat * cos_i) - (etai * cos_t)) / ((etat * cos_i) + (etai * cos_t));
+    float rperp = ((etai * cos_i) - (etat * cos_t)) / ((etai * cos_i) + (etat * cos_t));
+    return (rparl * rparl + rperp * rperp) / 2.0f;
+}
+PT_DEV RGB fr_conductor(float cos_i, RGB etai, RGB etat, RGB k) {  // reflection.rs:54-76
+    cos_i = clampf(cos_i, -1.0f, 1.0f);
+    RGB eta = etat / etai, etak = k / etai;
+    float cos2 = cos_i * cos_i, sin2 = 1.0f - cos2;
+    RGB eta2 = eta * eta, etak2 = etak * etak;
+    RGB t0 = eta2 - etak2 - RGB(sin2);
+    RGB a2plusb2 = sqrt_rgb(t0 * t0 + eta2 * etak2 * 4.0f);
+    RGB t1 = a2plusb2 + RGB(cos2);
+    RGB a = sqrt_rgb((a2plusb2 + t0) * 0.5f);
+    RGB t2 = a * cos_i * 2.0f;
+    RGB rs = (t1 - t2) / (t1 + t2);
+    RGB t3 = a2plusb2 * cos2 + RGB(sin2 * sin2);
+    RGB t4 = t2 * sin2;
+    RGB rp = rs * (t3 - t4) / (t3 + t4);
+    return (rp + rs) * 0.5f;
+}
+
+struct Lobe {
+    uint8_t kind, type, fresnel;
+    RGB r, t;        // R | T | Rd ; FresnelBlend: t = Rs ; conductor: r=1, t unused
+    float ax, ay;    // Trowbridge-Reitz alphas
+    float etaa, etab;  // dielectric etas (etai/etat of the Fresnel term, or lobe etaA/etaB)
+    RGB ck, ce;      // conductor k, eta
+    float A, B;      // Oren-Nayar
+    PT_DEV bool matches(int flags) const { return (type & flags) == type; }
+};
+
+PT_DEV RGB fresnel_eval(const Lobe &l, float cosi, float fi, float ft) {
+    if (l.fresnel == FR_NOOP) return RGB(1.0f);
+    if (l.fresnel == FR_DIELECTRIC) return RGB(fr_dielectric(cosi, fi, ft));
+    return fr_conductor(fabsf(cosi), RGB(1.0f), l.ce, l.ck);
+}
+
+// ---- Trowbridge-Reitz (microfacet.rs:249-406, samplevis = true) -----------------------------------------
+PT_DEV float roughness_to_alpha(float roughness) {  // microfacet.rs:334-340
+    roughness = maxf(roughness, 1.0e-3f);
+    float x = dm_logf(roughness);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+}
+PT_DEV float tr_d(float ax, float ay, V3 wh) {
+    float t2 = tan2_theta(wh);
+    if (__builtin_isinf(t2)) return 0.0f;
+    float c4 = cos2_theta(wh) * cos2_theta(wh);
+    float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * t2;
+    return 1.0f / (kPi * ax * ay * c4 * (1.0f + e) * (1.0f + e));
+}
+PT_DEV float tr_lambda(float ax, float ay, V3 w) {
+    float abs_tan = fabsf(tan_theta(w));
+    if (__builtin_isinf(abs_tan)) return 0.0f;
+    float alpha = sqrtf(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
+    float a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+    return (-1.0f + sqrtf(1.0f + a2t2)) / 2.0f;
+}
+PT_DEV float tr_g1(float ax, float ay, V3 w) { return 1.0f / (1.0f + tr_lambda(ax, ay, w)); }
+PT_DEV float tr_g(float ax, float ay, V3 wo, V3 wi) { return 1.0f / (1.0f + tr_lambda(ax, ay, wo) + tr_lambda(ax, ay, wi)); }
+PT_DEV float tr_pdf(float ax, float ay, V3 wo, V3 wh) { return tr_d(ax, ay, wh) * tr_g1(ax, ay, wo) * abs_dot(wo, wh) / abs_cos_theta(wo); }
+PT_DEV void tr_sample11(float cos_t, float u1, float u2, float &sx, float &sy) {  // microfacet.rs:249-291
+    if (cos_t > 0.9999f) {
+        float r = sqrtf(u1 / (1.0f - u1));
+        float phi = 6.28318530718f * u2;
+        float s, c; dm_sincosf(phi, s, c);
+        sx = r * c; sy = r * s;
+        return;
+    }
+    float sin_t = sqrtf(maxf(0.0f, 1.0f - cos_t * cos_t));
+    float tan_t = sin_t / cos_t;
+    float a = 1.0f / tan_t;
+    float G1 = 2.0f / (1.0f + sqrtf(1.0f + 1.0f / (a * a)));
+    float A = 2.0f * u1 / G1 - 1.0f;
+    float tmp = 1.0f / (A * A - 1.0f);
+    if (tmp > 1.0e10f) tmp = 1.0e10f;
+    float B = tan_t;
+    float D = sqrtf(maxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+    float sx1 = B * tmp - D, sx2 = B * tmp + D;
+    sx = (A < 0.0f || sx2 > 1.0f / tan_t) ? sx1 : sx2;
+    float S;
+    if (u2 > 0.5f) { S = 1.0f; u2 = 2.0f * (u2 - 0.5f); }
+    else { S = -1.0f; u2 = 2.0f * (0.5f - u2); }
+    float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) / (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    sy = S * z * sqrtf(1.0f + sx * sx);
+}
+PT_DEV V3 tr_sample_wh(float ax, float ay, V3 wo, P2 u) {  // microfacet.rs:293-316,394-401
+    bool flip = wo.z < 0.0f;
+    V3 wi = flip ? -wo : wo;
+    V3 wis = normalize(V3(ax * wi.x, ay * wi.y, wi.z));
+    float sx, sy;
+    tr_sample11(cos_theta(wis), u.x, u.y, sx, sy);
+    float tmp = cos_phi(wis) * sx - sin_phi(wis) * sy;
+    sy = sin_phi(wis) * sx + cos_phi(wis) * sy;
+    sx = tmp;
+    sx = ax * sx; sy = ay * sy;
+    V3 wh = normalize(V3(-sx, -sy, 1.0f));
+    return flip ? -wh : wh;
+}
+
+PT_DEV float pow5(float v) { return (v * v) * (v * v) * v; }
+
+PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
+    switch (b.kind) {
+    case LB_LAMBERT_R: return b.r * kInvPi;
+    case LB_LAMBERT_T: return b.t * kInvPi;
+    case LB_OREN_NAYAR: {  // reflection.rs:926-952
+        float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+        float max_cos = 0.0f;
+        if (sin_i > 1e-4f && sin_o > 1e-4f) {
+            float dcos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+            max_cos = maxf(dcos, 0.0f);
+        }
+        float sin_alpha, tan_beta;
+        if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sin_o; tan_beta = sin_i / abs_cos_theta(wi); }
+        else { sin_alpha = sin_i; tan_beta = sin_o / abs_cos_theta(wo); }
+        return b.r * kInvPi * (b.A + b.B * max_cos * sin_alpha * tan_beta);
+    }
+    case LB_SPEC_R: case LB_SPEC_T: return RGB(0.0f);
+    case LB_FRESNEL_SPEC: return RGB(1.0f);
+    case LB_MICRO_R: {  // reflection.rs:981-1003
+        float cos_o = abs_cos_theta(wo), cos_i = abs_cos_theta(wi);
+        V3 wh = wi + wo;
+        if (cos_i == 0.0f || cos_o == 0.0f) return RGB(0.0f);
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        RGB F = fresnel_eval(b, dot(wi, wh), b.etaa, b.etab);
+        float d = tr_d(b.ax, b.ay, wh), g = tr_g(b.ax, b.ay, wo, wi);
+        return b.r * d * g * F / (4.0f * cos_i * cos_o);
+    }
+    case LB_MICRO_T: {  // reflection.rs:1059-1092
+        if (same_hemisphere(wo, wi)) return RGB(0.0f);
+        float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+        if (cos_i == 0.0f || cos_o == 0.0f) return RGB(0.0f);
+        float eta = (cos_theta(wo) > 0.0f) ? b.etab / b.etaa : b.etaa / b.etab;
+        V3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0.0f) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0.0f) return RGB(0.0f);
+        RGB f = RGB(fr_dielectric(dot(wo, wh), b.etaa, b.etab));
+        float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        float factor = 1.0f / eta;
+        float s = tr_d(b.ax, b.ay, wh) * tr_g(b.ax, b.ay, wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor /
+                  (cos_i * cos_o * sqrt_denom * sqrt_denom);
+        return (RGB(1.0f) - f) * b.t * fabsf(s);
+    }
+    default: {  // LB_FRESNEL_BLEND, reflection.rs:1165-1182 (r = Rd, t = Rs)
+        RGB diffuse = b.r * (RGB(1.0f) - b.t) * (28.0f / (23.0f * kPi)) * (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wi))) *
+                      (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wo)));
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        RGB schlick = b.t + (RGB(1.0f) - b.t) * pow5(1.0f - dot(wi, wh));
+        RGB specular = schlick * (tr_d(b.ax, b.ay, wh) / (4.0f * abs_dot(wi, wh) * maxf(abs_cos_theta(wi), abs_cos_theta(wo))));
+        return diffuse + specular;
+    }
+    }
+}
+
+PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
+    switch (b.kind) {
+    case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_FRESNEL_SPEC:  // reflection.rs:439-445, :788-794
+        return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f;
+    case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) : 0.0f;  // :886-892
+    case LB_SPEC_R: case LB_SPEC_T: return 0.0f;
+    case LB_MICRO_R: {
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = normalize(wo + wi);
+        return tr_pdf(b.ax, b.ay, wo, wh) / (4.0f * dot(wo, wh));
+    }
+    case LB_MICRO_T: {
+        if (same_hemisphere(wo, wi)) return 0.0f;
+        float eta = (cos_theta(wo) > 0.0f) ? b.etaa / b.etab : b.etab / b.etaa;
+        V3 wh = normalize(wo + wi * eta);
+        if (dot(wo, wh) * dot(wi, wh) > 0.0f) return 0.0f;
+        float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        float dwh_dwi = fabsf(eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom);
+        return tr_pdf(b.ax, b.ay, wo, wh) * dwh_dwi;
+    }
+    default: {  // LB_FRESNEL_BLEND
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = normalize(wo + wi);
+        float pdf_wh = tr_pdf(b.ax, b.ay, wo, wh);
+        return 0.5f * (abs_cos_theta(wi) * kInvPi + pdf_wh / (4.0f * dot(wo, wh)));
+    }
+    }
+}
+
+PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
+    switch (b.kind) {
+    case LB_LAMBERT_R: case LB_OREN_NAYAR: {
+        wi = cosine_sample_hemisphere(u);
+        if (wo.z < 0.0f) wi.z *= -1.0f;
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    case LB_LAMBERT_T: {
+        wi = cosine_sample_hemisphere(u);
+        if (wo.z > 0.0f) wi.z *= -1.0f;
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    case LB_SPEC_R: {
+        wi = V3(-wo.x, -wo.y, wo.z);
+        pdf = 1.0f;
+        return fresnel_eval(b, cos_theta(wi), b.etaa, b.etab) * b.r / abs_cos_theta(wi);
+    }
+    case LB_SPEC_T: {
+        float etai, etat;
+        if (cos_theta(wo) > 0.0f) { etai = b.etaa; etat = b.etab; } else { etai = b.etab; etat = b.etaa; }
+        if (!refract(wo, face_forward(V3(0.0f, 0.0f, 1.0f), wo), etai / etat, wi)) return RGB(0.0f);
+        pdf = 1.0f;
+        RGB ft = b.t * (RGB(1.0f) - RGB(fr_dielectric(cos_theta(wi), b.etaa, b.etab)));
+        ft = ft * ((etai * etai) / (etat * etat));
+        return ft / abs_cos_theta(wi);
+    }
+    case LB_FRESNEL_SPEC: {
+        float f = fr_dielectric(cos_theta(wo), b.etaa, b.etab);
+        if (u.x < f) {
+            wi = V3(-wo.x, -wo.y, wo.z);
+            sampled = BSDF_SPECULAR | BSDF_REFLECTION;
+            pdf = f;
+            return b.r / abs_cos_theta(wi) * f;
+        }
+        float etai, etat;
+        if (cos_theta(wo) > 0.0f) { etai = b.etaa; etat = b.etab; } else { etai = b.etab; etat = b.etaa; }
+        if (!refract(wo, face_forward(V3(0.0f, 0.0f, 1.0f), wo), etai / etat, wi)) return RGB(0.0f);
+        RGB ft = b.t * (1.0f - f);
+        ft = ft * ((etai * etai) / (etat * etat));
+        sampled = BSDF_SPECULAR | BSDF_TRANSMISSION;
+        pdf = 1.0f - f;
+        return ft / abs_cos_theta(wi);
+    }
+    case LB_MICRO_R: {
+        if (wo.z == 0.0f) return RGB(0.0f);
+        V3 wh = tr_sample_wh(b.ax, b.ay, wo, u);
+        if (dot(wo, wh) < 0.0f) return RGB(0.0f);
+        wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, wi)) return RGB(0.0f);
+        pdf = tr_pdf(b.ax, b.ay, wo, wh) / (4.0f * dot(wo, wh));
+        return lobe_f(b, wo, wi);
+    }
+    case LB_MICRO_T: {
+        if (wo.z == 0.0f) return RGB(0.0f);
+        V3 wh = tr_sample_wh(b.ax, b.ay, wo, u);
+        if (dot(wo, wh) < 0.0f) return RGB(0.0f);
+        float eta = (cos_theta(wo) > 0.0f) ? b.etaa / b.etab : b.etab / b.etaa;
+        if (!refract(wo, wh, eta, wi)) return RGB(0.0f);
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    default: {  // LB_FRESNEL_BLEND
+        P2 uu = u;
+        if (uu.x < 0.5f) {
+            uu.x = minf(2.0f * uu.x, kOneMinusEps);
+            wi = cosine_sample_hemisphere(uu);
+            if (wo.z < 0.0f) wi.z *= -1.0f;
+        } else {
+            uu.x = minf(2.0f * (uu.x - 0.5f), kOneMinusEps);
+            V3 wh = tr_sample_wh(b.ax, b.ay, wo, uu);
+            wi = reflect(wo, wh);
+            if (!same_hemisphere(wo, wi)) return RGB(0.0f);
+        }
+        pdf = lobe_pdf(b, wo, wi);
+        return lobe_f(b, wo, wi);
+    }
+    }
+}
+
+// ---- BSDF (reflection.rs:1495-1689). MAXL = compile-time lobe capacity of the shade-queue class -----------
+template <int MAXL> struct Bsdf {
+    float eta;
+    V3 ns, ng, ss, ts;
+    int n;
+    Lobe l[MAXL];
+
+    PT_DEV void init(const SurfaceInteraction &si, float eta_) {
+        eta = eta_; ns = si.sh_n; ss = normalize(si.sh_dpdu); ng = si.n; ts = cross(ns, ss); n = 0;
+    }
+    PT_DEV void add(const Lobe &x) { if (n < MAXL) l[n++] = x; }
+    PT_DEV int num_components(int flags) const { int c = 0; for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) ++c; return c; }
+    PT_DEV V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+    PT_DEV V3 to_world(V3 v) const {
+        return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
+    }
+    PT_DEV RGB f(V3 wow, V3 wiw, int flags) const {
+        V3 wi = to_local(wiw), wo = to_local(wow);
+        if (wo.z == 0.0f) return RGB(0.0f);
+        bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
+        RGB res(0.0f);
+        for (int i = 0; i < MAXL; ++i)
+            if (i < n && l[i].matches(flags) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
+                res = res + lobe_f(l[i], wo, wi);
+        return res;
+    }
+    PT_DEV float pdf(V3 wow, V3 wiw, int flags) const {
+        if (n == 0) return 0.0f;
+        V3 wo = to_local(wow), wi = to_local(wiw);
+        if (wo.z == 0.0f) return 0.0f;
+        float p = 0.0f; int matching = 0;
+        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf(l[i], wo, wi); }
+        return matching > 0 ? p / (float)matching : 0.0f;
+    }
+    // `pdf` must hold the caller's previous value on entry (it is left untouched on the wo.z == 0 exit,
+    // reflection.rs:1603-1604).
+    PT_DEV RGB sample_f(V3 wow, V3 &wiw, P2 u, float &pdf, int ty, int &sampled) const {
+        int matching = num_components(ty);
+        if (matching == 0) { pdf = 0.0f; sampled = 0; return RGB(0.0f); }
+        int comp = (int)min(f2u32_sat(floorf(u.x * (float)matching)), (uint32_t)(matching - 1));
+        int idx = 0, count = comp;
+        for (int i = 0; i < MAXL; ++i) {
+            if (i >= n) break;
+            bool m = l[i].matches(ty);
+            if (m && count == 0) { idx = i; break; }
+            else if (m) --count;
+        }
+        P2 ur(minf(u.x * (float)matching - (float)comp, kOneMinusEps), u.y);
+        V3 wo = to_local(wow), wi;
+        if (wo.z == 0.0f) return RGB(0.0f);
+        pdf = 0.0f;
+        RGB fv(0.0f);
+        int btype = 0;
+        // select the lobe without dynamic register-array indexing
+        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = lobe_sample_f(l[i], wo, wi, ur, pdf, sampled); }
+        if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
+        wiw = to_world(wi);
+        if (!(btype & BSDF_SPECULAR) && matching > 1)
+            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf(l[i], wo, wi);
+        if (matching > 1) pdf /= (float)matching;
+        if (!(btype & BSDF_SPECULAR)) {
+            bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
+            fv = RGB(0.0f);
+            for (int i = 0; i < MAXL; ++i)
+                if (i < n && l[i].matches(ty) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
+                    fv = fv + lobe_f(l[i], wo, wi);
+        }
+        return fv;
+    }
+};
+
+PT_DEV RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
+PT_DEV Lobe mk_lobe(uint8_t kind, uint8_t type) { Lobe b; b.kind = kind; b.type = type; b.fresnel = FR_NOOP; b.ax = b.ay = 0.001f; b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; return b; }
+PT_DEV void set_dist(Lobe &b, float ax, float ay) { b.ax = maxf(ax, 0.001f); b.ay = maxf(ay, 0.001f); }  // microfacet.rs:325-331
+
+// Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None.
+template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL> &bsdf) {
+    switch (m.type) {
+    case PT_MAT_MATTE: {  // matte.rs:28-53
+        bsdf.init(si, 1.0f);
+        RGB r = rgb3(m.kd).clamps(0.0f, PT_INF);
+        float sig = clampf(m.sigma, 0.0f, 90.0f);
+        if (!r.is_black()) {
+            Lobe b = mk_lobe(sig == 0.0f ? LB_LAMBERT_R : LB_OREN_NAYAR, BSDF_REFLECTION | BSDF_DIFFUSE);
+            b.r = r;
+            if (sig != 0.0f) {  // reflection.rs:909-921
+                float sigma = (kPi / 180.0f) * sig;
+                float sigma2 = sigma * sigma;
+                b.A = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+                b.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+            }
+            bsdf.add(b);
+        }
+        return true;
+    }
+    case PT_MAT_MIRROR: {  // mirror.rs:23-42
+        bsdf.init(si, 1.0f);
+        RGB R = rgb3(m.kr).clamps(0.0f, PT_INF);
+        if (!R.is_black()) { Lobe b = mk_lobe(LB_SPEC_R, BSDF_REFLECTION | BSDF_SPECULAR); b.r = R; bsdf.add(b); }
+        return true;
+    }
+    case PT_MAT_GLASS: {  // glass.rs:35-92
+        float eta = m.eta, ur = m.u_roughness, vr = m.v_roughness;
+        RGB R = rgb3(m.kr).clamps(0.0f, PT_INF), T = rgb3(m.kt).clamps(0.0f, PT_INF);
+        bsdf.init(si, eta);
+        if (R.is_black() && T.is_black()) return false;
+        bool is_specular = ur == 0.0f && vr == 0.0f;
+        if (is_specular) {
+            Lobe b = mk_lobe(LB_FRESNEL_SPEC, BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
+            b.r = R; b.t = T; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+        } else {
+            if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+            if (!R.is_black()) {
+                Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = R; set_dist(b, ur, vr);
+                b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+            }
+            if (!T.is_black()) {
+                Lobe b = mk_lobe(LB_MICRO_T, BSDF_TRANSMISSION | BSDF_GLOSSY); b.t = T; set_dist(b, ur, vr);
+                b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+            }
+        }
+        return true;
+    }
+    case PT_MAT_PLASTIC: {  // plastic.rs:34-70
+        bsdf.init(si, 1.0f);
+        RGB kd = rgb3(m.kd).clamps(0.0f, PT_INF);
+        if (!kd.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_R, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = kd; bsdf.add(b); }
+        RGB ks = rgb3(m.ks).clamps(0.0f, PT_INF);
+        if (!ks.is_black()) {
+            float rough = m.roughness;
+            if (m.remap_roughness) rough = roughness_to_alpha(rough);
+            Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = ks; set_dist(b, rough, rough);
+            b.fresnel = FR_DIELECTRIC; b.etaa = 1.5f; b.etab = 1.0f; bsdf.add(b);
+        }
+        return true;
+    }
+    case PT_MAT_METAL: {  // metal.rs:78-112
+        bsdf.init(si, 1.0f);
+        float ur = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
+        float vr = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+        if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
+        Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = RGB(1.0f); set_dist(b, ur, vr);
+        b.fresnel = FR_CONDUCTOR; b.ce = rgb3(m.eta_rgb); b.ck = rgb3(m.k_rgb);
+        bsdf.add(b);
+        return true;
+    }
+    case PT_MAT_UBER: {  // uber.rs:40-106
+        float e = m.eta;
+        RGB op = rgb3(m.opacity).clamps(0.0f, PT_INF);
+        RGB t = RGB(-op.r + 1.0f, -op.g + 1.0f, -op.b + 1.0f).clamps(0.0f, PT_INF);
+        if (!t.is_black()) {
+            bsdf.init(si, 1.0f);
+            Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = t; b.etaa = 1.0f; b.etab = 1.0f; bsdf.add(b);
+        } else bsdf.init(si, e);
+        RGB kd = op * rgb3(m.kd).clamps(0.0f, PT_INF);
+        if (!kd.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_R, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = kd; bsdf.add(b); }
+        RGB ks = op * rgb3(m.ks).clamps(0.0f, PT_INF);
+        if (!ks.is_black()) {
+            float ru = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
+            float rv = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+            if (m.remap_roughness) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+            Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = ks; set_dist(b, ru, rv);
+            b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = e; bsdf.add(b);
+        }
+        RGB kr = op * rgb3(m.kr).clamps(0.0f, PT_INF);
+        if (!kr.is_black()) {
+            Lobe b = mk_lobe(LB_SPEC_R, BSDF_REFLECTION | BSDF_SPECULAR); b.r = kr; b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = e; bsdf.add(b);
+        }
+        RGB kt = op * rgb3(m.kt).clamps(0.0f, PT_INF);
+        if (!kt.is_black()) { Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = kt; b.etaa = 1.0f; b.etab = e; bsdf.add(b); }
+        return true;
+    }
+    default: {  // PT_MAT_SUBSTRATE, substrate.rs:34-60
+        bsdf.init(si, 1.0f);
+        RGB d = rgb3(m.kd).clamps(0.0f, PT_INF), s = rgb3(m.ks).clamps(0.0f, PT_INF);
+        float ru = m.u_roughness, rv = m.v_roughness;
+        if (!d.is_black() || !s.is_black()) {
+            if (m.remap_roughness) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+            Lobe b = mk_lobe(LB_FRESNEL_BLEND, BSDF_REFLECTION | BSDF_GLOSSY); b.r = d; b.t = s; set_dist(b, ru, rv);
+            bsdf.add(b);
+            return true;
+        }
+        return false;
+    }
+    }
+}
+
+}  // namespace ptd

@@ -1,0 +1,224 @@
+// dev_light.h -- light sampling/evaluation and light-selection distributions on device.
+//   lights/diffuse.rs:71-112; core/shape.rs:40-82; shapes/triangle.rs:556-584; lights/distant.rs:64-84;
+//   lights/point.rs:52-69; lights/infinite.rs:118-177; core/mipmap.rs:202-223,295-327;
+//   core/sampling.rs:38-85,94-145; core/lightdistrib.rs:112-340; core/pbrt.rs:184-204.
+#pragma once
+#include "dev_scene.h"
+#include "dev_sampler.h"
+
+namespace ptd {
+
+// core/pbrt.rs:184-204 over a cdf array: pred(i) = cdf[i] <= u
+PT_DEV int find_interval_cdf(const float *cdf, int size, float u) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    int r = first - 1;
+    return r < 0 ? 0 : (r > size - 2 ? size - 2 : r);
+}
+
+// A Distribution1D stored as func[n], cdf[n+1], func_int (sampling.rs:6-34 built on device or host).
+struct Dist1D { const float *func; const float *cdf; float func_int; int n; };
+
+PT_DEV int dist_sample_discrete(const Dist1D &d, float u, float &pdf) {  // sampling.rs:66-85
+    int off = find_interval_cdf(d.cdf, d.n + 1, u);
+    pdf = (d.func_int > 0.0f) ? d.func[off] / (d.func_int * (float)d.n) : 0.0f;
+    return off;
+}
+PT_DEV float dist_sample_continuous(const Dist1D &d, float u, float &pdf, int &off) {  // sampling.rs:38-64
+    off = find_interval_cdf(d.cdf, d.n + 1, u);
+    float du = u - d.cdf[off];
+    float diff = d.cdf[off + 1] - d.cdf[off];
+    if (diff > 0.0f) du /= diff;
+    pdf = (d.func_int > 0.0f) ? d.func[off] / d.func_int : 0.0f;
+    return ((float)off + du) / (float)d.n;
+}
+
+struct IData { V3 p, p_error, n; };
+
+PT_DEV void spawn_ray(const IData &it, V3 d, V3 &o) { o = offset_ray_origin(it.p, it.p_error, it.n, d); }  // interaction.rs:32-36
+PT_DEV void spawn_ray_to(const IData &a, const IData &b, V3 &o, V3 &d) {  // interaction.rs:45-52
+    o = offset_ray_origin(a.p, a.p_error, a.n, b.p - a.p);
+    V3 t = offset_ray_origin(b.p, b.p_error, b.n, o - b.p);
+    d = t - o;
+}
+
+// MIPMap::lookup(st, 0.0) == triangle(level 0) with Repeat wrap (mipmap.rs:202-223,295-327)
+PT_DEV RGB env_lookup(const DeviceScene &s, P2 st) {
+    int w = (int)s.env_w, h = (int)s.env_h;
+    float sf = st.x * (float)w - 0.5f, tf = st.y * (float)h - 0.5f;
+    int64_t s0 = f2i_sat(floorf(sf)), t0 = f2i_sat(floorf(tf));
+    float ds = sf - (float)s0, dt = tf - (float)t0;
+    auto texel = [&](int64_t ss, int64_t tt) -> RGB {
+        int64_t si = ss % w; if (si < 0) si += w;
+        int64_t ti = tt % h; if (ti < 0) ti += h;
+        const float *p = s.env_texels + 3 * ((size_t)ti * w + si);
+        return RGB(p[0], p[1], p[2]);
+    };
+    RGB tmp1 = texel(s0 + 1, t0 + 1) * (ds * dt);
+    RGB tmp2 = texel(s0 + 1, t0) * (ds * (1.0f - dt));
+    RGB tmp3 = texel(s0, t0 + 1) * ((1.0f - ds) * dt);
+    RGB tmp4 = texel(s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    return tmp4 + tmp3 + tmp2 + tmp1;
+}
+
+PT_DEV bool light_is_delta(const PtLight &L) { return L.type == PT_LIGHT_DISTANT || L.type == PT_LIGHT_POINT || L.type == PT_LIGHT_SPOT; }
+
+PT_DEV RGB area_l(const PtLight &L, V3 n, V3 w) {  // diffuse.rs:71-79
+    if (L.two_sided || dot(n, w) > 0.0f) return RGB(L.L[0], L.L[1], L.L[2]);
+    return RGB(0.0f);
+}
+PT_DEV M4 ldm4(const float *p) { M4 m; for (int i = 0; i < 16; ++i) m.m[i] = p[i]; return m; }
+
+PT_DEV RGB light_le(const DeviceScene &s, const PtLight &L, V3 ray_d) {  // infinite.rs:118-126 (others: 0)
+    if (L.type != PT_LIGHT_INFINITE) return RGB(0.0f);
+    V3 w = normalize(xf_vector(ldm4(L.world_to_light), ray_d));
+    P2 st(spherical_phi(w) * kInv2Pi, spherical_theta(w) * kInvPi);
+    return env_lookup(s, st);
+}
+
+// Distribution2D::sample_continuous / pdf over the env importance image (sampling.rs:119-145)
+PT_DEV P2 env_sample_continuous(const DeviceScene &s, P2 u, float &pdf) {
+    int nu = 2 * (int)s.env_w, nv = 2 * (int)s.env_h;
+    Dist1D marg{s.env_marg_func, s.env_marg_cdf, s.env_marg_int, nv};
+    float pdf1, pdf0; int v, dummy;
+    float d1 = dist_sample_continuous(marg, u.y, pdf1, v);
+    Dist1D cond{s.env_func + (size_t)v * nu, s.env_cdf + (size_t)v * (nu + 1), s.env_func_int[v], nu};
+    float d0 = dist_sample_continuous(cond, u.x, pdf0, dummy);
+    pdf = pdf0 * pdf1;
+    return P2(d0, d1);
+}
+PT_DEV float env_pdf(const DeviceScene &s, P2 p) {
+    int nu = 2 * (int)s.env_w, nv = 2 * (int)s.env_h;
+    uint32_t iu = f2u32_sat(p.x * (float)nu); if (iu > (uint32_t)(nu - 1)) iu = nu - 1;
+    uint32_t iv = f2u32_sat(p.y * (float)nv); if (iv > (uint32_t)(nv - 1)) iv = nv - 1;
+    return s.env_func[(size_t)iv * nu + iu] / s.env_marg_int;
+}
+
+// Light::sample_li. Returns Li; fills wi, pdf and the far end of the visibility segment.
+PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, P2 u, V3 &wi, float &pdf, IData &p1) {
+    const PtLight &L = s.lights[li];
+    p1.p = V3(); p1.p_error = V3(); p1.n = V3();
+    switch (L.type) {
+    case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
+        uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
+        float su0 = sqrtf(u.x);
+        float b0 = 1.0f - su0, b1 = u.y * su0;  // uniform_sample_triangle, sampling.rs:250-254
+        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+        V3 p0 = ld3(s.P, i0), p1v = ld3(s.P, i1), p2 = ld3(s.P, i2);
+        IData it;
+        float b2 = 1.0f - b0 - b1;
+        it.p = p0 * b0 + p1v * b1 + p2 * b2;
+        it.n = normalize(cross(p1v - p0, p2 - p0));
+        uint32_t fl = s.tri_flags[tri];
+        if (fl & PT_TRI_HAS_N) {
+            V3 ns = ld3(s.N, i0) * b0 + ld3(s.N, i1) * b1 + ld3(s.N, i2) * b2;
+            it.n = face_forward(it.n, ns);
+        } else if (((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) {
+            it.n = it.n * -1.0f;
+        }
+        V3 pabs = vabs(p0 * b0) + vabs(p1v * b1) + vabs(p2 * b2);
+        it.p_error = pabs * gammaf(6);
+        pdf = 1.0f / s.light_area[li];
+        V3 w = it.p - ref.p;
+        if (length_squared(w) == 0.0f) pdf = 0.0f;
+        else {
+            w = normalize(w);
+            pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -w);
+            if (__builtin_isinf(pdf)) pdf = 0.0f;
+        }
+        if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+        wi = normalize(it.p - ref.p);
+        p1 = it;
+        return area_l(L, it.n, -wi);
+    }
+    case PT_LIGHT_DISTANT: {  // distant.rs:64-84
+        V3 wl(L.dir[0], L.dir[1], L.dir[2]);
+        wi = wl; pdf = 1.0f;
+        p1.p = ref.p + wl * (2.0f * s.world_radius);
+        return RGB(L.L[0], L.L[1], L.L[2]);
+    }
+    case PT_LIGHT_POINT: {  // point.rs:52-69
+        V3 pl(L.pos[0], L.pos[1], L.pos[2]);
+        wi = normalize(pl - ref.p); pdf = 1.0f;
+        p1.p = pl;
+        return RGB(L.L[0], L.L[1], L.L[2]) / distance_squared(pl, ref.p);
+    }
+    case PT_LIGHT_INFINITE: {  // infinite.rs:140-177
+        float map_pdf = 0.0f;
+        P2 uv = env_sample_continuous(s, u, map_pdf);
+        if (map_pdf == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+        float theta = uv.y * kPi, phi = uv.x * 2.0f * kPi;
+        float cos_t, sin_t, sin_p, cos_p;
+        dm_sincosf(theta, sin_t, cos_t);
+        dm_sincosf(phi, sin_p, cos_p);
+        V3 v(sin_t * cos_p, sin_t * sin_p, cos_t);
+        wi = xf_vector(ldm4(L.light_to_world), v);
+        pdf = map_pdf / (2.0f * kPi * kPi * sin_t);
+        if (sin_t == 0.0f) pdf = 0.0f;
+        p1.p = ref.p + wi * (2.0f * s.world_radius);
+        return env_lookup(s, uv);
+    }
+    default: pdf = 0.0f; return RGB(0.0f);
+    }
+}
+
+// Light::pdf_li (area: Shape::pdf_wi re-intersects the light's own triangle, shape.rs:63-82)
+PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li, const IData &ref, V3 wi) {
+    const PtLight &L = s.lights[li];
+    if (L.type == PT_LIGHT_DIFFUSE_AREA) {
+        uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
+        V3 o; spawn_ray(ref, wi, o);
+        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+        V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
+        float t, b0, b1, b2;
+        if (!tri_hit_params(p0, p1, p2, o, wi, PT_INF, t, b0, b1, b2)) return 0.0f;
+        P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
+        V3 dpdu, dpdv;
+        if (!tri_partials(p0, p1, p2, uv, dpdu, dpdv)) return 0.0f;
+        SurfaceInteraction il;
+        tri_fill_interaction(s, tri, wi, b0, b1, b2, false, il);
+        float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * s.light_area[li]);
+        if (__builtin_isinf(pdf)) pdf = 0.0f;
+        return pdf;
+    }
+    if (L.type == PT_LIGHT_INFINITE) {  // infinite.rs:128-138
+        V3 w = xf_vector(ldm4(L.world_to_light), wi);
+        float theta = spherical_theta(w), phi = spherical_phi(w);
+        float sin_t = dm_sinf(theta);
+        if (sin_t == 0.0f) return 0.0f;
+        return env_pdf(s, P2(phi * kInv2Pi, theta * kInvPi)) / (2.0f * kPi * kPi * sin_t);
+    }
+    return 0.0f;
+}
+
+// ---- light-selection distributions (lightdistrib.rs) -------------------------------------------------
+struct LightGrid {
+    int strategy;            // PT_LS_* after the `one light => uniform` rule (lightdistrib.rs:21)
+    uint32_t nvox[3];
+    uint32_t n_lights;
+    const float *func;       // [ncell][n_lights]     (uniform/power: ncell == 1)
+    const float *cdf;        // [ncell][n_lights+1]
+    const float *func_int;   // [ncell]
+};
+PT_DEV Dist1D light_distribution_lookup(const LightGrid &g, const DeviceScene &s, V3 p) {  // lightdistrib.rs:233-247
+    size_t cell = 0;
+    if (g.strategy == PT_LS_SPATIAL) {
+        float o[3] = {p.x - s.wb_min[0], p.y - s.wb_min[1], p.z - s.wb_min[2]};  // Bounds3::offset, bounds.rs:372-390
+        uint32_t pi[3];
+        for (int i = 0; i < 3; ++i) {
+            if (s.wb_max[i] > s.wb_min[i]) o[i] /= s.wb_max[i] - s.wb_min[i];
+            int64_t v = f2i_sat(o[i] * (float)g.nvox[i]);
+            int64_t hi = (int64_t)g.nvox[i] - 1;
+            pi[i] = (uint32_t)(v < 0 ? 0 : (v > hi ? hi : v));
+        }
+        cell = ((size_t)pi[2] * g.nvox[1] + pi[1]) * g.nvox[0] + pi[0];
+    }
+    Dist1D d{g.func + cell * g.n_lights, g.cdf + cell * (g.n_lights + 1), g.func_int[cell], (int)g.n_lights};
+    return d;
+}
+
+}  // namespace ptd

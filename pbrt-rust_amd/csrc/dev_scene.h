@@ -1,0 +1,194 @@
+// dev_scene.h -- device-resident scene layout + triangle / bounds tests + BVH traversal.
+//   accelerators/bvh.rs:705-814 (traversal order), core/geometry/bounds.rs:559-580 (slab test),
+//   shapes/triangle.rs:136-398,400-548 (watertight test, partials, shading geometry).
+//
+// HBM layout (all read-only during render):
+//   nodes      : PtBVHNode[n_nodes]     32 B, reference order (left child = i+1, right = offset)
+//   leaf_tris  : TriPacket[n_prims]     48 B, in ordered_prims order -> a leaf is a contiguous run
+//                p0.xyz p1.xyz p2.xyz (9 f32) | prim id | shape ref | flags
+//   P/N/S/UV, indices, tri_flags, prim_* tables: shading-time data only (never touched by traversal)
+#pragma once
+#include "dev_math.h"
+#include "../../include/mi355pt.h"
+
+namespace ptd {
+
+struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads per test
+    float p0[3]; float p1x;
+    float p1yz[2]; float p2xy[2];
+    float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
+};
+enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9 };  // flags: low 8 bits = PT_TRI_* bits
+
+struct DeviceScene {
+    const PtBVHNode *nodes; uint32_t n_nodes;
+    const TriPacket *leaf; uint32_t n_prims;
+    const float *P; const float *N; const float *S; const float *UV;
+    const uint32_t *indices; const uint8_t *tri_flags; uint32_t n_triangles;
+    const PtSphere *spheres; uint32_t n_spheres;
+    const uint32_t *prim_shape; const uint32_t *prim_material; const uint32_t *prim_light;
+    const PtMaterial *materials; uint32_t n_materials;
+    const PtLight *lights; uint32_t n_lights;
+    const float *light_area;            // per light: Shape::area() of its primitive
+    const uint32_t *infinite_lights; uint32_t n_infinite;
+    const uint8_t *mat_class;           // per material: shade-queue class
+    // env map
+    uint32_t env_w, env_h; const float *env_texels;
+    const float *env_func; const float *env_cdf; const float *env_func_int;  // conditional rows (2h x 2w [+1]), marginal appended
+    const float *env_marg_func; const float *env_marg_cdf; float env_marg_int;
+    float wb_min[3], wb_max[3];
+    float world_radius; float world_center[3];
+};
+
+struct Ray { V3 o, d; float t_max; };
+
+struct Hit { uint32_t prim; float t, b0, b1, b2; };
+
+PT_DEV V3 ld3(const float *p, uint32_t i) { return V3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// Watertight ray-triangle test shared by intersect / intersect_p (triangle.rs:136-233 == :400-495).
+PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float t_max, float &t, float &b0, float &b1, float &b2) {
+    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    V3 ad = vabs(rd);
+    int kz = max_dimension(ad);
+    // permute(kx, ky, kz) with kx = kz+1 mod 3, ky = kx+1 mod 3
+    float dx, dy, dz;
+    if (kz == 0) { dx = rd.y; dy = rd.z; dz = rd.x; p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x); }
+    else if (kz == 1) { dx = rd.z; dy = rd.x; dz = rd.y; p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y); }
+    else { dx = rd.x; dy = rd.y; dz = rd.z; }
+    float Sx = -dx / dz, Sy = -dy / dz, Sz = 1.0f / dz;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // f64 fallback, triangle.rs:178-189
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tscaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0.0f && (tscaled >= 0.0f || tscaled < t_max * det)) return false;
+    else if (det > 0.0f && (tscaled <= 0.0f || tscaled >= t_max * det)) return false;
+    float invdet = 1.0f / det;
+    b0 = e0 * invdet; b1 = e1 * invdet; b2 = e2 * invdet;
+    t = tscaled * invdet;
+    float maxzt = max_component(vabs(V3(p0t.z, p1t.z, p2t.z)));
+    float deltaz = gammaf(3) * maxzt;
+    float maxxt = max_component(vabs(V3(p0t.x, p1t.x, p2t.x)));
+    float maxyt = max_component(vabs(V3(p0t.y, p1t.y, p2t.y)));
+    float deltax = gammaf(5) * (maxxt + maxzt);
+    float deltay = gammaf(5) * (maxyt + maxzt);
+    float deltae = 2.0f * (gammaf(2) * maxxt * maxyt + deltay * maxxt + deltax * maxyt);
+    float maxe = max_component(vabs(V3(e0, e1, e2)));
+    float deltat = 3.0f * (gammaf(3) * maxe * maxzt + deltae * maxzt + deltaz * maxe) * fabsf(invdet);
+    if (t <= deltat) return false;
+    return true;
+}
+
+PT_DEV void tri_uvs(const DeviceScene &s, uint32_t tri, uint32_t i0, uint32_t i1, uint32_t i2, P2 uv[3]) {  // triangle.rs:109-115
+    if (s.tri_flags[tri] & PT_TRI_HAS_UV) {
+        uv[0] = P2(s.UV[2 * i0], s.UV[2 * i0 + 1]); uv[1] = P2(s.UV[2 * i1], s.UV[2 * i1 + 1]); uv[2] = P2(s.UV[2 * i2], s.UV[2 * i2 + 1]);
+    } else { uv[0] = P2(0.0f, 0.0f); uv[1] = P2(1.0f, 0.0f); uv[2] = P2(1.0f, 1.0f); }
+}
+// dpdu/dpdv + the "intersection is bogus" rejection (triangle.rs:236-264). false => degenerate triangle.
+PT_DEV bool tri_partials(V3 p0, V3 p1, V3 p2, const P2 uv[3], V3 &dpdu, V3 &dpdv) {
+    float duv02x = uv[0].x - uv[2].x, duv02y = uv[0].y - uv[2].y;
+    float duv12x = uv[1].x - uv[2].x, duv12y = uv[1].y - uv[2].y;
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerateuv = fabsf(determinant) < 1.0e-8f;
+    dpdu = V3(); dpdv = V3();
+    if (!degenerateuv) {
+        float invdet = 1.0f / determinant;
+        dpdu = (dp02 * duv12y - dp12 * duv02y) * invdet;
+        dpdv = (dp02 * -duv12x + dp12 * duv02x) * invdet;
+    }
+    if (degenerateuv || length_squared(cross(dpdu, dpdv)) == 0.0f) {
+        V3 ng = cross(p2 - p0, p1 - p0);
+        if (length_squared(ng) == 0.0f) return false;
+        coordinate_system(normalize(ng), dpdu, dpdv);
+    }
+    return true;
+}
+
+// What Triangle::intersect leaves in `isect` (triangle.rs:266-392 + interaction.rs:186-249).
+struct SurfaceInteraction {
+    V3 p, p_error, n, wo;
+    V3 dpdu;             // == shading.dpdu unless the mesh has N/S
+    V3 sh_n, sh_dpdu;
+    uint32_t prim;
+};
+// `with_shape` = the `s: Option<Arc<Shapes>>` argument (None inside Shape::pdf_wi, shape.rs:72).
+PT_DEV void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
+    uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+    V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
+    P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
+    V3 dpdu, dpdv; tri_partials(p0, p1, p2, uv, dpdu, dpdv);
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float xabs = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
+    float yabs = fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y);
+    float zabs = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
+    si.p_error = V3(xabs, yabs, zabs) * gammaf(7);
+    si.p = p0 * b0 + p1 * b1 + p2 * b2;
+    si.dpdu = dpdu; si.sh_dpdu = dpdu;
+    uint32_t fl = s.tri_flags[tri];
+    bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
+    V3 nn = normalize(cross(dp02, dp12));
+    si.n = nn; si.sh_n = nn;
+    si.wo = -ray_d;  // triangle.rs:296
+    if (flip) { si.n = -nn; si.sh_n = -nn; }
+    if (fl & (PT_TRI_HAS_N | PT_TRI_HAS_S)) {
+        V3 ns;
+        if (fl & PT_TRI_HAS_N) {
+            ns = ld3(s.N, i0) * b0 + ld3(s.N, i1) * b1 + ld3(s.N, i2) * b2;
+            if (length_squared(ns) > 0.0f) ns = normalize(ns); else ns = si.n;
+        } else ns = si.n;
+        V3 ss;
+        if (fl & PT_TRI_HAS_S) {
+            ss = ld3(s.S, i0) * b0 + ld3(s.S, i1) * b1 + ld3(s.S, i2) * b2;
+            if (length_squared(ss) > 0.0f) ss = normalize(ss); else ss = normalize(si.dpdu);
+        } else ss = normalize(si.dpdu);
+        V3 ts = cross(ss, ns);
+        if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+        else coordinate_system(ns, ss, ts);
+        if (fl & PT_TRI_REVERSE_ORIENTATION) ts = -ts;
+        si.sh_n = normalize(cross(ss, ts));  // set_shading_geometry(.., true), interaction.rs:228-249
+        if (with_shape) {
+            if (flip) si.sh_n = -si.sh_n;
+            si.n = face_forward(si.n, si.sh_n);
+        }
+        si.sh_dpdu = ss;
+    }
+}
+PT_DEV float tri_area(V3 p0, V3 p1, V3 p2) { return 0.5f * length(cross(p1 - p0, p2 - p0)); }  // triangle.rs:550-554
+
+// Bounds3f::intersect_p2 (bounds.rs:559-580). bmin/bmax passed as two float4-ish groups.
+PT_DEV bool slab_test(const float bmin[3], const float bmax[3], V3 ro, V3 inv_dir, bool nx, bool ny, bool nz, float ray_tmax) {
+    float tmin = ((nx ? bmax[0] : bmin[0]) - ro.x) * inv_dir.x;
+    float tmax = ((nx ? bmin[0] : bmax[0]) - ro.x) * inv_dir.x;
+    float tymin = ((ny ? bmax[1] : bmin[1]) - ro.y) * inv_dir.y;
+    float tymax = ((ny ? bmin[1] : bmax[1]) - ro.y) * inv_dir.y;
+    const float k = 1.0f + 2.0f * gammaf(3);
+    tmax *= k; tymax *= k;
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? bmax[2] : bmin[2]) - ro.z) * inv_dir.z;
+    float tzmax = ((nz ? bmin[2] : bmax[2]) - ro.z) * inv_dir.z;
+    tzmax *= k;
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return (tmin < ray_tmax) && (tmax > 0.0f);
+}
+
+}  // namespace ptd

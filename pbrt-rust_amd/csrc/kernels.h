@@ -1,0 +1,100 @@
+// kernels.h -- shared declarations between the HIP kernels (kernels.hip) and the host driver (capi.hip).
+#pragma once
+#include "dev_scene.h"
+#include "dev_sampler.h"
+#include "dev_light.h"
+
+namespace ptd {
+
+constexpr int kNumClasses = 4;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber
+constexpr int kLdsStack = 24;       // traversal stack entries kept in LDS per lane; deeper entries spill to HBM
+constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
+constexpr int kTraceBlock = 256;
+
+// path flags (meta >> 24)
+enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_COUNTED = 16u };
+
+// SoA path state in HBM; index = path id (pid). Every array has `capacity` entries.
+struct PathSoA {
+    float *pfilm_x, *pfilm_y;
+    float *ox, *oy, *oz, *dx, *dy, *dz;                 // continuation ray (t_max = inf)
+    uint32_t *hit_prim; float *hit_b0, *hit_b1, *hit_b2; // closest hit of the continuation ray
+    float *beta_r, *beta_g, *beta_b, *L_r, *L_g, *L_b, *etascale;
+    uint64_t *sobol_index;
+    uint32_t *meta;                                      // dim (bits 0-15) | bounces (16-23) | flags (24-31)
+    // pending next-event estimation of the previous vertex
+    float *sh_ox, *sh_oy, *sh_oz, *sh_dx, *sh_dy, *sh_dz; // shadow ray (t_max = 1 - eps)
+    float *A_r, *A_g, *A_b;                              // f*Li*w/lightpdf if unoccluded
+    float *mis_ox, *mis_oy, *mis_oz, *mis_dx, *mis_dy, *mis_dz;
+    float *mis_f_r, *mis_f_g, *mis_f_b, *mis_w, *mis_spdf;
+    uint32_t *nee_light; float *nee_choice_pdf;
+    float *nb_r, *nb_g, *nb_b;                           // beta at NEE time
+    uint32_t *mis_prim; float *mis_b0, *mis_b1, *mis_b2; // closest hit of the MIS ray
+    uint8_t *occluded;
+};
+constexpr int kPathSoAFloatArrays = 50;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
+
+struct QueueSet {
+    uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)
+    uint32_t *shade[2][kNumClasses];  // pids to shade, per material class (ping-pong)
+    uint32_t *shadow, *mis;           // pids with pending shadow / MIS rays
+    // counters (device): layout documented in QCounters
+};
+struct QCounters {
+    uint32_t ext[2];
+    uint32_t shade[2][kNumClasses];
+    uint32_t shadow, mis;
+    uint32_t head[4];                 // persistent-wave work heads for the trace launches
+    uint32_t error;                   // PtStatus raised on device (stack / sobol overflow)
+    uint32_t pad;
+};
+
+struct DevCounters {  // PtCounters mirror, atomically updated once per wave
+    unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
+    unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
+};
+
+struct RenderConst {
+    // pass geometry
+    uint32_t n_tile_slots;            // tiles owned by this rank
+    uint32_t tile_rank, tile_world;
+    uint32_t ntx, nty;                // tile grid of integrator.rs:277-279
+    uint32_t spp, s_begin, s_count;   // samples of this pass: [s_begin, s_begin + s_count)
+    uint32_t n_pix_slots;             // n_tile_slots * 256
+    int32_t sample_bounds[4], pixel_bounds[4], crop[4];
+    SobolParams sobol;
+    M4 raster_to_camera, camera_to_world;
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+    uint32_t max_depth; float rr_threshold;
+    float filter_radius[2]; float max_sample_luminance;
+    uint32_t film_w, film_h;
+};
+
+struct TraceJob {
+    const uint32_t *queue;   // path ids (NULL => identity)
+    const uint32_t *count;   // device count of queue entries
+    uint32_t *head;          // persistent-wave work head (zeroed before launch)
+    const float *ox, *oy, *oz, *dx, *dy, *dz;
+    const float *tmax;       // per-ray t_max or NULL => scalar_tmax
+    float scalar_tmax;
+    // outputs (indexed by path id)
+    uint32_t *out_prim; float *out_t, *out_b0, *out_b1, *out_b2;
+    uint8_t *out_occluded;
+    // shade-queue routing (closest-hit of continuation rays only)
+    uint32_t *class_count;   // [kNumClasses] or NULL
+    uint32_t *class_buf[kNumClasses];
+    uint32_t *spill;         // [waves_in_grid][64 lanes][kMaxStack - kLdsStack]
+    uint32_t *error;
+    DevCounters *counters;
+};
+
+struct ShadeJob {
+    const uint32_t *queue; const uint32_t *count;
+    uint32_t *ext_next, *ext_next_count;
+    uint32_t *shade_next0, *shade_next0_count;   // resolve-only paths go to class 0 of the next iteration
+    uint32_t *shadow, *shadow_count, *mis, *mis_count;
+    uint32_t *error;
+    DevCounters *counters;
+};
+
+}  // namespace ptd

@@ -1,0 +1,565 @@
+// kernels.hip -- the gfx950 wavefront path-tracing kernels (wave64).
+//
+// Pipeline per pass (one pass = s_count samples of every pixel owned by this rank):
+//   k_generate   integrator.rs:331-346  sampler.rs:170-180  perspective.rs:120-179
+//   repeat until no path is alive:
+//     k_trace<closest>  bvh.rs:705-760 + triangle.rs:136-233   (continuation rays, then MIS rays)
+//     k_trace<any>      bvh.rs:762-814 + triangle.rs:400-495   (shadow rays)
+//     k_shade<class>    path.rs:97-217 + integrator.rs:81-237  (one launch per material class queue)
+//   k_film       integrator.rs:350-374 + film.rs:292-331
+// Queues hold path ids; path state is SoA in HBM (kernels.h). Compaction is wave64 ballot + popcount.
+#include "kernels.h"
+#include "dev_bsdf.h"
+
+using namespace ptd;
+
+// ---- wave-level helpers ------------------------------------------------------------------------
+PT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Stream compaction: append `value` for every lane with pred set; one atomic per wave.
+PT_DEV void queue_push(uint32_t *count, uint32_t *buf, uint32_t value, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) buf[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+PT_DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+PT_DEV void counter_add(unsigned long long *dst, unsigned long long v) {  // call wave-convergent
+    v = wave_sum(v);
+    if (lane_id() == 0 && v) atomicAdd(dst, v);
+}
+
+// ---- scene preparation ---------------------------------------------------------------------------
+// Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
+// (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, TriPacket *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n_prims) return;
+    uint32_t prim = ordered[i];
+    uint32_t shape = s.prim_shape[prim];
+    TriPacket p;
+    p.prim = prim; p.shape = shape; p.flags = 0;
+    if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
+        uint32_t tri = shape & 0x3fffffffu;
+        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+        V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
+        P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
+        V3 dpdu, dpdv;
+        bool ok = tri_partials(p0, p1, p2, uv, dpdu, dpdv);
+        p.p0[0] = p0.x; p.p0[1] = p0.y; p.p0[2] = p0.z; p.p1x = p1.x;
+        p.p1yz[0] = p1.y; p.p1yz[1] = p1.z; p.p2xy[0] = p2.x; p.p2xy[1] = p2.y; p.p2z = p2.z;
+        p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS);
+    } else {
+        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.flags = TP_SPHERE;
+    }
+    out[i] = p;
+}
+
+__global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight::new -> shape.area()
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n_lights) return;
+    float a = 0.0f;
+    const PtLight &L = s.lights[i];
+    if (L.type == PT_LIGHT_DIFFUSE_AREA) {
+        uint32_t shape = s.prim_shape[L.prim];
+        if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
+            uint32_t tri = shape & 0x3fffffffu;
+            a = tri_area(ld3(s.P, s.indices[3 * tri]), ld3(s.P, s.indices[3 * tri + 1]), ld3(s.P, s.indices[3 * tri + 2]));
+        }
+    }
+    area[i] = a;
+}
+
+// ---- BVH traversal ---------------------------------------------------------------------------------
+
+template <bool ANY>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 64) + lane;
+    uint32_t *spill = job.spill + ((size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 + lane) * (kMaxStack - kLdsStack);
+    const uint32_t count = *job.count;
+    const uint4 *nodes4 = reinterpret_cast<const uint4 *>(s.nodes);
+    const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
+    unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0;
+
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(job.head, 64u);
+        chunk = __shfl(chunk, 0);
+        if (chunk >= count) break;
+        const uint32_t qi = chunk + lane;
+        const bool valid = qi < count;
+        uint32_t pid = 0;
+        bool found = false;
+        uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+        if (valid) {
+            pid = job.queue ? job.queue[qi] : qi;
+            V3 ro(job.ox[pid], job.oy[pid], job.oz[pid]), rd(job.dx[pid], job.dy[pid], job.dz[pid]);
+            float t_max = job.tmax ? job.tmax[pid] : job.scalar_tmax;
+            n_rays++;
+            if (s.n_nodes > 0) {
+                V3 inv_dir(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                const bool nx = inv_dir.x < 0.0f, ny = inv_dir.y < 0.0f, nz = inv_dir.z < 0.0f;
+                uint32_t sp = 0, cur = 0;
+                for (;;) {
+                    const uint4 a = nodes4[2 * cur], b = nodes4[2 * cur + 1];
+                    n_nodes++;
+                    const float bmin[3] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)};
+                    const float bmax[3] = {__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)};
+                    bool pop = true;
+                    if (slab_test(bmin, bmax, ro, inv_dir, nx, ny, nz, t_max)) {
+                        const uint32_t nprims = b.w & 0xffffu;
+                        if (nprims > 0) {
+                            bool done = false;
+                            for (uint32_t i = 0; i < nprims; ++i) {
+                                const uint32_t li = b.z + i;
+                                const uint4 q0 = leaf4[3 * li], q1 = leaf4[3 * li + 1], q2 = leaf4[3 * li + 2];
+                                const uint32_t fl = q2.w;
+                                if (fl & TP_SPHERE) { continue; }  // spheres: row a14, not yet on device
+                                n_tris++;
+                                V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                                V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+                                V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+                                float t, b0, b1, b2;
+                                if (tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2)) {
+                                    if (ANY) { found = true; done = true; break; }
+                                    if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
+                                        found = true; t_max = t;  // primitive.rs:137
+                                        hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                                    }
+                                }
+                            }
+                            if (done) break;
+                        } else {
+                            const uint32_t axis = (b.w >> 16) & 0xffu;
+                            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                            const uint32_t far_child = neg ? cur + 1 : b.z;
+                            const uint32_t near_child = neg ? b.z : cur + 1;
+                            if (sp < (uint32_t)kLdsStack) stack[sp * 64] = far_child;
+                            else if (sp < (uint32_t)kMaxStack) spill[sp - kLdsStack] = far_child;
+                            else atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                            if (sp < (uint32_t)kMaxStack) sp++;
+                            cur = near_child;
+                            pop = false;
+                        }
+                    }
+                    if (pop) {
+                        if (sp == 0) break;
+                        sp--;
+                        cur = (sp < (uint32_t)kLdsStack) ? stack[sp * 64] : spill[sp - kLdsStack];
+                    }
+                }
+            }
+            if (ANY) job.out_occluded[pid] = found ? 1 : 0;
+            else {
+                job.out_prim[pid] = hit_prim;
+                if (job.out_t) job.out_t[pid] = hit_t;
+                job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
+            }
+        }
+        if (!ANY && job.class_count) {
+            uint32_t cls = 0;
+            if (valid && found) { uint32_t m = s.prim_material[hit_prim]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+            for (int c = 0; c < kNumClasses; ++c) queue_push(job.class_count + c, job.class_buf[c], pid, valid && cls == (uint32_t)c);
+        }
+    }
+    counter_add(&job.counters->nodes, n_nodes);
+    counter_add(&job.counters->tri_tests, n_tris);
+    counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
+}
+template __global__ void k_trace<false>(DeviceScene, TraceJob);
+template __global__ void k_trace<true>(DeviceScene, TraceJob);
+
+// ---- camera rays -------------------------------------------------------------------------------------
+// pixel slot -> pixel: slot = tile_slot*256 + ty*16 + tx, tile index = tile_rank + tile_slot*tile_world
+PT_DEV bool slot_to_pixel(const RenderConst &rc, uint32_t slot, int32_t &px, int32_t &py) {
+    uint32_t tile_slot = slot >> 8, in_tile = slot & 255u;
+    uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
+    uint32_t tx = tile % rc.ntx, ty = tile / rc.ntx;
+    px = rc.sample_bounds[0] + (int32_t)(tx * 16u + (in_tile & 15u));
+    py = rc.sample_bounds[1] + (int32_t)(ty * 16u + (in_tile >> 4));
+    if (ty >= rc.nty || px >= rc.sample_bounds[2] || py >= rc.sample_bounds[3]) return false;
+    // integrator.rs:328: pixels outside the integrator's pixel_bounds are skipped
+    return px >= rc.pixel_bounds[0] && px < rc.pixel_bounds[2] && py >= rc.pixel_bounds[1] && py < rc.pixel_bounds[3];
+}
+
+PT_DEV void camera_ray(const RenderConst &rc, float pfx, float pfy, float time_u, P2 plens_u, V3 &o, V3 &d) {  // perspective.rs:120-179
+    V3 pcamera = xf_point(rc.raster_to_camera, V3(pfx, pfy, 0.0f));
+    V3 ro(0.0f, 0.0f, 0.0f), rd = normalize(pcamera);
+    if (rc.lens_radius > 0.0f) {
+        P2 dsk = concentric_sample_disk(plens_u);
+        float lx = dsk.x * rc.lens_radius, ly = dsk.y * rc.lens_radius;
+        float ft = rc.focal_distance / rd.z;
+        V3 pfocus = ro + rd * ft;
+        ro = V3(lx, ly, 0.0f);
+        rd = normalize(pfocus - ro);
+    }
+    (void)time_u;  // ray.time = lerp(time, open, close) has no effect without animated transforms
+    // Transform::transform_ray (transform.rs:543-577)
+    V3 oerr;
+    V3 ow = xf_point_err(rc.camera_to_world, ro, oerr);
+    V3 dw = xf_vector(rc.camera_to_world, rd);
+    float l2 = length_squared(dw);
+    if (l2 > 0.0f) { float dt = dot(vabs(dw), oerr) / l2; ow = ow + dw * dt; }
+    o = ow; d = dw;
+}
+
+__global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = rc.n_pix_slots * rc.s_count;
+    bool alive = false;
+    if (pid < total) {
+        const uint32_t slot = pid % rc.n_pix_slots, sl = pid / rc.n_pix_slots;
+        int32_t px, py;
+        if (slot_to_pixel(rc, slot, px, py)) {
+            const uint64_t sample = rc.s_begin + sl;
+            const uint64_t index = sobol_interval_to_index(tabs, (uint32_t)rc.sobol.log2_resolution, sample,
+                                                           (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
+            // get_camera_sample (sampler.rs:170-180): pfilm = get_2d (y evaluated first), time = get_1d, plens = get_2d
+            const float fy = sobol_pixel_dim(tabs.m32, rc.sobol, index, 1, py);
+            const float fx = sobol_pixel_dim(tabs.m32, rc.sobol, index, 0, px);
+            const float pfx = (float)px + fx, pfy = (float)py + fy;
+            const float tm = sobol_sample_float(tabs.m32, index, 2);
+            const float ly = sobol_sample_float(tabs.m32, index, 4);
+            const float lx = sobol_sample_float(tabs.m32, index, 3);
+            V3 o, d;
+            camera_ray(rc, pfx, pfy, tm, P2(lx, ly), o, d);
+            ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
+            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+            ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+            ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
+            ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
+            ps.etascale[pid] = 1.0f;
+            ps.sobol_index[pid] = index;
+            ps.meta[pid] = 5u;  // dimension 5 after the camera sample, bounces 0, flags 0
+            alive = true;
+        }
+    }
+    queue_push(q_ext_count, q_ext, pid, alive);
+    counter_add(&counters->camera_rays, alive ? 1ull : 0ull);
+}
+
+// ---- shading ---------------------------------------------------------------------------------------------
+
+template <int MAXL>
+__global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count = *job.count;
+    const bool valid = qi < count;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
+    unsigned long long zero_num = 0, zero_den = 0;
+    int finished_bounces = -1;
+    uint32_t pid = 0;
+    if (valid) {
+        pid = job.queue[qi];
+        uint32_t meta = ps.meta[pid];
+        uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
+        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.overflow = false;
+        RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+        RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+
+        // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
+        if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) {
+            RGB Ld(0.0f);
+            const uint32_t li = ps.nee_light[pid];
+            if ((flags & PF_PEND_SHADOW) && !ps.occluded[pid]) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
+            if (flags & PF_PEND_MIS) {
+                const PtLight &Lt = s.lights[li];
+                V3 wi(ps.mis_dx[pid], ps.mis_dy[pid], ps.mis_dz[pid]);
+                RGB lrad(0.0f);
+                const uint32_t mp = ps.mis_prim[pid];
+                if (mp != PT_NONE) {
+                    if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
+                        SurfaceInteraction lsi;
+                        tri_fill_interaction(s, s.prim_shape[mp] & 0x3fffffffu, wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], true, lsi);
+                        lrad = area_l(Lt, lsi.n, -wi);
+                    }
+                } else lrad = light_le(s, Lt, wi);
+                if (!lrad.is_black()) {
+                    RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
+                    Ld = Ld + f * lrad * RGB(1.0f) * ps.mis_w[pid] / ps.mis_spdf[pid];
+                }
+            }
+            RGB nb(ps.nb_r[pid], ps.nb_g[pid], ps.nb_b[pid]);
+            RGB Ldb = nb * (Ld / ps.nee_choice_pdf[pid]);
+            if (Ldb.is_black()) zero_num++;
+            L = L + Ldb;
+            flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS);
+        }
+
+        if (flags & PF_DEAD) {
+            finished_bounces = (int)bounces;
+        } else {
+            V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+            const uint32_t hp = ps.hit_prim[pid];
+            const bool found = hp != PT_NONE;
+            SurfaceInteraction si;
+            if (found) tri_fill_interaction(s, s.prim_shape[hp] & 0x3fffffffu, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], true, si);
+            // path.rs:106-117
+            if (bounces == 0 || (flags & PF_SPECULAR)) {
+                if (found) {
+                    const uint32_t al = s.prim_light[hp];
+                    if (al != PT_NONE) L = L + area_l(s.lights[al], si.n, -rd) * beta;
+                } else {
+                    for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
+                }
+            }
+            bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
+            if (!terminated) {
+                Bsdf<MAXL> bsdf;
+                const uint32_t mi = s.prim_material[hp];
+                bool has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf);
+                IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
+                if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
+                    V3 o; spawn_ray(it, rd, o);
+                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    push_ext = true;
+                } else {
+                    const V3 wo = -rd;  // == isect.wo (triangle.rs:296)
+                    // uniform_sample_onelight (integrator.rs:81-106)
+                    if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                        zero_den++;
+                        bool nee_pending = false;
+                        if (s.n_lights > 0) {
+                            Dist1D distrib = light_distribution_lookup(grid, s, si.p);
+                            float choice_pdf = 0.0f;
+                            const uint32_t li = (uint32_t)dist_sample_discrete(distrib, smp.get_1d(), choice_pdf);
+                            if (choice_pdf != 0.0f) {
+                                const P2 ulight = smp.get_2d();
+                                const P2 uscatt = smp.get_2d();
+                                // estimate_direct (integrator.rs:109-237), flags = All & !Specular
+                                const int bf = BSDF_ALL & ~BSDF_SPECULAR;
+                                V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+                                RGB Li = light_sample_li(s, li, it, ulight, wi, lightpdf, p1);
+                                const bool delta = light_is_delta(s.lights[li]);
+                                if (lightpdf > 0.0f && !Li.is_black()) {
+                                    RGB f = bsdf.f(wo, wi, bf) * abs_dot(wi, si.sh_n);
+                                    scattpdf = bsdf.pdf(wo, wi, bf);
+                                    if (!f.is_black()) {
+                                        V3 so, sd; spawn_ray_to(it, p1, so, sd);
+                                        RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
+                                        ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
+                                        ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
+                                        ps.A_r[pid] = A.r; ps.A_g[pid] = A.g; ps.A_b[pid] = A.b;
+                                        flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true;
+                                    }
+                                }
+                                if (!delta) {
+                                    int sampled_type = 0;
+                                    RGB f = bsdf.sample_f(wo, wi, uscatt, scattpdf, bf, sampled_type);
+                                    f = f * abs_dot(wi, si.sh_n);
+                                    const bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+                                    if (!f.is_black() && scattpdf > 0.0f) {
+                                        float weight = 1.0f;
+                                        bool skip = false;
+                                        if (!sampled_specular) {
+                                            lightpdf = light_pdf_li(s, li, it, wi);
+                                            if (lightpdf == 0.0f) skip = true;  // `return Ld` (integrator.rs:204)
+                                            else weight = power_heuristic(scattpdf, lightpdf);
+                                        }
+                                        if (!skip) {
+                                            V3 mo; spawn_ray(it, wi, mo);
+                                            ps.mis_ox[pid] = mo.x; ps.mis_oy[pid] = mo.y; ps.mis_oz[pid] = mo.z;
+                                            ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
+                                            ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
+                                            ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
+                                            flags |= PF_PEND_MIS; push_mis = true; nee_pending = true;
+                                        }
+                                    }
+                                }
+                                if (nee_pending) {
+                                    ps.nee_light[pid] = li; ps.nee_choice_pdf[pid] = choice_pdf;
+                                    ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b;
+                                }
+                            }
+                        }
+                        if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
+                    }
+                    // path.rs:148-174: sample the BSDF for the next direction
+                    V3 wi; float pdf = 0.0f; int sflags = 0;
+                    RGB f = bsdf.sample_f(wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
+                    if (f.is_black() || pdf == 0.0f) terminated = true;
+                    else {
+                        beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
+                        if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
+                        float etascale = ps.etascale[pid];
+                        if ((sflags & BSDF_SPECULAR) && (sflags & BSDF_TRANSMISSION)) {
+                            const float eta = bsdf.eta;
+                            etascale *= (dot(wo, si.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
+                            ps.etascale[pid] = etascale;
+                        }
+                        V3 o; spawn_ray(it, wi, o);
+                        // path.rs:206-214 Russian roulette
+                        RGB rrbeta = beta * etascale;
+                        bool rr_kill = false;
+                        if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
+                            const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
+                            if (smp.get_1d() < q) rr_kill = true;
+                            else beta = beta / (1.0f - q);
+                        }
+                        if (rr_kill) terminated = true;
+                        else {
+                            bounces += 1;
+                            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                            ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                            push_ext = true;
+                        }
+                    }
+                }
+            }
+            if (terminated) {
+                if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
+                else finished_bounces = (int)bounces;
+            }
+        }
+        if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
+        ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
+        ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+        ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+    }
+    queue_push(job.ext_next_count, job.ext_next, pid, push_ext);
+    queue_push(job.shade_next0_count, job.shade_next0, pid, push_resolve);
+    queue_push(job.shadow_count, job.shadow, pid, push_shadow);
+    queue_push(job.mis_count, job.mis, pid, push_mis);
+    counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->zero_den, zero_den);
+    counter_add(&job.counters->stages, valid ? 1ull : 0ull);
+    // path length histogram (path.rs:219)
+    for (int b = 0; b < 16; ++b) {
+        unsigned long long m = __ballot(finished_bounces >= 0 && (finished_bounces > 15 ? 15 : finished_bounces) == b);
+        if (m && lane_id() == 0) atomicAdd(&job.counters->path_len[b], (unsigned long long)__popcll(m));
+    }
+}
+template __global__ void k_shade<1>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+template __global__ void k_shade<2>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+template __global__ void k_shade<5>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+
+// ---- film ----------------------------------------------------------------------------------------------------
+// One thread per pixel slot; its s_count samples are added in sample order (integrator.rs:331-376),
+// FilmTile::add_sample (film.rs:292-331) with the tile's pixel bounds == footprint clipped to the crop window.
+__global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long nan_c = 0, neg_c = 0, inf_c = 0, splats = 0;
+    int32_t px, py;
+    if (slot < rc.n_pix_slots && slot_to_pixel(rc, slot, px, py)) {
+        // tile pixel bounds (Film::get_film_tile, film.rs:125-140)
+        uint32_t tile_slot = slot >> 8;
+        uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
+        int32_t tx0 = rc.sample_bounds[0] + (int32_t)((tile % rc.ntx) * 16u), ty0 = rc.sample_bounds[1] + (int32_t)((tile / rc.ntx) * 16u);
+        int32_t tx1 = min(tx0 + 16, rc.sample_bounds[2]), ty1 = min(ty0 + 16, rc.sample_bounds[3]);
+        int64_t tb0 = max(f2i_sat(ceilf((float)tx0 - 0.5f - rc.filter_radius[0])), (int64_t)rc.crop[0]);
+        int64_t tb1 = max(f2i_sat(ceilf((float)ty0 - 0.5f - rc.filter_radius[1])), (int64_t)rc.crop[1]);
+        int64_t tb2 = min(f2i_sat(floorf((float)tx1 - 0.5f + rc.filter_radius[0])) + 1, (int64_t)rc.crop[2]);
+        int64_t tb3 = min(f2i_sat(floorf((float)ty1 - 0.5f + rc.filter_radius[1])) + 1, (int64_t)rc.crop[3]);
+        const float invrx = 1.0f / rc.filter_radius[0], invry = 1.0f / rc.filter_radius[1];
+        for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
+            const uint32_t pid = sl * rc.n_pix_slots + slot;
+            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+            // integrator.rs:350-368
+            if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
+            else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
+            else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
+            if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
+            const float dx = ps.pfilm_x[pid] - 0.5f, dy = ps.pfilm_y[pid] - 0.5f;
+            int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
+            int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
+            for (int64_t y = p0y; y < p1y; ++y) {
+                const float fy = fabsf(((float)y - dy) * invry * 16.0f);
+                const uint32_t iy = min(f2u32_sat(floorf(fy)), 15u);
+                for (int64_t x = p0x; x < p1x; ++x) {
+                    const float fx = fabsf(((float)x - dx) * invrx * 16.0f);
+                    const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
+                    const float fw = filter_table[iy * 16 + ix];
+                    const RGB c = L * RGB(1.0f) * RGB(fw);
+                    float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
+                    atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                    splats++;
+                }
+            }
+        }
+    }
+    counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
+    counter_add(&counters->san_inf, inf_c); counter_add(&counters->splats, splats);
+}
+
+// Film::merge_film_tile (film.rs:142-161): RGB sums -> XYZ, added to the caller's film.
+__global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float rgb[3] = {film_rgbw[4 * i], film_rgbw[4 * i + 1], film_rgbw[4 * i + 2]}, xyz[3];
+    rgb_to_xyz(rgb, xyz);
+    film_xyzw[4 * i] += xyz[0]; film_xyzw[4 * i + 1] += xyz[1]; film_xyzw[4 * i + 2] += xyz[2]; film_xyzw[4 * i + 3] += film_rgbw[4 * i + 3];
+}
+
+// ---- spatial light distribution (lightdistrib.rs:151-228), all voxels precomputed ---------------------------
+__global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t ncell = (size_t)nvx * nvy * nvz;
+    if (gid >= ncell * s.n_lights) return;
+    const uint32_t j = (uint32_t)(gid % s.n_lights);
+    const size_t cell = gid / s.n_lights;
+    const uint32_t pi0 = (uint32_t)(cell % nvx), pi1 = (uint32_t)((cell / nvx) % nvy), pi2 = (uint32_t)(cell / ((size_t)nvx * nvy));
+    V3 p0((float)pi0 / (float)nvx, (float)pi1 / (float)nvy, (float)pi2 / (float)nvz);
+    V3 p1((float)(pi0 + 1) / (float)nvx, (float)(pi1 + 1) / (float)nvy, (float)(pi2 + 1) / (float)nvz);
+    V3 a(lerpf(p0.x, s.wb_min[0], s.wb_max[0]), lerpf(p0.y, s.wb_min[1], s.wb_max[1]), lerpf(p0.z, s.wb_min[2], s.wb_max[2]));
+    V3 b(lerpf(p1.x, s.wb_min[0], s.wb_max[0]), lerpf(p1.y, s.wb_min[1], s.wb_max[1]), lerpf(p1.z, s.wb_min[2], s.wb_max[2]));
+    V3 vmin(minf(a.x, b.x), minf(a.y, b.y), minf(a.z, b.z)), vmax(maxf(a.x, b.x), maxf(a.y, b.y), maxf(a.z, b.z));
+    float contrib = 0.0f;
+    for (uint32_t i = 0; i < 128; ++i) {
+        V3 u3(radical_inverse(0, i), radical_inverse(1, i), radical_inverse(2, i));
+        IData intr;
+        intr.p = V3(lerpf(u3.x, vmin.x, vmax.x), lerpf(u3.y, vmin.y, vmax.y), lerpf(u3.z, vmin.z, vmax.z));
+        P2 u(radical_inverse(3, i), radical_inverse(4, i));
+        float pdf = 0.0f; V3 wi; IData vis;
+        RGB Li = light_sample_li(s, j, intr, u, wi, pdf, vis);
+        if (pdf > 0.0f) contrib += Li.y() / pdf;
+    }
+    func[gid] = contrib;
+}
+// Per voxel: floor at 0.001*avg, then Distribution1D::new (sampling.rs:12-34)
+__global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int) {
+    const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    float *f = func + cell * n_lights, *c = cdf + cell * (n_lights + 1);
+    float sum = 0.0f;
+    for (uint32_t j = 0; j < n_lights; ++j) sum += f[j];
+    const float avg = sum / (128.0f * (float)n_lights);
+    const float min_contrib = (avg > 0.0f) ? 0.001f * avg : 1.0f;
+    for (uint32_t j = 0; j < n_lights; ++j) f[j] = maxf(f[j], min_contrib);
+    c[0] = 0.0f;
+    for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] = c[i - 1] + f[i - 1] / (float)n_lights;
+    const float fi = c[n_lights];
+    if (fi == 0.0f) { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] = (float)i / (float)n_lights; }
+    else { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] /= fi; }
+    func_int[cell] = fi;
+}
+
+// ---- parity helpers -------------------------------------------------------------------------------------------
+__global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
+                                uint32_t n_dims, float *out, uint64_t *out_index) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
+    uint64_t index = sobol_interval_to_index(tabs, (uint32_t)sp.log2_resolution, sample_num[i], (uint32_t)(px - sp.sb_min[0]), (uint32_t)(py - sp.sb_min[1]));
+    if (out_index) out_index[i] = index;
+    for (uint32_t d = 0; d < n_dims; ++d)
+        out[(size_t)i * n_dims + d] = (d < 2) ? sobol_pixel_dim(tabs.m32, sp, index, (int)d, d == 0 ? px : py) : sobol_sample_float(tabs.m32, index, d);
+}
+__global__ void k_camera_rays(RenderConst rc, uint32_t n, const float *cs, float *out_o, float *out_d) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d;
+    camera_ray(rc, cs[5 * i], cs[5 * i + 1], cs[5 * i + 2], P2(cs[5 * i + 3], cs[5 * i + 4]), o, d);
+    out_o[3 * i] = o.x; out_o[3 * i + 1] = o.y; out_o[3 * i + 2] = o.z;
+    out_d[3 * i] = d.x; out_d[3 * i + 1] = d.y; out_d[3 * i + 2] = d.z;
+}

@@ -30,8 +30,6 @@ class Library:
         if not os.path.exists(path):
             raise PtError(f"{path} not found: build it with __graft_entry__.build() (no CPU fallback exists)")
         self.lib = A.bind(C.CDLL(path))
-        self.lib.pt_set_tables_path.argtypes = [C.c_char_p]
-        self.lib.pt_set_tables_path(TABLES_PATH.encode())
 
     def check(self, st, what=""):
         if st != A.PT_OK:
