@@ -95,7 +95,7 @@ typedef struct PtMaterial {
     float sigma;            /* matte             */
     float eta;              /* glass/uber index  */
     float roughness;        /* plastic/metal/uber "roughness" */
-    float u_roughness;      /* 0 => use roughness (uber/metal/glass/substrate)  */
+    float u_roughness;      /* glass/substrate: uroughness; metal/uber: < 0 => use `roughness` */
     float v_roughness;
     uint32_t remap_roughness;
 } PtMaterial;
@@ -230,7 +230,9 @@ typedef struct PtKernelStat {
     char name[32];
     uint64_t launches;
     double total_ms;                 /* HIP-event time on the render stream */
-    uint64_t items;                  /* rays / path vertices processed       */
+    uint64_t items;                  /* rays / path vertices / pixels processed */
+    uint64_t bvh_nodes;              /* trace kernels: Bounds3f::intersect_p2 executed (32 B each)  */
+    uint64_t triangle_tests;         /* trace kernels: triangle packets tested (48 B each)          */
 } PtKernelStat;
 
 typedef struct pt_scene pt_scene;

@@ -49,7 +49,7 @@ int upload_tables() {
     return PT_OK;
 }
 
-struct Stat { std::string name; uint64_t launches = 0; double ms = 0; uint64_t items = 0; };
+struct Stat { std::string name; uint64_t launches = 0; double ms = 0; uint64_t items = 0, nodes = 0, tris = 0; };
 struct TimedLaunch { int stat; hipEvent_t a, b; };
 
 }  // namespace
@@ -275,7 +275,7 @@ template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const
     hipLaunchKernelGGL(k_shade<MAXL>, dim3((upper + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
-int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
+int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
     const uint32_t total = rc.n_pix_slots * rc.s_count;
     QCounters *qc = sc->qc;
     HIP_TRY(hipMemsetAsync(qc, 0, offsetof(QCounters, error), sc->stream));
@@ -301,6 +301,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
         tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2;
         tj.class_count = &qc->shade[cur][0];
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
+        tj.kind = 0;
         sc->begin("extend", n_ext);
         int st = launch_trace(sc, false, tj, n_ext);
         sc->end();
@@ -310,6 +311,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
         tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;
         tj.out_prim = ps.mis_prim; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2;
         tj.class_count = nullptr;
+        tj.kind = 1;
         sc->begin("extend_mis", n_mis);
         st = launch_trace(sc, false, tj, n_mis);
         sc->end();
@@ -318,6 +320,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
         tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
         tj.ox = ps.sh_ox; tj.oy = ps.sh_oy; tj.oz = ps.sh_oz; tj.dx = ps.sh_dx; tj.dy = ps.sh_dy; tj.dz = ps.sh_dz;
         tj.out_occluded = ps.occluded;
+        tj.kind = 2;
         sc->begin("shadow", n_shadow);
         st = launch_trace(sc, true, tj, n_shadow);
         sc->end();
@@ -325,7 +328,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
         uint32_t class_n[kNumClasses];
         const uint32_t upper = n_ext + n_resolve;
-        if (sc->profile) {  // exact per-class item counts for the statistics (costs one extra sync per iteration)
+        if (rp_profile_exact) {  // exact per-class item counts for the statistics (costs one extra sync per iteration)
             QCounters h2;
             HIP_TRY(hipMemcpyAsync(&h2, qc, sizeof h2, hipMemcpyDeviceToHost, sc->stream));
             HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -339,7 +342,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid) {
             sj.shade_next0 = sc->q.shade[1 - cur][0]; sj.shade_next0_count = &qc->shade[1 - cur][0];
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc;
-            sc->begin(shade_names[c], sc->profile ? class_n[c] : 0);
+            sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
             else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
@@ -367,6 +370,8 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
+    static const char *kn[3] = {"extend", "extend_mis", "shadow"};
+    for (int k = 0; k < 3; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
 }
 
 }  // namespace
@@ -550,7 +555,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
-            if ((st = run_pass(sc, rc, sc->grid[eff]))) return st;
+            if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
         }
         float *dst = film_xyzw, *tmp = nullptr;
         std::vector<float> host;
@@ -598,6 +603,7 @@ int pt_get_kernel_stats(const pt_scene *sc, PtKernelStat *out, uint32_t max_entr
         std::memset(&out[i], 0, sizeof out[i]);
         std::snprintf(out[i].name, sizeof out[i].name, "%s", sc->stats[i].name.c_str());
         out[i].launches = sc->stats[i].launches; out[i].total_ms = sc->stats[i].ms; out[i].items = sc->stats[i].items;
+        out[i].bvh_nodes = sc->stats[i].nodes; out[i].triangle_tests = sc->stats[i].tris;
     }
     *n_out = n;
     return PT_OK;

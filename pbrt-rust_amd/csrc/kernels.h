@@ -52,6 +52,7 @@ struct QCounters {
 struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
+    unsigned long long k_nodes[3], k_tris[3], k_rays[3];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow
 };
 
 struct RenderConst {
@@ -86,6 +87,7 @@ struct TraceJob {
     uint32_t *spill;         // [waves_in_grid][64 lanes][kMaxStack - kLdsStack]
     uint32_t *error;
     DevCounters *counters;
+    uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow (per-kind work counters)
 };
 
 struct ShadeJob {

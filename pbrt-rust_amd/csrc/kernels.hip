@@ -176,6 +176,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     counter_add(&job.counters->nodes, n_nodes);
     counter_add(&job.counters->tri_tests, n_tris);
     counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
+    counter_add(&job.counters->k_nodes[job.kind], n_nodes);
+    counter_add(&job.counters->k_tris[job.kind], n_tris);
+    counter_add(&job.counters->k_rays[job.kind], n_rays);
 }
 template __global__ void k_trace<false>(DeviceScene, TraceJob);
 template __global__ void k_trace<true>(DeviceScene, TraceJob);

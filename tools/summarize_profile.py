@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel stats + PMC passes) into a compact text/JSON report.
+FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide streaming reads (MI355X_MICROARCH.md, HBM):
+reported raw AND doubled; WRITE_SIZE is exact for 16-B streaming stores and float atomics. Units: KiB."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+def short(name):
+    n = name.split("(")[0]
+    for k in ("k_trace<false>", "k_trace<true>", "k_shade<1>", "k_shade<2>", "k_shade<5>"):
+        if k in name:
+            return k
+    return n.replace("void ", "").strip()
+
+
+report = {}
+print("== kernel stats (rocprofv3 --kernel-trace --stats)")
+stats = list(rows("stats/**/*kernel_stats.csv"))
+for r in stats[:16]:
+    name = short(r.get("Name", ""))
+    calls, total, avg, pct = r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")
+    print(f"{name:32s} calls={calls:>6s} total_ms={float(total)/1e6:10.3f} avg_us={float(avg)/1e3:10.2f} pct={pct}")
+    report.setdefault("kernel_stats", []).append(dict(name=name, calls=int(calls), total_ms=float(total) / 1e6, avg_us=float(avg) / 1e3, pct=float(pct)))
+
+for tag, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+    acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(int)
+    for r in rows(f"{tag}/**/*counter_collection.csv"):
+        k = short(r.get("Kernel_Name", ""))
+        c = r.get("Counter_Name"); v = float(r.get("Counter_Value", 0))
+        acc[k][c] += v
+        if c == counters[0]:
+            n[k] += 1
+    if not acc:
+        continue
+    print(f"== {tag}")
+    for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
+        line = f"{k:32s} dispatches={n[k]:5d} " + " ".join(f"{c}={acc[k][c]:.4g} (per dispatch {acc[k][c]/max(1,n[k]):.4g})" for c in counters)
+        print(line)
+        report.setdefault(tag, {})[k] = dict(dispatches=n[k], **{c: acc[k][c] for c in counters})
+
+json.dump(report, open(os.path.join(out, "summary.json"), "w"), indent=1)
