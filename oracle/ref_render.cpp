@@ -574,3 +574,48 @@ void orc_offset_ray_origin(const float *p, const float *perr, const float *n, co
 }
 
 }  // extern "C"
+
+// ---- property tests restated from the reference's tests/shapes.rs (run inside the oracle for speed) ----
+extern "C" {
+// tests/shapes.rs:173-224 triangle_reintersect: same PCG32 seeds (RNG::new(i)), pexp(rng, 8), 10 000 spawned rays
+// per triangle must not re-hit it (intersect_p and intersect). Returns the number of violations; *n_tested counts
+// the triangles that were actually hit by the first ray.
+static float pexp_(RNG &rng, float e) { float logu = lerp(rng.uniform_float(), -e, e); return std::pow(10.0f, logu); }
+int orc_test_triangle_reintersect(int n_seeds, int rays_per_tri, int *n_tested) {
+    int failures = 0, tested = 0;
+    for (int i = 0; i < n_seeds; ++i) {
+        RNG rng((uint64_t)i);
+        V3 v[3];
+        for (int j = 0; j < 3; ++j) { v[j].x = pexp_(rng, 8.0f); v[j].y = pexp_(rng, 8.0f); v[j].z = pexp_(rng, 8.0f); }
+        if (length_squared(cross(v[1] - v[0], v[2] - v[0])) < 1.0e-20f) continue;
+        Scene s;
+        s.P = {v[0], v[1], v[2]}; s.idx = {0, 1, 2}; s.tri_flags = {0};
+        P2 u; u.x = rng.uniform_float(); u.y = rng.uniform_float();
+        P2 b = uniform_sample_triangle(u);
+        V3 ptri = v[0] * b.x + v[1] * b.y + v[2] * (1.0f - b.x - b.y);
+        V3 o; o.x = pexp_(rng, 8.0f); o.y = pexp_(rng, 8.0f); o.z = pexp_(rng, 8.0f);
+        Ray r(o, ptri - o, INF, 0.0f);
+        Float t, bb[3];
+        if (!s.tri_intersect(0, r, t, bb)) continue;
+        SurfaceInteraction isect; s.tri_fill_interaction(0, r, t, bb, true, isect);
+        tested++;
+        for (int j = 0; j < rays_per_tri; ++j) {
+            P2 uu; uu.x = rng.uniform_float(); uu.y = rng.uniform_float();
+            V3 w = uniform_sample_sphere(uu);
+            IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
+            Ray rout = spawn_ray(it, w);
+            Float t2, b2[3];
+            if (s.tri_hit_params(0, rout, t2, b2)) failures++;
+            if (s.tri_intersect(0, rout, t2, b2)) failures++;
+            V3 p2; p2.x = pexp_(rng, 8.0f); p2.y = pexp_(rng, 8.0f); p2.z = pexp_(rng, 8.0f);
+            // spawn_rayto_point, interaction.rs:38-43
+            V3 d = p2 - it.p;
+            Ray r2(offset_ray_origin(it.p, it.p_error, it.n, d), d, 1.0f - SHADOW_EPSILON, 0.0f);
+            if (s.tri_hit_params(0, r2, t2, b2)) failures++;
+            if (s.tri_intersect(0, r2, t2, b2)) failures++;
+        }
+    }
+    if (n_tested) *n_tested = tested;
+    return failures;
+}
+}
