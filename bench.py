@@ -116,7 +116,7 @@ def main():
     # --- roofline of the dominant kernel: algorithmic bytes / HIP-event time
     # trace kernels: 32 B per BVH node visited + 48 B per triangle packet tested + 44 B per ray (pid 4, ray 24, hit record 16)
     def algo_bytes(name, s):
-        if name in ("extend", "extend_mis", "shadow"):
+        if name in ("extend", "extend_mis", "shadow", "extend_camera"):
             return 32 * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
         return None
     dom = max(kstats.items(), key=lambda kv: kv[1]["total_ms"]) if kstats else None
@@ -125,7 +125,7 @@ def main():
         name, s = dom
         ab = algo_bytes(name, s)
         if ab is None:  # dominant kernel is not a trace kernel: report the heaviest trace kernel instead
-            tr = [(n, v) for n, v in kstats.items() if n in ("extend", "extend_mis", "shadow")]
+            tr = [(n, v) for n, v in kstats.items() if n in ("extend", "extend_mis", "shadow", "extend_camera")]
             name, s = max(tr, key=lambda kv: kv[1]["total_ms"])
             ab = algo_bytes(name, s)
         achieved = ab / (s["total_ms"] * 1e-3) / 1e9
@@ -140,7 +140,9 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         launches=s["launches"], avg_launch_ms=round(s["total_ms"] / max(1, s["launches"]), 4),
                         algorithmic_bytes_per_launch=int(ab / max(1, s["launches"])))
-    kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps) for n, v in kstats.items()}
+    kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps,
+                       **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in ("extend", "extend_mis", "shadow", "extend_camera") else {}))
+               for n, v in kstats.items()}
 
     cpu_baseline = None
     if args.cpu_seconds > 0 and world == 1:

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,6 +19,9 @@ namespace {
 std::string g_error;
 int g_device = -1;
 int g_num_cus = 256;
+// traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
+uint32_t g_refill_min[4] = {32, 32, 32, 64};     // per launch kind: extend, extend_mis, shadow, extend_camera
+uint32_t g_leaf_quorum[4] = {20, 20, 20, 8};
 SobolTables g_tabs = {nullptr, nullptr, nullptr};
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
@@ -137,8 +141,9 @@ void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func
     else { for (size_t i = 1; i < n + 1; ++i) cdf[i] /= func_int; }
 }
 
-int launch_trace(pt_scene *sc, bool any, const TraceJob &job, uint32_t n_upper) {
+int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
     if (n_upper == 0) return PT_OK;
+    job.refill_min = g_refill_min[job.kind & 3]; job.leaf_quorum = g_leaf_quorum[job.kind & 3];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
     if (any) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
@@ -154,7 +159,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         if ((st = sc->dalloc(&sc->qc, 1))) return st;
         if ((st = sc->dalloc(&sc->dc, 1))) return st;
         sc->spill_waves = (uint32_t)g_num_cus * 16u;  // 16 waves per CU resident at most (LDS: 6 KB per wave)
-        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * (kMaxStack - kLdsStack)))) return st;
+        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * (kMaxStack - kLdsStack)))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
     }
     if (capacity > sc->capacity) {
@@ -301,8 +306,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2;
         tj.class_count = &qc->shade[cur][0];
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
-        tj.kind = 0;
-        sc->begin("extend", n_ext);
+        tj.kind = (iter == 0) ? 3 : 0;
+        sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
         int st = launch_trace(sc, false, tj, n_ext);
         sc->end();
         if (st) return st;
@@ -370,8 +375,8 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
-    static const char *kn[3] = {"extend", "extend_mis", "shadow"};
-    for (int k = 0; k < 3; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
+    static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
+    for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
 }
 
 }  // namespace
@@ -388,6 +393,8 @@ int pt_init(int device_ordinal) {
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr}; }
     g_device = device_ordinal;
+    if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; } }
+    if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
     return upload_tables();
 }
 
@@ -437,7 +444,30 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     }
     // uploads
 #define UP(field, src, count) if ((st = sc->upload(&ds.field, src, (size_t)(count)))) return bail(st)
-    UP(nodes, sc->nodes.data(), sc->nodes.size()); ds.n_nodes = (uint32_t)sc->nodes.size();
+    std::vector<uint32_t> leaf_last;
+    {   // two-wide traversal records: one per interior node, children's bounds inline (dev_scene.h: WideNode)
+        const std::vector<PtBVHNode> &nn = sc->nodes;
+        if (nn.size() > (size_t)kRefMask || d->n_prims > kRefMask) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^25 BVH nodes / primitives"));
+        std::vector<uint32_t> wide_id(nn.size(), 0);
+        uint32_t n_int = 0;
+        for (size_t i = 0; i < nn.size(); ++i) { if (nn[i].n_prims == 0) wide_id[i] = n_int++; else leaf_last.push_back(nn[i].offset + nn[i].n_prims - 1); }
+        auto ref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | nn[i].offset) : wide_id[i]; };
+        std::vector<WideNode> wide(std::max<uint32_t>(1, n_int));
+        for (size_t i = 0; i < nn.size(); ++i) {
+            if (nn[i].n_prims) continue;
+            WideNode &w = wide[wide_id[i]];
+            const PtBVHNode &l = nn[i + 1], &r = nn[nn[i].offset];
+            w.lmin[0] = l.bmin[0]; w.lmin[1] = l.bmin[1]; w.lmin[2] = l.bmin[2]; w.lmax0 = l.bmax[0];
+            w.lmax12[0] = l.bmax[1]; w.lmax12[1] = l.bmax[2]; w.rmin01[0] = r.bmin[0]; w.rmin01[1] = r.bmin[1];
+            w.rmin2 = r.bmin[2]; w.rmax[0] = r.bmax[0]; w.rmax[1] = r.bmax[1]; w.rmax[2] = r.bmax[2];
+            w.left_ref = ref_of((uint32_t)i + 1); w.right_ref = ref_of(nn[i].offset);
+            w.meta = nn[i].axis; w.pad = 0;
+        }
+        UP(wide, wide.data(), wide.size());
+        ds.n_nodes = (uint32_t)nn.size();
+        for (int k = 0; k < 3; ++k) { ds.root_min[k] = nn[0].bmin[k]; ds.root_max[k] = nn[0].bmax[k]; }
+        ds.root_ref = ref_of(0);
+    }
     UP(P, d->P, 3 * (size_t)d->n_vertices);
     if (d->N) UP(N, d->N, 3 * (size_t)d->n_vertices);
     if (d->S) UP(S, d->S, 3 * (size_t)d->n_vertices);
@@ -490,10 +520,16 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const uint32_t *d_ordered = nullptr;
         if ((st = sc->upload(&d_ordered, sc->ordered.data(), sc->ordered.size()))) return bail(st);
         TriPacket *leaf = nullptr; float *area = nullptr;
-        if ((st = sc->dalloc(&leaf, d->n_prims))) return bail(st);
+        if ((st = sc->dalloc(&leaf, (size_t)d->n_prims + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
+        if (hipMemset(leaf, 0, ((size_t)d->n_prims + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         hipLaunchKernelGGL(k_build_packets, dim3((d->n_prims + 255) / 256), dim3(256), 0, 0, ds, d_ordered, leaf);
         ds.leaf = leaf;
+        {
+            const uint32_t *d_last = nullptr;
+            if ((st = sc->upload(&d_last, leaf_last.data(), leaf_last.size()))) return bail(st);
+            hipLaunchKernelGGL(k_mark_leaf_ends, dim3(((uint32_t)leaf_last.size() + 255) / 256), dim3(256), 0, 0, leaf, d_last, (uint32_t)leaf_last.size());
+        }
         if (d->n_lights) hipLaunchKernelGGL(k_light_area, dim3((d->n_lights + 255) / 256), dim3(256), 0, 0, ds, area);
         ds.light_area = area;
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return bail(fail(PT_ERR_HIP, "scene preparation kernels failed"));
@@ -543,7 +579,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
         uint32_t S = rp->spp_per_pass;
-        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 23) / rc.n_pix_slots);
+        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 25) / rc.n_pix_slots);  // ~33 M paths in flight (7 GB of state)
         S = std::min(S, rp->spp);
         if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
@@ -635,9 +671,14 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     tj.tmax = din + 6 * (size_t)n;
     tj.out_prim = dprim; tj.out_t = dout; tj.out_b0 = dout + n; tj.out_b1 = dout + 2 * (size_t)n; tj.out_b2 = dout + 3 * (size_t)n;
     tj.out_occluded = docc; tj.class_count = nullptr; tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
+    sc->profile = true; sc->stats.clear();
+    tj.kind = any ? 2 : 0;
+    sc->begin(any ? "trace_any_api" : "trace_closest_api", n);
     st = launch_trace(sc, any, tj, n);
+    sc->end();
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(sc->stream));
+    sc->resolve_timings();
     QCounters h;
     HIP_TRY(hipMemcpy(&h, sc->qc, sizeof h, hipMemcpyDeviceToHost));
     if (any) HIP_TRY(hipMemcpy(hit, docc, n, hipMemcpyDeviceToHost));

@@ -18,10 +18,25 @@ struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads p
     float p1yz[2]; float p2xy[2];
     float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
 };
-enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9 };  // flags: low 8 bits = PT_TRI_* bits
+enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
+
+// Two-wide traversal record (64 B, four dwordx4 loads): one per INTERIOR node of the reference tree, holding the
+// bounds of both children, so that a ray fetches once per interior node it enters instead of once per node it tests.
+// Child reference: bit 31 set => leaf, low bits = first packet of the leaf in `leaf`; else index of the child's record.
+struct WideNode {
+    float lmin[3]; float lmax0;
+    float lmax12[2]; float rmin01[2];
+    float rmin2; float rmax[3];
+    uint32_t left_ref, right_ref;
+    uint32_t meta;   // bits 0-7: split axis (bvh.rs:671,686)
+    uint32_t pad;
+};
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kRefMask = 0x01ffffffu;   // 25 bits: 33 M records / packets (stack entries pack 6 more bits above)
 
 struct DeviceScene {
-    const PtBVHNode *nodes; uint32_t n_nodes;
+    const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
+    float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
     const TriPacket *leaf; uint32_t n_prims;
     const float *P; const float *N; const float *S; const float *UV;
     const uint32_t *indices; const uint8_t *tri_flags; uint32_t n_triangles;
@@ -189,6 +204,28 @@ PT_DEV bool slab_test(const float bmin[3], const float bmax[3], V3 ro, V3 inv_di
     if (tzmin > tmin) tmin = tzmin;
     if (tzmax < tmax) tmax = tzmax;
     return (tmin < ray_tmax) && (tmax > 0.0f);
+}
+// The same arithmetic split in two: the part that does not depend on ray.t_max (returned bool: slabs overlap and
+// tmax > 0) and the entry distance tmin_out; intersect_p2 == slab_geo(..) && tmin_out < ray.t_max.
+PT_DEV bool slab_geo(const float bmin[3], const float bmax[3], V3 ro, V3 inv_dir, bool nx, bool ny, bool nz, float &tmin_out) {
+    float tmin = ((nx ? bmax[0] : bmin[0]) - ro.x) * inv_dir.x;
+    float tmax = ((nx ? bmin[0] : bmax[0]) - ro.x) * inv_dir.x;
+    float tymin = ((ny ? bmax[1] : bmin[1]) - ro.y) * inv_dir.y;
+    float tymax = ((ny ? bmin[1] : bmax[1]) - ro.y) * inv_dir.y;
+    const float k = 1.0f + 2.0f * gammaf(3);
+    tmax *= k; tymax *= k;
+    tmin_out = PT_INF;
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? bmax[2] : bmin[2]) - ro.z) * inv_dir.z;
+    float tzmax = ((nz ? bmin[2] : bmax[2]) - ro.z) * inv_dir.z;
+    tzmax *= k;
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    tmin_out = tmin;
+    return tmax > 0.0f;
 }
 
 }  // namespace ptd

@@ -7,7 +7,7 @@
 namespace ptd {
 
 constexpr int kNumClasses = 4;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber
-constexpr int kLdsStack = 24;       // traversal stack entries kept in LDS per lane; deeper entries spill to HBM
+constexpr int kLdsStack = 12;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
 
@@ -52,7 +52,7 @@ struct QCounters {
 struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
-    unsigned long long k_nodes[3], k_tris[3], k_rays[3];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow
+    unsigned long long k_nodes[4], k_tris[4], k_rays[4];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera
 };
 
 struct RenderConst {
@@ -84,10 +84,12 @@ struct TraceJob {
     // shade-queue routing (closest-hit of continuation rays only)
     uint32_t *class_count;   // [kNumClasses] or NULL
     uint32_t *class_buf[kNumClasses];
-    uint32_t *spill;         // [waves_in_grid][64 lanes][kMaxStack - kLdsStack]
+    uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - kLdsStack)]
     uint32_t *error;
     DevCounters *counters;
-    uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow (per-kind work counters)
+    uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera (per-kind work counters)
+    uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)
+    uint32_t leaf_quorum;    // leave the node phase once this many lanes wait at a leaf
 };
 
 struct ShadeJob {

@@ -63,6 +63,12 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, TriPacke
     out[i] = p;
 }
 
+// Mark the last packet of every leaf (offsets of the last primitive of each leaf, computed on the host).
+__global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) leaf[last_index[i]].flags |= TP_LAST;
+}
+
 __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight::new -> shape.area()
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n_lights) return;
@@ -80,98 +86,183 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 
 // ---- BVH traversal ---------------------------------------------------------------------------------
 
+// Persistent waves ("persistent threads"): every lane owns one ray at a time; lanes whose ray has finished are
+// refilled from the queue with one atomicAdd per wave, so a wave stays populated until the queue drains.
+//
+// The reference visits nodes one at a time (test node, then push far child / descend near child, bvh.rs:728-751).
+// Here one 64-byte record per interior node carries BOTH children's bounds, so a ray performs one dependent fetch
+// per interior node it enters instead of one per node it tests. Results and counters stay those of the reference:
+//  * the near child is tested immediately with the current t_max -- exactly when the reference tests it;
+//  * the far child's slab arithmetic is evaluated now but its `tmin < ray.t_max` comparison is deferred to pop time
+//    (tmin is kept on the stack), which is when the reference performs the whole test with the then-current t_max;
+//  * a far child whose t_max-independent part already fails is not pushed; the reference would pop, test and
+//    discard it later, so the number of such skipped entries lying directly below each pushed entry is carried along
+//    (6 bits in the stack word) and added to the node-visit counter at the moment the reference would pop them.
+// Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
+
 template <bool ANY>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
-    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 64];
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 64) + lane;
-    uint32_t *spill = job.spill + ((size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 + lane) * (kMaxStack - kLdsStack);
+    uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    uint32_t *spill = job.spill + ((size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 + lane) * (2 * (kMaxStack - kLdsStack));
     const uint32_t count = *job.count;
-    const uint4 *nodes4 = reinterpret_cast<const uint4 *>(s.nodes);
+    const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
-    unsigned long long n_nodes = 0, n_tris = 0, n_rays = 0;
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+
+    // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
+    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
+    uint32_t state = ST_IDLE;
+    bool exhausted = false;
+    uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
+    V3 ro, rd, inv_dir;
+    bool nx = false, ny = false, nz = false, found = false;
+    float t_max = 0.0f;
+    uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+
+    // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
+    auto pop_next = [&]() {
+        for (;;) {
+            n_nodes += pending; pending = 0;          // skipped far children above the top entry: popped + failed
+            if (sp == 0) { state = ST_DONE; return; }
+            sp--;
+            uint32_t w0, w1;
+            if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
+            else { w0 = spill[2 * (sp - kLdsStack)]; w1 = spill[2 * (sp - kLdsStack) + 1]; }
+            n_nodes++;                                 // the reference tests the popped node now
+            pending = (w0 >> 25) & 63u;
+            if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
+                cur = w0 & kRefMask;
+                state = (w0 & kLeafBit) ? ST_LEAF : ST_ENTER;
+                return;
+            }
+        }
+    };
 
     for (;;) {
-        uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(job.head, 64u);
-        chunk = __shfl(chunk, 0);
-        if (chunk >= count) break;
-        const uint32_t qi = chunk + lane;
-        const bool valid = qi < count;
-        uint32_t pid = 0;
-        bool found = false;
-        uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
-        if (valid) {
-            pid = job.queue ? job.queue[qi] : qi;
-            V3 ro(job.ox[pid], job.oy[pid], job.oz[pid]), rd(job.dx[pid], job.dy[pid], job.dz[pid]);
-            float t_max = job.tmax ? job.tmax[pid] : job.scalar_tmax;
-            n_rays++;
-            if (s.n_nodes > 0) {
-                V3 inv_dir(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                const bool nx = inv_dir.x < 0.0f, ny = inv_dir.y < 0.0f, nz = inv_dir.z < 0.0f;
-                uint32_t sp = 0, cur = 0;
-                for (;;) {
-                    const uint4 a = nodes4[2 * cur], b = nodes4[2 * cur + 1];
-                    n_nodes++;
-                    const float bmin[3] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)};
-                    const float bmax[3] = {__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)};
-                    bool pop = true;
-                    if (slab_test(bmin, bmax, ro, inv_dir, nx, ny, nz, t_max)) {
-                        const uint32_t nprims = b.w & 0xffffu;
-                        if (nprims > 0) {
-                            bool done = false;
-                            for (uint32_t i = 0; i < nprims; ++i) {
-                                const uint32_t li = b.z + i;
-                                const uint4 q0 = leaf4[3 * li], q1 = leaf4[3 * li + 1], q2 = leaf4[3 * li + 2];
-                                const uint32_t fl = q2.w;
-                                if (fl & TP_SPHERE) { continue; }  // spheres: row a14, not yet on device
-                                n_tris++;
-                                V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-                                V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-                                V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
-                                float t, b0, b1, b2;
-                                if (tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2)) {
-                                    if (ANY) { found = true; done = true; break; }
-                                    if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
-                                        found = true; t_max = t;  // primitive.rs:137
-                                        hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
-                                    }
-                                }
-                            }
-                            if (done) break;
-                        } else {
-                            const uint32_t axis = (b.w >> 16) & 0xffu;
-                            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                            const uint32_t far_child = neg ? cur + 1 : b.z;
-                            const uint32_t near_child = neg ? b.z : cur + 1;
-                            if (sp < (uint32_t)kLdsStack) stack[sp * 64] = far_child;
-                            else if (sp < (uint32_t)kMaxStack) spill[sp - kLdsStack] = far_child;
-                            else atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
-                            if (sp < (uint32_t)kMaxStack) sp++;
-                            cur = near_child;
-                            pop = false;
+        // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
+        //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
+        //      paid once per batch instead of once per ray.
+        const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
+        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF);
+        if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
+            const bool retire = state == ST_DONE;
+            if (retire) {
+                if (ANY) job.out_occluded[pid] = found ? 1 : 0;
+                else {
+                    job.out_prim[pid] = hit_prim;
+                    if (job.out_t) job.out_t[pid] = hit_t;
+                    job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
+                }
+            }
+            if (!ANY && job.class_count) {
+                uint32_t cls = 0;
+                if (retire && found) { uint32_t m = s.prim_material[hit_prim]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+                for (int c = 0; c < kNumClasses; ++c) queue_push(job.class_count + c, job.class_buf[c], pid, retire && cls == (uint32_t)c);
+            }
+            if (retire) state = ST_IDLE;
+            if (!exhausted) {
+                const uint32_t nidle = (uint32_t)__popcll(donem);
+                const uint32_t leader = (uint32_t)__ffsll((long long)donem) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(job.head, nidle);
+                base = __shfl(base, (int)leader);
+                if (base + nidle >= count) exhausted = true;
+                const uint32_t qi = base + (uint32_t)__popcll(donem & ((1ull << lane) - 1ull));
+                if (state == ST_IDLE && qi < count) {
+                    pid = job.queue ? job.queue[qi] : qi;
+                    ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]);
+                    rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
+                    t_max = job.tmax ? job.tmax[pid] : job.scalar_tmax;
+                    inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                    sp = 0; pending = 0; found = false;
+                    hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                    n_rays++;
+                    state = ST_DONE;
+                    if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
+                        n_nodes++;
+                        if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
+                            cur = s.root_ref & kRefMask;
+                            state = (s.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                         }
-                    }
-                    if (pop) {
-                        if (sp == 0) break;
-                        sp--;
-                        cur = (sp < (uint32_t)kLdsStack) ? stack[sp * 64] : spill[sp - kLdsStack];
                     }
                 }
             }
-            if (ANY) job.out_occluded[pid] = found ? 1 : 0;
-            else {
-                job.out_prim[pid] = hit_prim;
-                if (job.out_t) job.out_t[pid] = hit_t;
-                job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
+        }
+        if (__ballot(state != ST_IDLE) == 0ull) break;   // queue drained and every lane retired
+
+        // ---- phase 1: enter interior nodes
+        for (;;) {
+            const unsigned long long em = __ballot(state == ST_ENTER);
+            if (em == 0ull) break;
+            if ((uint32_t)__popcll(__ballot(state == ST_LEAF)) >= job.leaf_quorum) break;
+            if (state == ST_ENTER) {
+                const uint4 q0 = wide4[4 * (size_t)cur], q1 = wide4[4 * (size_t)cur + 1], q2 = wide4[4 * (size_t)cur + 2], q3 = wide4[4 * (size_t)cur + 3];
+                const float lmin[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+                const float lmax[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                const float rmin[3] = {__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+                const float rmax[3] = {__uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w)};
+                const uint32_t axis = q3.z & 0xffu;
+                const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);   // near child = right when the ray is negative along the split axis
+                float tmin_l, tmin_r;
+                const bool geo_l = slab_geo(lmin, lmax, ro, inv_dir, nx, ny, nz, tmin_l);
+                const bool geo_r = slab_geo(rmin, rmax, ro, inv_dir, nx, ny, nz, tmin_r);
+                const bool geo_near = neg ? geo_r : geo_l, geo_far = neg ? geo_l : geo_r;
+                const float tmin_near = neg ? tmin_r : tmin_l, tmin_far = neg ? tmin_l : tmin_r;
+                const uint32_t near_ref = neg ? q3.y : q3.x, far_ref = neg ? q3.x : q3.y;
+                // reference: push far, cur = near, test near
+                if (geo_far) {
+                    if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    else {
+                        const uint32_t w0 = far_ref | (pending << 25), w1 = __float_as_uint(tmin_far);
+                        if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
+                        else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = w1; }
+                        sp++; pending = 0;
+                    }
+                } else pending++;
+                n_nodes++;  // the near child's test
+                if (geo_near && tmin_near < t_max) {
+                    cur = near_ref & kRefMask;
+                    state = (near_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                } else pop_next();
             }
         }
-        if (!ANY && job.class_count) {
-            uint32_t cls = 0;
-            if (valid && found) { uint32_t m = s.prim_material[hit_prim]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
-            for (int c = 0; c < kNumClasses; ++c) queue_push(job.class_count + c, job.class_buf[c], pid, valid && cls == (uint32_t)c);
+
+        // ---- phase 2: leaf packets in ordered_prims order, two at a time (both loads in flight together)
+        if (state == ST_LEAF) {
+            bool last = false;
+            uint32_t li = cur;
+            while (!last) {
+                const uint4 a0 = leaf4[3 * (size_t)li], a1 = leaf4[3 * (size_t)li + 1], a2 = leaf4[3 * (size_t)li + 2];
+                const uint4 c0 = leaf4[3 * (size_t)li + 3], c1 = leaf4[3 * (size_t)li + 4], c2 = leaf4[3 * (size_t)li + 5];  // array is padded by one packet
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 q0 = k ? c0 : a0, q1 = k ? c1 : a1, q2 = k ? c2 : a2;
+                    const uint32_t fl = q2.w;
+                    if (!(fl & TP_SPHERE)) {  // spheres: row a14, not yet on device
+                        n_tris++;
+                        V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                        V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+                        V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+                        float t, b0, b1, b2;
+                        if (tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2)) {
+                            if (ANY) { found = true; last = true; state = ST_DONE; break; }
+                            if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
+                                found = true; t_max = t;  // primitive.rs:137
+                                hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                            }
+                        }
+                    }
+                    if (fl & TP_LAST) { last = true; break; }
+                }
+                li += 2;
+            }
+            if (state == ST_LEAF) pop_next();
         }
+
     }
     counter_add(&job.counters->nodes, n_nodes);
     counter_add(&job.counters->tri_tests, n_tris);
