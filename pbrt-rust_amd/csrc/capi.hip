@@ -277,7 +277,8 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 }
 
 template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
-    hipLaunchKernelGGL(k_shade<MAXL>, dim3((upper + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
+    hipLaunchKernelGGL(k_shade<MAXL>, dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
@@ -285,7 +286,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     QCounters *qc = sc->qc;
     HIP_TRY(hipMemsetAsync(qc, 0, offsetof(QCounters, error), sc->stream));
     sc->begin("generate", total);
-    hipLaunchKernelGGL(k_generate, dim3((total + 255) / 256), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
+    hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * 16u)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
     static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber"};
@@ -307,10 +308,18 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         tj.class_count = &qc->shade[cur][0];
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
         tj.kind = (iter == 0) ? 3 : 0;
+        tj.class_count = nullptr;
         sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
         int st = launch_trace(sc, false, tj, n_ext);
         sc->end();
         if (st) return st;
+        if (n_ext) {  // material-sorted shade queues
+            sc->begin("route", n_ext);
+            hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
+                               (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], (const uint32_t *)ps.hit_prim, &qc->shade[cur][0],
+                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3]);
+            sc->end();
+        }
         // MIS rays of the previous vertex (closest hit, integrator.rs:215)
         tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
         tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;

@@ -36,6 +36,37 @@ PT_DEV void counter_add(unsigned long long *dst, unsigned long long v) {  // cal
     if (lane_id() == 0 && v) atomicAdd(dst, v);
 }
 
+// Block-level staging of queue appends. A single global counter sustains only ~88 returning atomics per
+// microsecond (MI355X_MICROARCH.md, row "dequeue"); one atomic per wave made every queue-producing kernel atomic
+// bound. Appends therefore go to an LDS buffer with LDS atomics (one per wave) and a whole block flushes ~1000
+// entries with ONE global atomic. All threads of the block must call lq_sync_flush together.
+template <int CAP> struct LdsQueue { uint32_t count; uint32_t base; uint32_t buf[CAP]; };
+template <int CAP> PT_DEV void lq_init(LdsQueue<CAP> &q) { if (threadIdx.x == 0) { q.count = 0; q.base = 0; } }
+template <int CAP> PT_DEV void lq_push(LdsQueue<CAP> &q, uint32_t value, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&q.count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) q.buf[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+// Flush when fewer than `reserve` free slots remain (or force). Block-uniform; contains __syncthreads().
+template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount, uint32_t *gbuf, uint32_t reserve, bool force) {
+    __syncthreads();
+    const uint32_t n = q.count;
+    if (n != 0 && (force || n + reserve > (uint32_t)CAP)) {
+        if (threadIdx.x == 0) q.base = atomicAdd(gcount, n);
+        __syncthreads();
+        const uint32_t b = q.base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gbuf[b + i] = q.buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) q.count = 0;
+    }
+    __syncthreads();
+}
+
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
 // (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
@@ -116,6 +147,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
     uint32_t state = ST_IDLE;
     bool exhausted = false;
+    constexpr int kChunk = 256;
+    uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
     V3 ro, rd, inv_dir;
     bool nx = false, ny = false, nz = false, found = false;
@@ -157,21 +190,23 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                     job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
                 }
             }
-            if (!ANY && job.class_count) {
-                uint32_t cls = 0;
-                if (retire && found) { uint32_t m = s.prim_material[hit_prim]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
-                for (int c = 0; c < kNumClasses; ++c) queue_push(job.class_count + c, job.class_buf[c], pid, retire && cls == (uint32_t)c);
-            }
             if (retire) state = ST_IDLE;
             if (!exhausted) {
-                const uint32_t nidle = (uint32_t)__popcll(donem);
-                const uint32_t leader = (uint32_t)__ffsll((long long)donem) - 1u;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(job.head, nidle);
-                base = __shfl(base, (int)leader);
-                if (base + nidle >= count) exhausted = true;
-                const uint32_t qi = base + (uint32_t)__popcll(donem & ((1ull << lane) - 1ull));
-                if (state == ST_IDLE && qi < count) {
+                // work fetch: the wave reserves kChunk consecutive queue entries with one atomic and hands them
+                // out over several refills (consecutive entries are spatially coherent rays)
+                if (chunk_left == 0) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(job.head, (uint32_t)kChunk);
+                    chunk_next = __shfl(base, 0);
+                    chunk_left = (chunk_next < count) ? min((uint32_t)kChunk, count - chunk_next) : 0u;
+                    if (chunk_left == 0) exhausted = true;
+                }
+                const uint32_t rank = (uint32_t)__popcll(donem & ((1ull << lane) - 1ull));
+                const uint32_t take = min(chunk_left, (uint32_t)__popcll(donem));
+                const uint32_t qi = chunk_next + rank;
+                const bool get = state == ST_IDLE && rank < take;
+                chunk_next += take; chunk_left -= take;
+                if (get) {
                     pid = job.queue ? job.queue[qi] : qi;
                     ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]);
                     rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
@@ -274,6 +309,33 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
 template __global__ void k_trace<false>(DeviceScene, TraceJob);
 template __global__ void k_trace<true>(DeviceScene, TraceJob);
 
+// ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
+// Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
+// material's class (misses -> class 0). Block-level staged appends: one global atomic per ~1000 entries per class.
+__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *hit_prim,
+                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3) {
+    __shared__ LdsQueue<1024> q0, q1, q2, q3;
+    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3);
+    __syncthreads();
+    const uint32_t count = *count_ptr;
+    const uint32_t rounded = (count + 255u) & ~255u;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+        const bool valid = qi < count;
+        uint32_t pid = 0, cls = 0;
+        if (valid) {
+            pid = queue[qi];
+            const uint32_t hp = hit_prim[pid];
+            if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+        }
+        lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
+        lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u);
+        lq_sync_flush(q0, class_count + 0, c0, 256u, false); lq_sync_flush(q1, class_count + 1, c1, 256u, false);
+        lq_sync_flush(q2, class_count + 2, c2, 256u, false); lq_sync_flush(q3, class_count + 3, c3, 256u, false);
+    }
+    lq_sync_flush(q0, class_count + 0, c0, 0u, true); lq_sync_flush(q1, class_count + 1, c1, 0u, true);
+    lq_sync_flush(q2, class_count + 2, c2, 0u, true); lq_sync_flush(q3, class_count + 3, c3, 0u, true);
+}
+
 // ---- camera rays -------------------------------------------------------------------------------------
 // pixel slot -> pixel: slot = tile_slot*256 + ty*16 + tx, tile index = tile_rank + tile_slot*tile_world
 PT_DEV bool slot_to_pixel(const RenderConst &rc, uint32_t slot, int32_t &px, int32_t &py) {
@@ -309,56 +371,86 @@ PT_DEV void camera_ray(const RenderConst &rc, float pfx, float pfy, float time_u
 }
 
 __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
-    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    // LDS copies of what every lane needs: Sobol' rows of dimensions 0..4 and the two van-der-Corput matrices of m
+    __shared__ uint32_t s_rows[5 * 52];
+    __shared__ uint64_t s_vdc[2 * 52];
+    __shared__ LdsQueue<1024> s_q;
+    lq_init(s_q);
+    const uint32_t m = (uint32_t)rc.sobol.log2_resolution;
+    for (uint32_t i = threadIdx.x; i < 5 * 52; i += blockDim.x) s_rows[i] = tabs.m32[i];
+    if (m > 0) for (uint32_t i = threadIdx.x; i < 2 * 52; i += blockDim.x) s_vdc[i] = (i < 52) ? tabs.vdc[(m - 1) * 52 + i] : tabs.vdc_inv[(m - 1) * 52 + (i - 52)];
+    __syncthreads();
     const uint32_t total = rc.n_pix_slots * rc.s_count;
-    bool alive = false;
-    if (pid < total) {
-        const uint32_t slot = pid % rc.n_pix_slots, sl = pid / rc.n_pix_slots;
-        int32_t px, py;
-        if (slot_to_pixel(rc, slot, px, py)) {
-            const uint64_t sample = rc.s_begin + sl;
-            const uint64_t index = sobol_interval_to_index(tabs, (uint32_t)rc.sobol.log2_resolution, sample,
-                                                           (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
-            // get_camera_sample (sampler.rs:170-180): pfilm = get_2d (y evaluated first), time = get_1d, plens = get_2d
-            const float fy = sobol_pixel_dim(tabs.m32, rc.sobol, index, 1, py);
-            const float fx = sobol_pixel_dim(tabs.m32, rc.sobol, index, 0, px);
-            const float pfx = (float)px + fx, pfy = (float)py + fy;
-            const float tm = sobol_sample_float(tabs.m32, index, 2);
-            const float ly = sobol_sample_float(tabs.m32, index, 4);
-            const float lx = sobol_sample_float(tabs.m32, index, 3);
-            V3 o, d;
-            camera_ray(rc, pfx, pfy, tm, P2(lx, ly), o, d);
-            ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
-            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-            ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
-            ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
-            ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
-            ps.etascale[pid] = 1.0f;
-            ps.sobol_index[pid] = index;
-            ps.meta[pid] = 5u;  // dimension 5 after the camera sample, bounces 0, flags 0
-            alive = true;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounded = (total + 255u) & ~255u;   // whole blocks iterate together (block-level queue flushes)
+    unsigned long long n_alive = 0;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < rounded; pid += stride) {
+        bool alive = false;
+        if (pid < total) {
+            const uint32_t slot = pid % rc.n_pix_slots, sl = pid / rc.n_pix_slots;
+            int32_t px, py;
+            if (slot_to_pixel(rc, slot, px, py)) {
+                const uint64_t sample = rc.s_begin + sl;
+                const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
+                // get_camera_sample (sampler.rs:170-180): pfilm = get_2d, time = get_1d, plens = get_2d; one pass over the index bits
+                uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                for (uint64_t a = index; a != 0; a &= a - 1) {
+                    const int i = __builtin_ctzll(a);
+                    v0 ^= s_rows[i]; v1 ^= s_rows[52 + i]; v2 ^= s_rows[104 + i]; v3 ^= s_rows[156 + i]; v4 ^= s_rows[208 + i];
+                }
+                // sobol.rs:77-81: film dimensions are remapped to the pixel
+                float fx = sobol_to_float(v0) * (float)rc.sobol.resolution + (float)rc.sobol.sb_min[0];
+                fx = clampf(fx - (float)px, 0.0f, kOneMinusEps);
+                float fy = sobol_to_float(v1) * (float)rc.sobol.resolution + (float)rc.sobol.sb_min[1];
+                fy = clampf(fy - (float)py, 0.0f, kOneMinusEps);
+                const float pfx = (float)px + fx, pfy = (float)py + fy;
+                V3 o, d;
+                camera_ray(rc, pfx, pfy, sobol_to_float(v2), P2(sobol_to_float(v3), sobol_to_float(v4)), o, d);
+                ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
+                ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
+                ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
+                ps.etascale[pid] = 1.0f;
+                ps.sobol_index[pid] = index;
+                ps.meta[pid] = 5u;  // dimension 5 after the camera sample, bounces 0, flags 0
+                alive = true;
+            }
         }
+        lq_push(s_q, pid, alive);
+        lq_sync_flush(s_q, q_ext_count, q_ext, 256u, false);
+        n_alive += alive ? 1ull : 0ull;
     }
-    queue_push(q_ext_count, q_ext, pid, alive);
-    counter_add(&counters->camera_rays, alive ? 1ull : 0ull);
+    lq_sync_flush(s_q, q_ext_count, q_ext, 0u, true);
+    counter_add(&counters->camera_rays, n_alive);
 }
 
 // ---- shading ---------------------------------------------------------------------------------------------
 
 template <int MAXL>
 __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
-    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ uint32_t s_hist[16];
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    __syncthreads();
     const uint32_t count = *job.count;
+    const uint32_t rounded = (count + 255u) & ~255u;   // whole blocks iterate together
+    unsigned long long zero_num = 0, zero_den = 0, n_valid = 0;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
-    unsigned long long zero_num = 0, zero_den = 0;
     int finished_bounces = -1;
     uint32_t pid = 0;
     if (valid) {
+        n_valid++;
         pid = job.queue[qi];
         uint32_t meta = ps.meta[pid];
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.overflow = false;
+        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+        smp.base = 0xffffffffu;
         RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
         RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
 
@@ -410,6 +502,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
             }
             bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
             if (!terminated) {
+                smp.load_window();
                 Bsdf<MAXL> bsdf;
                 const uint32_t mi = s.prim_material[hp];
                 bool has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf);
@@ -521,18 +614,24 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
         ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
         ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
     }
-    queue_push(job.ext_next_count, job.ext_next, pid, push_ext);
-    queue_push(job.shade_next0_count, job.shade_next0, pid, push_resolve);
-    queue_push(job.shadow_count, job.shadow, pid, push_shadow);
-    queue_push(job.mis_count, job.mis, pid, push_mis);
+    lq_push(s_qext, pid, push_ext);
+    lq_push(s_qres, pid, push_resolve);
+    lq_push(s_qsh, pid, push_shadow);
+    lq_push(s_qmis, pid, push_mis);
+    if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)
+    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 256u, false);
+    lq_sync_flush(s_qmis, job.mis_count, job.mis, 256u, false);
+    }  // persistent loop over the queue
+    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->zero_den, zero_den);
-    counter_add(&job.counters->stages, valid ? 1ull : 0ull);
-    // path length histogram (path.rs:219)
-    for (int b = 0; b < 16; ++b) {
-        unsigned long long m = __ballot(finished_bounces >= 0 && (finished_bounces > 15 ? 15 : finished_bounces) == b);
-        if (m && lane_id() == 0) atomicAdd(&job.counters->path_len[b], (unsigned long long)__popcll(m));
-    }
+    counter_add(&job.counters->stages, n_valid);
 }
 template __global__ void k_shade<1>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
 template __global__ void k_shade<2>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
