@@ -118,13 +118,15 @@ def main():
     def algo_bytes(name, s):
         if name in ("extend", "extend_mis", "shadow", "extend_camera"):
             return 32 * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
+        if name.startswith("shade_"):
+            return s["bvh_nodes"]  # path-state + queue bytes counted in-kernel (PtKernelStat.bvh_nodes for shade kernels)
         return None
     dom = max(kstats.items(), key=lambda kv: kv[1]["total_ms"]) if kstats else None
     roofline = None
     if dom is not None:
         name, s = dom
         ab = algo_bytes(name, s)
-        if ab is None:  # dominant kernel is not a trace kernel: report the heaviest trace kernel instead
+        if ab is None:  # no byte model for this kernel: report the heaviest trace kernel instead
             tr = [(n, v) for n, v in kstats.items() if n in ("extend", "extend_mis", "shadow", "extend_camera")]
             name, s = max(tr, key=lambda kv: kv[1]["total_ms"])
             ab = algo_bytes(name, s)
@@ -140,7 +142,10 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         launches=s["launches"], avg_launch_ms=round(s["total_ms"] / max(1, s["launches"]), 4),
                         algorithmic_bytes_per_launch=int(ab / max(1, s["launches"])))
-    kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps,
+    def gbs(n, v):
+        ab = algo_bytes(n, v)
+        return {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
+    kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps, **gbs(n, v),
                        **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in ("extend", "extend_mis", "shadow", "extend_camera") else {}))
                for n, v in kstats.items()}
 

@@ -206,7 +206,8 @@ typedef struct PtRenderParams {
     uint32_t tile_rank, tile_world;
     /* Samples per pixel traced per wavefront pass (0 => library default). */
     uint32_t spp_per_pass;
-    /* Non-zero => record per-kernel HIP-event timings (see pt_get_kernel_stats). */
+    /* 1 => record per-kernel HIP-event timings (see pt_get_kernel_stats); 2 => also exact per-class launch sizes
+     * (one extra host sync per iteration). */
     uint32_t profile;
 } PtRenderParams;
 
@@ -231,7 +232,8 @@ typedef struct PtKernelStat {
     uint64_t launches;
     double total_ms;                 /* HIP-event time on the render stream */
     uint64_t items;                  /* rays / path vertices / pixels processed */
-    uint64_t bvh_nodes;              /* trace kernels: Bounds3f::intersect_p2 executed (32 B each)  */
+    uint64_t bvh_nodes;              /* trace kernels: Bounds3f::intersect_p2 executed (32 B each);
+                                        shade kernels: path-state + queue bytes moved                 */
     uint64_t triangle_tests;         /* trace kernels: triangle packets tested (48 B each)          */
 } PtKernelStat;
 

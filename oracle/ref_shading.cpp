@@ -389,7 +389,7 @@ void LightSampler::init(const Scene &s, int requested) {
     size_t nl = s.lights.size();
     strategy = requested;
     if (requested == PT_LS_UNIFORM || nl == 1) strategy = PT_LS_UNIFORM;  // lightdistrib.rs:21
-    if (nl == 0) { fixed.reset(); return; }
+    if (nl == 0) { strategy = PT_LS_UNIFORM; fixed = std::make_shared<Distribution1D>(std::vector<Float>()); return; }  // Distribution1D::new(vec![]) (lightdistrib.rs:79)
     if (strategy == PT_LS_UNIFORM) fixed = std::make_shared<Distribution1D>(std::vector<Float>(nl, 1.0f));
     else if (strategy == PT_LS_POWER) {  // integrator.rs:239-247
         std::vector<Float> p;

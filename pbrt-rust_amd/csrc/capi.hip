@@ -20,8 +20,8 @@ std::string g_error;
 int g_device = -1;
 int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
-uint32_t g_refill_min[4] = {32, 32, 32, 64};     // per launch kind: extend, extend_mis, shadow, extend_camera
-uint32_t g_leaf_quorum[4] = {20, 20, 20, 8};
+uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
+uint32_t g_leaf_quorum[4] = {8, 8, 8, 20};
 SobolTables g_tabs = {nullptr, nullptr, nullptr};
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
@@ -355,7 +355,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
             sj.shade_next0 = sc->q.shade[1 - cur][0]; sj.shade_next0_count = &qc->shade[1 - cur][0];
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
-            sj.error = &qc->error; sj.counters = sc->dc;
+            sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
             else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
@@ -384,6 +384,8 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
+    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber"};
+    for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
 }

@@ -52,6 +52,7 @@ struct QCounters {
 struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
+    unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long k_nodes[4], k_tris[4], k_rays[4];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera
 };
 
@@ -99,6 +100,7 @@ struct ShadeJob {
     uint32_t *shadow, *shadow_count, *mis, *mis_count;
     uint32_t *error;
     DevCounters *counters;
+    uint32_t cls;            // material class of this launch (statistics)
 };
 
 }  // namespace ptd

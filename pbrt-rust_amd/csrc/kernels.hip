@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     __syncthreads();
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;   // whole blocks iterate together
-    unsigned long long zero_num = 0, zero_den = 0, n_valid = 0;
+    unsigned long long zero_num = 0, zero_den = 0, n_valid = 0, n_bytes = 0;  // n_bytes: path-state + queue bytes
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     uint32_t pid = 0;
     if (valid) {
         n_valid++;
+        n_bytes += 4 + 4 + 8 + 12 + 12 + /* write back */ 12 + 12 + 4;   // queue, meta, sobol index, L, beta
         pid = job.queue[qi];
         uint32_t meta = ps.meta[pid];
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
         if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) {
+            n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
             RGB Ld(0.0f);
             const uint32_t li = ps.nee_light[pid];
             if ((flags & PF_PEND_SHADOW) && !ps.occluded[pid]) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
         if (flags & PF_DEAD) {
             finished_bounces = (int)bounces;
         } else {
+            n_bytes += 24 + 16;  // ray + hit record
             V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
             const uint32_t hp = ps.hit_prim[pid];
             const bool found = hp != PT_NONE;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                                         ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
                                         ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
                                         ps.A_r[pid] = A.r; ps.A_g[pid] = A.g; ps.A_b[pid] = A.b;
-                                        flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true;
+                                        flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 24 + 12 + 4;
                                     }
                                 }
                                 if (!delta) {
@@ -560,13 +563,13 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                                             ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
                                             ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
                                             ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
-                                            flags |= PF_PEND_MIS; push_mis = true; nee_pending = true;
+                                            flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
                                         }
                                     }
                                 }
                                 if (nee_pending) {
                                     ps.nee_light[pid] = li; ps.nee_choice_pdf[pid] = choice_pdf;
-                                    ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b;
+                                    ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b; n_bytes += 8 + 12;
                                 }
                             }
                         }
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                             bounces += 1;
                             ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
                             ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
-                            push_ext = true;
+                            push_ext = true; n_bytes += 24 + 4 + 4;  // new ray, etascale, ext queue entry
                         }
                     }
                 }
@@ -632,6 +635,8 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->zero_den, zero_den);
     counter_add(&job.counters->stages, n_valid);
+    counter_add(&job.counters->shade_items[job.cls], n_valid);
+    counter_add(&job.counters->shade_bytes[job.cls], n_bytes);
 }
 template __global__ void k_shade<1>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
 template __global__ void k_shade<2>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
