@@ -619,3 +619,57 @@ int orc_test_triangle_reintersect(int n_seeds, int rays_per_tri, int *n_tested) 
     return failures;
 }
 }
+
+extern "C" {
+// tests/shapes.rs:421-487,538-565: full / partial sphere re-intersection with the reference's seeds RNG::new(0..n).
+int orc_test_sphere_reintersect(int n_seeds, int rays_per_shape, int partial, int *n_tested) {
+    int failures = 0, tested = 0;
+    for (int i = 0; i < n_seeds; ++i) {
+        RNG rng((uint64_t)i);
+        float radius = pexp_(rng, 4.0f);
+        float zmin = -radius, zmax = radius, phimax = 360.0f;
+        if (partial) {
+            zmin = (rng.uniform_float() < 0.5f) ? -radius : lerp(rng.uniform_float(), -radius, radius);
+            zmax = (rng.uniform_float() < 0.5f) ? radius : lerp(rng.uniform_float(), -radius, radius);
+            phimax = (rng.uniform_float() < 0.5f) ? 360.0f : rng.uniform_float() * 360.0f;
+        }
+        PtSphere S; std::memset(&S, 0, sizeof S);   // Sphere::new (sphere.rs:31-50)
+        for (int k = 0; k < 4; ++k) S.object_to_world[5 * k] = S.world_to_object[5 * k] = 1.0f;
+        S.radius = radius;
+        S.z_min = clampv(std::fmin(zmin, zmax), -radius, radius); S.z_max = clampv(std::fmax(zmin, zmax), -radius, radius);
+        S.theta_min = std::acos(clampv(std::fmin(zmin, zmax) / radius, -1.0f, 1.0f));
+        S.theta_max = std::acos(clampv(std::fmax(zmin, zmax) / radius, -1.0f, 1.0f));
+        S.phi_max = (PI / 180.0f) * clampv(phimax, 0.0f, 360.0f);
+        Scene s; s.spheres.push_back(S);
+        // test_reintersect_convex
+        V3 o; o.x = pexp_(rng, 8.0f); o.y = pexp_(rng, 8.0f); o.z = pexp_(rng, 8.0f);
+        Bounds3 bbox = s.sphere_world_bound(0);
+        V3 t; t.x = rng.uniform_float(); t.y = rng.uniform_float(); t.z = rng.uniform_float();
+        V3 p2 = bbox.lerp3(t);
+        Ray r(o, p2 - o, INF, 0.0f);
+        if (rng.uniform_float() < 0.5f) r.d = normalize(r.d);
+        SurfaceInteraction isect; Float thit;
+        if (!s.sphere_intersect(0, r, thit, isect, true)) continue;
+        tested++;
+        for (int j = 0; j < rays_per_shape; ++j) {
+            P2 u; u.x = rng.uniform_float(); u.y = rng.uniform_float();
+            V3 w = face_forward(uniform_sample_sphere(u), isect.n);
+            IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
+            Ray rout = spawn_ray(it, w);
+            SurfaceInteraction tmp; Float th2;
+            if (s.sphere_intersect_p(0, rout)) failures++;
+            if (s.sphere_intersect(0, rout, th2, tmp, true)) failures++;
+            V3 p3; p3.x = pexp_(rng, 8.0f); p3.y = pexp_(rng, 8.0f); p3.z = pexp_(rng, 8.0f);
+            w = face_forward(p3 - isect.p, isect.n);
+            p3 = isect.p + w;
+            V3 d = p3 - it.p;
+            Ray r2(offset_ray_origin(it.p, it.p_error, it.n, d), d, 1.0f - SHADOW_EPSILON, 0.0f);
+            if (s.sphere_intersect_p(0, r2)) failures++;
+            // the reference overwrites `isect` here when the (unexpected) hit happens; it must not happen
+            if (s.sphere_intersect(0, r2, th2, tmp, true)) failures++;
+        }
+    }
+    if (n_tested) *n_tested = tested;
+    return failures;
+}
+}

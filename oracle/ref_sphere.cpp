@@ -1,9 +1,169 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ref_math.h header).
-// ref_sphere.cpp: Sphere (shapes/sphere.rs) -- NOT YET RESTATED; scenes with spheres are rejected by the
-// callers (orc_scene_create accepts them but every sphere test misses). Row a14 of SURVEY section 8.
+// ref_sphere.cpp: Sphere::intersect / intersect_p / object+world bounds with EFloat running error bounds.
+//   shapes/sphere.rs:31-305; core/efloat.rs (EFloat ops, quadratic :211-231); core/transform.rs:434-495,543-636
+//   (transform_point_error, transform_vector_error, transform_ray_error, transform_point_abs_error,
+//    transform_bounds, transform_surface_interaction); core/interaction.rs:186-216 (SurfaceInteraction::new, shape None).
 #include "ref_scene.h"
+
 namespace ref {
-Bounds3 Scene::sphere_world_bound(uint32_t) const { return Bounds3(); }
-bool Scene::sphere_intersect(uint32_t, const Ray &, Float &, SurfaceInteraction &, bool) const { return false; }
-bool Scene::sphere_intersect_p(uint32_t, const Ray &) const { return false; }
+
+// core/efloat.rs
+struct EFloat {
+    Float v, low, high;
+    EFloat() : v(0), low(0), high(0) {}
+    EFloat(Float v_, Float err) : v(v_) {
+        if (err == 0.0f) { low = v; high = v; }
+        else { low = next_float_down(v - err); high = next_float_up(v + err); }
+    }
+    explicit EFloat(Float f) : v(f), low(f), high(f) {}
+};
+static EFloat operator+(EFloat a, EFloat b) { EFloat r; r.v = a.v + b.v; r.low = next_float_down(a.low + b.low); r.high = next_float_up(a.high + b.high); return r; }
+static EFloat operator-(EFloat a, EFloat b) { EFloat r; r.v = a.v - b.v; r.low = next_float_down(a.low - b.high); r.high = next_float_up(a.high - b.low); return r; }
+static EFloat operator*(EFloat a, EFloat b) {
+    EFloat r; r.v = a.v * b.v;
+    Float p[4] = {a.low * b.low, a.high * b.low, a.low * b.high, a.high * b.high};
+    r.low = next_float_down(fmin_(fmin_(p[0], p[1]), fmin_(p[2], p[3])));
+    r.high = next_float_up(fmax_(fmax_(p[0], p[1]), fmax_(p[2], p[3])));
+    return r;
 }
+static EFloat operator/(EFloat a, EFloat b) {  // efloat.rs:124-146: the straddle test looks at the NUMERATOR (as written there)
+    EFloat r; r.v = a.v / b.v;
+    if (a.low < 0.0f && a.high > 0.0f) { r.low = -INF; r.high = INF; }
+    else {
+        Float d[4] = {a.low / b.low, a.high / b.low, a.low / b.high, a.high / b.high};
+        r.low = next_float_down(fmin_(fmin_(d[0], d[1]), fmin_(d[2], d[3])));
+        r.high = next_float_up(fmax_(fmax_(d[0], d[1]), fmax_(d[2], d[3])));
+    }
+    return r;
+}
+static bool quadratic(EFloat a, EFloat b, EFloat c, EFloat &t0, EFloat &t1) {  // efloat.rs:211-231
+    double discrim = (double)b.v * (double)b.v - 4.0 * (double)a.v * (double)c.v;
+    if (discrim < 0.0) return false;
+    double root = std::sqrt(discrim);
+    EFloat frd((Float)root, (Float)((double)MACHINE_EPSILON * root));
+    EFloat q = (b.v < 0.0f) ? (EFloat(-0.5f) * (b - frd)) : (EFloat(-0.5f) * (b + frd));  // Mul<Float>: from(f) * self
+    t0 = q / a; t1 = c / q;
+    if (t0.v > t1.v) std::swap(t0, t1);
+    return true;
+}
+
+static V3 xf_vector_err(const M4 &t, V3 v, V3 &err) {  // transform.rs:510-527
+    Float x = v.x, y = v.y, z = v.z;
+    Float g = gamma(3);
+    err.x = g * (std::fabs(x * t.m[0][0]) + std::fabs(y * t.m[0][1]) + std::fabs(z * t.m[0][2]));
+    err.y = g * (std::fabs(x * t.m[1][0]) + std::fabs(y * t.m[1][1]) + std::fabs(z * t.m[1][2]));
+    err.z = g * (std::fabs(x * t.m[2][0]) + std::fabs(y * t.m[2][1]) + std::fabs(z * t.m[2][2]));
+    return xf_vector(t, v);
+}
+static V3 xf_point_abs_err(const M4 &t, V3 p, V3 perr, V3 &abs_err) {  // transform.rs:461-494
+    Float x = p.x, y = p.y, z = p.z;
+    Float xp = x * t.m[0][0] + y * t.m[0][1] + z * t.m[0][2] + t.m[0][3];
+    Float yp = x * t.m[1][0] + y * t.m[1][1] + z * t.m[1][2] + t.m[1][3];
+    Float zp = x * t.m[2][0] + y * t.m[2][1] + z * t.m[2][2] + t.m[2][3];
+    Float wp = x * t.m[3][0] + y * t.m[3][1] + z * t.m[3][2] + t.m[3][3];
+    Float g = gamma(3);
+    abs_err.x = (g + 1.0f) * (std::fabs(t.m[0][0]) * perr.x + std::fabs(t.m[0][1]) * perr.y + std::fabs(t.m[0][2]) * perr.z) +
+                g * (std::fabs(t.m[0][0] * x) + std::fabs(t.m[0][1] * y) + std::fabs(t.m[0][2] * z) + std::fabs(t.m[0][3]));
+    abs_err.y = (g + 1.0f) * (std::fabs(t.m[1][0]) * perr.x + std::fabs(t.m[1][1]) * perr.y + std::fabs(t.m[1][2]) * perr.z) +
+                g * (std::fabs(t.m[1][0] * x) + std::fabs(t.m[1][1] * y) + std::fabs(t.m[1][2] * z) + std::fabs(t.m[1][3]));
+    abs_err.z = (g + 1.0f) * (std::fabs(t.m[2][0]) * perr.x + std::fabs(t.m[2][1]) * perr.y + std::fabs(t.m[2][2]) * perr.z) +
+                g * (std::fabs(t.m[2][0] * x) + std::fabs(t.m[2][1] * y) + std::fabs(t.m[2][2] * z) + std::fabs(t.m[2][3]));
+    if (wp == 1.0f) return V3(xp, yp, zp);
+    return V3(xp, yp, zp) / wp;
+}
+
+// Shared part of intersect / intersect_p: returns the object-space hit (shapes/sphere.rs:59-152 == :198-286, including the
+// `phi += 2.0 * phi` quirk of intersect_p and of intersect's second branch, App. A #8).
+static bool sphere_hit(const PtSphere &S, const Ray &r, bool is_intersect_p, Float &t_out, V3 &p_hit_out, Float &phi_out, Ray &ray_obj) {
+    M4 w2o = m4_from(S.world_to_object);
+    V3 oerr, derr;
+    V3 o = xf_point_err(w2o, r.o, oerr);
+    V3 d = xf_vector_err(w2o, r.d, derr);
+    Float l2 = length_squared(d);
+    if (l2 > 0.0f) { Float dt = dot(vabs(d), oerr) / l2; o = o + d * dt; }  // transform_ray_error :578-590
+    ray_obj = Ray(o, d, r.t_max, r.time);
+    EFloat ox(o.x, oerr.x), oy(o.y, oerr.y), oz(o.z, oerr.z), dx(d.x, derr.x), dy(d.y, derr.y), dz(d.z, derr.z);
+    EFloat a = dx * dx + dy * dy + dz * dz;
+    EFloat b = EFloat(2.0f) * (dx * ox + dy * oy + dz * oz);
+    EFloat c = ox * ox + oy * oy + oz * oz - EFloat(S.radius) * EFloat(S.radius);
+    EFloat t0, t1;
+    if (!quadratic(a, b, c, t0, t1)) return false;
+    if (t0.high > r.t_max || t1.low <= 0.0f) return false;
+    EFloat ts = t0;
+    bool used_t1 = false;
+    if (ts.low <= 0.0f) { ts = t1; used_t1 = true; if (ts.high > r.t_max) return false; }
+    auto refine = [&](Float t, V3 &ph) {
+        ph = o + d * t;
+        Float s = S.radius / length(ph);
+        ph = V3(ph.x * s, ph.y * s, ph.z * s);
+        if (ph.x == 0.0f && ph.y == 0.0f) ph.x = 1e-5f * S.radius;
+    };
+    V3 ph; refine(ts.v, ph);
+    Float phi = dm_atan2f(ph.y, ph.x);
+    if (phi < 0.0f) phi += is_intersect_p ? 2.0f * phi : 2.0f * PI;
+    auto clipped = [&](V3 p, Float ph_) { return (S.z_min > -S.radius && p.z < S.z_min) || (S.z_max < S.radius && p.z > S.z_max) || ph_ > S.phi_max; };
+    if (clipped(ph, phi)) {
+        if (ts.v == t1.v) return false;   // PartialEq compares v (efloat.rs:205-209)
+        (void)used_t1;
+        if (t1.high > r.t_max) return false;
+        ts = t1;
+        refine(ts.v, ph);
+        phi = dm_atan2f(ph.y, ph.x);
+        if (phi < 0.0f) phi += 2.0f * phi;
+        if (clipped(ph, phi)) return false;
+    }
+    t_out = ts.v; p_hit_out = ph; phi_out = phi;
+    return true;
+}
+
+Bounds3 Scene::sphere_world_bound(uint32_t si) const {  // shape.rs:23-25 + sphere.rs:53-57 + transform.rs:592-605
+    const PtSphere &S = spheres[si];
+    M4 o2w = m4_from(S.object_to_world);
+    V3 lo(-S.radius, -S.radius, S.z_min), hi(S.radius, S.radius, S.z_max);
+    V3 c[8] = {V3(lo.x, lo.y, lo.z), V3(hi.x, lo.y, lo.z), V3(lo.x, hi.y, lo.z), V3(lo.x, lo.y, hi.z),
+               V3(lo.x, hi.y, hi.z), V3(hi.x, hi.y, lo.z), V3(hi.x, lo.y, hi.z), V3(hi.x, hi.y, hi.z)};
+    V3 p0 = xf_point(o2w, c[0]);
+    Bounds3 ret; ret.pmin = p0; ret.pmax = p0;
+    for (int i = 1; i < 8; ++i) ret = union_p(ret, xf_point(o2w, c[i]));
+    return ret;
+}
+
+bool Scene::sphere_intersect_p(uint32_t si, const Ray &r) const {
+    Float t, phi; V3 ph; Ray ro;
+    return sphere_hit(spheres[si], r, true, t, ph, phi, ro);
+}
+
+bool Scene::sphere_intersect(uint32_t si, const Ray &r, Float &thit, SurfaceInteraction &out, bool) const {
+    const PtSphere &S = spheres[si];
+    Float t, phi; V3 p_hit; Ray ray;
+    if (!sphere_hit(S, r, false, t, p_hit, phi, ray)) return false;
+    // sphere.rs:148-192
+    Float u = phi / S.phi_max;
+    Float theta = dm_acosf(clampv(p_hit.z / S.radius, -1.0f, 1.0f));
+    Float v = (theta - S.theta_min) / (S.theta_max - S.theta_min);
+    Float zradius = std::sqrt(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+    Float inv_radius = 1.0f / zradius;
+    Float cos_phi = p_hit.x * inv_radius, sin_phi = p_hit.y * inv_radius;
+    V3 dpdu(-S.phi_max * p_hit.y, S.phi_max * p_hit.x, 0.0f);
+    V3 dpdv = V3(p_hit.z * cos_phi, p_hit.z * sin_phi, -S.radius * dm_sinf(theta)) * (S.theta_max - S.theta_min);
+    V3 p_error = vabs(p_hit) * gamma(5);
+    // SurfaceInteraction::new(.., shape = None): n = normalize(dpdu x dpdv), wo = normalize(-ray.d) (interaction.rs:186-216)
+    V3 n = normalize(cross(dpdu, dpdv));
+    V3 wo = normalize(-ray.d);
+    // transform_surface_interaction (transform.rs:607-636)
+    M4 o2w = m4_from(S.object_to_world), w2o = m4_from(S.world_to_object);
+    SurfaceInteraction ret;
+    ret.p = xf_point_abs_err(o2w, p_hit, p_error, ret.p_error);
+    ret.n = normalize(xf_normal_inv(w2o, n));
+    ret.wo = normalize(xf_vector(o2w, wo));
+    ret.uv = P2(u, v);
+    ret.dpdu = xf_vector(o2w, dpdu); ret.dpdv = xf_vector(o2w, dpdv);
+    ret.sh_n = normalize(xf_normal_inv(w2o, n));
+    ret.sh_dpdu = xf_vector(o2w, dpdu); ret.sh_dpdv = xf_vector(o2w, dpdv);
+    ret.sh_n = face_forward(ret.sh_n, ret.n);
+    out = ret;
+    thit = t;
+    return true;
+}
+
+}  // namespace ref

@@ -146,8 +146,11 @@ int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
     job.refill_min = g_refill_min[job.kind & 3]; job.leaf_quorum = g_leaf_quorum[job.kind & 3];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
-    if (any) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    const bool sph = sc->ds.n_spheres > 0;
+    if (any && sph) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    else if (any) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    else if (sph) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -278,7 +281,8 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
-    hipLaunchKernelGGL(k_shade<MAXL>, dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    if (sc->ds.n_spheres > 0) hipLaunchKernelGGL((k_shade<MAXL, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else hipLaunchKernelGGL((k_shade<MAXL, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
@@ -415,17 +419,19 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     if (!d || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (d->n_prims == 0 || !d->prim_shape || !d->prim_material || !d->prim_light) return fail(PT_ERR_INVALID_ARG, "scene has no primitives");
     if (d->n_triangles && (!d->P || !d->indices)) return fail(PT_ERR_INVALID_ARG, "triangle arrays missing");
-    if (d->n_spheres) return fail(PT_ERR_UNSUPPORTED, "spheres (SURVEY row a14) are not implemented on device yet");
+    if (d->n_spheres && !d->spheres) return fail(PT_ERR_INVALID_ARG, "sphere array missing");
     for (uint32_t i = 0; i < 3 * d->n_triangles; ++i) if (d->indices[i] >= d->n_vertices) return fail(PT_ERR_INVALID_ARG, "vertex index out of range");
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         uint32_t s = d->prim_shape[i];
-        if ((s >> 30) != PT_SHAPE_TRIANGLE || (s & 0x3fffffffu) >= d->n_triangles) return fail(PT_ERR_INVALID_ARG, "primitive shape reference out of range");
+        const uint32_t kind = s >> 30, idx = s & 0x3fffffffu;
+        if (!((kind == PT_SHAPE_TRIANGLE && idx < d->n_triangles) || (kind == PT_SHAPE_SPHERE && idx < d->n_spheres))) return fail(PT_ERR_INVALID_ARG, "primitive shape reference out of range");
         if (d->prim_material[i] != PT_NONE && d->prim_material[i] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "material index out of range");
         if (d->prim_light[i] != PT_NONE && d->prim_light[i] >= d->n_lights) return fail(PT_ERR_INVALID_ARG, "light index out of range");
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const PtLight &L = d->lights[i];
         if (L.type == PT_LIGHT_DIFFUSE_AREA && L.prim >= d->n_prims) return fail(PT_ERR_INVALID_ARG, "area light primitive out of range");
+        if (L.type == PT_LIGHT_DIFFUSE_AREA && (d->prim_shape[L.prim] >> 30) != PT_SHAPE_TRIANGLE) return fail(PT_ERR_UNSUPPORTED, "sphere area lights (sphere.rs:313-395) are not implemented on device yet");
         if (L.type == PT_LIGHT_SPOT) return fail(PT_ERR_UNSUPPORTED, "spot lights are not implemented on device yet");
         if (L.type == PT_LIGHT_INFINITE && !d->env_texels) return fail(PT_ERR_INVALID_ARG, "infinite light without env_texels");
     }
@@ -447,6 +453,18 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     } else {
         std::vector<pth::PrimBound> pb(d->n_prims);
         for (uint32_t i = 0; i < d->n_prims; ++i) {  // Triangle::world_bound (triangle.rs:130-134)
+            if ((d->prim_shape[i] >> 30) == PT_SHAPE_SPHERE) {  // Shape::world_bound = transform_bounds(object_bound) (shape.rs:23-25, sphere.rs:53-57, transform.rs:592-605)
+                const PtSphere &S = d->spheres[d->prim_shape[i] & 0x3fffffffu];
+                M4 o2w; std::memcpy(o2w.m, S.object_to_world, 64);
+                const float lo[3] = {-S.radius, -S.radius, S.z_min}, hi[3] = {S.radius, S.radius, S.z_max};
+                const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
+                for (int c = 0; c < 8; ++c) {
+                    V3 p = xf_point(o2w, V3(corner[c][0] ? hi[0] : lo[0], corner[c][1] ? hi[1] : lo[1], corner[c][2] ? hi[2] : lo[2]));
+                    const float pc[3] = {p.x, p.y, p.z};
+                    for (int k = 0; k < 3; ++k) { pb[i].lo[k] = c ? std::fmin(pb[i].lo[k], pc[k]) : pc[k]; pb[i].hi[k] = c ? std::fmax(pb[i].hi[k], pc[k]) : pc[k]; }
+                }
+                continue;
+            }
             uint32_t tri = d->prim_shape[i] & 0x3fffffffu;
             const float *a = d->P + 3 * (size_t)d->indices[3 * tri], *b = d->P + 3 * (size_t)d->indices[3 * tri + 1], *c = d->P + 3 * (size_t)d->indices[3 * tri + 2];
             for (int k = 0; k < 3; ++k) { pb[i].lo[k] = std::fmin(std::fmin(a[k], b[k]), c[k]); pb[i].hi[k] = std::fmax(std::fmax(a[k], b[k]), c[k]); }
@@ -493,6 +511,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     UP(prim_shape, d->prim_shape, d->n_prims); UP(prim_material, d->prim_material, d->n_prims); UP(prim_light, d->prim_light, d->n_prims);
     ds.n_prims = d->n_prims;
     UP(materials, d->materials, d->n_materials); ds.n_materials = d->n_materials;
+    UP(spheres, d->spheres, d->n_spheres); ds.n_spheres = d->n_spheres;
     UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
@@ -590,7 +609,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
         uint32_t S = rp->spp_per_pass;
-        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 25) / rc.n_pix_slots);  // ~33 M paths in flight (7 GB of state)
+        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 26) / rc.n_pix_slots);  // ~67 M paths in flight (14 GB of state; 288 GB HBM)
         S = std::min(S, rp->spp);
         if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;

@@ -10,6 +10,7 @@
 // Queues hold path ids; path state is SoA in HBM (kernels.h). Compaction is wave64 ballot + popcount.
 #include "kernels.h"
 #include "dev_bsdf.h"
+#include "dev_sphere.h"
 
 using namespace ptd;
 
@@ -131,7 +132,7 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 //    (6 bits in the stack word) and added to the node-visit counter at the moment the reference would pop them.
 // Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
 
-template <bool ANY>
+template <bool ANY, bool SPH>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
     const uint32_t lane = lane_id();
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     const uint32_t count = *job.count;
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
-    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0;
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 
     // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
@@ -277,7 +278,17 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                 for (int k = 0; k < 2; ++k) {
                     const uint4 q0 = k ? c0 : a0, q1 = k ? c1 : a1, q2 = k ? c2 : a2;
                     const uint32_t fl = q2.w;
-                    if (!(fl & TP_SPHERE)) {  // spheres: row a14, not yet on device
+                    if (fl & TP_SPHERE) {
+                        if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
+                            n_sph++;
+                            float t, phi; V3 ph, dobj;
+                            if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, ANY, t, ph, phi, dobj)) {
+                                if (ANY) { found = true; last = true; state = ST_DONE; break; }
+                                found = true; t_max = t;
+                                hit_prim = q2.y; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
+                            }
+                        }
+                    } else {
                         n_tris++;
                         V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
                         V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
@@ -301,13 +312,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     }
     counter_add(&job.counters->nodes, n_nodes);
     counter_add(&job.counters->tri_tests, n_tris);
+    if (SPH) counter_add(&job.counters->sphere_tests, n_sph);
     counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
     counter_add(&job.counters->k_nodes[job.kind], n_nodes);
     counter_add(&job.counters->k_tris[job.kind], n_tris);
     counter_add(&job.counters->k_rays[job.kind], n_rays);
 }
-template __global__ void k_trace<false>(DeviceScene, TraceJob);
-template __global__ void k_trace<true>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, false>(DeviceScene, TraceJob);
+template __global__ void k_trace<true, false>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, true>(DeviceScene, TraceJob);
+template __global__ void k_trace<true, true>(DeviceScene, TraceJob);
 
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
@@ -427,7 +441,14 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
 
 // ---- shading ---------------------------------------------------------------------------------------------
 
-template <int MAXL>
+// Rebuild the SurfaceInteraction of a recorded hit (triangle: from the barycentrics; sphere: re-evaluated from the ray).
+template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
+    const uint32_t sh = s.prim_shape[prim];
+    if (SPH && (sh >> 30) == PT_SHAPE_SPHERE) { sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], ro, rd, si); return; }
+    tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
+}
+
+template <int MAXL, bool SPH>
 __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                 if (mp != PT_NONE) {
                     if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
                         SurfaceInteraction lsi;
-                        tri_fill_interaction(s, s.prim_shape[mp] & 0x3fffffffu, wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], true, lsi);
+                        fill_hit<SPH>(s, mp, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);
                         lrad = area_l(Lt, lsi.n, -wi);
                     }
                 } else lrad = light_le(s, Lt, wi);
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
             const uint32_t hp = ps.hit_prim[pid];
             const bool found = hp != PT_NONE;
             SurfaceInteraction si;
-            if (found) tri_fill_interaction(s, s.prim_shape[hp] & 0x3fffffffu, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], true, si);
+            if (found) fill_hit<SPH>(s, hp, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
             // path.rs:106-117
             if (bounces == 0 || (flags & PF_SPECULAR)) {
                 if (found) {
@@ -515,7 +536,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                     ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
                     push_ext = true;
                 } else {
-                    const V3 wo = -rd;  // == isect.wo (triangle.rs:296)
+                    const V3 wo = -rd;  // path.rs:148; estimate_direct uses isect.wo (== -rd for triangles, triangle.rs:296)
                     // uniform_sample_onelight (integrator.rs:81-106)
                     if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
@@ -533,8 +554,8 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                                 RGB Li = light_sample_li(s, li, it, ulight, wi, lightpdf, p1);
                                 const bool delta = light_is_delta(s.lights[li]);
                                 if (lightpdf > 0.0f && !Li.is_black()) {
-                                    RGB f = bsdf.f(wo, wi, bf) * abs_dot(wi, si.sh_n);
-                                    scattpdf = bsdf.pdf(wo, wi, bf);
+                                    RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
+                                    scattpdf = bsdf.pdf(si.wo, wi, bf);
                                     if (!f.is_black()) {
                                         V3 so, sd; spawn_ray_to(it, p1, so, sd);
                                         RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                                 }
                                 if (!delta) {
                                     int sampled_type = 0;
-                                    RGB f = bsdf.sample_f(wo, wi, uscatt, scattpdf, bf, sampled_type);
+                                    RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, bf, sampled_type);
                                     f = f * abs_dot(wi, si.sh_n);
                                     const bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
                                     if (!f.is_black() && scattpdf > 0.0f) {
@@ -638,9 +659,8 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     counter_add(&job.counters->shade_items[job.cls], n_valid);
     counter_add(&job.counters->shade_bytes[job.cls], n_bytes);
 }
-template __global__ void k_shade<1>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
-template __global__ void k_shade<2>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
-template __global__ void k_shade<5>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+#define PT_INST_SHADE(L, S) template __global__ void k_shade<L, S>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+PT_INST_SHADE(1, false) PT_INST_SHADE(2, false) PT_INST_SHADE(5, false) PT_INST_SHADE(1, true) PT_INST_SHADE(2, true) PT_INST_SHADE(5, true)
 
 // ---- film ----------------------------------------------------------------------------------------------------
 // One thread per pixel slot; its s_count samples are added in sample order (integrator.rs:331-376),

@@ -117,3 +117,30 @@ def material_zoo(n=24, xres=96, yres=64, spp=16, maxdepth=5):
         b.trianglemesh(P, I, N=N)
         b.attribute_end()
     return b
+
+
+def spheres_c1(xres=400, yres=400, spp=64, maxdepth=5):
+    """S1 / config C1: LookAt 2 2 5 -> 0 -.4 0, fov 30, sobol, path maxdepth 5, box filter; matte ground quad
+    (2 tris, Kd .5), mirror sphere r=1 at x=-1.3, glass sphere (index 1.5) r=1 at x=+1.3, one distant light L=pi from
+    (0,10,0) and one two-triangle area light L=10."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres)
+    b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((2.0, 2.0, 5.0), (0.0, -0.4, 0.0), (0.0, 1.0, 0.0))
+    b.camera(fov=30.0)
+    b.world_begin()
+    b.light_source("distant", L=(3.14159265, 3.14159265, 3.14159265), from_=(0.0, 10.0, 0.0), to=(0.0, 0.0, 0.0))
+    b.attribute_begin()
+    b.area_light_source(L=(10.0, 10.0, 10.0))
+    P, I = quad((-0.75, 3.5, -0.75), (0.75, 3.5, -0.75), (0.75, 3.5, 0.75), (-0.75, 3.5, 0.75))
+    b.trianglemesh(P, I)
+    b.attribute_end()
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-8.0, -1.0, -8.0), (-8.0, -1.0, 8.0), (8.0, -1.0, 8.0), (8.0, -1.0, -8.0))
+    b.trianglemesh(P, I)
+    b.attribute_begin(); b.material("mirror", Kr=(0.9, 0.9, 0.9)); b.translate(-1.3, 0.0, 0.0); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.material("glass", eta=1.5); b.translate(1.3, 0.0, 0.0); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.material("plastic", Kd=(0.2, 0.5, 0.2)); b.translate(0.0, -0.6, 1.6); b.rotate(35.0, 1.0, 0.0, 0.0)
+    b.sphere(radius=0.4, zmin=-0.25, zmax=0.3, phimax=300.0); b.attribute_end()
+    return b

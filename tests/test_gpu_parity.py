@@ -195,3 +195,16 @@ def test_full_size_properties(pkg, gpu):
     b = g.render(rp)
     assert np.array_equal(a[..., 3], b[..., 3])
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-6, atol=1e-7)
+
+
+def test_spheres_c1_matches_oracle(pkg, gpu, oracle):
+    """Config C1: analytic spheres (mirror, glass, partial plastic sphere) + distant + area light."""
+    sd, rp = pkg.scenes.spheres_c1(xres=96, yres=96, spp=8).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    gn, go = g.bvh(); on, oo = orc.bvh()
+    assert bytes(gn) == bytes(on) and np.array_equal(go, oo)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)

@@ -202,3 +202,22 @@ def test_furnace_closed_form(oracle, pkg):
     expected = Le * sum(rho ** k for k in range(depth + 1))
     assert abs(rgb.mean() - expected) < 0.01 * expected
     assert np.abs(rgb.mean(axis=2) - expected).max() < 0.15 * expected  # 256-spp Monte Carlo noise per pixel
+
+
+def test_sphere_reintersect_property(oracle):
+    # tests/shapes.rs:472-487 (full) and :538-565 (partial), seeds RNG::new(0..99); 2 000 ray pairs per sphere here
+    f = oracle.lib.orc_test_sphere_reintersect
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    for partial in (0, 1):
+        n = C.c_int()
+        failures = f(100, 2000, partial, C.byref(n))
+        assert n.value > 20
+        assert failures == 0, (partial, failures)
+
+
+def test_spheres_scene_renders(oracle, pkg):
+    sd, rp = pkg.scenes.spheres_c1(xres=48, yres=48, spp=8).world_end()
+    s = oracle.scene(sd)
+    rgb = s.resolve(s.render(rp, nthreads=4))
+    c = s.counters()
+    assert c["sphere_tests"] > 0 and np.isfinite(rgb).all() and rgb.mean() > 0.01
