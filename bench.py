@@ -125,8 +125,9 @@ def main():
         return None
     # Group the per-launch-kind statistics by kernel symbol (what rocprofv3 --stats reports) and take the
     # symbol with the largest total time as the dominant kernel.
-    SYMBOL = {"extend_camera": "k_trace<false>", "extend": "k_trace<false>", "extend_mis": "k_trace<false>", "shadow": "k_trace<true>",
-              "shade_matte": "k_shade<1>", "shade_1lobe": "k_shade<1>", "shade_2lobe": "k_shade<2>", "shade_uber": "k_shade<5>"}
+    SYMBOL = {"extend_camera": "k_trace<false, false>", "extend": "k_trace<false, false>", "extend_mis": "k_trace<false, false>",
+              "shadow": "k_trace<true, false>", "shade_matte": "k_shade<1, false>", "shade_1lobe": "k_shade<1, false>",
+              "shade_2lobe": "k_shade<2, false>", "shade_uber": "k_shade<5, false>"}  # names as rocprofv3 prints them (no spheres in S2)
     groups = {}
     for n, v in kstats.items():
         ab = algo_bytes(n, v)

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 CSV output (kernel stats + PMC passes) into a compact text/JSON report.
 FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide streaming reads (MI355X_MICROARCH.md, HBM):
 reported raw AND doubled; WRITE_SIZE is exact for 16-B streaming stores and float atomics. Units: KiB."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 out = sys.argv[1]
@@ -16,11 +16,8 @@ def rows(pattern):
 
 
 def short(name):
-    n = name.split("(")[0]
-    for k in ("k_trace<false>", "k_trace<true>", "k_shade<1>", "k_shade<2>", "k_shade<5>"):
-        if k in name:
-            return k
-    return n.replace("void ", "").strip()
+    m = re.search(r"(k_[a-z_0-9]+(<[^>]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0].replace("void ", "").strip()
 
 
 report = {}
