@@ -132,6 +132,17 @@ typedef struct PtBVHNode {
     uint8_t pad;
 } PtBVHNode;
 
+/* Object instancing (core/api.rs:1630-1713, core/primitive.rs:40-88; static transforms only).
+ * An object is a contiguous range of the prim arrays that is NOT part of the top level; the library builds one BVH per
+ * object with more than one primitive (api.rs:1692-1700). An instance is a TransformedPrimitive of that object. */
+typedef struct PtObject { uint32_t first_prim, n_prims; } PtObject;
+typedef struct PtInstance {
+    uint32_t object;
+    float instance_to_world[16];   /* prim_to_world (start transform), row major */
+    float world_to_instance[16];
+} PtInstance;
+#define PT_TOP_INSTANCE 0x80000000u  /* top_refs entry: instance index | PT_TOP_INSTANCE, else a primitive index */
+
 typedef struct PtSceneDesc {
     /* All triangle meshes concatenated; P is world space (shapes/triangle.rs:39-41). */
     uint32_t n_vertices;
@@ -172,7 +183,13 @@ typedef struct PtSceneDesc {
     uint32_t max_node_prims;       /* bvh "maxnodeprims", default 4 */
     uint32_t n_nodes;
     const PtBVHNode *nodes;
-    const uint32_t *ordered_prims; /* n_prims entries, indices into prims */
+    const uint32_t *ordered_prims; /* n_top entries (n_prims without instancing): positions in the top-level list */
+
+    /* Instancing (all zero/NULL when unused). top_refs lists the scene's top-level primitives in creation order
+     * (RenderOptions.primitives, api.rs:1585-1617,1703-1712); NULL => every primitive, in order. */
+    uint32_t n_objects; const PtObject *objects;
+    uint32_t n_instances; const PtInstance *instances;
+    uint32_t n_top; const uint32_t *top_refs;
 } PtSceneDesc;
 
 /* ---- render parameters ---------------------------------------------------------------- */

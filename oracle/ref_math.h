@@ -328,6 +328,28 @@ inline V3 xf_normal_inv(const M4 &minv, V3 n) {
               x * minv.m[0][2] + y * minv.m[1][2] + z * minv.m[2][2]);
 }
 
+// transform.rs:461-494
+inline V3 xf_point_abs_err(const M4 &t, V3 p, V3 perr, V3 &abs_err) {
+    Float x = p.x, y = p.y, z = p.z;
+    Float xp = x * t.m[0][0] + y * t.m[0][1] + z * t.m[0][2] + t.m[0][3];
+    Float yp = x * t.m[1][0] + y * t.m[1][1] + z * t.m[1][2] + t.m[1][3];
+    Float zp = x * t.m[2][0] + y * t.m[2][1] + z * t.m[2][2] + t.m[2][3];
+    Float wp = x * t.m[3][0] + y * t.m[3][1] + z * t.m[3][2] + t.m[3][3];
+    Float g = gamma(3);
+    abs_err.x = (g + 1.0f) * (std::fabs(t.m[0][0]) * perr.x + std::fabs(t.m[0][1]) * perr.y + std::fabs(t.m[0][2]) * perr.z) +
+                g * (std::fabs(t.m[0][0] * x) + std::fabs(t.m[0][1] * y) + std::fabs(t.m[0][2] * z) + std::fabs(t.m[0][3]));
+    abs_err.y = (g + 1.0f) * (std::fabs(t.m[1][0]) * perr.x + std::fabs(t.m[1][1]) * perr.y + std::fabs(t.m[1][2]) * perr.z) +
+                g * (std::fabs(t.m[1][0] * x) + std::fabs(t.m[1][1] * y) + std::fabs(t.m[1][2] * z) + std::fabs(t.m[1][3]));
+    abs_err.z = (g + 1.0f) * (std::fabs(t.m[2][0]) * perr.x + std::fabs(t.m[2][1]) * perr.y + std::fabs(t.m[2][2]) * perr.z) +
+                g * (std::fabs(t.m[2][0] * x) + std::fabs(t.m[2][1] * y) + std::fabs(t.m[2][2] * z) + std::fabs(t.m[2][3]));
+    if (wp == 1.0f) return V3(xp, yp, zp);
+    return V3(xp, yp, zp) / wp;
+}
+inline bool m4_is_identity(const M4 &t) {  // transform.rs:248-253
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (t.m[r][c] != ((r == c) ? 1.0f : 0.0f)) return false;
+    return true;
+}
+
 struct Ray {
     V3 o, d;
     Float t_max;

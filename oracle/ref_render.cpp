@@ -420,9 +420,15 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
         s.env_importance.assign(d->env_importance, d->env_importance + (size_t)4 * s.env_w * s.env_h);
     }
     s.max_node_prims = d->max_node_prims ? d->max_node_prims : 4;
+    if (d->n_instances && d->top_refs) {
+        s.objects.assign(d->objects, d->objects + d->n_objects);
+        s.instances.assign(d->instances, d->instances + d->n_instances);
+        s.top_refs.assign(d->top_refs, d->top_refs + d->n_top);
+    }
+    s.build_object_accels();
     if (d->nodes && d->n_nodes) {
         s.nodes.assign(d->nodes, d->nodes + d->n_nodes);
-        s.ordered.assign(d->ordered_prims, d->ordered_prims + d->n_prims);
+        s.ordered.assign(d->ordered_prims, d->ordered_prims + s.n_top());
     } else s.build_bvh();
     if (!s.nodes.empty()) {
         s.wb.pmin = V3(s.nodes[0].bmin[0], s.nodes[0].bmin[1], s.nodes[0].bmin[2]);

@@ -66,6 +66,7 @@ struct SurfaceInteraction {
     V3 dpdu, dpdv;
     V3 sh_n, sh_dpdu, sh_dpdv;
     uint32_t prim = PT_NONE;
+    uint32_t inst = PT_NONE;   // instance (TransformedPrimitive) the hit went through
     Float t = 0;
     Float b[3] = {0, 0, 0};
 };
@@ -84,8 +85,13 @@ struct Scene {
     std::vector<RGB> env_texels;
     std::vector<Float> env_importance;
     uint32_t max_node_prims = 4;
-    std::vector<PtBVHNode> nodes;
-    std::vector<uint32_t> ordered;
+    std::vector<PtBVHNode> nodes;       // top-level accelerator
+    std::vector<uint32_t> ordered;      // positions in the top-level list (see top_ref)
+    struct Accel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };
+    std::vector<PtObject> objects; std::vector<PtInstance> instances; std::vector<uint32_t> top_refs;
+    std::vector<Accel> obj_accel;       // one per object (nodes empty when the object has a single primitive)
+    uint32_t top_ref(uint32_t pos) const { return top_refs.empty() ? pos : top_refs[pos]; }
+    size_t n_top() const { return top_refs.empty() ? prim_shape.size() : top_refs.size(); }
     Bounds3 wb;
 
     // ---- triangles ----
@@ -228,7 +234,13 @@ struct Scene {
 
     // ---- BVH ----
     Bounds3 prim_world_bound(uint32_t prim) const;
+    Bounds3 ref_world_bound(uint32_t ref) const;
     void build_bvh();
+    void build_object_accels();
+    bool accel_intersect(const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &ord, bool top, Ray &r, SurfaceInteraction &si, Counters &c) const;
+    bool accel_intersect_p(const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &ord, bool top, const Ray &r, Counters &c) const;
+    bool ref_intersect(uint32_t ref, Ray &r, SurfaceInteraction &si, Counters &c) const;
+    bool ref_intersect_p(uint32_t ref, const Ray &r, Counters &c) const;
     bool intersect(Ray &r, SurfaceInteraction &si, Counters &c) const;  // Scene::intersect
     bool intersect_p(const Ray &r, Counters &c) const;                 // Scene::intersect_p
     bool prim_intersect(uint32_t prim, Ray &r, SurfaceInteraction &si, Counters &c) const;
@@ -274,7 +286,7 @@ inline bool Scene::prim_intersect(uint32_t prim, Ray &r, SurfaceInteraction &si,
         Float t, b[3];
         if (!tri_intersect(i, r, t, b)) return false;
         r.t_max = t;
-        si.prim = prim; si.t = t; si.b[0] = b[0]; si.b[1] = b[1]; si.b[2] = b[2];
+        si.prim = prim; si.inst = PT_NONE; si.t = t; si.b[0] = b[0]; si.b[1] = b[1]; si.b[2] = b[2];
         return true;
     }
     c.sphere_tests++;
@@ -282,7 +294,7 @@ inline bool Scene::prim_intersect(uint32_t prim, Ray &r, SurfaceInteraction &si,
     SurfaceInteraction tmp;
     if (!sphere_intersect(i, r, t, tmp, true)) return false;
     r.t_max = t;
-    si = tmp; si.prim = prim; si.t = t;
+    si = tmp; si.prim = prim; si.inst = PT_NONE; si.t = t;
     return true;
 }
 inline bool Scene::prim_intersect_p(uint32_t prim, const Ray &r, Counters &c) const {
@@ -296,23 +308,45 @@ inline bool Scene::prim_intersect_p(uint32_t prim, const Ray &r, Counters &c) co
     return sphere_intersect_p(i, r);
 }
 
+// TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88), static transform
+inline bool Scene::ref_intersect(uint32_t ref, Ray &r, SurfaceInteraction &si, Counters &c) const {
+    if (!(ref & PT_TOP_INSTANCE)) return prim_intersect(ref, r, si, c);
+    const PtInstance &I = instances[ref & ~PT_TOP_INSTANCE];
+    const PtObject &O = objects[I.object];
+    Ray ray = xf_ray(m4_from(I.world_to_instance), r);
+    SurfaceInteraction tmp = si;
+    bool hit = (O.n_prims == 1) ? prim_intersect(O.first_prim, ray, tmp, c)
+                                : accel_intersect(obj_accel[I.object].nodes, obj_accel[I.object].ordered, false, ray, tmp, c);
+    if (!hit) return false;
+    r.t_max = ray.t_max;  // primitive.rs:70 (the dt of transform_ray is not added back)
+    si = tmp; si.inst = ref & ~PT_TOP_INSTANCE;
+    return true;
+}
+inline bool Scene::ref_intersect_p(uint32_t ref, const Ray &r, Counters &c) const {
+    if (!(ref & PT_TOP_INSTANCE)) return prim_intersect_p(ref, r, c);
+    const PtInstance &I = instances[ref & ~PT_TOP_INSTANCE];
+    const PtObject &O = objects[I.object];
+    Ray ray = xf_ray(m4_from(I.world_to_instance), r);
+    return (O.n_prims == 1) ? prim_intersect_p(O.first_prim, ray, c) : accel_intersect_p(obj_accel[I.object].nodes, obj_accel[I.object].ordered, false, ray, c);
+}
+
 // BVHAccel::intersect (bvh.rs:705-760)
-inline bool Scene::intersect(Ray &r, SurfaceInteraction &si, Counters &c) const {
-    c.intersect_tests++;
-    if (nodes.empty()) return false;
+inline bool Scene::accel_intersect(const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &ord, bool top, Ray &r, SurfaceInteraction &si, Counters &c) const {
+    if (nn.empty()) return false;
     bool hit = false;
     V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     int neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
     uint32_t to_visit = 0, cur = 0;
     uint32_t stack[64];
-    Ray r0 = r;
     for (;;) {
-        const PtBVHNode &node = nodes[cur];
+        const PtBVHNode &node = nn[cur];
         c.nodes++;
         if (bounds_intersect_p2(node, r, inv_dir, neg)) {
             if (node.n_prims > 0) {
-                for (uint32_t i = 0; i < node.n_prims; ++i)
-                    if (prim_intersect(ordered[node.offset + i], r, si, c)) hit = true;
+                for (uint32_t i = 0; i < node.n_prims; ++i) {
+                    uint32_t e = ord[node.offset + i];
+                    if (ref_intersect(top ? top_ref(e) : e, r, si, c)) hit = true;
+                }
                 if (to_visit == 0) break;
                 cur = stack[--to_visit];
             } else {
@@ -324,32 +358,57 @@ inline bool Scene::intersect(Ray &r, SurfaceInteraction &si, Counters &c) const 
             cur = stack[--to_visit];
         }
     }
+    return hit;
+}
+// Scene::intersect (scene.rs:54-59) + deferred construction of the SurfaceInteraction of the final hit
+inline bool Scene::intersect(Ray &r, SurfaceInteraction &si, Counters &c) const {
+    c.intersect_tests++;
+    Ray r0 = r;
+    si.inst = PT_NONE;
+    bool hit = accel_intersect(nodes, ordered, true, r, si, c);
     if (hit) {
         uint32_t s = prim_shape[si.prim];
+        const bool inst = si.inst != PT_NONE;
+        Ray rl = inst ? xf_ray(m4_from(instances[si.inst].world_to_instance), r0) : r0;
         if ((s >> 30) == PT_SHAPE_TRIANGLE) {
             Float t = si.t, b[3] = {si.b[0], si.b[1], si.b[2]};
-            uint32_t prim = si.prim;
-            tri_fill_interaction(s & 0x3fffffffu, r0, t, b, true, si);
-            si.prim = prim;
+            uint32_t prim = si.prim, ii = si.inst;
+            tri_fill_interaction(s & 0x3fffffffu, rl, t, b, true, si);
+            si.prim = prim; si.inst = ii;
+        }
+        if (inst) {  // transform_surface_interaction (transform.rs:607-636) unless the instance transform is the identity
+            M4 i2w = m4_from(instances[si.inst].instance_to_world), w2i = m4_from(instances[si.inst].world_to_instance);
+            if (!m4_is_identity(i2w)) {
+                SurfaceInteraction ret = si;
+                ret.p = xf_point_abs_err(i2w, si.p, si.p_error, ret.p_error);
+                ret.n = normalize(xf_normal_inv(w2i, si.n));
+                ret.wo = normalize(xf_vector(i2w, si.wo));
+                ret.dpdu = xf_vector(i2w, si.dpdu); ret.dpdv = xf_vector(i2w, si.dpdv);
+                ret.sh_n = normalize(xf_normal_inv(w2i, si.sh_n));
+                ret.sh_dpdu = xf_vector(i2w, si.sh_dpdu); ret.sh_dpdv = xf_vector(i2w, si.sh_dpdv);
+                ret.sh_n = face_forward(ret.sh_n, ret.n);
+                si = ret;
+            }
         }
     }
     return hit;
 }
 // BVHAccel::intersect_p (bvh.rs:762-814)
-inline bool Scene::intersect_p(const Ray &r, Counters &c) const {
-    c.shadow_tests++;
-    if (nodes.empty()) return false;
+inline bool Scene::accel_intersect_p(const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &ord, bool top, const Ray &r, Counters &c) const {
+    if (nn.empty()) return false;
     V3 inv_dir(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     int neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
     uint32_t to_visit = 0, cur = 0;
     uint32_t stack[64];
     for (;;) {
-        const PtBVHNode &node = nodes[cur];
+        const PtBVHNode &node = nn[cur];
         c.nodes++;
         if (bounds_intersect_p2(node, r, inv_dir, neg)) {
             if (node.n_prims > 0) {
-                for (uint32_t i = 0; i < node.n_prims; ++i)
-                    if (prim_intersect_p(ordered[node.offset + i], r, c)) return true;
+                for (uint32_t i = 0; i < node.n_prims; ++i) {
+                    uint32_t e = ord[node.offset + i];
+                    if (ref_intersect_p(top ? top_ref(e) : e, r, c)) return true;
+                }
                 if (to_visit == 0) break;
                 cur = stack[--to_visit];
             } else {
@@ -362,6 +421,10 @@ inline bool Scene::intersect_p(const Ray &r, Counters &c) const {
         }
     }
     return false;
+}
+inline bool Scene::intersect_p(const Ray &r, Counters &c) const {  // Scene::intersect_p (scene.rs:61-66)
+    c.shadow_tests++;
+    return accel_intersect_p(nodes, ordered, true, r, c);
 }
 
 // ---- SAH build (bvh.rs:145-375, 662-693) ---------------------------------------------------
@@ -387,12 +450,11 @@ template <class Pred> size_t partition_in_place(PrimInfo *a, size_t n, Pred pred
 }
 
 struct Builder {
-    const Scene &scene;
     uint32_t max_prims;
     std::vector<PrimInfo> info;
     std::vector<BuildNode> arena;
     std::vector<uint32_t> ordered;
-    Builder(const Scene &s, uint32_t mp) : scene(s), max_prims(std::min(255u, mp)) {}
+    explicit Builder(uint32_t mp) : max_prims(std::min(255u, mp)) {}
 
     int make_leaf(int node, size_t start, size_t end, const Bounds3 &bounds) {
         uint32_t off = (uint32_t)ordered.size();
@@ -471,16 +533,16 @@ struct Builder {
 };
 }  // namespace bvhbuild
 
-inline void Scene::build_bvh() {
+// BVHAccel::new over `bounds[i]` (item i keeps number i): fills nodes + ordered item numbers
+inline void build_accel(const std::vector<Bounds3> &bounds, uint32_t max_node_prims, std::vector<PtBVHNode> &nodes, std::vector<uint32_t> &ordered) {
     nodes.clear(); ordered.clear();
-    size_t n = prim_shape.size();
+    size_t n = bounds.size();
     if (n == 0) return;
-    bvhbuild::Builder b(*this, max_node_prims);
+    bvhbuild::Builder b(max_node_prims);
     b.info.resize(n);
     for (size_t i = 0; i < n; ++i) {
-        Bounds3 bb = prim_world_bound((uint32_t)i);
-        b.info[i].number = (uint32_t)i; b.info[i].bounds = bb;
-        b.info[i].centroid = bb.pmin * 0.5f + bb.pmax * 0.5f;
+        b.info[i].number = (uint32_t)i; b.info[i].bounds = bounds[i];
+        b.info[i].centroid = bounds[i].pmin * 0.5f + bounds[i].pmax * 0.5f;
     }
     b.arena.reserve(2 * n);
     int root = b.recursive_build(0, n);
@@ -488,6 +550,41 @@ inline void Scene::build_bvh() {
     uint32_t off = 0;
     b.flatten(nodes, root, off);
     ordered.swap(b.ordered);
+}
+inline Bounds3 xf_bounds(const M4 &t, const Bounds3 &b) {  // transform.rs:592-605
+    V3 lo = b.pmin, hi = b.pmax;
+    V3 c[8] = {V3(lo.x, lo.y, lo.z), V3(hi.x, lo.y, lo.z), V3(lo.x, hi.y, lo.z), V3(lo.x, lo.y, hi.z),
+               V3(lo.x, hi.y, hi.z), V3(hi.x, hi.y, lo.z), V3(hi.x, lo.y, hi.z), V3(hi.x, hi.y, hi.z)};
+    V3 p0 = xf_point(t, c[0]);
+    Bounds3 ret; ret.pmin = p0; ret.pmax = p0;
+    for (int i = 1; i < 8; ++i) ret = union_p(ret, xf_point(t, c[i]));
+    return ret;
+}
+inline Bounds3 Scene::ref_world_bound(uint32_t ref) const {
+    if (!(ref & PT_TOP_INSTANCE)) return prim_world_bound(ref);
+    const PtInstance &I = instances[ref & ~PT_TOP_INSTANCE];
+    const PtObject &O = objects[I.object];
+    Bounds3 inner;
+    if (O.n_prims == 1) inner = prim_world_bound(O.first_prim);
+    else { const PtBVHNode &r = obj_accel[I.object].nodes[0]; inner.pmin = V3(r.bmin[0], r.bmin[1], r.bmin[2]); inner.pmax = V3(r.bmax[0], r.bmax[1], r.bmax[2]); }
+    return xf_bounds(m4_from(I.instance_to_world), inner);  // TransformedPrimitive::world_bound -> motion_bounds (transform.rs:1564-1567)
+}
+inline void Scene::build_object_accels() {  // api.rs:1692-1700: one BVH per object with more than one primitive
+    obj_accel.assign(objects.size(), Accel());
+    for (size_t o = 0; o < objects.size(); ++o) {
+        const PtObject &O = objects[o];
+        if (O.n_prims <= 1) continue;
+        std::vector<Bounds3> bb(O.n_prims);
+        for (uint32_t i = 0; i < O.n_prims; ++i) bb[i] = prim_world_bound(O.first_prim + i);
+        build_accel(bb, max_node_prims, obj_accel[o].nodes, obj_accel[o].ordered);
+        for (auto &e : obj_accel[o].ordered) e += O.first_prim;  // item number -> primitive index
+    }
+}
+inline void Scene::build_bvh() {
+    size_t n = n_top();
+    std::vector<Bounds3> bb(n);
+    for (size_t i = 0; i < n; ++i) bb[i] = ref_world_bound(top_ref((uint32_t)i));
+    build_accel(bb, max_node_prims, nodes, ordered);
 }
 
 }  // namespace ref

@@ -279,6 +279,7 @@ RGB LightSampler::power(uint32_t li) const {
     }
     case PT_LIGHT_DISTANT: return c * PI * world_radius * world_radius;  // distant.rs:47-50
     case PT_LIGHT_POINT: return c * 4.0f * PI;                            // point.rs:44-46
+    case PT_LIGHT_SPOT: return c * 2.0f * PI * (1.0f - 0.5f * (L.cos_falloff_start + L.cos_total_width));  // spot.rs:64-66
     case PT_LIGHT_INFINITE: {                                             // infinite.rs:103-109 (lookup width .5 => top level)
         RGB v = env_lookup(P2(0.5f, 0.5f));  // NOTE: exact only for 1x1 maps (top MIP level == the texel)
         return v * world_radius * world_radius * PI;
@@ -335,6 +336,17 @@ RGB LightSampler::sample_li(uint32_t li, const IData &ref, P2 u, V3 &wi, Float &
         wi = normalize(pl - ref.p); pdf = 1.0f;
         p1.p = pl;
         return RGB(L.L[0], L.L[1], L.L[2]) / distance_squared(pl, ref.p);
+    }
+    case PT_LIGHT_SPOT: {  // spot.rs:48-56,71-87
+        V3 pl(L.pos[0], L.pos[1], L.pos[2]);
+        wi = normalize(pl - ref.p); pdf = 1.0f;
+        p1.p = pl;
+        V3 wl = normalize(xf_vector(m4_from(L.world_to_light), -wi));
+        Float cos_theta = wl.z, fall;
+        if (cos_theta < L.cos_total_width) fall = 0.0f;
+        else if (cos_theta >= L.cos_falloff_start) fall = 1.0f;
+        else { Float delta = (cos_theta - L.cos_total_width) / (L.cos_falloff_start - L.cos_total_width); fall = (delta * delta) * (delta * delta); }
+        return RGB(L.L[0], L.L[1], L.L[2]) * fall / distance_squared(pl, ref.p);
     }
     case PT_LIGHT_INFINITE: {  // infinite.rs:140-177
         Float map_pdf = 0.0f;

@@ -55,23 +55,6 @@ static V3 xf_vector_err(const M4 &t, V3 v, V3 &err) {  // transform.rs:510-527
     err.z = g * (std::fabs(x * t.m[2][0]) + std::fabs(y * t.m[2][1]) + std::fabs(z * t.m[2][2]));
     return xf_vector(t, v);
 }
-static V3 xf_point_abs_err(const M4 &t, V3 p, V3 perr, V3 &abs_err) {  // transform.rs:461-494
-    Float x = p.x, y = p.y, z = p.z;
-    Float xp = x * t.m[0][0] + y * t.m[0][1] + z * t.m[0][2] + t.m[0][3];
-    Float yp = x * t.m[1][0] + y * t.m[1][1] + z * t.m[1][2] + t.m[1][3];
-    Float zp = x * t.m[2][0] + y * t.m[2][1] + z * t.m[2][2] + t.m[2][3];
-    Float wp = x * t.m[3][0] + y * t.m[3][1] + z * t.m[3][2] + t.m[3][3];
-    Float g = gamma(3);
-    abs_err.x = (g + 1.0f) * (std::fabs(t.m[0][0]) * perr.x + std::fabs(t.m[0][1]) * perr.y + std::fabs(t.m[0][2]) * perr.z) +
-                g * (std::fabs(t.m[0][0] * x) + std::fabs(t.m[0][1] * y) + std::fabs(t.m[0][2] * z) + std::fabs(t.m[0][3]));
-    abs_err.y = (g + 1.0f) * (std::fabs(t.m[1][0]) * perr.x + std::fabs(t.m[1][1]) * perr.y + std::fabs(t.m[1][2]) * perr.z) +
-                g * (std::fabs(t.m[1][0] * x) + std::fabs(t.m[1][1] * y) + std::fabs(t.m[1][2] * z) + std::fabs(t.m[1][3]));
-    abs_err.z = (g + 1.0f) * (std::fabs(t.m[2][0]) * perr.x + std::fabs(t.m[2][1]) * perr.y + std::fabs(t.m[2][2]) * perr.z) +
-                g * (std::fabs(t.m[2][0] * x) + std::fabs(t.m[2][1] * y) + std::fabs(t.m[2][2] * z) + std::fabs(t.m[2][3]));
-    if (wp == 1.0f) return V3(xp, yp, zp);
-    return V3(xp, yp, zp) / wp;
-}
-
 // Shared part of intersect / intersect_p: returns the object-space hit (shapes/sphere.rs:59-152 == :198-286, including the
 // `phi += 2.0 * phi` quirk of intersect_p and of intersect's second branch, App. A #8).
 static bool sphere_hit(const PtSphere &S, const Ray &r, bool is_intersect_p, Float &t_out, V3 &p_hit_out, Float &phi_out, Ray &ray_obj) {

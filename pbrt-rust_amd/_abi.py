@@ -53,6 +53,17 @@ class PtBVHNode(C.Structure):
     _fields_ = [("bmin", f32 * 3), ("bmax", f32 * 3), ("offset", u32), ("n_prims", u16), ("axis", u8), ("pad", u8)]
 
 
+class PtObject(C.Structure):
+    _fields_ = [("first_prim", u32), ("n_prims", u32)]
+
+
+class PtInstance(C.Structure):
+    _fields_ = [("object", u32), ("instance_to_world", f32 * 16), ("world_to_instance", f32 * 16)]
+
+
+PT_TOP_INSTANCE = 0x80000000
+
+
 class PtSceneDesc(C.Structure):
     _fields_ = [("n_vertices", u32), ("P", fp), ("N", fp), ("S", fp), ("UV", fp),
                 ("n_triangles", u32), ("indices", u32p), ("tri_flags", u8p),
@@ -61,7 +72,9 @@ class PtSceneDesc(C.Structure):
                 ("n_materials", u32), ("materials", C.POINTER(PtMaterial)),
                 ("n_lights", u32), ("lights", C.POINTER(PtLight)),
                 ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp),
-                ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p)]
+                ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
+                ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
+                ("n_top", u32), ("top_refs", u32p)]
 
 
 class PtRenderParams(C.Structure):

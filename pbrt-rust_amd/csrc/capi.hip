@@ -65,6 +65,7 @@ struct pt_scene {
     std::vector<uint32_t> ordered;
     bool class_used[kNumClasses] = {true, false, false, false};
     uint32_t n_lights = 0;
+    std::vector<PtLight> host_lights; uint32_t env_w = 0, env_h = 0; float env_texel0[3] = {0, 0, 0};
     // light grids (lazy, per effective strategy)
     LightGrid grid[3]{}; bool grid_ready[3] = {false, false, false};
     // render workspace
@@ -146,7 +147,7 @@ int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
     job.refill_min = g_refill_min[job.kind & 3]; job.leaf_quorum = g_leaf_quorum[job.kind & 3];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
-    const bool sph = sc->ds.n_spheres > 0;
+    const bool sph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;  // general kernels: spheres and/or instances
     if (any && sph) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
     else if (any) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
     else if (sph) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
@@ -179,7 +180,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
                         &ps.mis_ox, &ps.mis_oy, &ps.mis_oz, &ps.mis_dx, &ps.mis_dy, &ps.mis_dz, &ps.mis_f_r, &ps.mis_f_g, &ps.mis_f_b,
                         &ps.mis_w, &ps.mis_spdf, &ps.nee_choice_pdf, &ps.nb_r, &ps.nb_g, &ps.nb_b, &ps.mis_b0, &ps.mis_b1, &ps.mis_b2};
         for (float **f : fa) { *f = (float *)p; p += capacity * 4; }
-        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim};
+        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim, &ps.hit_inst};
         for (uint32_t **u : ua) { *u = (uint32_t *)p; p += capacity * 4; }
         ps.occluded = (uint8_t *)p;
         static_assert(sizeof(fa) / sizeof(fa[0]) + sizeof(ua) / sizeof(ua[0]) <= kPathSoAFloatArrays, "slab too small");
@@ -210,9 +211,29 @@ int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
     g.strategy = effective; g.n_lights = sc->n_lights; g.nvox[0] = g.nvox[1] = g.nvox[2] = 1;
     const uint32_t nl = sc->n_lights;
     if (nl == 0) { g.func = g.cdf = g.func_int = nullptr; sc->grid_ready[effective] = true; return PT_OK; }
-    if (effective == PT_LS_POWER) return fail(PT_ERR_UNSUPPORTED, "lightsamplestrategy \"power\" is not implemented on device yet");
-    if (effective == PT_LS_UNIFORM) {
+    if (effective == PT_LS_UNIFORM || effective == PT_LS_POWER) {
         std::vector<float> func(nl, 1.0f), cdf; float fi;
+        if (effective == PT_LS_POWER) {  // compute_light_power_distribution (integrator.rs:239-247): Light::power().y() per light
+            std::vector<float> area(nl);
+            HIP_TRY(hipMemcpy(area.data(), sc->ds.light_area, nl * sizeof(float), hipMemcpyDeviceToHost));
+            const float wr = sc->ds.world_radius;
+            for (uint32_t i = 0; i < nl; ++i) {
+                const PtLight &L = sc->host_lights[i];
+                RGB c(L.L[0], L.L[1], L.L[2]), p(0.0f);
+                switch (L.type) {
+                case PT_LIGHT_DIFFUSE_AREA: p = c * area[i] * kPi; break;                                  // diffuse.rs:82-84
+                case PT_LIGHT_DISTANT: p = c * kPi * wr * wr; break;                                      // distant.rs:47-50
+                case PT_LIGHT_POINT: p = c * 4.0f * kPi; break;                                           // point.rs:44-46
+                case PT_LIGHT_SPOT: p = c * 2.0f * kPi * (1.0f - 0.5f * (L.cos_falloff_start + L.cos_total_width)); break;  // spot.rs:64-66
+                case PT_LIGHT_INFINITE: {                                                                  // infinite.rs:103-109
+                    if (sc->env_w != 1 || sc->env_h != 1) return fail(PT_ERR_UNSUPPORTED, "power light distribution with an image environment map");
+                    p = RGB(sc->env_texel0[0], sc->env_texel0[1], sc->env_texel0[2]) * wr * wr * kPi; break;
+                }
+                default: break;
+                }
+                func[i] = p.y();
+            }
+        }
         dist1d(func, cdf, fi);
         int st;
         if ((st = sc->upload(&g.func, func.data(), nl))) return st;
@@ -281,7 +302,7 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
-    if (sc->ds.n_spheres > 0) hipLaunchKernelGGL((k_shade<MAXL, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade<MAXL, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
@@ -308,7 +329,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // continuation rays -> hit record + material-class routing
         tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
         tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
-        tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2;
+        tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
         tj.class_count = &qc->shade[cur][0];
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
         tj.kind = (iter == 0) ? 3 : 0;
@@ -327,7 +348,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // MIS rays of the previous vertex (closest hit, integrator.rs:215)
         tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
         tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;
-        tj.out_prim = ps.mis_prim; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2;
+        tj.out_prim = ps.mis_prim; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2; tj.out_inst = nullptr;
         tj.class_count = nullptr;
         tj.kind = 1;
         sc->begin("extend_mis", n_mis);
@@ -432,7 +453,6 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const PtLight &L = d->lights[i];
         if (L.type == PT_LIGHT_DIFFUSE_AREA && L.prim >= d->n_prims) return fail(PT_ERR_INVALID_ARG, "area light primitive out of range");
         if (L.type == PT_LIGHT_DIFFUSE_AREA && (d->prim_shape[L.prim] >> 30) != PT_SHAPE_TRIANGLE) return fail(PT_ERR_UNSUPPORTED, "sphere area lights (sphere.rs:313-395) are not implemented on device yet");
-        if (L.type == PT_LIGHT_SPOT) return fail(PT_ERR_UNSUPPORTED, "spot lights are not implemented on device yet");
         if (L.type == PT_LIGHT_INFINITE && !d->env_texels) return fail(PT_ERR_INVALID_ARG, "infinite light without env_texels");
     }
     int st = ensure_device();
@@ -440,48 +460,91 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     pt_scene *sc = new pt_scene();
     auto bail = [&](int code) { pt_scene_destroy(sc); return code; };
     DeviceScene &ds = sc->ds;
-    // accelerator: adopt or build
+    // ---- accelerators: one BVH per multi-primitive object (api.rs:1692-1700) + the top-level BVH (adopted or built)
+    const bool instanced = d->n_instances > 0 && d->top_refs && d->n_top > 0;
+    if (d->n_instances && !instanced) return bail(fail(PT_ERR_INVALID_ARG, "instances given without top_refs"));
+    const uint32_t n_top = instanced ? d->n_top : d->n_prims;
+    auto prim_bound = [&](uint32_t i, pth::PrimBound &out) {
+        if ((d->prim_shape[i] >> 30) == PT_SHAPE_SPHERE) {  // Shape::world_bound = transform_bounds(object_bound) (shape.rs:23-25, sphere.rs:53-57, transform.rs:592-605)
+            const PtSphere &S = d->spheres[d->prim_shape[i] & 0x3fffffffu];
+            M4 o2w; std::memcpy(o2w.m, S.object_to_world, 64);
+            const float lo[3] = {-S.radius, -S.radius, S.z_min}, hi[3] = {S.radius, S.radius, S.z_max};
+            const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
+            for (int c = 0; c < 8; ++c) {
+                V3 p = xf_point(o2w, V3(corner[c][0] ? hi[0] : lo[0], corner[c][1] ? hi[1] : lo[1], corner[c][2] ? hi[2] : lo[2]));
+                const float pc[3] = {p.x, p.y, p.z};
+                for (int k = 0; k < 3; ++k) { out.lo[k] = c ? std::fmin(out.lo[k], pc[k]) : pc[k]; out.hi[k] = c ? std::fmax(out.hi[k], pc[k]) : pc[k]; }
+            }
+            return;
+        }
+        uint32_t tri = d->prim_shape[i] & 0x3fffffffu;  // Triangle::world_bound (triangle.rs:130-134)
+        const float *a = d->P + 3 * (size_t)d->indices[3 * tri], *b = d->P + 3 * (size_t)d->indices[3 * tri + 1], *c = d->P + 3 * (size_t)d->indices[3 * tri + 2];
+        for (int k = 0; k < 3; ++k) { out.lo[k] = std::fmin(std::fmin(a[k], b[k]), c[k]); out.hi[k] = std::fmax(std::fmax(a[k], b[k]), c[k]); }
+    };
+    const uint32_t maxp = d->max_node_prims ? d->max_node_prims : 4;
+    struct ObjAccel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };
+    std::vector<ObjAccel> obj(instanced ? d->n_objects : 0);
+    if (instanced) {
+        for (uint32_t o = 0; o < d->n_objects; ++o) {
+            const PtObject &O = d->objects[o];
+            if (O.n_prims == 0 || (uint64_t)O.first_prim + O.n_prims > d->n_prims) return bail(fail(PT_ERR_INVALID_ARG, "object primitive range out of bounds"));
+            if (O.n_prims == 1) continue;
+            std::vector<pth::PrimBound> pb(O.n_prims);
+            for (uint32_t i = 0; i < O.n_prims; ++i) prim_bound(O.first_prim + i, pb[i]);
+            pth::build_sah_bvh(pb, maxp, obj[o].nodes, obj[o].ordered);
+            for (auto &e : obj[o].ordered) e += O.first_prim;
+        }
+        for (uint32_t i = 0; i < d->n_instances; ++i) if (d->instances[i].object >= d->n_objects) return bail(fail(PT_ERR_INVALID_ARG, "instance object index out of range"));
+        for (uint32_t i = 0; i < n_top; ++i) {
+            uint32_t r = d->top_refs[i];
+            if ((r & PT_TOP_INSTANCE) ? ((r & ~PT_TOP_INSTANCE) >= d->n_instances) : (r >= d->n_prims)) return bail(fail(PT_ERR_INVALID_ARG, "top_refs entry out of range"));
+        }
+    }
+    auto top_ref = [&](uint32_t pos) { return instanced ? d->top_refs[pos] : pos; };
     if (d->nodes && d->n_nodes && d->ordered_prims) {
         sc->nodes.assign(d->nodes, d->nodes + d->n_nodes);
-        sc->ordered.assign(d->ordered_prims, d->ordered_prims + d->n_prims);
-        for (uint32_t i = 0; i < d->n_prims; ++i) if (sc->ordered[i] >= d->n_prims) return bail(fail(PT_ERR_INVALID_ARG, "ordered_prims entry out of range"));
+        sc->ordered.assign(d->ordered_prims, d->ordered_prims + n_top);
+        for (uint32_t i = 0; i < n_top; ++i) if (sc->ordered[i] >= n_top) return bail(fail(PT_ERR_INVALID_ARG, "ordered_prims entry out of range"));
         for (uint32_t i = 0; i < d->n_nodes; ++i) {
             const PtBVHNode &n = sc->nodes[i];
-            bool ok = n.n_prims ? ((uint64_t)n.offset + n.n_prims <= d->n_prims) : (n.offset < d->n_nodes && i + 1 < d->n_nodes && n.axis < 3);
+            bool ok = n.n_prims ? ((uint64_t)n.offset + n.n_prims <= n_top) : (n.offset < d->n_nodes && i + 1 < d->n_nodes && n.axis < 3);
             if (!ok) return bail(fail(PT_ERR_INVALID_ARG, "malformed BVH node"));
         }
     } else {
-        std::vector<pth::PrimBound> pb(d->n_prims);
-        for (uint32_t i = 0; i < d->n_prims; ++i) {  // Triangle::world_bound (triangle.rs:130-134)
-            if ((d->prim_shape[i] >> 30) == PT_SHAPE_SPHERE) {  // Shape::world_bound = transform_bounds(object_bound) (shape.rs:23-25, sphere.rs:53-57, transform.rs:592-605)
-                const PtSphere &S = d->spheres[d->prim_shape[i] & 0x3fffffffu];
-                M4 o2w; std::memcpy(o2w.m, S.object_to_world, 64);
-                const float lo[3] = {-S.radius, -S.radius, S.z_min}, hi[3] = {S.radius, S.radius, S.z_max};
-                const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
-                for (int c = 0; c < 8; ++c) {
-                    V3 p = xf_point(o2w, V3(corner[c][0] ? hi[0] : lo[0], corner[c][1] ? hi[1] : lo[1], corner[c][2] ? hi[2] : lo[2]));
-                    const float pc[3] = {p.x, p.y, p.z};
-                    for (int k = 0; k < 3; ++k) { pb[i].lo[k] = c ? std::fmin(pb[i].lo[k], pc[k]) : pc[k]; pb[i].hi[k] = c ? std::fmax(pb[i].hi[k], pc[k]) : pc[k]; }
-                }
-                continue;
+        std::vector<pth::PrimBound> pb(n_top);
+        for (uint32_t i = 0; i < n_top; ++i) {
+            const uint32_t r = top_ref(i);
+            if (!(r & PT_TOP_INSTANCE)) { prim_bound(r, pb[i]); continue; }
+            // TransformedPrimitive::world_bound = prim_to_world.motion_bounds(inner bound) (primitive.rs:53-55, transform.rs:1564-1567,592-605)
+            const PtInstance &I = d->instances[r & ~PT_TOP_INSTANCE];
+            const PtObject &O = d->objects[I.object];
+            pth::PrimBound inner;
+            if (O.n_prims == 1) prim_bound(O.first_prim, inner);
+            else for (int k = 0; k < 3; ++k) { inner.lo[k] = obj[I.object].nodes[0].bmin[k]; inner.hi[k] = obj[I.object].nodes[0].bmax[k]; }
+            M4 i2w; std::memcpy(i2w.m, I.instance_to_world, 64);
+            const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
+            for (int c = 0; c < 8; ++c) {
+                V3 p = xf_point(i2w, V3(corner[c][0] ? inner.hi[0] : inner.lo[0], corner[c][1] ? inner.hi[1] : inner.lo[1], corner[c][2] ? inner.hi[2] : inner.lo[2]));
+                const float pc[3] = {p.x, p.y, p.z};
+                for (int k = 0; k < 3; ++k) { pb[i].lo[k] = c ? std::fmin(pb[i].lo[k], pc[k]) : pc[k]; pb[i].hi[k] = c ? std::fmax(pb[i].hi[k], pc[k]) : pc[k]; }
             }
-            uint32_t tri = d->prim_shape[i] & 0x3fffffffu;
-            const float *a = d->P + 3 * (size_t)d->indices[3 * tri], *b = d->P + 3 * (size_t)d->indices[3 * tri + 1], *c = d->P + 3 * (size_t)d->indices[3 * tri + 2];
-            for (int k = 0; k < 3; ++k) { pb[i].lo[k] = std::fmin(std::fmin(a[k], b[k]), c[k]); pb[i].hi[k] = std::fmax(std::fmax(a[k], b[k]), c[k]); }
         }
-        pth::build_sah_bvh(pb, d->max_node_prims ? d->max_node_prims : 4, sc->nodes, sc->ordered);
+        pth::build_sah_bvh(pb, maxp, sc->nodes, sc->ordered);
     }
     // uploads
 #define UP(field, src, count) if ((st = sc->upload(&ds.field, src, (size_t)(count)))) return bail(st)
-    std::vector<uint32_t> leaf_last;
-    {   // two-wide traversal records: one per interior node, children's bounds inline (dev_scene.h: WideNode)
-        const std::vector<PtBVHNode> &nn = sc->nodes;
-        if (nn.size() > (size_t)kRefMask || d->n_prims > kRefMask) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^25 BVH nodes / primitives"));
+    // Two-wide traversal records (dev_scene.h: WideNode) and the packet order of every accelerator, concatenated:
+    // [top level][object 0][object 1]... ; references inside an accelerator are offset by its bases.
+    std::vector<uint32_t> leaf_last, packet_refs;
+    std::vector<WideNode> wide;
+    std::vector<DevInstance> dinst(instanced ? d->n_instances : 0);
+    auto append_accel = [&](const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &refs, uint32_t &root_ref) {
+        const uint32_t wbase = (uint32_t)wide.size(), pbase = (uint32_t)packet_refs.size();
         std::vector<uint32_t> wide_id(nn.size(), 0);
         uint32_t n_int = 0;
-        for (size_t i = 0; i < nn.size(); ++i) { if (nn[i].n_prims == 0) wide_id[i] = n_int++; else leaf_last.push_back(nn[i].offset + nn[i].n_prims - 1); }
-        auto ref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | nn[i].offset) : wide_id[i]; };
-        std::vector<WideNode> wide(std::max<uint32_t>(1, n_int));
+        for (size_t i = 0; i < nn.size(); ++i) { if (nn[i].n_prims == 0) wide_id[i] = wbase + n_int++; else leaf_last.push_back(pbase + nn[i].offset + nn[i].n_prims - 1); }
+        auto ref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | (pbase + nn[i].offset)) : wide_id[i]; };
+        wide.resize(wbase + n_int);
         for (size_t i = 0; i < nn.size(); ++i) {
             if (nn[i].n_prims) continue;
             WideNode &w = wide[wide_id[i]];
@@ -492,10 +555,36 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             w.left_ref = ref_of((uint32_t)i + 1); w.right_ref = ref_of(nn[i].offset);
             w.meta = nn[i].axis; w.pad = 0;
         }
+        packet_refs.insert(packet_refs.end(), refs.begin(), refs.end());
+        root_ref = ref_of(0);
+    };
+    {
+        std::vector<uint32_t> top_order(n_top);
+        for (uint32_t i = 0; i < n_top; ++i) top_order[i] = top_ref(sc->ordered[i]);
+        append_accel(sc->nodes, top_order, ds.root_ref);
+        ds.n_nodes = (uint32_t)sc->nodes.size();
+        for (int k = 0; k < 3; ++k) { ds.root_min[k] = sc->nodes[0].bmin[k]; ds.root_max[k] = sc->nodes[0].bmax[k]; }
+        std::vector<uint32_t> obj_root(obj.size(), 0);
+        for (size_t o = 0; o < obj.size(); ++o) {
+            if (d->objects[o].n_prims == 1) {  // single primitive: a one-packet "leaf" without a BVH
+                obj_root[o] = kLeafBit | (uint32_t)packet_refs.size();
+                leaf_last.push_back((uint32_t)packet_refs.size());
+                packet_refs.push_back(d->objects[o].first_prim);
+            } else append_accel(obj[o].nodes, obj[o].ordered, obj_root[o]);
+        }
+        for (size_t i = 0; i < dinst.size(); ++i) {
+            const PtInstance &I = d->instances[i]; DevInstance &D = dinst[i];
+            std::memcpy(D.world_to_instance, I.world_to_instance, 64); std::memcpy(D.instance_to_world, I.instance_to_world, 64);
+            D.single = d->objects[I.object].n_prims == 1; D.root_ref = obj_root[I.object]; D.pad = 0;
+            for (int k = 0; k < 3; ++k) { D.root_min[k] = D.single ? 0.0f : obj[I.object].nodes[0].bmin[k]; D.root_max[k] = D.single ? 0.0f : obj[I.object].nodes[0].bmax[k]; }
+            bool ident = true;
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ident = ident && I.instance_to_world[4 * r + c] == ((r == c) ? 1.0f : 0.0f);
+            D.identity = ident;
+        }
+        if (wide.size() > (size_t)kRefMask || packet_refs.size() > (size_t)kRefMask) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^25 BVH records / packets"));
+        if (wide.empty()) wide.resize(1);
         UP(wide, wide.data(), wide.size());
-        ds.n_nodes = (uint32_t)nn.size();
-        for (int k = 0; k < 3; ++k) { ds.root_min[k] = nn[0].bmin[k]; ds.root_max[k] = nn[0].bmax[k]; }
-        ds.root_ref = ref_of(0);
+        UP(instances, dinst.data(), dinst.size()); ds.n_instances = (uint32_t)dinst.size();
     }
     UP(P, d->P, 3 * (size_t)d->n_vertices);
     if (d->N) UP(N, d->N, 3 * (size_t)d->n_vertices);
@@ -513,6 +602,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     UP(materials, d->materials, d->n_materials); ds.n_materials = d->n_materials;
     UP(spheres, d->spheres, d->n_spheres); ds.n_spheres = d->n_spheres;
     UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
+    if (d->n_lights) sc->host_lights.assign(d->lights, d->lights + d->n_lights);
+    if (d->env_texels) { sc->env_w = d->env_width; sc->env_h = d->env_height; for (int k = 0; k < 3; ++k) sc->env_texel0[k] = d->env_texels[k]; }
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
         for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }
@@ -548,12 +639,13 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     // leaf triangle packets + light areas (device)
     {
         const uint32_t *d_ordered = nullptr;
-        if ((st = sc->upload(&d_ordered, sc->ordered.data(), sc->ordered.size()))) return bail(st);
+        const uint32_t n_packets = (uint32_t)packet_refs.size();
+        if ((st = sc->upload(&d_ordered, packet_refs.data(), packet_refs.size()))) return bail(st);
         TriPacket *leaf = nullptr; float *area = nullptr;
-        if ((st = sc->dalloc(&leaf, (size_t)d->n_prims + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
-        if (hipMemset(leaf, 0, ((size_t)d->n_prims + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
+        if ((st = sc->dalloc(&leaf, (size_t)n_packets + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
+        if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
-        hipLaunchKernelGGL(k_build_packets, dim3((d->n_prims + 255) / 256), dim3(256), 0, 0, ds, d_ordered, leaf);
+        hipLaunchKernelGGL(k_build_packets, dim3((n_packets + 255) / 256), dim3(256), 0, 0, ds, d_ordered, n_packets, leaf);
         ds.leaf = leaf;
         {
             const uint32_t *d_last = nullptr;

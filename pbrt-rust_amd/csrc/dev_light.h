@@ -147,6 +147,17 @@ PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, 
         p1.p = pl;
         return RGB(L.L[0], L.L[1], L.L[2]) / distance_squared(pl, ref.p);
     }
+    case PT_LIGHT_SPOT: {  // spot.rs:48-56,71-87
+        V3 pl(L.pos[0], L.pos[1], L.pos[2]);
+        wi = normalize(pl - ref.p); pdf = 1.0f;
+        p1.p = pl;
+        V3 wl = normalize(xf_vector(ldm4(L.world_to_light), -wi));
+        float cos_theta = wl.z, fall;
+        if (cos_theta < L.cos_total_width) fall = 0.0f;
+        else if (cos_theta >= L.cos_falloff_start) fall = 1.0f;
+        else { float delta = (cos_theta - L.cos_total_width) / (L.cos_falloff_start - L.cos_total_width); fall = (delta * delta) * (delta * delta); }
+        return RGB(L.L[0], L.L[1], L.L[2]) * fall / distance_squared(pl, ref.p);
+    }
     case PT_LIGHT_INFINITE: {  // infinite.rs:140-177
         float map_pdf = 0.0f;
         P2 uv = env_sample_continuous(s, u, map_pdf);

@@ -18,7 +18,7 @@ struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads p
     float p1yz[2]; float p2xy[2];
     float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
 };
-enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
+enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
 
 // Two-wide traversal record (64 B, four dwordx4 loads): one per INTERIOR node of the reference tree, holding the
 // bounds of both children, so that a ray fetches once per interior node it enters instead of once per node it tests.
@@ -34,6 +34,16 @@ struct WideNode {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefMask = 0x01ffffffu;   // 25 bits: 33 M records / packets (stack entries pack 6 more bits above)
 
+// TransformedPrimitive (primitive.rs:40-88) on device: transforms + entry into the object's BVH
+struct DevInstance {
+    float world_to_instance[16], instance_to_world[16];
+    float root_min[3], root_max[3];   // bounds of the object's BVH root (unused when `single`)
+    uint32_t root_ref;                // wide-record index or kLeafBit | first packet
+    uint32_t single;                  // object holds one primitive: no BVH, no root test (api.rs:1692)
+    uint32_t identity;                // Transform::is_identity(instance_to_world) (primitive.rs:73)
+    uint32_t pad;
+};
+
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
@@ -41,6 +51,7 @@ struct DeviceScene {
     const float *P; const float *N; const float *S; const float *UV;
     const uint32_t *indices; const uint8_t *tri_flags; uint32_t n_triangles;
     const PtSphere *spheres; uint32_t n_spheres;
+    const DevInstance *instances; uint32_t n_instances;
     const uint32_t *prim_shape; const uint32_t *prim_material; const uint32_t *prim_light;
     const PtMaterial *materials; uint32_t n_materials;
     const PtLight *lights; uint32_t n_lights;

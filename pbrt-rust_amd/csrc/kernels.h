@@ -19,6 +19,7 @@ struct PathSoA {
     float *pfilm_x, *pfilm_y;
     float *ox, *oy, *oz, *dx, *dy, *dz;                 // continuation ray (t_max = inf)
     uint32_t *hit_prim; float *hit_b0, *hit_b1, *hit_b2; // closest hit of the continuation ray
+    uint32_t *hit_inst;                                  // instance the hit went through (PT_NONE: top level)
     float *beta_r, *beta_g, *beta_b, *L_r, *L_g, *L_b, *etascale;
     uint64_t *sobol_index;
     uint32_t *meta;                                      // dim (bits 0-15) | bounces (16-23) | flags (24-31)
@@ -32,7 +33,7 @@ struct PathSoA {
     uint32_t *mis_prim; float *mis_b0, *mis_b1, *mis_b2; // closest hit of the MIS ray
     uint8_t *occluded;
 };
-constexpr int kPathSoAFloatArrays = 50;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
+constexpr int kPathSoAFloatArrays = 51;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)
@@ -81,6 +82,7 @@ struct TraceJob {
     float scalar_tmax;
     // outputs (indexed by path id)
     uint32_t *out_prim; float *out_t, *out_b0, *out_b1, *out_b2;
+    uint32_t *out_inst;      // may be NULL
     uint8_t *out_occluded;
     // shade-queue routing (closest-hit of continuation rays only)
     uint32_t *class_count;   // [kNumClasses] or NULL

@@ -71,12 +71,18 @@ template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount,
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
 // (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
-__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, TriPacket *out) {
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n_prims) return;
-    uint32_t prim = ordered[i];
-    uint32_t shape = s.prim_shape[prim];
+    if (i >= n_refs) return;
+    uint32_t prim = ordered[i];      // primitive index, or PT_TOP_INSTANCE | instance index
     TriPacket p;
+    if (prim & PT_TOP_INSTANCE) {
+        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
+        out[i] = p;
+        return;
+    }
+    uint32_t shape = s.prim_shape[prim];
     p.prim = prim; p.shape = shape; p.flags = 0;
     if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
         uint32_t tri = shape & 0x3fffffffu;
@@ -132,6 +138,7 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 //    (6 bits in the stack word) and added to the node-visit counter at the moment the reference would pop them.
 // Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
 
+// GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
 template <bool ANY, bool SPH>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
@@ -155,6 +162,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     bool nx = false, ny = false, nz = false, found = false;
     float t_max = 0.0f;
     uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
+    uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
+    constexpr uint32_t kMarker = 0xFFC0DEADu;   // stack word 1 of an "end of instance" entry (never a real tmin)
 
     // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
     auto pop_next = [&]() {
@@ -165,6 +175,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
             uint32_t w0, w1;
             if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
             else { w0 = spill[2 * (sp - kLdsStack)]; w1 = spill[2 * (sp - kLdsStack) + 1]; }
+            if (SPH && w1 == kMarker) {                // the object's BVH is exhausted: back to world space (primitive.rs:70-77)
+                pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
+                ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]); rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
+                inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
+                in_inst = PT_NONE; inst_hit = false;
+                if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; return; }  // remaining packets of the outer leaf
+                continue;
+            }
             n_nodes++;                                 // the reference tests the popped node now
             pending = (w0 >> 25) & 63u;
             if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
@@ -189,6 +209,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                     job.out_prim[pid] = hit_prim;
                     if (job.out_t) job.out_t[pid] = hit_t;
                     job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
+                    if (SPH && job.out_inst) job.out_inst[pid] = hit_inst;
                 }
             }
             if (retire) state = ST_IDLE;
@@ -216,6 +237,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                     sp = 0; pending = 0; found = false;
                     hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                    in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
                     n_rays++;
                     state = ST_DONE;
                     if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
 
         // ---- phase 2: leaf packets in ordered_prims order, two at a time (both loads in flight together)
         if (state == ST_LEAF) {
-            bool last = false;
+            bool last = false, entered_instance = false;
             uint32_t li = cur;
             while (!last) {
                 const uint4 a0 = leaf4[3 * (size_t)li], a1 = leaf4[3 * (size_t)li + 1], a2 = leaf4[3 * (size_t)li + 2];
@@ -278,7 +300,38 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                 for (int k = 0; k < 2; ++k) {
                     const uint4 q0 = k ? c0 : a0, q1 = k ? c1 : a1, q2 = k ? c2 : a2;
                     const uint32_t fl = q2.w;
-                    if (fl & TP_SPHERE) {
+                    if (fl & TP_INSTANCE) {
+                        if constexpr (SPH) {  // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
+                            const DevInstance &I = s.instances[q2.z];
+                            // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
+                            const M4 w2i = ldm4g(I.world_to_instance);
+                            V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+                            const float l2 = length_squared(d2);
+                            float tm2 = t_max;
+                            if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
+                            const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
+                            const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
+                            bool enter = true;
+                            if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+                            if (enter) {
+                                // remember where to resume: the rest of this leaf (if any) and the outer skip count
+                                const bool more = !(fl & TP_LAST);
+                                const uint32_t w0 = (more ? (kLeafBit | ((li + (uint32_t)k + 1u) & kRefMask)) : 0u) | (pending << 25);
+                                if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                                else {
+                                    if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
+                                    else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = kMarker; }
+                                    sp++; pending = 0;
+                                    t_max_world = t_max; in_inst = q2.z; inst_hit = false;
+                                    ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
+                                    cur = I.root_ref & kRefMask;
+                                    state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                                    last = true; entered_instance = true;
+                                    break;
+                                }
+                            }
+                        }
+                    } else if (fl & TP_SPHERE) {
                         if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
                             n_sph++;
                             float t, phi; V3 ph, dobj;
@@ -286,6 +339,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                                 if (ANY) { found = true; last = true; state = ST_DONE; break; }
                                 found = true; t_max = t;
                                 hit_prim = q2.y; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
+                                hit_inst = in_inst; inst_hit = in_inst != PT_NONE;
                             }
                         }
                     } else {
@@ -299,6 +353,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                             if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
                                 found = true; t_max = t;  // primitive.rs:137
                                 hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                                if (SPH) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
                             }
                         }
                     }
@@ -306,7 +361,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                 }
                 li += 2;
             }
-            if (state == ST_LEAF) pop_next();
+            if (state == ST_LEAF && !entered_instance) pop_next();
         }
 
     }
@@ -442,8 +497,27 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
 // ---- shading ---------------------------------------------------------------------------------------------
 
 // Rebuild the SurfaceInteraction of a recorded hit (triangle: from the barycentrics; sphere: re-evaluated from the ray).
-template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
+template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, uint32_t inst, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
     const uint32_t sh = s.prim_shape[prim];
+    if (SPH && inst != PT_NONE) {  // TransformedPrimitive::intersect (primitive.rs:58-80): object-space interaction, then to world
+        const DevInstance &I = s.instances[inst];
+        const M4 w2i = ldm4g(I.world_to_instance), i2w = ldm4g(I.instance_to_world);
+        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+        const float l2 = length_squared(d2);
+        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; }
+        if ((sh >> 30) == PT_SHAPE_SPHERE) sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], o2, d2, si);
+        else tri_fill_interaction(s, sh & 0x3fffffffu, d2, b0, b1, b2, true, si);
+        if (!I.identity) {  // transform_surface_interaction (transform.rs:607-636)
+            V3 perr;
+            si.p = xf_point_abs_err(i2w, si.p, si.p_error, perr); si.p_error = perr;
+            si.n = normalize(xf_normal_inv(w2i, si.n));
+            si.wo = normalize(xf_vector(i2w, si.wo));
+            si.dpdu = xf_vector(i2w, si.dpdu);
+            si.sh_n = face_forward(normalize(xf_normal_inv(w2i, si.sh_n)), si.n);
+            si.sh_dpdu = xf_vector(i2w, si.sh_dpdu);
+        }
+        return;
+    }
     if (SPH && (sh >> 30) == PT_SHAPE_SPHERE) { sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], ro, rd, si); return; }
     tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
 }
@@ -490,7 +564,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                 if (mp != PT_NONE) {
                     if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
                         SurfaceInteraction lsi;
-                        fill_hit<SPH>(s, mp, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);
+                        fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);  // lights are never inside instances (api.rs:1605-1608)
                         lrad = area_l(Lt, lsi.n, -wi);
                     }
                 } else lrad = light_le(s, Lt, wi);
@@ -514,7 +588,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
             const uint32_t hp = ps.hit_prim[pid];
             const bool found = hp != PT_NONE;
             SurfaceInteraction si;
-            if (found) fill_hit<SPH>(s, hp, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+            if (found) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
             // path.rs:106-117
             if (bounces == 0 || (flags & PF_SPECULAR)) {
                 if (found) {

@@ -144,6 +144,11 @@ class SceneBuilder:
         self.prim_shape, self.prim_material, self.prim_light = [], [], []
         self.nprims = 0
         self.env = None
+        self.top_refs = []            # RenderOptions.primitives: prim indices / PT_TOP_INSTANCE | instance
+        self.objects = {}             # name -> [first_prim, n_prims]
+        self.object_list = []
+        self.instances = []
+        self.current_object = None
         # options block defaults (api.rs:215-241, film.rs:364-398, sobol.rs:120, path.rs:228-249)
         self.film = dict(xres=1280, yres=720, crop=(0.0, 1.0, 0.0, 1.0), scale=1.0, max_lum=float("inf"))
         self.filter = dict(kind="box", radius=(0.5, 0.5), alpha=2.0)
@@ -208,6 +213,19 @@ class SceneBuilder:
             p = np.asarray(kw.get("from_", (0, 0, 0)), dtype=F)
             t = l2w * Transform.translate((p[0], p[1], p[0]))
             l.type = A.PT_LIGHT_POINT; l.L = (C.c_float * 3)(*I); l.pos = (C.c_float * 3)(*t.point((0, 0, 0)))
+        elif kind == "spot":  # spot.rs:118-147
+            I = np.asarray(kw.get("I", (1, 1, 1)), dtype=F) * F(sc)
+            frm, to = np.asarray(kw.get("from_", (0, 0, 0)), dtype=F), np.asarray(kw.get("to", (0, 0, 1)), dtype=F)
+            coneangle, conedelta = F(kw.get("coneangle", 30.0)), F(kw.get("conedeltaangle", 5.0))
+            d = to - frm; d = d / np.sqrt((d * d).sum(dtype=F))
+            if abs(d[0]) > abs(d[1]): du = np.array([-d[2], 0, d[0]], dtype=F) / np.sqrt(d[0] * d[0] + d[2] * d[2])
+            else: du = np.array([0, d[2], -d[1]], dtype=F) / np.sqrt(d[1] * d[1] + d[2] * d[2])
+            dv = np.cross(d.astype(np.float64), du.astype(np.float64)).astype(F)
+            mat = np.eye(4, dtype=F); mat[0, :3] = du; mat[1, :3] = dv; mat[2, :3] = d
+            t = l2w * Transform.translate(frm) * Transform(mat).inverse()
+            l.type = A.PT_LIGHT_SPOT; l.L = (C.c_float * 3)(*I); l.pos = (C.c_float * 3)(*t.point((0, 0, 0)))
+            l.cos_total_width = math.cos(F(math.pi / 180.0) * coneangle); l.cos_falloff_start = math.cos(F(math.pi / 180.0) * (coneangle - conedelta))
+            l.light_to_world = (C.c_float * 16)(*t.m.flatten()); l.world_to_light = (C.c_float * 16)(*t.m_inv.flatten())
         elif kind == "infinite":  # infinite.rs:243-259, constant-L map = 1x1 texel
             L = np.asarray(kw.get("L", (1, 1, 1)), dtype=F) * F(sc)
             l.type = A.PT_LIGHT_INFINITE
@@ -244,10 +262,12 @@ class SceneBuilder:
         self.prim_shape.append((np.uint32(A.PT_SHAPE_TRIANGLE << 30) | (np.arange(nt, dtype=np.uint32) + np.uint32(self.ntris))).astype(np.uint32))
         mid = A.PT_NONE if self.material_id is None else self.material_id
         self.prim_material.append(np.full(nt, mid, dtype=np.uint32))
-        if self.area_light is None:
+        if self.area_light is None or self.current_object is not None:  # api.rs:1605-1608: area lights inside instances are dropped
             self.prim_light.append(np.full(nt, A.PT_NONE, dtype=np.uint32))
         else:
             self.prim_light.append(np.array([self._new_area_light(first_prim + t) for t in range(nt)], dtype=np.uint32))
+        if self.current_object is None: self.top_refs.append(np.arange(first_prim, first_prim + nt, dtype=np.uint32))
+        else: self.objects[self.current_object][1] += nt
         self.nverts += nv; self.ntris += nt; self.nprims += nt
         return first_prim
 
@@ -268,9 +288,33 @@ class SceneBuilder:
         first_prim = self.nprims
         self.prim_shape.append(np.array([(A.PT_SHAPE_SPHERE << 30) | (len(self.spheres) - 1)], dtype=np.uint32))
         self.prim_material.append(np.array([A.PT_NONE if self.material_id is None else self.material_id], dtype=np.uint32))
-        self.prim_light.append(np.array([A.PT_NONE if self.area_light is None else self._new_area_light(first_prim)], dtype=np.uint32))
+        self.prim_light.append(np.array([A.PT_NONE if (self.area_light is None or self.current_object is not None) else self._new_area_light(first_prim)], dtype=np.uint32))
+        if self.current_object is None: self.top_refs.append(np.array([first_prim], dtype=np.uint32))
+        else: self.objects[self.current_object][1] += 1
         self.nprims += 1
         return first_prim
+
+    # -- instancing (api.rs:1630-1713)
+    def object_begin(self, name):
+        self.attribute_begin()
+        self.objects[name] = [self.nprims, 0]
+        self.current_object = name
+
+    def object_end(self):
+        self.current_object = None
+        self.attribute_end()
+
+    def object_instance(self, name):
+        first, n = self.objects[name]
+        if n == 0:
+            return
+        if name not in [o[0] for o in self.object_list]:
+            self.object_list.append((name, first, n))
+        oid = [o[0] for o in self.object_list].index(name)
+        inst = A.PtInstance(); inst.object = oid
+        inst.instance_to_world = (C.c_float * 16)(*self.ctm.m.flatten()); inst.world_to_instance = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+        self.instances.append(inst)
+        self.top_refs.append(np.array([A.PT_TOP_INSTANCE | (len(self.instances) - 1)], dtype=np.uint32))
 
     # -- WorldEnd (api.rs:1715-1748): flatten to the C ABI structs
     def world_end(self):
@@ -359,6 +403,10 @@ class SceneData:
         self.env = b.env
         self.max_node_prims = b.max_node_prims
         self.nodes = None; self.ordered = None
+        self.n_objects, self.n_instances = len(b.object_list), len(b.instances)
+        self.objects = (A.PtObject * max(1, self.n_objects))(*[A.PtObject(f, n) for _, f, n in b.object_list])
+        self.instances = (A.PtInstance * max(1, self.n_instances))(*b.instances)
+        self.top_refs = np.ascontiguousarray(np.concatenate(b.top_refs), dtype=np.uint32) if (b.instances and b.top_refs) else None
 
     def set_bvh(self, nodes, ordered):
         """Adopt a prebuilt accelerator (what a Rust host would pass: BVHAccel.nodes / ordered prims)."""
@@ -381,4 +429,7 @@ class SceneData:
         d.max_node_prims = self.max_node_prims
         if self.nodes is not None:
             d.n_nodes = len(self.nodes); d.nodes = self.nodes; d.ordered_prims = ptr(self.ordered, A.u32p)
+        if self.top_refs is not None:
+            d.n_objects = self.n_objects; d.objects = self.objects; d.n_instances = self.n_instances; d.instances = self.instances
+            d.n_top = len(self.top_refs); d.top_refs = ptr(self.top_refs, A.u32p)
         return d

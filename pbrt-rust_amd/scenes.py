@@ -144,3 +144,44 @@ def spheres_c1(xres=400, yres=400, spp=64, maxdepth=5):
     b.attribute_begin(); b.material("plastic", Kd=(0.2, 0.5, 0.2)); b.translate(0.0, -0.6, 1.6); b.rotate(35.0, 1.0, 0.0, 0.0)
     b.sphere(radius=0.4, zmin=-0.25, zmax=0.3, phimax=300.0); b.attribute_end()
     return b
+
+
+def instanced_garden(n_inst=24, plant_n=10, xres=96, yres=64, spp=8, flatten=False, seed=7):
+    """S4-style instancing test (config C4 in miniature): a ground mesh + `n_inst` ObjectInstances of two small
+    "plant" objects (one multi-primitive, one single-triangle object) with random translate/rotate/scale (numpy PCG64
+    seed), constant environment + one area light. `flatten=True` emits the same geometry without instancing."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.look_at((0.0, 3.0, 9.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=45.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.4, 0.45, 0.5))
+    b.attribute_begin(); b.area_light_source(L=(25.0, 22.0, 18.0))
+    P, I = quad((-1.5, 7.0, -1.5), (1.5, 7.0, -1.5), (1.5, 7.0, 1.5), (-1.5, 7.0, 1.5)); b.trianglemesh(P, I); b.attribute_end()
+    b.material("matte", Kd=(0.35, 0.3, 0.2))
+    P, I = quad((-12.0, 0.0, -12.0), (-12.0, 0.0, 12.0), (12.0, 0.0, 12.0), (12.0, 0.0, -12.0)); b.trianglemesh(P, I)
+    plantP, plantI, plantN = displaced_sphere(plant_n, with_normals=True)
+    leafP = np.array([(0.0, 0.0, 0.0), (0.6, 1.2, 0.0), (-0.6, 1.2, 0.1)], dtype=F); leafI = np.array([[0, 1, 2]], dtype=np.uint32)
+    if not flatten:
+        b.object_begin("plant"); b.material("plastic", Kd=(0.1, 0.5, 0.15), Ks=(0.2, 0.2, 0.2), roughness=0.2)
+        b.translate(0.0, 0.5, 0.0); b.scale(0.5, 0.9, 0.5); b.trianglemesh(plantP, plantI, N=plantN); b.object_end()
+        b.object_begin("leaf"); b.material("matte", Kd=(0.6, 0.2, 0.1)); b.trianglemesh(leafP, leafI); b.object_end()
+    for k in range(n_inst):
+        tx, tz = rng.uniform(-6, 6, 2); ang = rng.uniform(0, 360); sc = rng.uniform(0.6, 1.4)
+        b.attribute_begin()
+        b.translate(float(tx), 0.0, float(tz)); b.rotate(float(ang), 0.0, 1.0, 0.0); b.scale(float(sc), float(sc), float(sc))
+        name = "plant" if k % 3 else "leaf"
+        if not flatten:
+            b.object_instance(name)
+        elif name == "plant":
+            b.material("plastic", Kd=(0.1, 0.5, 0.15), Ks=(0.2, 0.2, 0.2), roughness=0.2)
+            b.translate(0.0, 0.5, 0.0); b.scale(0.5, 0.9, 0.5); b.trianglemesh(plantP, plantI, N=plantN)
+        else:
+            b.material("matte", Kd=(0.6, 0.2, 0.1)); b.trianglemesh(leafP, leafI)
+        b.attribute_end()
+    # one instance with the identity transform (transform_surface_interaction is skipped: primitive.rs:73-75)
+    if not flatten:
+        b.object_instance("leaf")
+    else:
+        b.material("matte", Kd=(0.6, 0.2, 0.1)); b.trianglemesh(leafP, leafI)
+    return b

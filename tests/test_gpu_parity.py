@@ -208,3 +208,28 @@ def test_spheres_c1_matches_oracle(pkg, gpu, oracle):
     for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats"):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_spot_light_and_power_distribution(pkg, gpu, oracle):
+    b = pkg.scenes.ganesha_scale(n=16, xres=48, yres=32, spp=4, strategy="power")
+    b.light_source("spot", I=(40.0, 40.0, 30.0), from_=(1.0, 3.0, 2.0), to=(0.0, 0.0, 0.0), coneangle=25.0, conedeltaangle=8.0)
+    b.light_source("point", I=(5.0, 5.0, 9.0), from_=(-2.0, 2.0, 1.0))
+    sd, rp = b.world_end()
+    _compare_render(pkg, gpu, oracle, sd, rp)
+
+
+def test_instancing_matches_oracle(pkg, gpu, oracle):
+    """Row a12 / config C4 in miniature: ObjectInstances (multi-primitive objects with their own BVH, a single-triangle
+    object without one, an identity-transform instance) over a ground mesh; two-level traversal, bit-exact counters."""
+    sd, rp = pkg.scenes.instanced_garden(xres=96, yres=64, spp=8).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    gn, go = g.bvh(); on, oo = orc.bvh()
+    assert bytes(gn) == bytes(on) and np.array_equal(go, oo)
+    _compare_render(pkg, gpu, oracle, sd, rp)
+    # closest-hit records through instances
+    o, d = _random_rays(50000, 11)
+    o[:, 1] += 2.0
+    tmax = np.full(len(o), np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(o, d, tmax); op, ot, ob = orc.trace_closest(o, d, tmax)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    assert np.array_equal(g.trace_any(o, d, np.full(len(o), 5.0, np.float32)), orc.trace_any(o, d, np.full(len(o), 5.0, np.float32)))

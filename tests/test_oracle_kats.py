@@ -221,3 +221,15 @@ def test_spheres_scene_renders(oracle, pkg):
     rgb = s.resolve(s.render(rp, nthreads=4))
     c = s.counters()
     assert c["sphere_tests"] > 0 and np.isfinite(rgb).all() and rgb.mean() > 0.01
+
+
+def test_instancing_equals_flattened_geometry(oracle, pkg):
+    """TransformedPrimitive (primitive.rs:58-88): rendering ObjectInstances must agree with the same geometry emitted
+    explicitly, up to the float differences of the object-space round trip (a few divergent paths)."""
+    imgs = []
+    for flatten in (False, True):
+        sd, rp = pkg.scenes.instanced_garden(xres=64, yres=48, spp=16, flatten=flatten).world_end()
+        s = oracle.scene(sd)
+        imgs.append(s.resolve(s.render(rp, nthreads=4)))
+    d = np.abs(imgs[0] - imgs[1])
+    assert d.mean() < 5e-3 and (d.max(axis=2) > 0.1).mean() < 0.03
