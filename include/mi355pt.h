@@ -78,7 +78,9 @@ typedef enum PtMaterialType {
     PT_MAT_PLASTIC = 3,    /* materials/plastic.rs    */
     PT_MAT_METAL = 4,      /* materials/metal.rs      */
     PT_MAT_UBER = 5,       /* materials/uber.rs       */
-    PT_MAT_SUBSTRATE = 6   /* materials/substrate.rs  */
+    PT_MAT_SUBSTRATE = 6,  /* materials/substrate.rs  */
+    PT_MAT_SUBSURFACE = 7  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
+                              subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
 } PtMaterialType;
 
 /* Constant-texture material parameters (texture evaluation is a "next" row). Field use
@@ -98,6 +100,12 @@ typedef struct PtMaterial {
     float u_roughness;      /* glass/substrate: uroughness; metal/uber: < 0 => use `roughness` */
     float v_roughness;
     uint32_t remap_roughness;
+    /* subsurface (materials/subsurface.rs:47-106): sigma_a/sigma_s (before `scale`), scale, and the index of the
+     * material's BSSRDFTable in PtSceneDesc.bssrdf_tables (built by the host: compute_beam_diffusion_bssrdf). */
+    float sigma_a[3];
+    float sigma_s[3];
+    float scale;
+    uint32_t bssrdf_table;
 } PtMaterial;
 
 typedef enum PtLightType {
@@ -142,6 +150,16 @@ typedef struct PtInstance {
     float world_to_instance[16];
 } PtInstance;
 #define PT_TOP_INSTANCE 0x80000000u  /* top_refs entry: instance index | PT_TOP_INSTANCE, else a primitive index */
+
+/* core/bssrdf.rs:241-268 BSSRDFTable (100 albedo x 64 radius samples in the reference). */
+typedef struct PtBSSRDFTable {
+    uint32_t n_rho, n_radius;
+    const float *rho_samples;     /* n_rho              */
+    const float *radius_samples;  /* n_radius           */
+    const float *profile;         /* n_rho * n_radius   */
+    const float *rhoeff;          /* n_rho              */
+    const float *profile_cdf;     /* n_rho * n_radius   */
+} PtBSSRDFTable;
 
 typedef struct PtSceneDesc {
     /* All triangle meshes concatenated; P is world space (shapes/triangle.rs:39-41). */
@@ -190,6 +208,8 @@ typedef struct PtSceneDesc {
     uint32_t n_objects; const PtObject *objects;
     uint32_t n_instances; const PtInstance *instances;
     uint32_t n_top; const uint32_t *top_refs;
+
+    uint32_t n_bssrdf_tables; const PtBSSRDFTable *bssrdf_tables;
 } PtSceneDesc;
 
 /* ---- render parameters ---------------------------------------------------------------- */

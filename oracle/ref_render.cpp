@@ -3,7 +3,7 @@
 // the tile render loop, and the oracle's C ABI (driven from tests/ and bench.py's cpu_baseline leg).
 //   materials/{matte,mirror,glass,plastic,metal,uber,substrate}.rs; core/integrator.rs:81-237,263-403;
 //   integrators/path.rs:79-222; cameras/perspective.rs:120-179; core/film.rs:104-161,217-258,292-331.
-#include "ref_shading.h"
+#include "ref_bssrdf.h"
 #include <thread>
 #include <atomic>
 #include <chrono>
@@ -15,7 +15,8 @@ static RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
 static TRDist make_dist(Float ax, Float ay) { TRDist d; d.ax = fmax_(ax, 0.001f); d.ay = fmax_(ay, 0.001f); return d; }  // microfacet.rs:325-331
 
 // Returns false when the material leaves `si.bsdf == None` (null surface, path.rs:124-129).
-static bool compute_scattering_functions(const Scene &scene, const SurfaceInteraction &si, BSDF &bsdf) {
+static bool compute_scattering_functions(const Scene &scene, const SurfaceInteraction &si, BSDF &bsdf,
+                                         TabulatedBSSRDF *bssrdf = nullptr, bool *has_bssrdf = nullptr) {
     uint32_t mi = scene.prim_material[si.prim];
     if (mi == PT_NONE) return false;  // primitive.rs:168-170: no material => no bsdf
     const PtMaterial &m = scene.materials[mi];
@@ -133,6 +134,34 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
         }
         return false;  // App. A #14
     }
+    case PT_MAT_SUBSURFACE: {  // subsurface.rs:47-106 (kdsubsurface.rs:45-103 after the host-side subsurface_from_diffuse)
+        Float eta = m.eta, urough = m.u_roughness, vrough = m.v_roughness;
+        RGB R = rgb3(m.kr).clamps(0.0f, INF), T = rgb3(m.kt).clamps(0.0f, INF);
+        bsdf.init(si, eta);
+        if (R.is_black() && T.is_black()) return false;
+        bool is_specular = urough == 0.0f && vrough == 0.0f;
+        if (is_specular) {
+            Bxdf b; b.kind = BX_FRESNEL_SPEC; b.type = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+            b.r = R; b.t = T; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+        } else {
+            if (m.remap_roughness) { urough = TRDist::roughness_to_alpha(urough); vrough = TRDist::roughness_to_alpha(vrough); }
+            TRDist d = make_dist(urough, vrough);
+            if (!R.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = R; b.dist = d;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+            if (!T.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_T; b.type = BSDF_TRANSMISSION | BSDF_GLOSSY; b.t = T; b.dist = d; b.etaa = 1.0f; b.etab = eta;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+        }
+        if (bssrdf) {
+            RGB siga = rgb3(m.sigma_a).clamps(0.0f, INF) * m.scale, sigs = rgb3(m.sigma_s).clamps(0.0f, INF) * m.scale;
+            bssrdf->init(si, mi, eta, siga, sigs, &scene.bssrdf_tables[m.bssrdf_table]);
+            *has_bssrdf = true;
+        }
+        return true;
+    }
     }
     return false;
 }
@@ -226,7 +255,8 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
         }
         if (!found || bounces >= pp.max_depth) break;
         BSDF bsdf;
-        if (!compute_scattering_functions(*ctx.scene, isect, bsdf)) {
+        TabulatedBSSRDF bssrdf; bool has_bssrdf = false;
+        if (!compute_scattering_functions(*ctx.scene, isect, bsdf, &bssrdf, &has_bssrdf)) {
             IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
             ray = spawn_ray(it, ray.d);
             continue;
@@ -250,7 +280,44 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
         }
         IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
         ray = spawn_ray(it, wi);
-        // (BSSRDF branch path.rs:177-204: no subsurface material in the implemented rows)
+        if (has_bssrdf && (flags & BSDF_TRANSMISSION)) {  // path.rs:177-204
+            P2 s2 = sampler.get_2d();
+            Float s1 = sampler.get_1d();
+            // TabulatedBSSRDF::sample_s -> sample_sp (bssrdf.rs:334-410)
+            V3 start, target; Float u1n = 0.0f;
+            if (!bssrdf.probe_segment(s1, s2, start, target, u1n)) break;   // S black
+            IData base; base.p = start; base.p_error = V3(0, 0, 0); base.n = V3(0, 0, 0);
+            std::vector<SurfaceInteraction> chain;
+            for (;;) {
+                // spawn_rayto_point (interaction.rs:38-43): d = p2 - p measured from the un-offset point
+                V3 d = target - base.p;
+                Ray r(offset_ray_origin(base.p, base.p_error, base.n, d), d, 1.0f - SHADOW_EPSILON, 0.0f);
+                SurfaceInteraction si2;
+                if ((d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) || !ctx.scene->intersect(r, si2, *ctx.c)) break;
+                base.p = si2.p; base.p_error = si2.p_error; base.n = si2.n;
+                if (ctx.scene->prim_material[si2.prim] == bssrdf.material) chain.push_back(si2);
+            }
+            size_t nfound = chain.size();
+            if (nfound == 0) break;
+            size_t selected = (size_t)clampv((int64_t)(u1n * (Float)nfound), (int64_t)0, (int64_t)nfound - 1);
+            SurfaceInteraction pi = chain[selected];
+            pdf = bssrdf.pdf_sp(pi.p, pi.n) / (Float)nfound;
+            RGB S = bssrdf.sr(length(bssrdf.po_p - pi.p));
+            if (S.is_black() || pdf == 0.0f) break;
+            // sample_s (bssrdf.rs:559-574): BSDF::new(pi, 1.0) + SeparableBSSRDFAdapter, pi.wo = shading.n
+            BSDF pibsdf; pibsdf.init(pi, 1.0f);
+            { Bxdf b; b.kind = BX_BSSRDF; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.etab = bssrdf.eta; pibsdf.add(b); }
+            pi.wo = pi.sh_n;
+            beta *= S / pdf;
+            const Distribution1D *d2 = ctx.lights->lookup(pi.p);
+            L += beta * uniform_sample_onelight(ctx, pi, pibsdf, sampler, d2);
+            RGB ff = pibsdf.sample_f(pi.wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
+            if (ff.is_black() || pdf == 0.0f) break;
+            beta *= ff * abs_dot(wi, pi.sh_n) / pdf;
+            specular_bounce = (flags & BSDF_SPECULAR) != 0;
+            IData pit; pit.p = pi.p; pit.p_error = pi.p_error; pit.n = pi.n;
+            ray = spawn_ray(pit, wi);
+        }
         RGB rrbeta = beta * etascale;
         if (rrbeta.max_component_value() < pp.rr_threshold && bounces > 3) {
             Float q = fmax_(1.0f - rrbeta.max_component_value(), 0.05f);
@@ -411,6 +478,16 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
     s.prim_material.assign(d->prim_material, d->prim_material + d->n_prims);
     s.prim_light.assign(d->prim_light, d->prim_light + d->n_prims);
     if (d->n_materials) s.materials.assign(d->materials, d->materials + d->n_materials);
+    for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {
+        const PtBSSRDFTable &t = d->bssrdf_tables[i];
+        BssrdfTable b; b.n_rho = (int)t.n_rho; b.n_radius = (int)t.n_radius;
+        b.rho_samples.assign(t.rho_samples, t.rho_samples + t.n_rho); b.radius_samples.assign(t.radius_samples, t.radius_samples + t.n_radius);
+        b.profile.assign(t.profile, t.profile + (size_t)t.n_rho * t.n_radius); b.rhoeff.assign(t.rhoeff, t.rhoeff + t.n_rho);
+        b.profile_cdf.assign(t.profile_cdf, t.profile_cdf + (size_t)t.n_rho * t.n_radius);
+        s.bssrdf_tables.push_back(std::move(b));
+    }
+    for (const PtMaterial &m : s.materials)
+        if (m.type == PT_MAT_SUBSURFACE && m.bssrdf_table >= s.bssrdf_tables.size()) return PT_ERR_INVALID_ARG;
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) if (s.lights[i].type == PT_LIGHT_INFINITE) s.infinite_lights.push_back(i);
     if (d->env_texels) {

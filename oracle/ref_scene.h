@@ -71,6 +71,13 @@ struct SurfaceInteraction {
     Float b[3] = {0, 0, 0};
 };
 
+// core/bssrdf.rs:241-268 BSSRDFTable (built by the host, see pbrt-rust_amd/bssrdf.py)
+struct BssrdfTable {
+    int n_rho = 0, n_radius = 0;
+    std::vector<Float> rho_samples, radius_samples, profile, rhoeff, profile_cdf;
+    Float eval_profile(int ri, int di) const { return profile[(size_t)ri * n_radius + di]; }
+};
+
 struct Scene {
     std::vector<V3> P, N, S;
     std::vector<P2> UV;
@@ -79,6 +86,7 @@ struct Scene {
     std::vector<PtSphere> spheres;
     std::vector<uint32_t> prim_shape, prim_material, prim_light;
     std::vector<PtMaterial> materials;
+    std::vector<BssrdfTable> bssrdf_tables;
     std::vector<PtLight> lights;
     std::vector<uint32_t> infinite_lights;
     uint32_t env_w = 0, env_h = 0;

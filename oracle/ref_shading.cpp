@@ -1,6 +1,6 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ref_math.h header).
 // Implementations for ref_shading.h. Each function cites the reference lines it restates.
-#include "ref_shading.h"
+#include "ref_bssrdf.h"
 
 namespace ref {
 
@@ -13,6 +13,7 @@ static inline Float pow5(Float v) { return (v * v) * (v * v) * v; }
 RGB bxdf_f(const Bxdf &b, V3 wo, V3 wi) {
     switch (b.kind) {
     case BX_LAMBERT_R: return b.r * INV_PI;  // reflection.rs:822-824
+    case BX_BSSRDF: return RGB(bssrdf_sw(b.etab, wi)) * (b.etab * b.etab);  // bssrdf.rs:594-602 (mode == Radiance)
     case BX_LAMBERT_T: return b.t * INV_PI;  // :861-863
     case BX_OREN_NAYAR: {                    // :926-952
         Float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
@@ -70,7 +71,7 @@ RGB bxdf_f(const Bxdf &b, V3 wo, V3 wi) {
 
 Float bxdf_pdf(const Bxdf &b, V3 wo, V3 wi) {
     switch (b.kind) {
-    case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_FRESNEL_SPEC: return default_pdf(wo, wi);  // FresnelSpecular: :788-794
+    case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_FRESNEL_SPEC: case BX_BSSRDF: return default_pdf(wo, wi);  // FresnelSpecular: :788-794
     case BX_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) : 0.0f;              // :886-892 (no INV_PI, App. A #10)
     case BX_SPEC_R: case BX_SPEC_T: return 0.0f;
     case BX_MICRO_R: {  // :1021-1027
@@ -99,7 +100,7 @@ Float bxdf_pdf(const Bxdf &b, V3 wo, V3 wi) {
 
 RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) {
     switch (b.kind) {
-    case BX_LAMBERT_R: case BX_OREN_NAYAR: {  // default BxDF::sample_f :392-403
+    case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_BSSRDF: {  // default BxDF::sample_f :392-403
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;
         pdf = bxdf_pdf(b, wo, wi);

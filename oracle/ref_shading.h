@@ -96,7 +96,7 @@ inline Float power_heuristic(int nf, Float fpdf, int ng, Float gpdf) {  // sampl
 
 // ---- BxDFs (core/reflection.rs) ---------------------------------------------------------------
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum BxdfKind { BX_LAMBERT_R, BX_LAMBERT_T, BX_OREN_NAYAR, BX_SPEC_R, BX_SPEC_T, BX_FRESNEL_SPEC, BX_MICRO_R, BX_MICRO_T, BX_FRESNEL_BLEND };
+enum BxdfKind { BX_LAMBERT_R, BX_LAMBERT_T, BX_OREN_NAYAR, BX_SPEC_R, BX_SPEC_T, BX_FRESNEL_SPEC, BX_MICRO_R, BX_MICRO_T, BX_FRESNEL_BLEND, BX_BSSRDF };
 enum FresnelKind { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR };
 
 inline Float cos_theta(V3 w) { return w.z; }

@@ -18,7 +18,7 @@ PT_TRI_HAS_UV = 16
 PT_SHAPE_TRIANGLE, PT_SHAPE_SPHERE = 0, 1
 PT_NONE = 0xFFFFFFFF
 
-PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE = range(7)
+PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE = range(8)
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 
@@ -40,7 +40,8 @@ class PtSphere(C.Structure):
 class PtMaterial(C.Structure):
     _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
-                ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32)]
+                ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
+                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32)]
 
 
 class PtLight(C.Structure):
@@ -64,6 +65,11 @@ class PtInstance(C.Structure):
 PT_TOP_INSTANCE = 0x80000000
 
 
+class PtBSSRDFTable(C.Structure):
+    _fields_ = [("n_rho", u32), ("n_radius", u32), ("rho_samples", fp), ("radius_samples", fp), ("profile", fp),
+                ("rhoeff", fp), ("profile_cdf", fp)]
+
+
 class PtSceneDesc(C.Structure):
     _fields_ = [("n_vertices", u32), ("P", fp), ("N", fp), ("S", fp), ("UV", fp),
                 ("n_triangles", u32), ("indices", u32p), ("tri_flags", u8p),
@@ -74,7 +80,7 @@ class PtSceneDesc(C.Structure):
                 ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp),
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
-                ("n_top", u32), ("top_refs", u32p)]
+                ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable))]
 
 
 class PtRenderParams(C.Structure):

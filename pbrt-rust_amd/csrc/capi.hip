@@ -64,6 +64,8 @@ struct pt_scene {
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
     bool class_used[kNumClasses] = {true, false, false, false};
+    bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
+    void *bss_slab = nullptr; BssSoA bs{};
     uint32_t n_lights = 0;
     std::vector<PtLight> host_lights; uint32_t env_w = 0, env_h = 0; float env_texel0[3] = {0, 0, 0};
     // light grids (lazy, per effective strategy)
@@ -168,6 +170,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
     }
     if (capacity > sc->capacity) {
         if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
+        if (sc->bss_slab) { hipFree(sc->bss_slab); sc->bss_slab = nullptr; }
         size_t bytes = capacity * (size_t)(kPathSoAFloatArrays * 4 + 8 + 1) + 4096;
         hipError_t e = hipMalloc(&sc->slab, bytes);
         if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "path-state slab: " + std::string(hipGetErrorString(e)));
@@ -184,14 +187,27 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         for (uint32_t **u : ua) { *u = (uint32_t *)p; p += capacity * 4; }
         ps.occluded = (uint8_t *)p;
         static_assert(sizeof(fa) / sizeof(fa[0]) + sizeof(ua) / sizeof(ua[0]) <= kPathSoAFloatArrays, "slab too small");
-        // queues: ext[2] + shade[2][classes] + shadow + mis
-        size_t nq = 2 + 2 * kNumClasses + 2;
+        if (sc->has_bssrdf) {
+            e = hipMalloc(&sc->bss_slab, capacity * (size_t)kBssSoAArrays * 4);
+            if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "BSSRDF probe state: " + std::string(hipGetErrorString(e)));
+            BssSoA &bs = sc->bs;
+            float *bp = (float *)sc->bss_slab;
+            float **ba[] = {&bs.start_x, &bs.start_y, &bs.start_z, &bs.target_x, &bs.target_y, &bs.target_z, &bs.po_x, &bs.po_y, &bs.po_z,
+                            &bs.ns_x, &bs.ns_y, &bs.ns_z, &bs.ss_x, &bs.ss_y, &bs.ss_z, &bs.u1n};
+            for (float **f : ba) { *f = bp; bp += capacity; }
+            bs.mat = (uint32_t *)bp; bp += capacity; bs.cnt = (uint32_t *)bp;
+            static_assert(sizeof(ba) / sizeof(ba[0]) + 2 == kBssSoAArrays, "BssSoA layout");
+        }
+        // queues: ext[2] + shade[2][classes] + shadow + mis (+ probe[2])
+        size_t nq = 2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0);
         e = hipMalloc((void **)&sc->qbuf, nq * capacity * 4);
         if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "queues: " + std::string(hipGetErrorString(e)));
         uint32_t *qp = sc->qbuf;
         for (int i = 0; i < 2; ++i) { sc->q.ext[i] = qp; qp += capacity; }
         for (int i = 0; i < 2; ++i) for (int c = 0; c < kNumClasses; ++c) { sc->q.shade[i][c] = qp; qp += capacity; }
-        sc->q.shadow = qp; qp += capacity; sc->q.mis = qp;
+        sc->q.shadow = qp; qp += capacity; sc->q.mis = qp; qp += capacity;
+        sc->q.probe[0] = sc->q.probe[1] = nullptr;
+        if (sc->has_bssrdf) { sc->q.probe[0] = qp; qp += capacity; sc->q.probe[1] = qp; }
         sc->capacity = capacity;
     }
     if (film_px > sc->film_px) {
@@ -294,10 +310,10 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
     // mask bit0: next ext + next shade queues; bit1: shadow + mis; bit2: trace heads; bit3: current ext + shade
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int nxt = 1 - cur;
-    if (mask & 1u) { qc->ext[nxt] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[nxt][c] = 0; }
+    if (mask & 1u) { qc->ext[nxt] = 0; qc->probe[nxt] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[nxt][c] = 0; }
     if (mask & 2u) { qc->shadow = 0; qc->mis = 0; }
     if (mask & 4u) { for (int i = 0; i < 4; ++i) qc->head[i] = 0; }
-    if (mask & 8u) { qc->ext[cur] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[cur][c] = 0; }
+    if (mask & 8u) { qc->ext[cur] = 0; qc->probe[cur] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[cur][c] = 0; }
 }
 
 template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
@@ -320,8 +336,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
         if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : "Sobol dimension overflow (>= 1024)");
-        const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][0], n_shadow = h.shadow, n_mis = h.mis;
-        if (n_ext == 0 && n_resolve == 0) break;
+        const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][0], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
+        if (n_ext == 0 && n_resolve == 0 && n_probe == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
         tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.scalar_tmax = INFINITY;
@@ -365,6 +381,28 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         sc->end();
         if (st) return st;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
+        if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-395): one segment per iteration, then k_bssrdf
+            tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
+            tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
+            tj.out_prim = ps.hit_prim; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
+            tj.out_occluded = nullptr; tj.kind = 0;
+            sc->begin("extend_probe", n_probe);
+            st = launch_trace(sc, false, tj, n_probe);
+            sc->end();
+            if (st) return st;
+            BssrdfJob bj{};
+            bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
+            bj.probe_next = sc->q.probe[1 - cur]; bj.probe_next_count = &qc->probe[1 - cur];
+            bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
+            bj.shade_next0 = sc->q.shade[1 - cur][0]; bj.shade_next0_count = &qc->shade[1 - cur][0];
+            bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
+            bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
+            const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * 8u);
+            sc->begin("bssrdf", n_probe);
+            if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_bssrdf<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+            else hipLaunchKernelGGL((k_bssrdf<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+            sc->end();
+        }
         uint32_t class_n[kNumClasses];
         const uint32_t upper = n_ext + n_resolve;
         if (rp_profile_exact) {  // exact per-class item counts for the statistics (costs one extra sync per iteration)
@@ -381,6 +419,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sj.shade_next0 = sc->q.shade[1 - cur][0]; sj.shade_next0_count = &qc->shade[1 - cur][0];
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
+            if (c == 3 && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
             else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
@@ -413,6 +452,7 @@ void read_counters(pt_scene *sc) {
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
+    for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
 }
 
 }  // namespace
@@ -448,6 +488,13 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (!((kind == PT_SHAPE_TRIANGLE && idx < d->n_triangles) || (kind == PT_SHAPE_SPHERE && idx < d->n_spheres))) return fail(PT_ERR_INVALID_ARG, "primitive shape reference out of range");
         if (d->prim_material[i] != PT_NONE && d->prim_material[i] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "material index out of range");
         if (d->prim_light[i] != PT_NONE && d->prim_light[i] >= d->n_lights) return fail(PT_ERR_INVALID_ARG, "light index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const PtMaterial &m = d->materials[i];
+        if (m.type != PT_MAT_SUBSURFACE) continue;
+        if (!d->bssrdf_tables || m.bssrdf_table >= d->n_bssrdf_tables) return fail(PT_ERR_INVALID_ARG, "subsurface material without a BSSRDF table");
+        const PtBSSRDFTable &t = d->bssrdf_tables[m.bssrdf_table];
+        if (t.n_rho < 2 || t.n_radius < 2 || !t.rho_samples || !t.radius_samples || !t.profile || !t.rhoeff || !t.profile_cdf) return fail(PT_ERR_INVALID_ARG, "incomplete BSSRDF table");
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const PtLight &L = d->lights[i];
@@ -608,6 +655,19 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
         for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }
         UP(mat_class, mc.data(), mc.size());
+        std::vector<DevBssTable> bt(d->n_bssrdf_tables);
+        for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {
+            const PtBSSRDFTable &t = d->bssrdf_tables[i];
+            bt[i].n_rho = (int)t.n_rho; bt[i].n_radius = (int)t.n_radius;
+            if (!t.rho_samples || !t.radius_samples || !t.profile || !t.rhoeff || !t.profile_cdf) continue;   // unreferenced slot
+            if ((st = sc->upload(&bt[i].rho_samples, t.rho_samples, t.n_rho))) return bail(st);
+            if ((st = sc->upload(&bt[i].radius_samples, t.radius_samples, t.n_radius))) return bail(st);
+            if ((st = sc->upload(&bt[i].profile, t.profile, (size_t)t.n_rho * t.n_radius))) return bail(st);
+            if ((st = sc->upload(&bt[i].rhoeff, t.rhoeff, t.n_rho))) return bail(st);
+            if ((st = sc->upload(&bt[i].profile_cdf, t.profile_cdf, (size_t)t.n_rho * t.n_radius))) return bail(st);
+        }
+        UP(bss_tables, bt.data(), bt.size()); ds.n_bss_tables = d->n_bssrdf_tables;
+        for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].type == PT_MAT_SUBSURFACE) sc->has_bssrdf = true;
         std::vector<uint32_t> inf;
         for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == PT_LIGHT_INFINITE) inf.push_back(i);
         UP(infinite_lights, inf.data(), inf.size()); ds.n_infinite = (uint32_t)inf.size();
@@ -665,6 +725,7 @@ void pt_scene_destroy(pt_scene *sc) {
     for (void *p : sc->allocs) hipFree(p);
     if (sc->slab) hipFree(sc->slab);
     if (sc->qbuf) hipFree(sc->qbuf);
+    if (sc->bss_slab) hipFree(sc->bss_slab);
     if (sc->film_rgbw) hipFree(sc->film_rgbw);
     for (auto e : sc->event_pool) hipEventDestroy(e);
     if (sc->stream) hipStreamDestroy(sc->stream);

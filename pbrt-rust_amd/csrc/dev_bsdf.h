@@ -428,6 +428,7 @@ template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInt
         if (!R.is_black()) { Lobe b = mk_lobe(LB_SPEC_R, BSDF_REFLECTION | BSDF_SPECULAR); b.r = R; bsdf.add(b); }
         return true;
     }
+    case PT_MAT_SUBSURFACE:  // subsurface.rs:56-98 / kdsubsurface.rs:53-93: the same dielectric BSDF as glass
     case PT_MAT_GLASS: {  // glass.rs:35-92
         float eta = m.eta, ur = m.u_roughness, vr = m.v_roughness;
         RGB R = rgb3(m.kr).clamps(0.0f, PT_INF), T = rgb3(m.kt).clamps(0.0f, PT_INF);

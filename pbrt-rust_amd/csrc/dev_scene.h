@@ -44,6 +44,9 @@ struct DevInstance {
     uint32_t pad;
 };
 
+// core/bssrdf.rs:241-268 BSSRDFTable (device copy of PtBSSRDFTable)
+struct DevBssTable { int n_rho, n_radius; const float *rho_samples, *radius_samples, *profile, *rhoeff, *profile_cdf; };
+
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
@@ -58,6 +61,7 @@ struct DeviceScene {
     const float *light_area;            // per light: Shape::area() of its primitive
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class
+    const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)
     // env map
     uint32_t env_w, env_h; const float *env_texels;
     const float *env_func; const float *env_cdf; const float *env_func_int;  // conditional rows (2h x 2w [+1]), marginal appended

@@ -3,6 +3,7 @@
 #include "dev_scene.h"
 #include "dev_sampler.h"
 #include "dev_light.h"
+#include "dev_bssrdf.h"
 
 namespace ptd {
 
@@ -12,7 +13,7 @@ constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/
 constexpr int kTraceBlock = 256;
 
 // path flags (meta >> 24)
-enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_COUNTED = 16u };
+enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u };
 
 // SoA path state in HBM; index = path id (pid). Every array has `capacity` entries.
 struct PathSoA {
@@ -33,18 +34,30 @@ struct PathSoA {
     uint32_t *mis_prim; float *mis_b0, *mis_b1, *mis_b2; // closest hit of the MIS ray
     uint8_t *occluded;
 };
+// Per-path subsurface probe state (allocated only for scenes with a subsurface material): the sampled probe segment of
+// TabulatedBSSRDF::sample_sp (bssrdf.rs:357-365), the outgoing point's frame, and the chain counters.
+struct BssSoA {
+    float *start_x, *start_y, *start_z, *target_x, *target_y, *target_z;
+    float *po_x, *po_y, *po_z, *ns_x, *ns_y, *ns_z, *ss_x, *ss_y, *ss_z;
+    float *u1n;
+    uint32_t *mat;   // material id of the BSSRDF (Arc::ptr_eq test of the chain, bssrdf.rs:385-391)
+    uint32_t *cnt;   // nfound (bits 0-15) | matches seen on the re-walk (16-30) | phase (31: 0 counting, 1 re-walk to `selected`)
+};
+constexpr int kBssSoAArrays = 18;
 constexpr int kPathSoAFloatArrays = 51;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)
     uint32_t *shade[2][kNumClasses];  // pids to shade, per material class (ping-pong)
     uint32_t *shadow, *mis;           // pids with pending shadow / MIS rays
+    uint32_t *probe[2];               // pids walking a BSSRDF probe chain (ping-pong; NULL without subsurface materials)
     // counters (device): layout documented in QCounters
 };
 struct QCounters {
     uint32_t ext[2];
     uint32_t shade[2][kNumClasses];
     uint32_t shadow, mis;
+    uint32_t probe[2];
     uint32_t head[4];                 // persistent-wave work heads for the trace launches
     uint32_t error;                   // PtStatus raised on device (stack / sobol overflow)
     uint32_t pad;
@@ -54,6 +67,7 @@ struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
+    unsigned long long bss_items, bss_bytes;   // k_bssrdf: probe steps processed / state bytes moved
     unsigned long long k_nodes[4], k_tris[4], k_rays[4];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera
 };
 
@@ -103,6 +117,19 @@ struct ShadeJob {
     uint32_t *error;
     DevCounters *counters;
     uint32_t cls;            // material class of this launch (statistics)
+    uint32_t *probe_next, *probe_next_count;     // paths starting a BSSRDF probe chain (class 3 only)
+    BssSoA bs;
+};
+
+struct BssrdfJob {           // k_bssrdf: one step of every probe chain + the finish of chains that reached their exit point
+    const uint32_t *queue; const uint32_t *count;
+    uint32_t *probe_next, *probe_next_count;
+    uint32_t *ext_next, *ext_next_count;
+    uint32_t *shade_next0, *shade_next0_count;
+    uint32_t *shadow, *shadow_count, *mis, *mis_count;
+    uint32_t *error;
+    DevCounters *counters;
+    BssSoA bs;
 };
 
 }  // namespace ptd

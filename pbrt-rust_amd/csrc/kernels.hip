@@ -522,12 +522,109 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
     tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
 }
 
+// Resolve the pending next-event estimation of the previous vertex once its shadow / MIS rays are traced
+// (integrator.rs:150-171,199-233): L += beta_at_nee * Ld / choice_pdf.
+template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
+                                                unsigned long long &zero_num, unsigned long long &n_bytes) {
+    if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
+    n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
+    RGB Ld(0.0f);
+    const uint32_t li = ps.nee_light[pid];
+    if ((flags & PF_PEND_SHADOW) && !ps.occluded[pid]) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
+    if (flags & PF_PEND_MIS) {
+        const PtLight &Lt = s.lights[li];
+        V3 wi(ps.mis_dx[pid], ps.mis_dy[pid], ps.mis_dz[pid]);
+        RGB lrad(0.0f);
+        const uint32_t mp = ps.mis_prim[pid];
+        if (mp != PT_NONE) {
+            if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
+                SurfaceInteraction lsi;
+                fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);  // lights are never inside instances (api.rs:1605-1608)
+                lrad = area_l(Lt, lsi.n, -wi);
+            }
+        } else lrad = light_le(s, Lt, wi);
+        if (!lrad.is_black()) {
+            RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
+            Ld = Ld + f * lrad * RGB(1.0f) * ps.mis_w[pid] / ps.mis_spdf[pid];
+        }
+    }
+    RGB nb(ps.nb_r[pid], ps.nb_g[pid], ps.nb_b[pid]);
+    RGB Ldb = nb * (Ld / ps.nee_choice_pdf[pid]);
+    if (Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
+    L = L + Ldb;
+    flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
+}
+
+// uniform_sample_onelight + estimate_direct (integrator.rs:81-237) at one vertex: samples the light and the BSDF,
+// records the shadow / MIS rays and their weights in the path state; the estimate is summed by resolve_pending once
+// both rays are traced. Returns whether anything is pending (false: Ld is black).
+template <class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
+                                          const SurfaceInteraction &si, const IData &it, const B &bsdf, RGB beta, uint32_t &flags,
+                                          bool &push_shadow, bool &push_mis, unsigned long long &n_bytes) {
+    bool nee_pending = false;
+    if (s.n_lights > 0) {
+        Dist1D distrib = light_distribution_lookup(grid, s, si.p);
+        float choice_pdf = 0.0f;
+        const uint32_t li = (uint32_t)dist_sample_discrete(distrib, smp.get_1d(), choice_pdf);
+        if (choice_pdf != 0.0f) {
+            const P2 ulight = smp.get_2d();
+            const P2 uscatt = smp.get_2d();
+            // estimate_direct (integrator.rs:109-237), flags = All & !Specular
+            const int bf = BSDF_ALL & ~BSDF_SPECULAR;
+            V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+            RGB Li = light_sample_li(s, li, it, ulight, wi, lightpdf, p1);
+            const bool delta = light_is_delta(s.lights[li]);
+            if (lightpdf > 0.0f && !Li.is_black()) {
+                RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
+                scattpdf = bsdf.pdf(si.wo, wi, bf);
+                if (!f.is_black()) {
+                    V3 so, sd; spawn_ray_to(it, p1, so, sd);
+                    RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
+                    ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
+                    ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
+                    ps.A_r[pid] = A.r; ps.A_g[pid] = A.g; ps.A_b[pid] = A.b;
+                    flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 24 + 12 + 4;
+                }
+            }
+            if (!delta) {
+                int sampled_type = 0;
+                RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, bf, sampled_type);
+                f = f * abs_dot(wi, si.sh_n);
+                const bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+                if (!f.is_black() && scattpdf > 0.0f) {
+                    float weight = 1.0f;
+                    bool skip = false;
+                    if (!sampled_specular) {
+                        lightpdf = light_pdf_li(s, li, it, wi);
+                        if (lightpdf == 0.0f) skip = true;  // `return Ld` (integrator.rs:204)
+                        else weight = power_heuristic(scattpdf, lightpdf);
+                    }
+                    if (!skip) {
+                        V3 mo; spawn_ray(it, wi, mo);
+                        ps.mis_ox[pid] = mo.x; ps.mis_oy[pid] = mo.y; ps.mis_oz[pid] = mo.z;
+                        ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
+                        ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
+                        ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
+                        flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
+                    }
+                }
+            }
+            if (nee_pending) {
+                ps.nee_light[pid] = li; ps.nee_choice_pdf[pid] = choice_pdf;
+                ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b; n_bytes += 8 + 12;
+            }
+        }
+    }
+    return nee_pending;
+}
+
 template <int MAXL, bool SPH>
 __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
     __shared__ uint32_t s_hist[16];
-    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -536,7 +633,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     unsigned long long zero_num = 0, zero_den = 0, n_valid = 0, n_bytes = 0;  // n_bytes: path-state + queue bytes
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
-    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
     int finished_bounces = -1;
     uint32_t pid = 0;
     if (valid) {
@@ -551,34 +648,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
         RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
-        if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) {
-            n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
-            RGB Ld(0.0f);
-            const uint32_t li = ps.nee_light[pid];
-            if ((flags & PF_PEND_SHADOW) && !ps.occluded[pid]) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
-            if (flags & PF_PEND_MIS) {
-                const PtLight &Lt = s.lights[li];
-                V3 wi(ps.mis_dx[pid], ps.mis_dy[pid], ps.mis_dz[pid]);
-                RGB lrad(0.0f);
-                const uint32_t mp = ps.mis_prim[pid];
-                if (mp != PT_NONE) {
-                    if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
-                        SurfaceInteraction lsi;
-                        fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);  // lights are never inside instances (api.rs:1605-1608)
-                        lrad = area_l(Lt, lsi.n, -wi);
-                    }
-                } else lrad = light_le(s, Lt, wi);
-                if (!lrad.is_black()) {
-                    RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
-                    Ld = Ld + f * lrad * RGB(1.0f) * ps.mis_w[pid] / ps.mis_spdf[pid];
-                }
-            }
-            RGB nb(ps.nb_r[pid], ps.nb_g[pid], ps.nb_b[pid]);
-            RGB Ldb = nb * (Ld / ps.nee_choice_pdf[pid]);
-            if (Ldb.is_black()) zero_num++;
-            L = L + Ldb;
-            flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS);
-        }
+        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
 
         if (flags & PF_DEAD) {
             finished_bounces = (int)bounces;
@@ -614,60 +684,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                     // uniform_sample_onelight (integrator.rs:81-106)
                     if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
-                        bool nee_pending = false;
-                        if (s.n_lights > 0) {
-                            Dist1D distrib = light_distribution_lookup(grid, s, si.p);
-                            float choice_pdf = 0.0f;
-                            const uint32_t li = (uint32_t)dist_sample_discrete(distrib, smp.get_1d(), choice_pdf);
-                            if (choice_pdf != 0.0f) {
-                                const P2 ulight = smp.get_2d();
-                                const P2 uscatt = smp.get_2d();
-                                // estimate_direct (integrator.rs:109-237), flags = All & !Specular
-                                const int bf = BSDF_ALL & ~BSDF_SPECULAR;
-                                V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
-                                RGB Li = light_sample_li(s, li, it, ulight, wi, lightpdf, p1);
-                                const bool delta = light_is_delta(s.lights[li]);
-                                if (lightpdf > 0.0f && !Li.is_black()) {
-                                    RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
-                                    scattpdf = bsdf.pdf(si.wo, wi, bf);
-                                    if (!f.is_black()) {
-                                        V3 so, sd; spawn_ray_to(it, p1, so, sd);
-                                        RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
-                                        ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
-                                        ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
-                                        ps.A_r[pid] = A.r; ps.A_g[pid] = A.g; ps.A_b[pid] = A.b;
-                                        flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 24 + 12 + 4;
-                                    }
-                                }
-                                if (!delta) {
-                                    int sampled_type = 0;
-                                    RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, bf, sampled_type);
-                                    f = f * abs_dot(wi, si.sh_n);
-                                    const bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
-                                    if (!f.is_black() && scattpdf > 0.0f) {
-                                        float weight = 1.0f;
-                                        bool skip = false;
-                                        if (!sampled_specular) {
-                                            lightpdf = light_pdf_li(s, li, it, wi);
-                                            if (lightpdf == 0.0f) skip = true;  // `return Ld` (integrator.rs:204)
-                                            else weight = power_heuristic(scattpdf, lightpdf);
-                                        }
-                                        if (!skip) {
-                                            V3 mo; spawn_ray(it, wi, mo);
-                                            ps.mis_ox[pid] = mo.x; ps.mis_oy[pid] = mo.y; ps.mis_oz[pid] = mo.z;
-                                            ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
-                                            ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
-                                            ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
-                                            flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
-                                        }
-                                    }
-                                }
-                                if (nee_pending) {
-                                    ps.nee_light[pid] = li; ps.nee_choice_pdf[pid] = choice_pdf;
-                                    ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b; n_bytes += 8 + 12;
-                                }
-                            }
-                        }
+                        const bool nee_pending = nee_vertex(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes);
                         if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
                     }
                     // path.rs:148-174: sample the BSDF for the next direction
@@ -684,16 +701,44 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                             ps.etascale[pid] = etascale;
                         }
                         V3 o; spawn_ray(it, wi, o);
+                        bool rr_kill = false, to_probe = false;
+                        if constexpr (MAXL == 5) {
+                            // path.rs:177-183: importance sample the BSSRDF; the probe chain of sample_sp (bssrdf.rs:367-395)
+                            // is walked by k_bssrdf over the following wavefront iterations
+                            if (s.materials[mi].type == PT_MAT_SUBSURFACE && (sflags & BSDF_TRANSMISSION)) {
+                                const P2 s2 = smp.get_2d();
+                                const float s1 = smp.get_1d();
+                                DevBssrdf bss; bss.init_medium(s.materials[mi], s.bss_tables); bss.init_frame(si);
+                                V3 start, target; float u1n = 0.0f;
+                                const BssSoA &bs = job.bs;
+                                if (!bss.probe_segment(s1, s2, start, target, u1n)) rr_kill = true;   // S is black: `break`
+                                else {
+                                    const V3 pd = target - start;
+                                    if (pd.x == 0.0f && pd.y == 0.0f && pd.z == 0.0f) rr_kill = true;  // empty chain: nfound == 0
+                                    else {
+                                        bs.start_x[pid] = start.x; bs.start_y[pid] = start.y; bs.start_z[pid] = start.z;
+                                        bs.target_x[pid] = target.x; bs.target_y[pid] = target.y; bs.target_z[pid] = target.z;
+                                        bs.po_x[pid] = si.p.x; bs.po_y[pid] = si.p.y; bs.po_z[pid] = si.p.z;
+                                        bs.ns_x[pid] = bss.ns.x; bs.ns_y[pid] = bss.ns.y; bs.ns_z[pid] = bss.ns.z;
+                                        bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
+                                        bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
+                                        // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
+                                        ps.ox[pid] = start.x; ps.oy[pid] = start.y; ps.oz[pid] = start.z;
+                                        ps.dx[pid] = pd.x; ps.dy[pid] = pd.y; ps.dz[pid] = pd.z;
+                                        to_probe = true; push_probe = true; n_bytes += 18 * 4 + 24 + 4;
+                                    }
+                                }
+                            }
+                        }
                         // path.rs:206-214 Russian roulette
                         RGB rrbeta = beta * etascale;
-                        bool rr_kill = false;
-                        if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
+                        if (!to_probe && !rr_kill && rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                             const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
                             if (smp.get_1d() < q) rr_kill = true;
                             else beta = beta / (1.0f - q);
                         }
                         if (rr_kill) terminated = true;
-                        else {
+                        else if (!to_probe) {
                             bounces += 1;
                             ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
                             ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
@@ -721,11 +766,13 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
     lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
     lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 256u, false);
     lq_sync_flush(s_qmis, job.mis_count, job.mis, 256u, false);
+    if constexpr (MAXL == 5) if (job.probe_next) { lq_push(s_qprobe, pid, push_probe); lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 256u, false); }
     }  // persistent loop over the queue
     lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 0u, true);
     lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
     lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
+    if constexpr (MAXL == 5) if (job.probe_next) lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->zero_den, zero_den);
@@ -735,6 +782,169 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
 }
 #define PT_INST_SHADE(L, S) template __global__ void k_shade<L, S>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
 PT_INST_SHADE(1, false) PT_INST_SHADE(2, false) PT_INST_SHADE(5, false) PT_INST_SHADE(1, true) PT_INST_SHADE(2, true) PT_INST_SHADE(5, true)
+
+// ---- subsurface scattering: probe chains + exit-point vertex (path.rs:177-204, bssrdf.rs:334-410,559-574) --------------
+// One launch per wavefront iteration while any path walks a probe chain. Each queue entry is a path whose probe ray
+// (ps.ox.. / ps.dx.., t_max = 1 - eps) was just traced into ps.hit_*. The chain is walked twice: a counting walk
+// (nfound) and, once the miss ends it, a re-walk from the segment start up to match number `selected` -- the reference
+// keeps the chain in a Vec and indexes it; re-walking is deterministic and keeps the per-path state fixed-size.
+// When the exit point pi is reached the lane finishes the vertex: resolve po's next-event estimation, beta *= S / pdf,
+// NEE at pi through the adapter BSDF, sample the adapter BSDF, Russian roulette, bounces += 1.
+template <bool SPH>
+__global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
+    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis, s_qprobe;
+    __shared__ uint32_t s_hist[16];
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const BssSoA &bs = job.bs;
+    const uint32_t count = *job.count;
+    const uint32_t rounded = (count + 255u) & ~255u;
+    unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+    const bool valid = qi < count;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
+    int finished_bounces = -1;
+    uint32_t pid = 0;
+    if (valid) {
+        n_valid++;
+        pid = job.queue[qi];
+        const V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+        const V3 target(bs.target_x[pid], bs.target_y[pid], bs.target_z[pid]);
+        const uint32_t hp = ps.hit_prim[pid];
+        const uint32_t mat = bs.mat[pid];
+        uint32_t cnt = bs.cnt[pid];
+        uint32_t nfound = cnt & 0xffffu, seen = (cnt >> 16) & 0x7fffu; const bool rewalk = (cnt >> 31) != 0u;
+        const float u1n = bs.u1n[pid];
+        bool chain_end = false, at_exit = false, dead = false;
+        SurfaceInteraction si;
+        if (hp != PT_NONE) {
+            fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+            const bool match = s.prim_material[hp] == mat;   // bssrdf.rs:385-391
+            if (!rewalk) { if (match && nfound < 0xffffu) nfound++; }
+            else if (match) {
+                // bssrdf.rs:398: selected = clamp((u1n * nfound) as usize, 0, nfound - 1)
+                const uint32_t selected = min(f2u32_sat(u1n * (float)nfound), nfound - 1u);
+                if (seen == selected) at_exit = true;
+                seen++;
+            }
+            if (!at_exit) {  // base = si.get_data(); next segment base -> target (interaction.rs:38-43)
+                const V3 d = target - si.p;
+                if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) chain_end = true;
+                else {
+                    const V3 o = offset_ray_origin(si.p, si.p_error, si.n, d);
+                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                    push_probe = true;
+                }
+            }
+        } else chain_end = true;
+        if (chain_end) {
+            if (!rewalk && nfound > 0u) {  // chain counted: walk it again up to the selected intersection
+                const V3 start(bs.start_x[pid], bs.start_y[pid], bs.start_z[pid]);
+                const V3 d = target - start;
+                ps.ox[pid] = start.x; ps.oy[pid] = start.y; ps.oz[pid] = start.z;
+                ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                cnt = nfound | (1u << 31); seen = 0u;
+                bs.cnt[pid] = cnt;
+                push_probe = true;
+            } else dead = true;   // nfound == 0: S = 0 (bssrdf.rs:397); a re-walk never ends before `selected`
+        } else if (push_probe) bs.cnt[pid] = nfound | (seen << 16) | (rewalk ? (1u << 31) : 0u);
+        n_bytes += 4 + 24 + 16 + 12 + 8 + 4 + (push_probe ? 24 + 4 + 4 : 0);
+
+        if (at_exit || dead) {
+            uint32_t meta = ps.meta[pid];
+            uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
+            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+            smp.base = 0xffffffffu;
+            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+            RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+            n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
+            // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
+            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
+            bool terminated = dead;
+            if (at_exit) {
+                const PtMaterial &m = s.materials[mat];
+                DevBssrdf bss; bss.init_medium(m, s.bss_tables);
+                bss.ns = V3(bs.ns_x[pid], bs.ns_y[pid], bs.ns_z[pid]); bss.ss = V3(bs.ss_x[pid], bs.ss_y[pid], bs.ss_z[pid]);
+                bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
+                n_bytes += 36;
+                // bssrdf.rs:403-405: pdf = pdf_sp(pi) / nfound ; Sp = sr(|po - pi|)
+                float pdf = bss.pdf_sp(si.p, si.n) / (float)nfound;
+                const RGB S = bss.sr(length(bss.po_p - si.p));
+                if (S.is_black() || pdf == 0.0f) terminated = true;   // path.rs:185
+                else {
+                    smp.load_window();
+                    beta = beta * (S / pdf);
+                    // sample_s (bssrdf.rs:563-571): BSDF::new(pi, 1.0) + adapter lobe; pi.wo = shading.n
+                    BssrdfAdapterBsdf bsdf; bsdf.init(si, bss.eta);
+                    si.wo = si.sh_n;
+                    IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
+                    // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
+                    if (nee_vertex(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes)) flags |= PF_NEE_UNCOUNTED;
+                    // path.rs:194-201: indirect component
+                    V3 wi; int sflags = 0;
+                    const RGB ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
+                    if (ff.is_black() || pdf == 0.0f) terminated = true;
+                    else {
+                        beta = beta * (ff * abs_dot(wi, si.sh_n) / pdf);
+                        if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
+                        V3 o; spawn_ray(it, wi, o);
+                        // path.rs:206-214 Russian roulette
+                        const RGB rrbeta = beta * ps.etascale[pid];
+                        bool rr_kill = false;
+                        if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
+                            const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
+                            if (smp.get_1d() < q) rr_kill = true;
+                            else beta = beta / (1.0f - q);
+                        }
+                        if (rr_kill) terminated = true;
+                        else {
+                            bounces += 1;
+                            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                            ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                            push_ext = true; n_bytes += 24 + 4 + 4;
+                        }
+                    }
+                }
+            }
+            if (terminated) {
+                if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
+                else finished_bounces = (int)bounces;
+            }
+            if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
+            ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
+            ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+            ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+        }
+    }
+    lq_push(s_qprobe, pid, push_probe);
+    lq_push(s_qext, pid, push_ext);
+    lq_push(s_qres, pid, push_resolve);
+    lq_push(s_qsh, pid, push_shadow);
+    lq_push(s_qmis, pid, push_mis);
+    if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
+    lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 256u, false);
+    lq_sync_flush(s_qmis, job.mis_count, job.mis, 256u, false);
+    }
+    lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->stages, n_valid);
+    counter_add(&job.counters->bss_items, n_valid);
+    counter_add(&job.counters->bss_bytes, n_bytes);
+}
+template __global__ void k_bssrdf<false>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, BssrdfJob);
+template __global__ void k_bssrdf<true>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, BssrdfJob);
 
 // ---- film ----------------------------------------------------------------------------------------------------
 // One thread per pixel slot; its s_count samples are added in sample order (integrator.rs:331-376),

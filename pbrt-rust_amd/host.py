@@ -136,6 +136,7 @@ class SceneBuilder:
         self.material_id = None
         self.area_light = None
         self.materials = []
+        self.bssrdf_tables = []
         self.lights = []
         self.P, self.N, self.UV, self.S, self.idx, self.tri_flags = [], [], [], [], [], []
         self.nverts = 0
@@ -177,13 +178,18 @@ class SceneBuilder:
     def material(self, kind, **kw):
         m = A.PtMaterial()
         kinds = dict(matte=A.PT_MAT_MATTE, mirror=A.PT_MAT_MIRROR, glass=A.PT_MAT_GLASS, plastic=A.PT_MAT_PLASTIC,
-                     metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE)
+                     metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE,
+                     subsurface=A.PT_MAT_SUBSURFACE, kdsubsurface=A.PT_MAT_SUBSURFACE)
         m.type = kinds[kind]
         d = dict(  # create_*_material defaults
             matte=dict(Kd=0.5, sigma=0.0), mirror=dict(Kr=0.9), glass=dict(Kr=1.0, Kt=1.0, eta=1.5, uroughness=0.0, vroughness=0.0),
             plastic=dict(Kd=0.25, Ks=0.25, roughness=0.1), metal=dict(roughness=0.01, uroughness=-1.0, vroughness=-1.0),
             uber=dict(Kd=0.25, Ks=0.25, Kr=0.0, Kt=0.0, roughness=0.1, uroughness=-1.0, vroughness=-1.0, opacity=1.0, eta=1.5),
-            substrate=dict(Kd=0.5, Ks=0.5, uroughness=0.1, vroughness=0.1))[kind]
+            substrate=dict(Kd=0.5, Ks=0.5, uroughness=0.1, vroughness=0.1),
+            # subsurface.rs:108-139 / kdsubsurface.rs:106-126
+            subsurface=dict(Kr=1.0, Kt=1.0, eta=1.33, uroughness=0.0, vroughness=0.0, scale=1.0, g=0.0, name="",
+                            sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77)),
+            kdsubsurface=dict(Kr=1.0, Kt=1.0, eta=1.33, uroughness=0.0, vroughness=0.0, scale=1.0, g=0.0, Kd=0.5, mfp=1.0))[kind]
         d.update(kw)
         three = lambda v: (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
         m.kd = three(d.get("Kd", 0)); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", 0)); m.kt = three(d.get("Kt", 0))
@@ -191,6 +197,30 @@ class SceneBuilder:
         m.sigma = d.get("sigma", 0.0); m.eta = d.get("eta", 1.5); m.roughness = d.get("roughness", 0.1)
         m.u_roughness = d.get("uroughness", -1.0); m.v_roughness = d.get("vroughness", -1.0)
         m.remap_roughness = 1 if d.get("remaproughness", True) else 0
+        if m.type == A.PT_MAT_SUBSURFACE:
+            from . import bssrdf as B
+            g = float(d["g"])
+            if kind == "subsurface":
+                siga, sigs = d["sigma_a"], d["sigma_s"]
+                if d["name"]:  # subsurface.rs:111-122: a named medium overrides the defaults and forces g = 0
+                    if d["name"] in B.NAMED_MEDIA:
+                        sigs, siga = B.NAMED_MEDIA[d["name"]]
+                        if "sigma_a" in kw: siga = kw["sigma_a"]
+                        if "sigma_s" in kw: sigs = kw["sigma_s"]
+                        g = 0.0
+                table = B.compute_beam_diffusion_bssrdf(g, float(d["eta"]))
+                m.scale = float(d["scale"])
+            else:  # kdsubsurface.rs:96-99: mfp * scale, then subsurface_from_diffuse (constant textures -> host side)
+                table = B.compute_beam_diffusion_bssrdf(g, float(d["eta"]))
+                three_np = lambda v: np.asarray([v] * 3 if np.isscalar(v) else v, dtype=F)
+                mfree = np.maximum(three_np(d["mfp"]), F(0)) * F(d["scale"])
+                siga, sigs = B.subsurface_from_diffuse(table, np.maximum(three_np(d["Kd"]), F(0)), mfree)
+                m.scale = 1.0
+            m.sigma_a = three(siga); m.sigma_s = three(sigs)
+            for i, t in enumerate(self.bssrdf_tables):
+                if t is table: m.bssrdf_table = i; break
+            else:
+                self.bssrdf_tables.append(table); m.bssrdf_table = len(self.bssrdf_tables) - 1
         self.materials.append(m)
         self.material_id = len(self.materials) - 1
 
@@ -407,6 +437,14 @@ class SceneData:
         self.objects = (A.PtObject * max(1, self.n_objects))(*[A.PtObject(f, n) for _, f, n in b.object_list])
         self.instances = (A.PtInstance * max(1, self.n_instances))(*b.instances)
         self.top_refs = np.ascontiguousarray(np.concatenate(b.top_refs), dtype=np.uint32) if (b.instances and b.top_refs) else None
+        self.bssrdf_src = list(b.bssrdf_tables)
+        self.bssrdf_tables = (A.PtBSSRDFTable * max(1, len(self.bssrdf_src)))()
+        for i, t in enumerate(self.bssrdf_src):
+            e = self.bssrdf_tables[i]
+            e.n_rho, e.n_radius = t.n_rho, t.n_radius
+            e.rho_samples = t.rho_samples.ctypes.data_as(A.fp); e.radius_samples = t.radius_samples.ctypes.data_as(A.fp)
+            e.profile = t.profile.ctypes.data_as(A.fp); e.rhoeff = t.rhoeff.ctypes.data_as(A.fp)
+            e.profile_cdf = t.profile_cdf.ctypes.data_as(A.fp)
 
     def set_bvh(self, nodes, ordered):
         """Adopt a prebuilt accelerator (what a Rust host would pass: BVHAccel.nodes / ordered prims)."""
@@ -432,4 +470,5 @@ class SceneData:
         if self.top_refs is not None:
             d.n_objects = self.n_objects; d.objects = self.objects; d.n_instances = self.n_instances; d.instances = self.instances
             d.n_top = len(self.top_refs); d.top_refs = ptr(self.top_refs, A.u32p)
+        d.n_bssrdf_tables = len(self.bssrdf_src); d.bssrdf_tables = self.bssrdf_tables
         return d

@@ -185,3 +185,32 @@ def instanced_garden(n_inst=24, plant_n=10, xres=96, yres=64, spp=8, flatten=Fal
     else:
         b.material("matte", Kd=(0.6, 0.2, 0.1)); b.trianglemesh(leafP, leafI)
     return b
+
+
+def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False):
+    """Config C5: a displaced sphere with a `subsurface` material (skin-like medium, mm units
+    scaled so the mean free path is a visible fraction of the object), a `kdsubsurface` sphere shape and a matte floor,
+    lit by an area light and a dim environment.  Exercises path.rs:177-204 / bssrdf.rs sample_s."""
+    from .host import SceneBuilder
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 1.6, 6.0), (0.0, 0.2, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.25, 0.3, 0.35))
+    b.attribute_begin(); b.area_light_source(L=(30.0, 27.0, 22.0))
+    P, I = quad((-1.5, 4.0, -0.5), (1.5, 4.0, -0.5), (1.5, 4.0, 1.5), (-1.5, 4.0, 1.5))
+    b.trianglemesh(P, I); b.attribute_end()
+    b.material("matte", Kd=(0.45, 0.45, 0.5))
+    P, I = quad((-8.0, -1.0, -8.0), (-8.0, -1.0, 8.0), (8.0, -1.0, 8.0), (8.0, -1.0, -8.0))
+    b.trianglemesh(P, I)
+    b.attribute_begin()
+    kw = dict(uroughness=0.2, vroughness=0.1) if rough else {}
+    b.material("subsurface", name="Skin1", scale=8.0, eta=1.33, **kw)
+    b.translate(-1.1, 0.0, 0.0)
+    P, I, N = displaced_sphere(n, with_normals=True)
+    b.trianglemesh(P, I, N=N); b.attribute_end()
+    b.attribute_begin()
+    b.material("kdsubsurface", Kd=(0.7, 0.35, 0.2), mfp=(0.25, 0.15, 0.08), eta=1.4)
+    b.translate(1.2, 0.0, 0.3); b.sphere(radius=0.9); b.attribute_end()
+    return b
