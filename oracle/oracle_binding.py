@@ -49,6 +49,11 @@ class Oracle:
         lib.orc_tri_intersect.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, f, A.fp, A.fp, A.fp, A.fp, A.fp]
         lib.orc_tri_intersect_p.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, f]
         lib.orc_offset_ray_origin.argtypes = [A.fp] * 5
+        tp = C.POINTER(A.PtBSSRDFTable)
+        lib.orc_bssrdf_sr.argtypes = [tp, A.fp, A.fp, f, C.c_uint32, A.fp, A.fp, A.fp]
+        lib.orc_bssrdf_sample_sr.argtypes = [tp, A.fp, A.fp, f, C.c_int, C.c_uint32, A.fp, A.fp]
+        lib.orc_catmull_rom_weights.argtypes = [C.c_int, A.fp, f, C.POINTER(C.c_int), A.fp]
+        lib.orc_bssrdf_sw.restype = f; lib.orc_bssrdf_sw.argtypes = [f, f]
         if lib.orc_load_tables(tables_path.encode()) != 0:
             raise RuntimeError("oracle: cannot load " + tables_path)
         self.lib = lib

@@ -756,3 +756,34 @@ int orc_test_sphere_reintersect(int n_seeds, int rays_per_shape, int partial, in
     return failures;
 }
 }
+
+// ---- KAT hooks for the BSSRDF restatement (tests/test_oracle_kats.py) -------------------------------------------
+extern "C" {
+using namespace ref;
+static void kat_bssrdf(const PtBSSRDFTable *t, const float *sigma_a, const float *sigma_s, float eta, BssrdfTable &tb, TabulatedBSSRDF &b) {
+    tb.n_rho = (int)t->n_rho; tb.n_radius = (int)t->n_radius;
+    tb.rho_samples.assign(t->rho_samples, t->rho_samples + t->n_rho); tb.radius_samples.assign(t->radius_samples, t->radius_samples + t->n_radius);
+    tb.profile.assign(t->profile, t->profile + (size_t)t->n_rho * t->n_radius); tb.rhoeff.assign(t->rhoeff, t->rhoeff + t->n_rho);
+    tb.profile_cdf.assign(t->profile_cdf, t->profile_cdf + (size_t)t->n_rho * t->n_radius);
+    SurfaceInteraction si; si.p = V3(0, 0, 0); si.n = V3(0, 0, 1); si.sh_n = V3(0, 0, 1); si.sh_dpdu = V3(1, 0, 0);
+    b.init(si, 0, eta, RGB(sigma_a[0], sigma_a[1], sigma_a[2]), RGB(sigma_s[0], sigma_s[1], sigma_s[2]), &tb);
+}
+// Sr(r) and pdf_sr(ch, r) for n radii
+int orc_bssrdf_sr(const PtBSSRDFTable *t, const float *sigma_a, const float *sigma_s, float eta, uint32_t n, const float *r, float *sr3, float *pdf3) {
+    BssrdfTable tb; TabulatedBSSRDF b; kat_bssrdf(t, sigma_a, sigma_s, eta, tb, b);
+    for (uint32_t i = 0; i < n; ++i) {
+        RGB s = b.sr(r[i]);
+        for (int c = 0; c < 3; ++c) { sr3[3 * i + c] = s.c[c]; pdf3[3 * i + c] = b.pdf_sr(c, r[i]); }
+    }
+    return 0;
+}
+int orc_bssrdf_sample_sr(const PtBSSRDFTable *t, const float *sigma_a, const float *sigma_s, float eta, int ch, uint32_t n, const float *u, float *r) {
+    BssrdfTable tb; TabulatedBSSRDF b; kat_bssrdf(t, sigma_a, sigma_s, eta, tb, b);
+    for (uint32_t i = 0; i < n; ++i) r[i] = b.sample_sr(ch, u[i]);
+    return 0;
+}
+int orc_catmull_rom_weights(int size, const float *nodes, float x, int *offset, float *w4) {
+    return catmull_rom_weights(size, nodes, x, *offset, w4) ? 1 : 0;
+}
+float orc_bssrdf_sw(float eta, float cos_theta_) { return bssrdf_sw(eta, V3(std::sqrt(fmax_(0.0f, 1.0f - cos_theta_ * cos_theta_)), 0.0f, cos_theta_)); }
+}
