@@ -54,6 +54,8 @@ class Oracle:
         lib.orc_bssrdf_sample_sr.argtypes = [tp, A.fp, A.fp, f, C.c_int, C.c_uint32, A.fp, A.fp]
         lib.orc_catmull_rom_weights.argtypes = [C.c_int, A.fp, f, C.POINTER(C.c_int), A.fp]
         lib.orc_bssrdf_sw.restype = f; lib.orc_bssrdf_sw.argtypes = [f, f]
+        lib.orc_light_sample_li.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, A.fp, C.c_uint32, A.fp, A.fp, A.fp, A.fp]
+        lib.orc_light_pdf_li.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, A.fp, C.c_uint32, A.fp, A.fp]
         if lib.orc_load_tables(tables_path.encode()) != 0:
             raise RuntimeError("oracle: cannot load " + tables_path)
         self.lib = lib

@@ -787,3 +787,27 @@ int orc_catmull_rom_weights(int size, const float *nodes, float x, int *offset, 
 }
 float orc_bssrdf_sw(float eta, float cos_theta_) { return bssrdf_sw(eta, V3(std::sqrt(fmax_(0.0f, 1.0f - cos_theta_ * cos_theta_)), 0.0f, cos_theta_)); }
 }
+
+// ---- KAT hooks for light sampling (tests/test_oracle_kats.py) ----------------------------------------------------
+extern "C" {
+using namespace ref;
+// sample_li for n sample points u (2n floats) from the reference point (p, p_error, n); outputs wi (3n), pdf (n), L (3n)
+int orc_light_sample_li(orc_scene *h, uint32_t li, const float *p, const float *perr, const float *nrm, uint32_t n, const float *u,
+                        float *wi_out, float *pdf_out, float *L_out) {
+    LightSampler ls; ls.init(h->scene, PT_LS_UNIFORM);
+    IData ref; ref.p = V3(p[0], p[1], p[2]); ref.p_error = V3(perr[0], perr[1], perr[2]); ref.n = V3(nrm[0], nrm[1], nrm[2]);
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 wi(0, 0, 0); Float pdf = 0.0f; IData p1;
+        RGB L = ls.sample_li(li, ref, P2(u[2 * i], u[2 * i + 1]), wi, pdf, p1);
+        wi_out[3 * i] = wi.x; wi_out[3 * i + 1] = wi.y; wi_out[3 * i + 2] = wi.z; pdf_out[i] = pdf;
+        for (int c = 0; c < 3; ++c) L_out[3 * i + c] = L.c[c];
+    }
+    return 0;
+}
+int orc_light_pdf_li(orc_scene *h, uint32_t li, const float *p, const float *perr, const float *nrm, uint32_t n, const float *wi, float *pdf_out) {
+    LightSampler ls; ls.init(h->scene, PT_LS_UNIFORM);
+    IData ref; ref.p = V3(p[0], p[1], p[2]); ref.p_error = V3(perr[0], perr[1], perr[2]); ref.n = V3(nrm[0], nrm[1], nrm[2]);
+    for (uint32_t i = 0; i < n; ++i) pdf_out[i] = ls.pdf_li(li, ref, V3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
+    return 0;
+}
+}

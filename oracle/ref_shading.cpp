@@ -5,6 +5,7 @@
 namespace ref {
 
 // ---- BxDF evaluation --------------------------------------------------------------------------
+static Float shape_area(const Scene &s, uint32_t sh);
 static Float default_pdf(V3 wo, V3 wi) {  // reflection.rs:439-445
     return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * INV_PI : 0.0f;
 }
@@ -274,9 +275,7 @@ RGB LightSampler::power(uint32_t li) const {
     RGB c(L.L[0], L.L[1], L.L[2]);
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:82-84
-        uint32_t s = scene->prim_shape[L.prim];
-        Float area = scene->tri_area(s & 0x3fffffffu);
-        return c * area * PI;
+        return c * shape_area(*scene, scene->prim_shape[L.prim]) * PI;
     }
     case PT_LIGHT_DISTANT: return c * PI * world_radius * world_radius;  // distant.rs:47-50
     case PT_LIGHT_POINT: return c * 4.0f * PI;                            // point.rs:44-46
@@ -289,6 +288,56 @@ RGB LightSampler::power(uint32_t li) const {
     return RGB(0.0f);
 }
 
+// Shape::area: triangle.rs:550-554, sphere.rs:291-293
+static Float shape_area(const Scene &s, uint32_t sh) {
+    if ((sh >> 30) == PT_SHAPE_SPHERE) { const PtSphere &S = s.spheres[sh & 0x3fffffffu]; return S.phi_max * S.radius * (S.z_max - S.z_min); }
+    return s.tri_area(sh & 0x3fffffffu);
+}
+
+// Sphere::sample_interaction (sphere.rs:313-378) incl. Sphere::sample (:295-311). App. A #7: the cone branch leaves
+// it.n = (0,0,0) (`it.n *= 1.0`), so one-sided sphere lights return L = 0 from sample_li and the shadow ray's far end is
+// not offset.
+static IData sphere_sample_interaction(const PtSphere &S, const IData &ref, P2 u, Float &pdf) {
+    M4 o2w = m4_from(S.object_to_world), w2o = m4_from(S.world_to_object);
+    V3 pcenter = xf_point(o2w, V3(0.0f, 0.0f, 0.0f));
+    V3 porigin = offset_ray_origin(ref.p, ref.p_error, ref.n, pcenter - ref.p);
+    IData it;
+    if (distance_squared(porigin, pcenter) <= S.radius * S.radius) {
+        V3 pobj = V3(0.0f, 0.0f, 0.0f) + uniform_sample_sphere(u) * S.radius;
+        it.n = normalize(xf_normal_inv(w2o, pobj));
+        if (S.reverse_orientation) it.n = it.n * -1.0f;
+        pobj = pobj * (S.radius / length(pobj));
+        V3 perr = vabs(pobj) * gamma(5);
+        it.p = xf_point_abs_err(o2w, pobj, perr, it.p_error);
+        pdf = 1.0f / (S.phi_max * S.radius * (S.z_max - S.z_min));
+        V3 wi = it.p - ref.p;
+        if (length_squared(wi) == 0.0f) pdf = 0.0f;
+        else { wi = normalize(wi); pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -wi); }
+        if (std::isinf(pdf)) pdf = 0.0f;
+        return it;
+    }
+    Float dc = length(ref.p - pcenter);
+    Float invdc = 1.0f / dc;
+    V3 wc = (pcenter - ref.p) * invdc, wcx, wcy;
+    coordinate_system(wc, wcx, wcy);
+    Float sin_thetamax = S.radius * invdc;
+    Float sin_thetamax2 = sin_thetamax * sin_thetamax;
+    Float inv_sin_thetamax = 1.0f / sin_thetamax;
+    Float cos_thetamax = std::sqrt(fmax_(1.0f - sin_thetamax2, 0.0f));
+    Float cos_theta = (cos_thetamax - 1.0f) * u.x + 1.0f;
+    Float sin_theta2 = 1.0f - cos_theta * cos_theta;
+    if (sin_thetamax2 < 0.00068523f) { sin_theta2 = sin_thetamax2 * u.x; cos_theta = std::sqrt(1.0f - sin_theta2); }
+    Float cos_alpha = sin_theta2 * inv_sin_thetamax + cos_theta * std::sqrt(fmax_(1.0f - sin_theta2 * inv_sin_thetamax * inv_sin_thetamax, 0.0f));
+    Float sin_alpha = std::sqrt(fmax_(1.0f - cos_alpha * cos_alpha, 0.0f));
+    Float phi = u.y * 2.0f * PI;
+    // spherical_direction_basis(sin_alpha, cos_alpha, phi, -wcx, -wcy, -wc) (geometry.rs:36-38)
+    V3 nworld = (-wcx) * sin_alpha * dm_cosf(phi) + (-wcy) * sin_alpha * dm_sinf(phi) + (-wc) * cos_alpha;
+    V3 pworld = pcenter + V3(nworld.x, nworld.y, nworld.z) * S.radius;
+    it.p = pworld; it.p_error = vabs(pworld) * gamma(5); it.n = V3(0.0f, 0.0f, 0.0f);
+    pdf = 1.0f / (2.0f * PI * (1.0f - cos_thetamax));
+    return it;
+}
+
 RGB LightSampler::sample_li(uint32_t li, const IData &ref, P2 u, V3 &wi, Float &pdf, IData &p1) const {
     const Scene &s = *scene;
     const PtLight &L = s.lights[li];
@@ -296,6 +345,13 @@ RGB LightSampler::sample_li(uint32_t li, const IData &ref, P2 u, V3 &wi, Float &
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
         uint32_t sh = s.prim_shape[L.prim];
+        if ((sh >> 30) == PT_SHAPE_SPHERE) {
+            IData it = sphere_sample_interaction(s.spheres[sh & 0x3fffffffu], ref, u, pdf);
+            if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+            wi = normalize(it.p - ref.p);
+            p1 = it;
+            return area_l(li, it.n, -wi);
+        }
         uint32_t tri = sh & 0x3fffffffu;
         P2 b = uniform_sample_triangle(u);
         V3 p0, p1v, p2; s.tri_positions(tri, p0, p1v, p2);
@@ -373,6 +429,23 @@ Float LightSampler::pdf_li(uint32_t li, const IData &ref, V3 wi) const {
     const PtLight &L = s.lights[li];
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // shape.rs:63-82 (intersect with s = None)
+        if ((s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {  // Sphere::pdf_wi (sphere.rs:380-395)
+            uint32_t si_ = s.prim_shape[L.prim] & 0x3fffffffu;
+            const PtSphere &S = s.spheres[si_];
+            V3 pcenter = xf_point(m4_from(S.object_to_world), V3(0.0f, 0.0f, 0.0f));
+            V3 porigin = offset_ray_origin(ref.p, ref.p_error, ref.n, pcenter - ref.p);
+            if (distance_squared(porigin, pcenter) <= S.radius * S.radius) {  // shape_pdfwi (shape.rs:117-136)
+                Ray ray = spawn_ray(ref, wi);
+                Float thit; SurfaceInteraction il;
+                if (!s.sphere_intersect(si_, ray, thit, il, false)) return 0.0f;
+                Float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * shape_area(s, s.prim_shape[L.prim]));
+                if (std::isinf(pdf)) pdf = 0.0f;
+                return pdf;
+            }
+            Float sin_thetamax2 = S.radius * S.radius / distance_squared(ref.p, pcenter);
+            Float cos_thetamax = std::sqrt(fmax_(1.0f - sin_thetamax2, 0.0f));
+            return 1.0f / (2.0f * PI * (1.0f - cos_thetamax));
+        }
         uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
         Ray ray = spawn_ray(ref, wi);
         Float t, b[3];

@@ -499,7 +499,6 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const PtLight &L = d->lights[i];
         if (L.type == PT_LIGHT_DIFFUSE_AREA && L.prim >= d->n_prims) return fail(PT_ERR_INVALID_ARG, "area light primitive out of range");
-        if (L.type == PT_LIGHT_DIFFUSE_AREA && (d->prim_shape[L.prim] >> 30) != PT_SHAPE_TRIANGLE) return fail(PT_ERR_UNSUPPORTED, "sphere area lights (sphere.rs:313-395) are not implemented on device yet");
         if (L.type == PT_LIGHT_INFINITE && !d->env_texels) return fail(PT_ERR_INVALID_ARG, "infinite light without env_texels");
     }
     int st = ensure_device();

@@ -5,6 +5,7 @@
 #pragma once
 #include "dev_scene.h"
 #include "dev_sampler.h"
+#include "dev_sphere.h"
 
 namespace ptd {
 
@@ -98,12 +99,66 @@ PT_DEV float env_pdf(const DeviceScene &s, P2 p) {
     return s.env_func[(size_t)iv * nu + iu] / s.env_marg_int;
 }
 
+// Sphere::sample_interaction (sphere.rs:313-378) incl. Sphere::sample (:295-311). The cone branch leaves it.n = 0
+// (SURVEY App. A #7): one-sided sphere lights return L = 0 from sample_li; the far end of the shadow ray is not offset.
+PT_DEV IData sphere_sample_interaction(const PtSphere &S, const IData &ref, P2 u, float &pdf) {
+    const M4 o2w = ldm4g(S.object_to_world), w2o = ldm4g(S.world_to_object);
+    const V3 pcenter = xf_point(o2w, V3(0.0f, 0.0f, 0.0f));
+    const V3 porigin = offset_ray_origin(ref.p, ref.p_error, ref.n, pcenter - ref.p);
+    IData it;
+    if (distance_squared(porigin, pcenter) <= S.radius * S.radius) {
+        const float z = 1.0f - 2.0f * u.x;                           // uniform_sample_sphere, sampling.rs:212-218
+        const float r = sqrtf(maxf(1.0f - z * z, 0.0f));
+        const float phi = 2.0f * kPi * u.y;
+        float sn, cs; dm_sincosf(phi, sn, cs);
+        V3 pobj = V3(0.0f, 0.0f, 0.0f) + V3(r * cs, r * sn, z) * S.radius;
+        it.n = normalize(xf_normal_inv(w2o, pobj));
+        if (S.reverse_orientation) it.n = it.n * -1.0f;
+        pobj = pobj * (S.radius / length(pobj));
+        const V3 perr = vabs(pobj) * gammaf(5);
+        it.p = xf_point_abs_err(o2w, pobj, perr, it.p_error);
+        pdf = 1.0f / (S.phi_max * S.radius * (S.z_max - S.z_min));
+        V3 wi = it.p - ref.p;
+        if (length_squared(wi) == 0.0f) pdf = 0.0f;
+        else { wi = normalize(wi); pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -wi); }
+        if (__builtin_isinf(pdf)) pdf = 0.0f;
+        return it;
+    }
+    const float dc = length(ref.p - pcenter);
+    const float invdc = 1.0f / dc;
+    const V3 wc = (pcenter - ref.p) * invdc; V3 wcx, wcy;
+    coordinate_system(wc, wcx, wcy);
+    const float sin_thetamax = S.radius * invdc;
+    const float sin_thetamax2 = sin_thetamax * sin_thetamax;
+    const float inv_sin_thetamax = 1.0f / sin_thetamax;
+    const float cos_thetamax = sqrtf(maxf(1.0f - sin_thetamax2, 0.0f));
+    float cos_theta = (cos_thetamax - 1.0f) * u.x + 1.0f;
+    float sin_theta2 = 1.0f - cos_theta * cos_theta;
+    if (sin_thetamax2 < 0.00068523f) { sin_theta2 = sin_thetamax2 * u.x; cos_theta = sqrtf(1.0f - sin_theta2); }
+    const float cos_alpha = sin_theta2 * inv_sin_thetamax + cos_theta * sqrtf(maxf(1.0f - sin_theta2 * inv_sin_thetamax * inv_sin_thetamax, 0.0f));
+    const float sin_alpha = sqrtf(maxf(1.0f - cos_alpha * cos_alpha, 0.0f));
+    const float phi = u.y * 2.0f * kPi;
+    float sn, cs; dm_sincosf(phi, sn, cs);
+    const V3 nworld = (-wcx) * sin_alpha * cs + (-wcy) * sin_alpha * sn + (-wc) * cos_alpha;   // spherical_direction_basis
+    const V3 pworld = pcenter + V3(nworld.x, nworld.y, nworld.z) * S.radius;
+    it.p = pworld; it.p_error = vabs(pworld) * gammaf(5); it.n = V3(0.0f, 0.0f, 0.0f);
+    pdf = 1.0f / (2.0f * kPi * (1.0f - cos_thetamax));
+    return it;
+}
+
 // Light::sample_li. Returns Li; fills wi, pdf and the far end of the visibility segment.
-PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, P2 u, V3 &wi, float &pdf, IData &p1) {
+template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, P2 u, V3 &wi, float &pdf, IData &p1) {
     const PtLight &L = s.lights[li];
     p1.p = V3(); p1.p_error = V3(); p1.n = V3();
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
+        if (SPH && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {   // SPH == false: the scene holds no sphere
+            IData it = sphere_sample_interaction(s.spheres[s.prim_shape[L.prim] & 0x3fffffffu], ref, u, pdf);
+            if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+            wi = normalize(it.p - ref.p);
+            p1 = it;
+            return area_l(L, it.n, -wi);
+        }
         uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
         float su0 = sqrtf(u.x);
         float b0 = 1.0f - su0, b1 = u.y * su0;  // uniform_sample_triangle, sampling.rs:250-254
@@ -178,8 +233,24 @@ PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, 
 }
 
 // Light::pdf_li (area: Shape::pdf_wi re-intersects the light's own triangle, shape.rs:63-82)
-PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li, const IData &ref, V3 wi) {
+template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li, const IData &ref, V3 wi) {
     const PtLight &L = s.lights[li];
+    if (SPH && L.type == PT_LIGHT_DIFFUSE_AREA && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {  // Sphere::pdf_wi (sphere.rs:380-395)
+        const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];
+        const V3 pcenter = xf_point(ldm4g(S.object_to_world), V3(0.0f, 0.0f, 0.0f));
+        const V3 porigin = offset_ray_origin(ref.p, ref.p_error, ref.n, pcenter - ref.p);
+        if (distance_squared(porigin, pcenter) <= S.radius * S.radius) {  // shape_pdfwi (shape.rs:117-136)
+            V3 o; spawn_ray(ref, wi, o);
+            SurfaceInteraction il;
+            if (!sphere_fill_interaction(S, o, wi, il)) return 0.0f;
+            float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * s.light_area[li]);
+            if (__builtin_isinf(pdf)) pdf = 0.0f;
+            return pdf;
+        }
+        const float sin_thetamax2 = S.radius * S.radius / distance_squared(ref.p, pcenter);
+        const float cos_thetamax = sqrtf(maxf(1.0f - sin_thetamax2, 0.0f));
+        return 1.0f / (2.0f * kPi * (1.0f - cos_thetamax));
+    }
     if (L.type == PT_LIGHT_DIFFUSE_AREA) {
         uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
         V3 o; spawn_ray(ref, wi, o);

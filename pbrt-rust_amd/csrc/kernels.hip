@@ -117,6 +117,9 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
         if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
             uint32_t tri = shape & 0x3fffffffu;
             a = tri_area(ld3(s.P, s.indices[3 * tri]), ld3(s.P, s.indices[3 * tri + 1]), ld3(s.P, s.indices[3 * tri + 2]));
+        } else {  // Sphere::area (sphere.rs:291-293)
+            const PtSphere &S = s.spheres[shape & 0x3fffffffu];
+            a = S.phi_max * S.radius * (S.z_max - S.z_min);
         }
     }
     area[i] = a;
@@ -558,7 +561,7 @@ template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const Path
 // uniform_sample_onelight + estimate_direct (integrator.rs:81-237) at one vertex: samples the light and the BSDF,
 // records the shadow / MIS rays and their weights in the path state; the estimate is summed by resolve_pending once
 // both rays are traced. Returns whether anything is pending (false: Ld is black).
-template <class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
+template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
                                           const SurfaceInteraction &si, const IData &it, const B &bsdf, RGB beta, uint32_t &flags,
                                           bool &push_shadow, bool &push_mis, unsigned long long &n_bytes) {
     bool nee_pending = false;
@@ -572,7 +575,7 @@ template <class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid 
             // estimate_direct (integrator.rs:109-237), flags = All & !Specular
             const int bf = BSDF_ALL & ~BSDF_SPECULAR;
             V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
-            RGB Li = light_sample_li(s, li, it, ulight, wi, lightpdf, p1);
+            RGB Li = light_sample_li<SPH>(s, li, it, ulight, wi, lightpdf, p1);
             const bool delta = light_is_delta(s.lights[li]);
             if (lightpdf > 0.0f && !Li.is_black()) {
                 RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
@@ -595,7 +598,7 @@ template <class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid 
                     float weight = 1.0f;
                     bool skip = false;
                     if (!sampled_specular) {
-                        lightpdf = light_pdf_li(s, li, it, wi);
+                        lightpdf = light_pdf_li<SPH>(s, li, it, wi);
                         if (lightpdf == 0.0f) skip = true;  // `return Ld` (integrator.rs:204)
                         else weight = power_heuristic(scattpdf, lightpdf);
                     }
@@ -618,8 +621,11 @@ template <class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid 
     return nee_pending;
 }
 
+#ifndef PT_SHADE_ATTR
+#define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
+#endif
 template <int MAXL, bool SPH>
-__global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+__global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, RenderConst rc, So
                     // uniform_sample_onelight (integrator.rs:81-106)
                     if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
-                        const bool nee_pending = nee_vertex(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes);
+                        const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes);
                         if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
                     }
                     // path.rs:148-174: sample the BSDF for the next direction
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                     si.wo = si.sh_n;
                     IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
-                    if (nee_vertex(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes)) flags |= PF_NEE_UNCOUNTED;
+                    if (nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes)) flags |= PF_NEE_UNCOUNTED;
                     // path.rs:194-201: indirect component
                     V3 wi; int sflags = 0;
                     const RGB ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint3
         intr.p = V3(lerpf(u3.x, vmin.x, vmax.x), lerpf(u3.y, vmin.y, vmax.y), lerpf(u3.z, vmin.z, vmax.z));
         P2 u(radical_inverse(3, i), radical_inverse(4, i));
         float pdf = 0.0f; V3 wi; IData vis;
-        RGB Li = light_sample_li(s, j, intr, u, wi, pdf, vis);
+        RGB Li = light_sample_li<true>(s, j, intr, u, wi, pdf, vis);
         if (pdf > 0.0f) contrib += Li.y() / pdf;
     }
     func[gid] = contrib;

@@ -259,9 +259,11 @@ class SceneBuilder:
         elif kind == "infinite":  # infinite.rs:243-259, constant-L map = 1x1 texel
             L = np.asarray(kw.get("L", (1, 1, 1)), dtype=F) * F(sc)
             l.type = A.PT_LIGHT_INFINITE
-            tex = kw.get("texels")
+            tex = kw.get("texels")   # rows = v (theta), columns = u (phi), as read_image returns them
             if tex is None:
                 tex = L.reshape(1, 1, 3)
+            else:
+                tex = (np.asarray(tex, dtype=F) * L.reshape(1, 1, 3)).astype(F)   # infinite.rs:46-50: texels *= L * scale
             tex = np.ascontiguousarray(tex, dtype=F)
             self.env = dict(texels=tex, importance=_env_importance(tex))
         else:
@@ -389,22 +391,33 @@ class SceneBuilder:
 
 
 def _env_importance(tex):
-    """lights/infinite.rs:62-81 importance image (2w x 2h) for a level-0 map; bilinear lookups
-    (MIPMap::lookup with width fwidth resolves to `triangle` on a 1-level pyramid only for 1x1 maps;
-    general maps go through the trilinear path -> restated for 1x1 here, the only case in scope)."""
+    """lights/infinite.rs:62-81 importance image (2w x 2h): `map.lookup(st, fwidth).y() * sin(theta)` with
+    fwidth = 0.5 / min(2w, 2h).  MIPMap::lookup (mipmap.rs:202-223) picks level = levels - 1 + log2(fwidth)
+    = log2(max(w,h)/min(w,h)) - 2, which is < 0 for power-of-two maps with aspect <= 2:1 -> `triangle(0, st)`, the
+    level-0 bilinear lookup with Repeat wrap (mipmap.rs:295-327).  Other sizes need the resampled pyramid
+    (mipmap.rs:60-190) and are rejected here: resample on the host first."""
     h, w, _ = tex.shape
-    if (w, h) != (1, 1):
-        raise NotImplementedError("env maps other than constant-L (1x1) are a 'next' row (SURVEY 8f-1)")
+    pow2 = lambda n: n > 0 and (n & (n - 1)) == 0
+    if not (pow2(w) and pow2(h) and max(w, h) <= 2 * min(w, h)):
+        raise NotImplementedError("environment maps must be power-of-two sized with aspect <= 2:1 (MIPMap resampling / pyramid levels > 0 are not restated)")
     W, H = 2 * w, 2 * h
-    img = np.zeros((H, W), dtype=F)
     y_w = np.array([0.212671, 0.715160, 0.072169], dtype=F)
-    texel = tex[0, 0]
-    lum = F(y_w[0] * texel[0] + y_w[1] * texel[1] + y_w[2] * texel[2])
-    for v in range(H):
-        sin_theta = F(math.sin(F(math.pi) * (F(v) + F(0.5)) / F(H)))
-        for u in range(W):
-            img[v, u] = lum * sin_theta  # levels()==1: lookup returns texel(0,0,0) (mipmap.rs:210-211)
-    return img
+    lum = (y_w[0] * tex[..., 0] + y_w[1] * tex[..., 1] + y_w[2] * tex[..., 2]).astype(F)
+    up = ((np.arange(W, dtype=F) + F(0.5)) / F(W)).astype(F)
+    vp = ((np.arange(H, dtype=F) + F(0.5)) / F(H)).astype(F)
+    sx = (up * F(w) - F(0.5)).astype(F); ty = (vp * F(h) - F(0.5)).astype(F)
+    s0 = np.floor(sx).astype(np.int64); t0 = np.floor(ty).astype(np.int64)
+    ds = (sx - s0.astype(F)).astype(F)[None, :]; dt = (ty - t0.astype(F)).astype(F)[:, None]
+    tx = lambda si, ti: tex[np.mod(ti, h)[:, None], np.mod(si, w)[None, :]].astype(F)   # texel(level 0, s, t), Repeat
+    one = F(1.0)
+    # RGBSpectrum arithmetic first (tmp4 + tmp3 + tmp2 + tmp1), then y(), exactly as `triangle(..).y()`
+    rgb = ((tx(s0, t0) * ((one - ds) * (one - dt))[..., None] + tx(s0, t0 + 1) * ((one - ds) * dt)[..., None]).astype(F)
+           + tx(s0 + 1, t0) * (ds * (one - dt))[..., None]).astype(F)
+    rgb = (rgb + tx(s0 + 1, t0 + 1) * (ds * dt)[..., None]).astype(F)
+    img = ((y_w[0] * rgb[..., 0] + y_w[1] * rgb[..., 1]).astype(F) + y_w[2] * rgb[..., 2]).astype(F)
+    sin_theta = np.sin(F(math.pi) * (np.arange(H, dtype=F) + F(0.5)) / F(H)).astype(F)
+    del lum
+    return np.ascontiguousarray(img * sin_theta[:, None], dtype=F)
 
 
 class SceneData:

@@ -7,7 +7,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi355pt.so")
+LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "csrc", "libmi355pt.so")   # PT_LIB_PATH: kernel-variant experiments
 TABLES_PATH = os.path.join(_HERE, "data", "sobol_tables.bin")
 
 

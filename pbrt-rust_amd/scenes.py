@@ -214,3 +214,37 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False):
     b.material("kdsubsurface", Kd=(0.7, 0.35, 0.2), mfp=(0.25, 0.15, 0.08), eta=1.4)
     b.translate(1.2, 0.0, 0.3); b.sphere(radius=0.9); b.attribute_end()
     return b
+
+
+def sky_env(w=16, h=8):
+    """A small procedural lat-long environment (rows = theta from +z pole, columns = phi): blue-to-white gradient with a
+    bright 'sun' patch, so that the importance image is strongly non-uniform."""
+    v = (np.arange(h, dtype=np.float64) + 0.5) / h
+    u = (np.arange(w, dtype=np.float64) + 0.5) / w
+    sky = np.stack([0.25 + 0.5 * v, 0.35 + 0.45 * v, 0.8 - 0.2 * v], axis=-1)[:, None, :] * np.ones((1, w, 1))
+    sun = np.exp(-(((u[None, :] - 0.3) * w / 1.5) ** 2 + ((v[:, None] - 0.35) * h / 1.2) ** 2))
+    return (sky + 40.0 * sun[..., None] * np.array([1.0, 0.9, 0.7])).astype(F)
+
+
+def sphere_lights(xres=96, yres=64, spp=16, maxdepth=4):
+    """Sphere area lights (row a14 `Sphere::sample_interaction/pdf_wi`, a21 DiffuseAreaLight on a sphere): a two-sided small
+    sphere light (cone sampling), a one-sided sphere light (App. A #7: NEE light samples return L = 0; only BSDF-sampled rays
+    see it), and a large two-sided partial sphere around a diffuse object (reference point INSIDE the light: uniform-area
+    branch + shape_pdfwi)."""
+    from .host import SceneBuilder
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.0, 7.0), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.attribute_begin(); b.area_light_source(L=(30.0, 26.0, 20.0), twosided=True); b.translate(-1.5, 2.5, 0.5); b.sphere(radius=0.3); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(8.0, 12.0, 20.0)); b.translate(2.0, 1.2, -0.5); b.sphere(radius=0.5); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(0.6, 0.5, 0.4), twosided=True); b.translate(0.0, 0.0, 0.0); b.rotate(-90.0, 1.0, 0.0, 0.0)
+    b.sphere(radius=30.0, zmin=-5.0, zmax=30.0); b.attribute_end()
+    b.material("matte", Kd=(0.55, 0.55, 0.5))
+    P, I = quad((-6.0, -1.0, -6.0), (-6.0, -1.0, 6.0), (6.0, -1.0, 6.0), (6.0, -1.0, -6.0))
+    b.trianglemesh(P, I)
+    b.attribute_begin(); b.material("plastic", Kd=(0.5, 0.2, 0.2), Ks=(0.4, 0.4, 0.4), roughness=0.05)
+    P, I, N = displaced_sphere(12, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
+    b.attribute_begin(); b.material("glass", eta=1.5); b.translate(1.6, -0.4, 1.5); b.sphere(radius=0.6); b.attribute_end()
+    return b

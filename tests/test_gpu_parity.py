@@ -254,3 +254,28 @@ def test_subsurface_matches_oracle(pkg, gpu, oracle, rough):
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
     assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(16, 8), (8, 8)])
+def test_image_environment_map_matches_oracle(pkg, gpu, oracle, shape):
+    """Row a21 InfiniteAreaLight with an image map: level-0 bilinear `le`, Distribution2D importance sampling / pdf, and the
+    spatial light grid built from it."""
+    tex = pkg.scenes.sky_env(*shape)
+    b = pkg.scenes.ganesha_scale(n=16, xres=64, yres=40, spp=8, env=False)
+    b.rotate(-90.0, 1.0, 0.0, 0.0)
+    b.light_source("infinite", texels=tex, L=(0.5, 0.5, 0.5), scale=2.0)
+    sd, rp = b.world_end()
+    _compare_render(pkg, gpu, oracle, sd, rp)
+
+
+def test_sphere_area_lights_match_oracle(pkg, gpu, oracle):
+    """Rows a14/a21: DiffuseAreaLight on sphere shapes -- cone sampling (two-sided and the one-sided zero-normal quirk),
+    the inside-the-sphere branch with shape_pdfwi (negative pdfs squared by the power heuristic), spatial light grid."""
+    sd, rp = pkg.scenes.sphere_lights(xres=96, yres=64, spp=8).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
+              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
