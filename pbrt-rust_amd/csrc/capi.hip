@@ -453,6 +453,15 @@ void read_counters(pt_scene *sc) {
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
     for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
+#ifdef PT_REGION_PROFILE
+    {
+        static const char *rn[16] = {"0 loop/queue read", "1 resolve", "2 resolve env le", "3 load ray/hit + fill_hit + Le", "4 sobol window", "5 light choice",
+                                     "6 light sample_li", "7 bsdf f/pdf + shadow ray", "8 MIS bsdf sample + store", "9 MIS light pdf_li", "10 bsdf build", "11 continuation sample + RR",
+                                     "12 state write-back", "13 queue push/flush", "14 tail", "15 prologue"};
+        unsigned long long tot = 0; for (int i = 0; i < 16; ++i) tot += d.regions[i];
+        for (int i = 0; i < 16; ++i) fprintf(stderr, "[region] %-34s %6.2f %%  %.3e cycles\n", rn[i], tot ? 100.0 * (double)d.regions[i] / (double)tot : 0.0, (double)d.regions[i]);
+    }
+#endif
 }
 
 }  // namespace

@@ -53,16 +53,22 @@ PT_DEV RGB env_lookup(const DeviceScene &s, P2 st) {
     float sf = st.x * (float)w - 0.5f, tf = st.y * (float)h - 0.5f;
     int64_t s0 = f2i_sat(floorf(sf)), t0 = f2i_sat(floorf(tf));
     float ds = sf - (float)s0, dt = tf - (float)t0;
-    auto texel = [&](int64_t ss, int64_t tt) -> RGB {
-        int64_t si = ss % w; if (si < 0) si += w;
-        int64_t ti = tt % h; if (ti < 0) ti += h;
+    // mod_(s, u) (mipmap.rs:303): st lies in [0,1] for every caller, so s0 is in [-1, w]; wrap with one compare each side
+    // (a 64-bit `%` costs > 100 instructions on this ISA); anything outside [-w, 2w) takes the general path.
+    auto wrap = [](int64_t v, int n) -> int {
+        if (v >= -(int64_t)n && v < 2 * (int64_t)n) { int r = (int)v; if (r < 0) r += n; else if (r >= n) r -= n; return r; }
+        int64_t r = v % n; if (r < 0) r += n;
+        return (int)r;
+    };
+    const int sa = wrap(s0, w), sb = wrap(s0 + 1, w), ta = wrap(t0, h), tb = wrap(t0 + 1, h);
+    auto texel = [&](int si, int ti) -> RGB {
         const float *p = s.env_texels + 3 * ((size_t)ti * w + si);
         return RGB(p[0], p[1], p[2]);
     };
-    RGB tmp1 = texel(s0 + 1, t0 + 1) * (ds * dt);
-    RGB tmp2 = texel(s0 + 1, t0) * (ds * (1.0f - dt));
-    RGB tmp3 = texel(s0, t0 + 1) * ((1.0f - ds) * dt);
-    RGB tmp4 = texel(s0, t0) * ((1.0f - ds) * (1.0f - dt));
+    RGB tmp1 = texel(sb, tb) * (ds * dt);
+    RGB tmp2 = texel(sb, ta) * (ds * (1.0f - dt));
+    RGB tmp3 = texel(sa, tb) * ((1.0f - ds) * dt);
+    RGB tmp4 = texel(sa, ta) * ((1.0f - ds) * (1.0f - dt));
     return tmp4 + tmp3 + tmp2 + tmp1;
 }
 
@@ -235,6 +241,9 @@ template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li
 // Light::pdf_li (area: Shape::pdf_wi re-intersects the light's own triangle, shape.rs:63-82)
 template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li, const IData &ref, V3 wi) {
     const PtLight &L = s.lights[li];
+#ifdef PT_ABL_LIGHTPDF   // timing ablation only
+    return 0.5f + 0.0f * L.L[0];
+#endif
     if (SPH && L.type == PT_LIGHT_DIFFUSE_AREA && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {  // Sphere::pdf_wi (sphere.rs:380-395)
         const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];
         const V3 pcenter = xf_point(ldm4g(S.object_to_world), V3(0.0f, 0.0f, 0.0f));

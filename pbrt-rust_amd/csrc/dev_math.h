@@ -9,6 +9,13 @@
 
 #define PT_DEV __device__ __forceinline__
 #define PT_HD __host__ __device__ __forceinline__
+#ifdef PT_NOINLINE_HEAVY   // code-size experiment: heavy helpers as real functions
+#define PT_HDX __host__ __device__ __noinline__
+#define PT_DEVX __device__ __noinline__
+#else
+#define PT_HDX PT_HD
+#define PT_DEVX PT_DEV
+#endif
 
 namespace ptd {
 
@@ -93,7 +100,14 @@ PT_HD double dm_cos_k(double r) {
     return 1.0 - r2 * p;
 }
 // sin and cos of one argument share the reduction.
-PT_HD void dm_sincosf(float xf, float &s, float &c) {
+struct DmSC { float s, c; };
+PT_HD void dm_sincosf_impl(float xf, float &s, float &c);
+PT_HDX DmSC dm_sincosf2(float xf) { DmSC r; dm_sincosf_impl(xf, r.s, r.c); return r; }
+PT_HD void dm_sincosf(float xf, float &s, float &c) { DmSC r = dm_sincosf2(xf); s = r.s; c = r.c; }
+PT_HD void dm_sincosf_impl(float xf, float &s, float &c) {
+#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
+    s = __sinf(xf); c = __cosf(xf); return;   // timing ablation only (results differ)
+#endif
     double x = xf;
     if (!(__builtin_fabs(x) < 1.0e9)) { s = c = __builtin_nanf(""); return; }
     double kd = __builtin_floor(x * kDm2OverPi + 0.5);
@@ -136,7 +150,7 @@ PT_HD double dm_atan01(double z) {
     return dm_atan_tab(k) + (t + t * (t2 * p));
 }
 PT_HD double dm_atan_pos(double z) { return (z > 1.0) ? kDmPio2Hi - dm_atan01(1.0 / z) : dm_atan01(z); }
-PT_HD double dm_atan2d(double y, double x) {
+PT_HDX double dm_atan2d(double y, double x) {
     if (x != x || y != y) return __builtin_nan("");
     double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     double a;
@@ -147,8 +161,15 @@ PT_HD double dm_atan2d(double y, double x) {
     if (__builtin_signbit(x)) a = kDmPi - a;
     return __builtin_signbit(y) ? -a : a;
 }
+#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
+PT_HD float dm_atan2f(float y, float x) { return atan2f(y, x); }
+#else
 PT_HD float dm_atan2f(float y, float x) { return (float)dm_atan2d((double)y, (double)x); }
+#endif
 PT_HD float dm_acosf(float xf) {
+#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
+    return acosf(xf);
+#endif
     double x = xf;
     if (!(x >= -1.0 && x <= 1.0)) return __builtin_nanf("");
     double s = __builtin_sqrt((1.0 - x) * (1.0 + x));
@@ -274,7 +295,7 @@ PT_HD V3 xf_vector(const M4 &t, V3 v) {  // transform.rs:496-508
 }
 
 // geometry.rs:6-24
-PT_HD V3 offset_ray_origin(V3 p, V3 perr, V3 n, V3 w) {
+PT_HDX V3 offset_ray_origin(V3 p, V3 perr, V3 n, V3 w) {
     float d = dot(vabs(n), perr);
     V3 offset = n * d;
     if (dot(w, n) < 0.0f) offset = -offset;

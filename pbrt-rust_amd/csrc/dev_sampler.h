@@ -66,6 +66,10 @@ struct Sampler {
     PT_DEV void load_window() {
         base = dim;
         w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0;
+#ifdef PT_ABL_SOBOL   // timing ablation only: a cheap hash instead of the generator-matrix products (results differ)
+        { uint32_t h = (uint32_t)index * 0x9E3779B9u ^ (uint32_t)(index >> 32) ^ (base * 0x85EBCA6Bu);
+          w0 = h; w1 = h * 3u; w2 = h * 5u; w3 = h * 7u; w4 = h * 11u; w5 = h * 13u; w6 = h * 17u; w7 = h * 19u; return; }
+#endif
         if (base + 8 <= kSobolLdsDims) {
             const uint32_t *row = lds + base * 52;
             uint64_t a = index;

@@ -158,7 +158,7 @@ struct SurfaceInteraction {
     uint32_t prim;
 };
 // `with_shape` = the `s: Option<Arc<Shapes>>` argument (None inside Shape::pdf_wi, shape.rs:72).
-PT_DEV void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
+PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
     uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
     V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
     P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);

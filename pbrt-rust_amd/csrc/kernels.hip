@@ -37,10 +37,11 @@ PT_DEV void counter_add(unsigned long long *dst, unsigned long long v) {  // cal
     if (lane_id() == 0 && v) atomicAdd(dst, v);
 }
 
-// Block-level staging of queue appends. A single global counter sustains only ~88 returning atomics per
-// microsecond (MI355X_MICROARCH.md, row "dequeue"); one atomic per wave made every queue-producing kernel atomic
-// bound. Appends therefore go to an LDS buffer with LDS atomics (one per wave) and a whole block flushes ~1000
-// entries with ONE global atomic. All threads of the block must call lq_sync_flush together.
+// Staging of queue appends in LDS. A single global counter sustains only ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md, row "dequeue"); one atomic per wave per append made every queue-producing kernel atomic bound.
+//
+// LdsQueue (block level, streaming kernels): appends go to a block-wide LDS buffer with LDS atomics (one per wave) and
+// the whole block flushes ~1000 entries with ONE global atomic. All threads of the block call lq_sync_flush together.
 template <int CAP> struct LdsQueue { uint32_t count; uint32_t base; uint32_t buf[CAP]; };
 template <int CAP> PT_DEV void lq_init(LdsQueue<CAP> &q) { if (threadIdx.x == 0) { q.count = 0; q.base = 0; } }
 template <int CAP> PT_DEV void lq_push(LdsQueue<CAP> &q, uint32_t value, bool pred) {
@@ -67,6 +68,10 @@ template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount,
     }
     __syncthreads();
 }
+
+// (Measured alternative, not kept: barrier-free per-wave buffers. With 256-entry buffers the 4x more frequent returning
+// atomics made every producer slower; with 768-entry buffers k_shade still lost 10 % -- the barriers keep the four waves of
+// a block in lockstep through a 150 KB kernel, which evidently helps instruction fetch.)
 
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
@@ -525,11 +530,26 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
     tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
 }
 
+// ---- optional region timers (build with -DPT_REGION_PROFILE): wave time between markers is charged to the region of the
+// previous marker; one lane per wave updates three LDS words. Printed by the host when the scene is destroyed.
+#ifdef PT_REGION_PROFILE
+struct Prof { long long *t; int *r; unsigned long long *acc; };
+#define PT_T(k) do { if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) { const long long _n = clock64(); const int _w = threadIdx.x >> 6; \
+    prof.acc[_w * 16 + prof.r[_w]] += (unsigned long long)(_n - prof.t[_w]); prof.t[_w] = _n; prof.r[_w] = (k); } } while (0)
+#define PT_PROF_ARG , Prof prof
+#define PT_PROF_PASS , prof
+#else
+#define PT_T(k) do {} while (0)
+#define PT_PROF_ARG
+#define PT_PROF_PASS
+#endif
+
 // Resolve the pending next-event estimation of the previous vertex once its shadow / MIS rays are traced
 // (integrator.rs:150-171,199-233): L += beta_at_nee * Ld / choice_pdf.
 template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
-                                                unsigned long long &zero_num, unsigned long long &n_bytes) {
+                                                unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
+    PT_T(1);
     n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
     RGB Ld(0.0f);
     const uint32_t li = ps.nee_light[pid];
@@ -545,7 +565,7 @@ template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const Path
                 fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);  // lights are never inside instances (api.rs:1605-1608)
                 lrad = area_l(Lt, lsi.n, -wi);
             }
-        } else lrad = light_le(s, Lt, wi);
+        } else { PT_T(2); lrad = light_le(s, Lt, wi); PT_T(1); }
         if (!lrad.is_black()) {
             RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
             Ld = Ld + f * lrad * RGB(1.0f) * ps.mis_w[pid] / ps.mis_spdf[pid];
@@ -563,9 +583,10 @@ template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const Path
 // both rays are traced. Returns whether anything is pending (false: Ld is black).
 template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
                                           const SurfaceInteraction &si, const IData &it, const B &bsdf, RGB beta, uint32_t &flags,
-                                          bool &push_shadow, bool &push_mis, unsigned long long &n_bytes) {
+                                          bool &push_shadow, bool &push_mis, unsigned long long &n_bytes PT_PROF_ARG) {
     bool nee_pending = false;
     if (s.n_lights > 0) {
+        PT_T(5);
         Dist1D distrib = light_distribution_lookup(grid, s, si.p);
         float choice_pdf = 0.0f;
         const uint32_t li = (uint32_t)dist_sample_discrete(distrib, smp.get_1d(), choice_pdf);
@@ -575,7 +596,9 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
             // estimate_direct (integrator.rs:109-237), flags = All & !Specular
             const int bf = BSDF_ALL & ~BSDF_SPECULAR;
             V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+            PT_T(6);
             RGB Li = light_sample_li<SPH>(s, li, it, ulight, wi, lightpdf, p1);
+            PT_T(7);
             const bool delta = light_is_delta(s.lights[li]);
             if (lightpdf > 0.0f && !Li.is_black()) {
                 RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
@@ -590,6 +613,7 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
                 }
             }
             if (!delta) {
+                PT_T(8);
                 int sampled_type = 0;
                 RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, bf, sampled_type);
                 f = f * abs_dot(wi, si.sh_n);
@@ -598,7 +622,9 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
                     float weight = 1.0f;
                     bool skip = false;
                     if (!sampled_specular) {
+                        PT_T(9);
                         lightpdf = light_pdf_li<SPH>(s, li, it, wi);
+                        PT_T(8);
                         if (lightpdf == 0.0f) skip = true;  // `return Ld` (integrator.rs:204)
                         else weight = power_heuristic(scattpdf, lightpdf);
                     }
@@ -625,13 +651,21 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
 #define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
 #endif
 template <int MAXL, bool SPH>
-__global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+__global__ __launch_bounds__(256, (MAXL == 1 && SPH) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
+    // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
+    // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
     __shared__ uint32_t s_hist[16];
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 64) s_pacc[threadIdx.x] = 0;
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};
+#endif
     sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t count = *job.count;
@@ -642,6 +676,7 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
     int finished_bounces = -1;
     uint32_t pid = 0;
+    PT_T(0);
     if (valid) {
         n_valid++;
         n_bytes += 4 + 4 + 8 + 12 + 12 + /* write back */ 12 + 12 + 4;   // queue, meta, sobol index, L, beta
@@ -654,8 +689,9 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
         RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
-        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
+        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
 
+        PT_T(3);
         if (flags & PF_DEAD) {
             finished_bounces = (int)bounces;
         } else {
@@ -676,7 +712,9 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
             }
             bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
             if (!terminated) {
+                PT_T(4);
                 smp.load_window();
+                PT_T(10);
                 Bsdf<MAXL> bsdf;
                 const uint32_t mi = s.prim_material[hp];
                 bool has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf);
@@ -690,10 +728,11 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
                     // uniform_sample_onelight (integrator.rs:81-106)
                     if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
-                        const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes);
+                        const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
                         if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
                     }
                     // path.rs:148-174: sample the BSDF for the next direction
+                    PT_T(11);
                     V3 wi; float pdf = 0.0f; int sflags = 0;
                     RGB f = bsdf.sample_f(wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
                     if (f.is_black() || pdf == 0.0f) terminated = true;
@@ -758,11 +797,13 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
                 else finished_bounces = (int)bounces;
             }
         }
+        PT_T(12);
         if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
         ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
         ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
         ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
     }
+    PT_T(13);
     lq_push(s_qext, pid, push_ext);
     lq_push(s_qres, pid, push_resolve);
     lq_push(s_qsh, pid, push_shadow);
@@ -779,6 +820,12 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(DeviceScene s, Rend
     lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
     if constexpr (MAXL == 5) if (job.probe_next) lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    __syncthreads();   // s_hist complete
+#ifdef PT_REGION_PROFILE
+    PT_T(14);
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(&job.counters->regions[threadIdx.x], s_pacc[threadIdx.x] + s_pacc[16 + threadIdx.x] + s_pacc[32 + threadIdx.x] + s_pacc[48 + threadIdx.x]);
+#endif
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->zero_den, zero_den);
@@ -805,6 +852,11 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};
+#endif
     const BssSoA &bs = job.bs;
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -869,7 +921,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
             n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
             // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
-            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
+            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
@@ -889,7 +941,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                     si.wo = si.sh_n;
                     IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
-                    if (nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes)) flags |= PF_NEE_UNCOUNTED;
+                    if (nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS)) flags |= PF_NEE_UNCOUNTED;
                     // path.rs:194-201: indirect component
                     V3 wi; int sflags = 0;
                     const RGB ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
