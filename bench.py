@@ -126,8 +126,8 @@ def main():
     # Group the per-launch-kind statistics by kernel symbol (what rocprofv3 --stats reports) and take the
     # symbol with the largest total time as the dominant kernel.
     SYMBOL = {"extend_camera": "k_trace<false, false>", "extend": "k_trace<false, false>", "extend_mis": "k_trace<false, false>",
-              "shadow": "k_trace<true, false>", "shade_matte": "k_shade<1, false>", "shade_1lobe": "k_shade<1, false>",
-              "shade_2lobe": "k_shade<2, false>", "shade_uber": "k_shade<5, false>"}  # names as rocprofv3 prints them (no spheres in S2)
+              "shadow": "k_trace<true, false>", "shade_matte": "k_shade<1, 0>", "shade_1lobe": "k_shade<1, 0>",
+              "shade_2lobe": "k_shade<2, 0>", "shade_uber": "k_shade<5, 0>"}  # names as rocprofv3 prints them (no spheres in S2)
     groups = {}
     for n, v in kstats.items():
         ab = algo_bytes(n, v)

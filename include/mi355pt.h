@@ -83,8 +83,62 @@ typedef enum PtMaterialType {
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
 } PtMaterialType;
 
-/* Constant-texture material parameters (texture evaluation is a "next" row). Field use
- * per type follows the reference's create_*_material parameter names. */
+/* ---- textures (core/texture.rs, textures/*.rs, core/mipmap.rs) --------------------------------------
+ * A texture is a node of a tree, exactly as the reference's Arc<Textures<..>> values: children are texture indices
+ * (constants are ConstantTexture nodes, as TextureParams::get_*texture creates them, paramset.rs:500-600). Float-valued
+ * textures use component 0. Not covered yet: noise textures (fbm, wrinkled, windy, marble, dots), bump maps, alpha masks,
+ * ImageWrap::Clamp (the reference's texel() clamps to `u` instead of `u - 1`, mipmap.rs:305). */
+typedef enum PtTextureType {
+    PT_TEX_CONSTANT = 0,        /* textures/constant.rs                                  value[]                 */
+    PT_TEX_SCALE = 1,           /* textures/scaled.rs:30-33    tex1 * tex2               child[0], child[1]      */
+    PT_TEX_MIX = 2,             /* textures/mix.rs:29-35       t1*(1-amt) + t2*amt       child[0..2] (amount = 2) */
+    PT_TEX_CHECKERBOARD2D = 3,  /* textures/checkerboard.rs:27-70   mapping, aamode      child[0], child[1]      */
+    PT_TEX_CHECKERBOARD3D = 4,  /* textures/checkerboard.rs:87-100  world_to_texture     child[0], child[1]      */
+    PT_TEX_IMAGEMAP = 5,        /* textures/imagemap.rs:167-176 + MIPMap::lookup2        mapping, image          */
+    PT_TEX_UV = 6,              /* textures/uv.rs:21-33                                  mapping                 */
+    PT_TEX_BILERP = 7           /* textures/biler.rs:27-36                               mapping, v00..v11       */
+} PtTextureType;
+typedef enum PtMappingType { PT_MAP_UV = 0, PT_MAP_PLANAR = 1, PT_MAP_SPHERICAL = 2, PT_MAP_CYLINDRICAL = 3 } PtMappingType;  /* core/texture.rs:112-270 */
+typedef enum PtImageWrap { PT_WRAP_REPEAT = 0, PT_WRAP_BLACK = 1 } PtImageWrap;                                             /* core/mipmap.rs:52 */
+
+typedef struct PtTexture {
+    uint32_t type;              /* PtTextureType */
+    int32_t child[3];           /* texture indices, -1 = unused */
+    float value[3];             /* CONSTANT */
+    float v00[3], v01[3], v10[3], v11[3];   /* BILERP */
+    /* TextureMapping2D (get_mapping2d, texture.rs:439-466) / IdentityMapping3D for CHECKERBOARD3D */
+    uint32_t mapping;           /* PtMappingType */
+    float su, sv, du, dv;       /* uv: uscale vscale udelta vdelta ; planar: du = udelta (ds), dv = vdelta (dt) */
+    float vs[3], vt[3];         /* planar v1, v2 */
+    float world_to_texture[16]; /* spherical / cylindrical / 3-D checkerboard: inverse(texture-to-world CTM), row major */
+    uint32_t aa_closedform;     /* CHECKERBOARD2D: 0 = "none" (the reference's default), 1 = "closedform" */
+    /* IMAGEMAP */
+    uint32_t image;             /* index into PtSceneDesc.images */
+    uint32_t trilinear;         /* "trilinear" (false => EWA) */
+    float max_anisotropy;       /* "maxanisotropy" (8) */
+    uint32_t wrap;              /* PtImageWrap */
+} PtTexture;
+
+/* MIPMap pyramid (core/mipmap.rs:75-198), built by the host exactly as MIPMap::new does (power-of-two resampling with the
+ * Lanczos weights of :264-291, then 2x2 box filtering per level) after the y flip, scale and inverse gamma of
+ * imagemap.rs:141-157. Level l has max(1, width >> l) x max(1, height >> l) texels, rows = t, stored consecutively. */
+typedef struct PtImage {
+    uint32_t width, height;     /* level 0, powers of two */
+    uint32_t n_levels;          /* 1 + log2(max(width, height)) */
+    uint32_t channels;          /* 3 = RGBSpectrum memory, 1 = Float memory */
+    const float *texels;        /* all levels, level 0 first */
+} PtImage;
+
+/* Material parameter slots that may be textured (PtMaterial.tex[slot] = texture index or -1 => the constant field). */
+typedef enum PtMatParam {
+    PT_MP_KD = 0, PT_MP_KS = 1, PT_MP_KR = 2, PT_MP_KT = 3, PT_MP_OPACITY = 4, PT_MP_ETA_RGB = 5, PT_MP_K_RGB = 6,
+    PT_MP_SIGMA_A = 7, PT_MP_SIGMA_S = 8,
+    PT_MP_SIGMA = 9, PT_MP_ROUGHNESS = 10, PT_MP_U_ROUGHNESS = 11, PT_MP_V_ROUGHNESS = 12, PT_MP_ETA = 13,
+    PT_MP_COUNT = 16
+} PtMatParam;
+
+/* Material parameters. Field use per type follows the reference's create_*_material parameter names; every field is the
+ * value of a ConstantTexture unless tex[slot] names a texture. */
 typedef struct PtMaterial {
     uint32_t type;
     float kd[3];
@@ -106,6 +160,7 @@ typedef struct PtMaterial {
     float sigma_s[3];
     float scale;
     uint32_t bssrdf_table;
+    int32_t tex[16];        /* PtMatParam slot -> texture index, -1 = constant (a zeroed struct must set these to -1) */
 } PtMaterial;
 
 typedef enum PtLightType {
@@ -210,6 +265,10 @@ typedef struct PtSceneDesc {
     uint32_t n_top; const uint32_t *top_refs;
 
     uint32_t n_bssrdf_tables; const PtBSSRDFTable *bssrdf_tables;
+
+    uint32_t n_textures; const PtTexture *textures;
+    uint32_t n_images; const PtImage *images;
+    const float *ewa_weight_lut;   /* [128] = exp(-2 r2) - exp(-2), r2 = i/127 (mipmap.rs:40-50); required with EWA image maps */
 } PtSceneDesc;
 
 /* ---- render parameters ---------------------------------------------------------------- */

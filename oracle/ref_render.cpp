@@ -4,6 +4,7 @@
 //   materials/{matte,mirror,glass,plastic,metal,uber,substrate}.rs; core/integrator.rs:81-237,263-403;
 //   integrators/path.rs:79-222; cameras/perspective.rs:120-179; core/film.rs:104-161,217-258,292-331.
 #include "ref_bssrdf.h"
+#include "ref_texture.h"
 #include <thread>
 #include <atomic>
 #include <chrono>
@@ -14,17 +15,31 @@ namespace ref {
 static RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
 static TRDist make_dist(Float ax, Float ay) { TRDist d; d.ax = fmax_(ax, 0.001f); d.ay = fmax_(ay, 0.001f); return d; }  // microfacet.rs:325-331
 
+// Texture::evaluate of a material parameter: a ConstantTexture (the field) unless tex[slot] names a texture node.
+struct MatEval {
+    const Scene &scene; const PtMaterial &m; const TexCtx *ctx;
+    RGB spec(int slot, const float *field) const {
+        if (ctx && scene.textures && m.tex[slot] >= 0) return scene.textures->eval(m.tex[slot], *ctx);
+        return RGB(field[0], field[1], field[2]);
+    }
+    Float flt(int slot, Float field) const {
+        if (ctx && scene.textures && m.tex[slot] >= 0) return scene.textures->eval(m.tex[slot], *ctx).c[0];
+        return field;
+    }
+};
+
 // Returns false when the material leaves `si.bsdf == None` (null surface, path.rs:124-129).
 static bool compute_scattering_functions(const Scene &scene, const SurfaceInteraction &si, BSDF &bsdf,
-                                         TabulatedBSSRDF *bssrdf = nullptr, bool *has_bssrdf = nullptr) {
+                                         TabulatedBSSRDF *bssrdf = nullptr, bool *has_bssrdf = nullptr, const TexCtx *tctx = nullptr) {
     uint32_t mi = scene.prim_material[si.prim];
     if (mi == PT_NONE) return false;  // primitive.rs:168-170: no material => no bsdf
     const PtMaterial &m = scene.materials[mi];
+    const MatEval E{scene, m, tctx};
     switch (m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
-        RGB r = rgb3(m.kd).clamps(0.0f, INF);
-        Float sig = clampv(m.sigma, 0.0f, 90.0f);
+        RGB r = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);
+        Float sig = clampv(E.flt(PT_MP_SIGMA, m.sigma), 0.0f, 90.0f);
         if (!r.is_black()) {
             Bxdf b; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = r;
             if (sig == 0.0f) b.kind = BX_LAMBERT_R;
@@ -41,13 +56,13 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
     }
     case PT_MAT_MIRROR: {  // mirror.rs:23-42
         bsdf.init(si, 1.0f);
-        RGB R = rgb3(m.kr).clamps(0.0f, INF);
+        RGB R = E.spec(PT_MP_KR, m.kr).clamps(0.0f, INF);
         if (!R.is_black()) { Bxdf b; b.kind = BX_SPEC_R; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.r = R; b.fresnel.kind = FR_NOOP; bsdf.add(b); }
         return true;
     }
     case PT_MAT_GLASS: {  // glass.rs:35-92 (allow_multiple_lobes = true, mode = Radiance)
-        Float eta = m.eta, urough = m.u_roughness, vrough = m.v_roughness;
-        RGB R = rgb3(m.kr).clamps(0.0f, INF), T = rgb3(m.kt).clamps(0.0f, INF);
+        Float eta = E.flt(PT_MP_ETA, m.eta), urough = E.flt(PT_MP_U_ROUGHNESS, m.u_roughness), vrough = E.flt(PT_MP_V_ROUGHNESS, m.v_roughness);
+        RGB R = E.spec(PT_MP_KR, m.kr).clamps(0.0f, INF), T = E.spec(PT_MP_KT, m.kt).clamps(0.0f, INF);
         bsdf.init(si, eta);
         if (R.is_black() && T.is_black()) return false;  // App. A #14
         bool is_specular = urough == 0.0f && vrough == 0.0f;
@@ -70,11 +85,11 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
     }
     case PT_MAT_PLASTIC: {  // plastic.rs:34-70
         bsdf.init(si, 1.0f);
-        RGB kd = rgb3(m.kd).clamps(0.0f, INF);
+        RGB kd = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);
         if (!kd.is_black()) { Bxdf b; b.kind = BX_LAMBERT_R; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = kd; bsdf.add(b); }
-        RGB ks = rgb3(m.ks).clamps(0.0f, INF);
+        RGB ks = E.spec(PT_MP_KS, m.ks).clamps(0.0f, INF);
         if (!ks.is_black()) {
-            Float rough = m.roughness;
+            Float rough = E.flt(PT_MP_ROUGHNESS, m.roughness);
             if (m.remap_roughness) rough = TRDist::roughness_to_alpha(rough);
             Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = ks; b.dist = make_dist(rough, rough);
             b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.5f; b.fresnel.etat = 1.0f; bsdf.add(b);
@@ -83,39 +98,40 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
     }
     case PT_MAT_METAL: {  // metal.rs:78-112
         bsdf.init(si, 1.0f);
-        Float urough = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
-        Float vrough = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+        // metal.rs:88-96: uroughness / vroughness textures fall back to the `roughness` texture when absent
+        Float urough = (m.tex[PT_MP_U_ROUGHNESS] >= 0 || m.u_roughness >= 0.0f) ? E.flt(PT_MP_U_ROUGHNESS, m.u_roughness) : E.flt(PT_MP_ROUGHNESS, m.roughness);
+        Float vrough = (m.tex[PT_MP_V_ROUGHNESS] >= 0 || m.v_roughness >= 0.0f) ? E.flt(PT_MP_V_ROUGHNESS, m.v_roughness) : E.flt(PT_MP_ROUGHNESS, m.roughness);
         if (m.remap_roughness) { urough = TRDist::roughness_to_alpha(urough); vrough = TRDist::roughness_to_alpha(vrough); }
         Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = RGB(1.0f); b.dist = make_dist(urough, vrough);
-        b.fresnel.kind = FR_CONDUCTOR; b.fresnel.ci = RGB(1.0f); b.fresnel.ct = rgb3(m.eta_rgb); b.fresnel.k = rgb3(m.k_rgb);
+        b.fresnel.kind = FR_CONDUCTOR; b.fresnel.ci = RGB(1.0f); b.fresnel.ct = E.spec(PT_MP_ETA_RGB, m.eta_rgb); b.fresnel.k = E.spec(PT_MP_K_RGB, m.k_rgb);
         bsdf.add(b);
         return true;
     }
     case PT_MAT_UBER: {  // uber.rs:40-106
-        Float e = m.eta;
-        RGB op = rgb3(m.opacity).clamps(0.0f, INF);
+        Float e = E.flt(PT_MP_ETA, m.eta);
+        RGB op = E.spec(PT_MP_OPACITY, m.opacity).clamps(0.0f, INF);
         RGB t = RGB(-op.c[0] + 1.0f, -op.c[1] + 1.0f, -op.c[2] + 1.0f).clamps(0.0f, INF);
         if (!t.is_black()) {
             bsdf.init(si, 1.0f);
             Bxdf b; b.kind = BX_SPEC_T; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.t = t; b.etaa = 1.0f; b.etab = 1.0f;
             b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = 1.0f; bsdf.add(b);
         } else bsdf.init(si, e);
-        RGB kd = op * rgb3(m.kd).clamps(0.0f, INF);
+        RGB kd = op * E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);
         if (!kd.is_black()) { Bxdf b; b.kind = BX_LAMBERT_R; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = kd; bsdf.add(b); }
-        RGB ks = op * rgb3(m.ks).clamps(0.0f, INF);
+        RGB ks = op * E.spec(PT_MP_KS, m.ks).clamps(0.0f, INF);
         if (!ks.is_black()) {
-            Float ru = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
-            Float rv = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+            Float ru = (m.tex[PT_MP_U_ROUGHNESS] >= 0 || m.u_roughness >= 0.0f) ? E.flt(PT_MP_U_ROUGHNESS, m.u_roughness) : E.flt(PT_MP_ROUGHNESS, m.roughness);
+            Float rv = (m.tex[PT_MP_V_ROUGHNESS] >= 0 || m.v_roughness >= 0.0f) ? E.flt(PT_MP_V_ROUGHNESS, m.v_roughness) : E.flt(PT_MP_ROUGHNESS, m.roughness);
             if (m.remap_roughness) { ru = TRDist::roughness_to_alpha(ru); rv = TRDist::roughness_to_alpha(rv); }
             Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = ks; b.dist = make_dist(ru, rv);
             b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
         }
-        RGB kr = op * rgb3(m.kr).clamps(0.0f, INF);
+        RGB kr = op * E.spec(PT_MP_KR, m.kr).clamps(0.0f, INF);
         if (!kr.is_black()) {
             Bxdf b; b.kind = BX_SPEC_R; b.type = BSDF_REFLECTION | BSDF_SPECULAR; b.r = kr;
             b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
         }
-        RGB kt = op * rgb3(m.kt).clamps(0.0f, INF);
+        RGB kt = op * E.spec(PT_MP_KT, m.kt).clamps(0.0f, INF);
         if (!kt.is_black()) {
             Bxdf b; b.kind = BX_SPEC_T; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.t = kt; b.etaa = 1.0f; b.etab = e;
             b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
@@ -124,8 +140,8 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
     }
     case PT_MAT_SUBSTRATE: {  // substrate.rs:34-60
         bsdf.init(si, 1.0f);
-        RGB d = rgb3(m.kd).clamps(0.0f, INF), s = rgb3(m.ks).clamps(0.0f, INF);
-        Float ru = m.u_roughness, rv = m.v_roughness;
+        RGB d = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF), s = E.spec(PT_MP_KS, m.ks).clamps(0.0f, INF);
+        Float ru = E.flt(PT_MP_U_ROUGHNESS, m.u_roughness), rv = E.flt(PT_MP_V_ROUGHNESS, m.v_roughness);
         if (!d.is_black() || !s.is_black()) {
             if (m.remap_roughness) { ru = TRDist::roughness_to_alpha(ru); rv = TRDist::roughness_to_alpha(rv); }
             Bxdf b; b.kind = BX_FRESNEL_BLEND; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = d; b.rs = s; b.dist = make_dist(ru, rv);
@@ -135,8 +151,8 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
         return false;  // App. A #14
     }
     case PT_MAT_SUBSURFACE: {  // subsurface.rs:47-106 (kdsubsurface.rs:45-103 after the host-side subsurface_from_diffuse)
-        Float eta = m.eta, urough = m.u_roughness, vrough = m.v_roughness;
-        RGB R = rgb3(m.kr).clamps(0.0f, INF), T = rgb3(m.kt).clamps(0.0f, INF);
+        Float eta = E.flt(PT_MP_ETA, m.eta), urough = E.flt(PT_MP_U_ROUGHNESS, m.u_roughness), vrough = E.flt(PT_MP_V_ROUGHNESS, m.v_roughness);
+        RGB R = E.spec(PT_MP_KR, m.kr).clamps(0.0f, INF), T = E.spec(PT_MP_KT, m.kt).clamps(0.0f, INF);
         bsdf.init(si, eta);
         if (R.is_black() && T.is_black()) return false;
         bool is_specular = urough == 0.0f && vrough == 0.0f;
@@ -156,7 +172,7 @@ static bool compute_scattering_functions(const Scene &scene, const SurfaceIntera
             }
         }
         if (bssrdf) {
-            RGB siga = rgb3(m.sigma_a).clamps(0.0f, INF) * m.scale, sigs = rgb3(m.sigma_s).clamps(0.0f, INF) * m.scale;
+            RGB siga = E.spec(PT_MP_SIGMA_A, m.sigma_a).clamps(0.0f, INF) * m.scale, sigs = E.spec(PT_MP_SIGMA_S, m.sigma_s).clamps(0.0f, INF) * m.scale;
             bssrdf->init(si, mi, eta, siga, sigs, &scene.bssrdf_tables[m.bssrdf_table]);
             *has_bssrdf = true;
         }
@@ -241,7 +257,7 @@ static RGB uniform_sample_onelight(const RenderCtx &ctx, const SurfaceInteractio
 // ---- PathIntegrator::li (integrators/path.rs:79-222) ------------------------------------------------
 struct PathParams { uint32_t max_depth; Float rr_threshold; };
 
-static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSampler &sampler) {
+static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSampler &sampler, RayDiff rdiff = RayDiff()) {
     RGB L(0.0f), beta(1.0f);
     bool specular_bounce = false;
     uint32_t bounces = 0;
@@ -256,7 +272,13 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
         if (!found || bounces >= pp.max_depth) break;
         BSDF bsdf;
         TabulatedBSSRDF bssrdf; bool has_bssrdf = false;
-        if (!compute_scattering_functions(*ctx.scene, isect, bsdf, &bssrdf, &has_bssrdf)) {
+        // SurfaceInteraction::compute_scattering_functions (interaction.rs:262-267): differentials of THIS ray first;
+        // only the camera ray carries them (every spawn_ray below creates a ray without differentials)
+        TexCtx tctx;
+        const bool textured = (bool)ctx.scene->textures;
+        if (textured) tctx = compute_differentials(isect, rdiff);
+        rdiff.has = false;
+        if (!compute_scattering_functions(*ctx.scene, isect, bsdf, &bssrdf, &has_bssrdf, textured ? &tctx : nullptr)) {
             IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
             ray = spawn_ray(it, ray.d);
             continue;
@@ -346,6 +368,38 @@ static Ray generate_ray(const Camera &cam, const CameraSample &cs) {
     r.time = lerp(cs.time, cam.shutter_open, cam.shutter_close);
     return xf_ray(cam.camera_to_world, r);
 }
+// generate_ray_differential's auxiliary rays (perspective.rs:143-176) after Transform::transform_ray (:565-575) and
+// Ray::scale_differential(1 / sqrt(spp)) (geometry/ray.rs:34-41, integrator.rs:340). `ray` is the transformed main ray.
+static RayDiff generate_ray_differentials(const Camera &cam, const CameraSample &cs, const Ray &ray, uint32_t spp) {
+    V3 pcamera = xf_point(cam.raster_to_camera, V3(cs.pfilm.x, cs.pfilm.y, 0.0f));
+    // PerspectiveCamera::new (perspective.rs:64-70)
+    V3 p2t = xf_point(cam.raster_to_camera, V3(0.0f, 0.0f, 0.0f));
+    V3 dx_camera = xf_point(cam.raster_to_camera, V3(1.0f, 0.0f, 0.0f)) - p2t;
+    V3 dy_camera = xf_point(cam.raster_to_camera, V3(0.0f, 1.0f, 0.0f)) - p2t;
+    RayDiff d; d.has = true;
+    if (cam.lens_radius > 0.0f) {
+        P2 dk = concentric_sample_disk(cs.plens);
+        P2 plens(dk.x * cam.lens_radius, dk.y * cam.lens_radius);
+        V3 dx = normalize(pcamera + dx_camera);
+        Float ft = cam.focal_distance / dx.z;
+        V3 pfocus = V3(0.0f, 0.0f, 0.0f) + (dx * ft);
+        d.rx_o = V3(plens.x, plens.y, 0.0f); d.rx_d = normalize(pfocus - d.rx_o);
+        V3 dy = normalize(pcamera + dy_camera);
+        ft = cam.focal_distance / dy.z;
+        pfocus = V3(0.0f, 0.0f, 0.0f) + (dy * ft);
+        d.ry_o = V3(plens.x, plens.y, 0.0f); d.ry_d = normalize(pfocus - d.ry_o);
+    } else {
+        // rd.o before the lens branch is (0,0,0); the main ray's camera-space origin
+        d.rx_o = V3(0.0f, 0.0f, 0.0f); d.ry_o = V3(0.0f, 0.0f, 0.0f);
+        d.rx_d = normalize(pcamera + dx_camera); d.ry_d = normalize(pcamera + dy_camera);
+    }
+    d.rx_o = xf_point(cam.camera_to_world, d.rx_o); d.ry_o = xf_point(cam.camera_to_world, d.ry_o);
+    d.rx_d = xf_vector(cam.camera_to_world, d.rx_d); d.ry_d = xf_vector(cam.camera_to_world, d.ry_d);
+    const Float sc = 1.0f / std::sqrt((Float)spp);
+    d.rx_o = ray.o + (d.rx_o - ray.o) * sc; d.ry_o = ray.o + (d.ry_o - ray.o) * sc;
+    d.rx_d = ray.d + (d.rx_d - ray.d) * sc; d.ry_d = ray.d + (d.ry_d - ray.d) * sc;
+    return d;
+}
 
 // ---- film (core/film.rs) -------------------------------------------------------------------------
 struct FilmParams {
@@ -420,7 +474,9 @@ static void render_tiles(const RenderJob &job, float *film_xyzw, int nthreads, C
                         CameraSample cs = sampler.get_camera_sample(x, y);
                         Ray ray = generate_ray(job.cam, cs);
                         c.camera_rays++;
-                        RGB L = path_li(ctx, pp, ray, sampler);
+                        RayDiff rdiff;
+                        if (job.scene->textures) rdiff = generate_ray_differentials(job.cam, cs, ray, rp.spp);
+                        RGB L = path_li(ctx, pp, ray, sampler, rdiff);
                         if (L.has_nans()) { L = RGB(0.0f); c.san_nan++; }
                         else if (L.y() < -1.0e-5f) { L = RGB(0.0f); c.san_neg++; }
                         else if (std::isinf(L.y())) { L = RGB(0.0f); c.san_inf++; }
@@ -488,6 +544,26 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
     }
     for (const PtMaterial &m : s.materials)
         if (m.type == PT_MAT_SUBSURFACE && m.bssrdf_table >= s.bssrdf_tables.size()) return PT_ERR_INVALID_ARG;
+    if (d->n_textures) {
+        auto ts = std::make_shared<TextureSet>();
+        ts->tex.assign(d->textures, d->textures + d->n_textures);
+        for (uint32_t i = 0; i < d->n_images; ++i) {
+            const PtImage &im = d->images[i];
+            ImagePyramid p; p.width = (int)im.width; p.height = (int)im.height; p.n_levels = (int)im.n_levels; p.channels = (int)im.channels;
+            size_t off = 0;
+            for (int l = 0; l < p.n_levels; ++l) { p.offset.push_back(off); off += (size_t)p.ures(l) * p.vres(l) * p.channels; }
+            p.texels.assign(im.texels, im.texels + off);
+            ts->images.push_back(std::move(p));
+        }
+        if (d->ewa_weight_lut) ts->ewa_lut.assign(d->ewa_weight_lut, d->ewa_weight_lut + 128);
+        else ts->ewa_lut.assign(128, 0.0f);
+        for (const PtTexture &t : ts->tex) {
+            for (int k = 0; k < 3; ++k) if (t.child[k] >= (int32_t)d->n_textures) return PT_ERR_INVALID_ARG;
+            if (t.type == PT_TEX_IMAGEMAP && t.image >= d->n_images) return PT_ERR_INVALID_ARG;
+        }
+        for (const PtMaterial &m : s.materials) for (int k = 0; k < 16; ++k) if (m.tex[k] >= (int32_t)d->n_textures) return PT_ERR_INVALID_ARG;
+        s.textures = ts;
+    }
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) if (s.lights[i].type == PT_LIGHT_INFINITE) s.infinite_lights.push_back(i);
     if (d->env_texels) {

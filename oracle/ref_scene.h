@@ -4,6 +4,7 @@
 //   shapes/triangle.rs:101-584; core/primitive.rs:126-153; core/scene.rs:54-66;
 //   core/interaction.rs:186-249; core/shape.rs:40-82.
 #pragma once
+#include <memory>
 #include "ref_math.h"
 #include "../include/mi355pt.h"
 #include <vector>
@@ -87,6 +88,7 @@ struct Scene {
     std::vector<uint32_t> prim_shape, prim_material, prim_light;
     std::vector<PtMaterial> materials;
     std::vector<BssrdfTable> bssrdf_tables;
+    std::shared_ptr<struct TextureSet> textures;   // ref_texture.h (null: no textures)
     std::vector<PtLight> lights;
     std::vector<uint32_t> infinite_lights;
     uint32_t env_w = 0, env_h = 0;

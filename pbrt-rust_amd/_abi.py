@@ -41,7 +41,7 @@ class PtMaterial(C.Structure):
     _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
                 ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
-                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32)]
+                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16)]
 
 
 class PtLight(C.Structure):
@@ -65,6 +65,23 @@ class PtInstance(C.Structure):
 PT_TOP_INSTANCE = 0x80000000
 
 
+(PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD2D, PT_TEX_CHECKERBOARD3D, PT_TEX_IMAGEMAP, PT_TEX_UV, PT_TEX_BILERP) = range(8)
+PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_CYLINDRICAL = range(4)
+PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
+(PT_MP_KD, PT_MP_KS, PT_MP_KR, PT_MP_KT, PT_MP_OPACITY, PT_MP_ETA_RGB, PT_MP_K_RGB, PT_MP_SIGMA_A, PT_MP_SIGMA_S,
+ PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA) = range(14)
+
+
+class PtTexture(C.Structure):
+    _fields_ = [("type", u32), ("child", C.c_int32 * 3), ("value", f32 * 3), ("v00", f32 * 3), ("v01", f32 * 3), ("v10", f32 * 3), ("v11", f32 * 3),
+                ("mapping", u32), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32), ("vs", f32 * 3), ("vt", f32 * 3),
+                ("world_to_texture", f32 * 16), ("aa_closedform", u32), ("image", u32), ("trilinear", u32), ("max_anisotropy", f32), ("wrap", u32)]
+
+
+class PtImage(C.Structure):
+    _fields_ = [("width", u32), ("height", u32), ("n_levels", u32), ("channels", u32), ("texels", fp)]
+
+
 class PtBSSRDFTable(C.Structure):
     _fields_ = [("n_rho", u32), ("n_radius", u32), ("rho_samples", fp), ("radius_samples", fp), ("profile", fp),
                 ("rhoeff", fp), ("profile_cdf", fp)]
@@ -80,7 +97,8 @@ class PtSceneDesc(C.Structure):
                 ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp),
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
-                ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable))]
+                ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable)),
+                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp)]
 
 
 class PtRenderParams(C.Structure):

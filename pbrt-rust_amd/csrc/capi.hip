@@ -296,6 +296,13 @@ void fill_render_const(const PtRenderParams *rp, RenderConst &rc) {
     std::memcpy(rc.raster_to_camera.m, rp->raster_to_camera, 64);
     std::memcpy(rc.camera_to_world.m, rp->camera_to_world, 64);
     rc.lens_radius = rp->lens_radius; rc.focal_distance = rp->focal_distance;
+    {   // PerspectiveCamera::new (perspective.rs:64-70): dx_camera / dy_camera
+        const V3 p2t = xf_point(rc.raster_to_camera, V3(0.0f, 0.0f, 0.0f));
+        const V3 dx = xf_point(rc.raster_to_camera, V3(1.0f, 0.0f, 0.0f)) - p2t, dy = xf_point(rc.raster_to_camera, V3(0.0f, 1.0f, 0.0f)) - p2t;
+        rc.dx_camera[0] = dx.x; rc.dx_camera[1] = dx.y; rc.dx_camera[2] = dx.z;
+        rc.dy_camera[0] = dy.x; rc.dy_camera[1] = dy.y; rc.dy_camera[2] = dy.z;
+        rc.inv_sqrt_spp = 1.0f / std::sqrt((float)rp->spp);
+    }
     rc.shutter_open = rp->shutter_open; rc.shutter_close = rp->shutter_close;
     rc.max_depth = rp->max_depth; rc.rr_threshold = rp->rr_threshold;
     rc.filter_radius[0] = rp->filter_radius[0]; rc.filter_radius[1] = rp->filter_radius[1];
@@ -318,8 +325,9 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
-    if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade<MAXL, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
-    else hipLaunchKernelGGL((k_shade<MAXL, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade<MAXL, 1>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else hipLaunchKernelGGL((k_shade<MAXL, 0>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
@@ -505,6 +513,30 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const PtBSSRDFTable &t = d->bssrdf_tables[m.bssrdf_table];
         if (t.n_rho < 2 || t.n_radius < 2 || !t.rho_samples || !t.radius_samples || !t.profile || !t.rhoeff || !t.profile_cdf) return fail(PT_ERR_INVALID_ARG, "incomplete BSSRDF table");
     }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const PtTexture &t = d->textures[i];
+        if (t.type > PT_TEX_BILERP) return fail(PT_ERR_UNSUPPORTED, "texture type not implemented");
+        for (int k = 0; k < 3; ++k) if (t.child[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "texture child index out of range");
+        if (t.type == PT_TEX_IMAGEMAP) {
+            if (!d->images || t.image >= d->n_images) return fail(PT_ERR_INVALID_ARG, "image texture without an image");
+            const PtImage &im = d->images[t.image];
+            auto pow2 = [](uint32_t v) { return v && !(v & (v - 1)); };
+            if (!pow2(im.width) || !pow2(im.height) || !im.texels || (im.channels != 1 && im.channels != 3) || im.n_levels == 0 || im.n_levels > 16)
+                return fail(PT_ERR_INVALID_ARG, "PtImage must be a power-of-two MIPMap pyramid with 1 or 3 channels");
+            if (t.wrap > PT_WRAP_BLACK) return fail(PT_ERR_UNSUPPORTED, "ImageWrap::Clamp is not implemented");
+            if (!t.trilinear && !d->ewa_weight_lut) return fail(PT_ERR_INVALID_ARG, "EWA image texture without ewa_weight_lut");
+        }
+        if ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D) && (t.child[0] < 0 || t.child[1] < 0)) return fail(PT_ERR_INVALID_ARG, "texture node needs two children");
+        if (t.type == PT_TEX_MIX && (t.child[0] < 0 || t.child[1] < 0 || t.child[2] < 0)) return fail(PT_ERR_INVALID_ARG, "mix texture needs three children");
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const PtMaterial &m = d->materials[i];
+        for (int k = 0; k < 16; ++k) {
+            if (d->n_textures == 0 && m.tex[k] > 0) return fail(PT_ERR_INVALID_ARG, "material references a texture but the scene has none");
+            if (d->n_textures && m.tex[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "material texture index out of range");
+        }
+        if (d->n_textures && m.type == PT_MAT_SUBSURFACE && (m.tex[PT_MP_SIGMA_A] >= 0 || m.tex[PT_MP_SIGMA_S] >= 0)) return fail(PT_ERR_UNSUPPORTED, "textured sigma_a / sigma_s");
+    }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const PtLight &L = d->lights[i];
         if (L.type == PT_LIGHT_DIFFUSE_AREA && L.prim >= d->n_prims) return fail(PT_ERR_INVALID_ARG, "area light primitive out of range");
@@ -675,6 +707,41 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if ((st = sc->upload(&bt[i].profile_cdf, t.profile_cdf, (size_t)t.n_rho * t.n_radius))) return bail(st);
         }
         UP(bss_tables, bt.data(), bt.size()); ds.n_bss_tables = d->n_bssrdf_tables;
+        if (d->n_textures) {   // textures: nodes as given + one postfix program per node (children before parent)
+            std::vector<PtMaterial> mats(d->materials, d->materials + d->n_materials);
+            UP(textures, d->textures, d->n_textures); ds.n_textures = d->n_textures;
+            std::vector<uint32_t> off(d->n_textures + 1, 0), prog;
+            for (uint32_t r = 0; r < d->n_textures; ++r) {
+                off[r] = (uint32_t)prog.size();
+                // iterative post-order; the value-stack depth is tracked to validate kTexStack
+                struct Fr { int node; int next; };
+                std::vector<Fr> st{{(int)r, 0}};
+                int depth = 0, max_depth = 0; size_t guard = 0;
+                while (!st.empty()) {
+                    Fr &f = st.back();
+                    const PtTexture &t = d->textures[f.node];
+                    const int nchild = (t.type == PT_TEX_MIX) ? 3 : (t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D) ? 2 : 0;
+                    if (f.next < nchild) { const int c = t.child[f.next++]; st.push_back({c, 0}); if (++guard > 4096 || st.size() > 64) return bail(fail(PT_ERR_INVALID_ARG, "texture graph too deep or cyclic")); continue; }
+                    prog.push_back((uint32_t)f.node);
+                    depth += 1 - nchild; max_depth = std::max(max_depth, depth + nchild);
+                    st.pop_back();
+                }
+                if (max_depth > kTexStack) return bail(fail(PT_ERR_UNSUPPORTED, "texture expression needs a deeper value stack than kTexStack"));
+            }
+            off[d->n_textures] = (uint32_t)prog.size();
+            UP(tex_prog_offset, off.data(), off.size()); UP(tex_prog, prog.data(), prog.size());
+            std::vector<DevImage> imgs(d->n_images);
+            for (uint32_t i = 0; i < d->n_images; ++i) {
+                const PtImage &im = d->images[i];
+                imgs[i].width = im.width; imgs[i].height = im.height; imgs[i].n_levels = im.n_levels; imgs[i].channels = im.channels;
+                if (!im.texels || im.n_levels == 0 || im.n_levels > 16) continue;   // unreferenced slot
+                size_t o = 0;
+                for (uint32_t l = 0; l < im.n_levels; ++l) { imgs[i].level_offset[l] = (uint32_t)o; o += (size_t)std::max(1u, im.width >> l) * std::max(1u, im.height >> l) * im.channels; }
+                if ((st = sc->upload(&imgs[i].texels, im.texels, o))) return bail(st);
+            }
+            UP(images, imgs.data(), imgs.size());
+            if (d->ewa_weight_lut) UP(ewa_lut, d->ewa_weight_lut, 128);
+        }
         for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].type == PT_MAT_SUBSURFACE) sc->has_bssrdf = true;
         std::vector<uint32_t> inf;
         for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == PT_LIGHT_INFINITE) inf.push_back(i);

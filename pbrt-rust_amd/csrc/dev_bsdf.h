@@ -402,13 +402,21 @@ PT_DEV RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
 PT_DEV Lobe mk_lobe(uint8_t kind, uint8_t type) { Lobe b; b.kind = kind; b.type = type; b.fresnel = FR_NOOP; b.ax = b.ay = 0.001f; b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; return b; }
 PT_DEV void set_dist(Lobe &b, float ax, float ay) { b.ax = maxf(ax, 0.001f); b.ay = maxf(ay, 0.001f); }  // microfacet.rs:325-331
 
-// Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None.
-template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL> &bsdf) {
+// Texture::evaluate of a material parameter when no texture can be bound (scenes without textures): the constant field.
+struct ConstMatEval {
+    PT_DEV RGB spec(const PtMaterial &, int, const float *field) const { return RGB(field[0], field[1], field[2]); }
+    PT_DEV float flt(const PtMaterial &, int, float field) const { return field; }
+    PT_DEV bool bound(const PtMaterial &, int) const { return false; }
+};
+
+// Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None. `E` evaluates the
+// (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
+template <int MAXL, class ME> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL> &bsdf, const ME &E) {
     switch (m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
-        RGB r = rgb3(m.kd).clamps(0.0f, PT_INF);
-        float sig = clampf(m.sigma, 0.0f, 90.0f);
+        RGB r = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
+        float sig = clampf(E.flt(m, PT_MP_SIGMA, m.sigma), 0.0f, 90.0f);
         if (!r.is_black()) {
             Lobe b = mk_lobe(sig == 0.0f ? LB_LAMBERT_R : LB_OREN_NAYAR, BSDF_REFLECTION | BSDF_DIFFUSE);
             b.r = r;
@@ -424,14 +432,14 @@ template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInt
     }
     case PT_MAT_MIRROR: {  // mirror.rs:23-42
         bsdf.init(si, 1.0f);
-        RGB R = rgb3(m.kr).clamps(0.0f, PT_INF);
+        RGB R = E.spec(m, PT_MP_KR, m.kr).clamps(0.0f, PT_INF);
         if (!R.is_black()) { Lobe b = mk_lobe(LB_SPEC_R, BSDF_REFLECTION | BSDF_SPECULAR); b.r = R; bsdf.add(b); }
         return true;
     }
     case PT_MAT_SUBSURFACE:  // subsurface.rs:56-98 / kdsubsurface.rs:53-93: the same dielectric BSDF as glass
     case PT_MAT_GLASS: {  // glass.rs:35-92
-        float eta = m.eta, ur = m.u_roughness, vr = m.v_roughness;
-        RGB R = rgb3(m.kr).clamps(0.0f, PT_INF), T = rgb3(m.kt).clamps(0.0f, PT_INF);
+        float eta = E.flt(m, PT_MP_ETA, m.eta), ur = E.flt(m, PT_MP_U_ROUGHNESS, m.u_roughness), vr = E.flt(m, PT_MP_V_ROUGHNESS, m.v_roughness);
+        RGB R = E.spec(m, PT_MP_KR, m.kr).clamps(0.0f, PT_INF), T = E.spec(m, PT_MP_KT, m.kt).clamps(0.0f, PT_INF);
         bsdf.init(si, eta);
         if (R.is_black() && T.is_black()) return false;
         bool is_specular = ur == 0.0f && vr == 0.0f;
@@ -453,11 +461,11 @@ template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInt
     }
     case PT_MAT_PLASTIC: {  // plastic.rs:34-70
         bsdf.init(si, 1.0f);
-        RGB kd = rgb3(m.kd).clamps(0.0f, PT_INF);
+        RGB kd = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
         if (!kd.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_R, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = kd; bsdf.add(b); }
-        RGB ks = rgb3(m.ks).clamps(0.0f, PT_INF);
+        RGB ks = E.spec(m, PT_MP_KS, m.ks).clamps(0.0f, PT_INF);
         if (!ks.is_black()) {
-            float rough = m.roughness;
+            float rough = E.flt(m, PT_MP_ROUGHNESS, m.roughness);
             if (m.remap_roughness) rough = roughness_to_alpha(rough);
             Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = ks; set_dist(b, rough, rough);
             b.fresnel = FR_DIELECTRIC; b.etaa = 1.5f; b.etab = 1.0f; bsdf.add(b);
@@ -466,44 +474,45 @@ template <int MAXL> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInt
     }
     case PT_MAT_METAL: {  // metal.rs:78-112
         bsdf.init(si, 1.0f);
-        float ur = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
-        float vr = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+        // metal.rs:88-96: the uroughness / vroughness textures fall back to the `roughness` texture when absent
+        float ur = (E.bound(m, PT_MP_U_ROUGHNESS) || m.u_roughness >= 0.0f) ? E.flt(m, PT_MP_U_ROUGHNESS, m.u_roughness) : E.flt(m, PT_MP_ROUGHNESS, m.roughness);
+        float vr = (E.bound(m, PT_MP_V_ROUGHNESS) || m.v_roughness >= 0.0f) ? E.flt(m, PT_MP_V_ROUGHNESS, m.v_roughness) : E.flt(m, PT_MP_ROUGHNESS, m.roughness);
         if (m.remap_roughness) { ur = roughness_to_alpha(ur); vr = roughness_to_alpha(vr); }
         Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = RGB(1.0f); set_dist(b, ur, vr);
-        b.fresnel = FR_CONDUCTOR; b.ce = rgb3(m.eta_rgb); b.ck = rgb3(m.k_rgb);
+        b.fresnel = FR_CONDUCTOR; b.ce = E.spec(m, PT_MP_ETA_RGB, m.eta_rgb); b.ck = E.spec(m, PT_MP_K_RGB, m.k_rgb);
         bsdf.add(b);
         return true;
     }
     case PT_MAT_UBER: {  // uber.rs:40-106
-        float e = m.eta;
-        RGB op = rgb3(m.opacity).clamps(0.0f, PT_INF);
+        float e = E.flt(m, PT_MP_ETA, m.eta);
+        RGB op = E.spec(m, PT_MP_OPACITY, m.opacity).clamps(0.0f, PT_INF);
         RGB t = RGB(-op.r + 1.0f, -op.g + 1.0f, -op.b + 1.0f).clamps(0.0f, PT_INF);
         if (!t.is_black()) {
             bsdf.init(si, 1.0f);
             Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = t; b.etaa = 1.0f; b.etab = 1.0f; bsdf.add(b);
         } else bsdf.init(si, e);
-        RGB kd = op * rgb3(m.kd).clamps(0.0f, PT_INF);
+        RGB kd = op * E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
         if (!kd.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_R, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = kd; bsdf.add(b); }
-        RGB ks = op * rgb3(m.ks).clamps(0.0f, PT_INF);
+        RGB ks = op * E.spec(m, PT_MP_KS, m.ks).clamps(0.0f, PT_INF);
         if (!ks.is_black()) {
-            float ru = (m.u_roughness >= 0.0f) ? m.u_roughness : m.roughness;
-            float rv = (m.v_roughness >= 0.0f) ? m.v_roughness : m.roughness;
+            float ru = (E.bound(m, PT_MP_U_ROUGHNESS) || m.u_roughness >= 0.0f) ? E.flt(m, PT_MP_U_ROUGHNESS, m.u_roughness) : E.flt(m, PT_MP_ROUGHNESS, m.roughness);
+            float rv = (E.bound(m, PT_MP_V_ROUGHNESS) || m.v_roughness >= 0.0f) ? E.flt(m, PT_MP_V_ROUGHNESS, m.v_roughness) : E.flt(m, PT_MP_ROUGHNESS, m.roughness);
             if (m.remap_roughness) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
             Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = ks; set_dist(b, ru, rv);
             b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = e; bsdf.add(b);
         }
-        RGB kr = op * rgb3(m.kr).clamps(0.0f, PT_INF);
+        RGB kr = op * E.spec(m, PT_MP_KR, m.kr).clamps(0.0f, PT_INF);
         if (!kr.is_black()) {
             Lobe b = mk_lobe(LB_SPEC_R, BSDF_REFLECTION | BSDF_SPECULAR); b.r = kr; b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = e; bsdf.add(b);
         }
-        RGB kt = op * rgb3(m.kt).clamps(0.0f, PT_INF);
+        RGB kt = op * E.spec(m, PT_MP_KT, m.kt).clamps(0.0f, PT_INF);
         if (!kt.is_black()) { Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = kt; b.etaa = 1.0f; b.etab = e; bsdf.add(b); }
         return true;
     }
     default: {  // PT_MAT_SUBSTRATE, substrate.rs:34-60
         bsdf.init(si, 1.0f);
-        RGB d = rgb3(m.kd).clamps(0.0f, PT_INF), s = rgb3(m.ks).clamps(0.0f, PT_INF);
-        float ru = m.u_roughness, rv = m.v_roughness;
+        RGB d = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF), s = E.spec(m, PT_MP_KS, m.ks).clamps(0.0f, PT_INF);
+        float ru = E.flt(m, PT_MP_U_ROUGHNESS, m.u_roughness), rv = E.flt(m, PT_MP_V_ROUGHNESS, m.v_roughness);
         if (!d.is_black() || !s.is_black()) {
             if (m.remap_roughness) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
             Lobe b = mk_lobe(LB_FRESNEL_BLEND, BSDF_REFLECTION | BSDF_GLOSSY); b.r = d; b.t = s; set_dist(b, ru, rv);

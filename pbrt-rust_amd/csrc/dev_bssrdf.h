@@ -99,10 +99,12 @@ struct DevBssrdf {
     float eta;
 
     // subsurface.rs:100-103 (sigma * scale) + TabulatedBSSRDF::new
-    PT_DEV void init_medium(const PtMaterial &m, const DevBssTable *tables) {
+    // siga / sigs: the evaluated sigma_a / sigma_s textures (constants: the material fields)
+    PT_DEV void init_medium(const PtMaterial &m, const DevBssTable *tables, RGB siga, RGB sigs) {
         tb = tables[m.bssrdf_table]; eta = m.eta;
+        const float sa3[3] = {siga.r, siga.g, siga.b}, ss3[3] = {sigs.r, sigs.g, sigs.b};
         for (int i = 0; i < 3; ++i) {
-            float sa = clampf(m.sigma_a[i], 0.0f, PT_INF) * m.scale, ss_ = clampf(m.sigma_s[i], 0.0f, PT_INF) * m.scale;
+            float sa = clampf(sa3[i], 0.0f, PT_INF) * m.scale, ss_ = clampf(ss3[i], 0.0f, PT_INF) * m.scale;
             sigma_t[i] = sa + ss_;
             rho[i] = (sigma_t[i] != 0.0f) ? ss_ / sigma_t[i] : 0.0f;
         }

@@ -47,6 +47,9 @@ struct DevInstance {
 // core/bssrdf.rs:241-268 BSSRDFTable (device copy of PtBSSRDFTable)
 struct DevBssTable { int n_rho, n_radius; const float *rho_samples, *radius_samples, *profile, *rhoeff, *profile_cdf; };
 
+// MIPMap pyramid on the device (PtImage + per-level offsets in floats)
+struct DevImage { uint32_t width, height, n_levels, channels; const float *texels; uint32_t level_offset[16]; };
+
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
@@ -62,6 +65,9 @@ struct DeviceScene {
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class
     const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)
+    // textures (8f-1): nodes, one postfix program per node (tex_prog[tex_prog_offset[i] .. tex_prog_offset[i+1])), images
+    const PtTexture *textures; uint32_t n_textures; const uint32_t *tex_prog_offset; const uint32_t *tex_prog;
+    const DevImage *images; const float *ewa_lut;
     // env map
     uint32_t env_w, env_h; const float *env_texels;
     const float *env_func; const float *env_cdf; const float *env_func_int;  // conditional rows (2h x 2w [+1]), marginal appended
@@ -155,6 +161,7 @@ struct SurfaceInteraction {
     V3 p, p_error, n, wo;
     V3 dpdu;             // == shading.dpdu unless the mesh has N/S
     V3 sh_n, sh_dpdu;
+    V3 dpdv; P2 uv;      // read by texture evaluation only (dead code elsewhere)
     uint32_t prim;
 };
 // `with_shape` = the `s: Option<Arc<Shapes>>` argument (None inside Shape::pdf_wi, shape.rs:72).
@@ -169,7 +176,8 @@ PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, 
     float zabs = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
     si.p_error = V3(xabs, yabs, zabs) * gammaf(7);
     si.p = p0 * b0 + p1 * b1 + p2 * b2;
-    si.dpdu = dpdu; si.sh_dpdu = dpdu;
+    si.dpdu = dpdu; si.sh_dpdu = dpdu; si.dpdv = dpdv;
+    si.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);   // triangle.rs:266-268
     uint32_t fl = s.tri_flags[tri];
     bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
     V3 nn = normalize(cross(dp02, dp12));

@@ -116,6 +116,7 @@ PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceIn
     float t, phi; V3 p_hit, d_obj;
     if (!sphere_hit(S, r_o, r_d, PT_INF, false, t, p_hit, phi, d_obj)) return false;
     const float theta = dm_acosf(clampf(p_hit.z / S.radius, -1.0f, 1.0f));
+    si.uv = P2(phi / S.phi_max, (theta - S.theta_min) / (S.theta_max - S.theta_min));   // sphere.rs:148-152
     const float zradius = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
     const float inv_radius = 1.0f / zradius;
     const float cos_phi = p_hit.x * inv_radius, sin_phi = p_hit.y * inv_radius;
@@ -128,7 +129,7 @@ PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceIn
     si.p = xf_point_abs_err(o2w, p_hit, p_error, si.p_error);
     si.n = normalize(xf_normal_inv(w2o, n));
     si.wo = normalize(xf_vector(o2w, wo));
-    si.dpdu = xf_vector(o2w, dpdu);
+    si.dpdu = xf_vector(o2w, dpdu); si.dpdv = xf_vector(o2w, dpdv);
     si.sh_n = face_forward(normalize(xf_normal_inv(w2o, n)), si.n);
     si.sh_dpdu = si.dpdu;
     return true;

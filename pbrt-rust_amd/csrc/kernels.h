@@ -13,7 +13,8 @@ constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/
 constexpr int kTraceBlock = 256;
 
 // path flags (meta >> 24)
-enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u };
+enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
+                  PF_CAMERA_RAY = 32u };   // the ray still carries the camera's differentials (cleared at the first shaded vertex)
 
 // SoA path state in HBM; index = path id (pid). Every array has `capacity` entries.
 struct PathSoA {
@@ -83,6 +84,8 @@ struct RenderConst {
     SobolParams sobol;
     M4 raster_to_camera, camera_to_world;
     float lens_radius, focal_distance, shutter_open, shutter_close;
+    float dx_camera[3], dy_camera[3];  // perspective.rs:64-70
+    float inv_sqrt_spp;                // Ray::scale_differential factor (integrator.rs:340)
     uint32_t max_depth; float rr_threshold;
     float filter_radius[2]; float max_sample_luminance;
     uint32_t film_w, film_h;

@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "dev_bsdf.h"
 #include "dev_sphere.h"
+#include "dev_texture.h"
 
 using namespace ptd;
 
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
                 ps.etascale[pid] = 1.0f;
                 ps.sobol_index[pid] = index;
-                ps.meta[pid] = 5u;  // dimension 5 after the camera sample, bounces 0, flags 0
+                ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
                 alive = true;
             }
         }
@@ -520,7 +521,7 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
             si.p = xf_point_abs_err(i2w, si.p, si.p_error, perr); si.p_error = perr;
             si.n = normalize(xf_normal_inv(w2i, si.n));
             si.wo = normalize(xf_vector(i2w, si.wo));
-            si.dpdu = xf_vector(i2w, si.dpdu);
+            si.dpdu = xf_vector(i2w, si.dpdu); si.dpdv = xf_vector(i2w, si.dpdv);
             si.sh_n = face_forward(normalize(xf_normal_inv(w2i, si.sh_n)), si.n);
             si.sh_dpdu = xf_vector(i2w, si.sh_dpdu);
         }
@@ -647,11 +648,50 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
     return nee_pending;
 }
 
+// ---- textured material parameters (8f-1) ---------------------------------------------------------------------
+struct TexMatEval {
+    const DeviceScene &s; const TexCtx &c;
+    PT_DEV bool bound(const PtMaterial &m, int slot) const { return m.tex[slot] >= 0; }
+    PT_DEV RGB spec(const PtMaterial &m, int slot, const float *field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c) : RGB(field[0], field[1], field[2]); }
+    PT_DEV float flt(const PtMaterial &m, int slot, float field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c).r : field; }
+};
+// The auxiliary rays of PerspectiveCamera::generate_ray_differential (perspective.rs:143-176) after transform_ray
+// (transform.rs:565-575) and Ray::scale_differential(1 / sqrt(spp)) (ray.rs:34-41, integrator.rs:340), recomputed from the
+// film position (and the lens sample, Sobol' dimensions 3 and 4) instead of being carried in the path state.
+PT_DEV RayDiff camera_ray_differentials(const RenderConst &rc, float pfx, float pfy, P2 plens_u, V3 ray_o, V3 ray_d) {
+    const V3 pcamera = xf_point(rc.raster_to_camera, V3(pfx, pfy, 0.0f));
+    const V3 dxc(rc.dx_camera[0], rc.dx_camera[1], rc.dx_camera[2]), dyc(rc.dy_camera[0], rc.dy_camera[1], rc.dy_camera[2]);
+    RayDiff d; d.has = true;
+    if (rc.lens_radius > 0.0f) {
+        const P2 dk = concentric_sample_disk(plens_u);
+        const float lx = dk.x * rc.lens_radius, ly = dk.y * rc.lens_radius;
+        const V3 dx = normalize(pcamera + dxc);
+        float ft = rc.focal_distance / dx.z;
+        V3 pfocus = V3(0.0f, 0.0f, 0.0f) + (dx * ft);
+        d.rx_o = V3(lx, ly, 0.0f); d.rx_d = normalize(pfocus - d.rx_o);
+        const V3 dy = normalize(pcamera + dyc);
+        ft = rc.focal_distance / dy.z;
+        pfocus = V3(0.0f, 0.0f, 0.0f) + (dy * ft);
+        d.ry_o = V3(lx, ly, 0.0f); d.ry_d = normalize(pfocus - d.ry_o);
+    } else {
+        d.rx_o = V3(0.0f, 0.0f, 0.0f); d.ry_o = V3(0.0f, 0.0f, 0.0f);
+        d.rx_d = normalize(pcamera + dxc); d.ry_d = normalize(pcamera + dyc);
+    }
+    d.rx_o = xf_point(rc.camera_to_world, d.rx_o); d.ry_o = xf_point(rc.camera_to_world, d.ry_o);
+    d.rx_d = xf_vector(rc.camera_to_world, d.rx_d); d.ry_d = xf_vector(rc.camera_to_world, d.ry_d);
+    const float sc = rc.inv_sqrt_spp;
+    d.rx_o = ray_o + (d.rx_o - ray_o) * sc; d.ry_o = ray_o + (d.ry_o - ray_o) * sc;
+    d.rx_d = ray_d + (d.rx_d - ray_d) * sc; d.ry_d = ray_d + (d.ry_d - ray_d) * sc;
+    return d;
+}
+
 #ifndef PT_SHADE_ATTR
 #define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
 #endif
-template <int MAXL, bool SPH>
-__global__ __launch_bounds__(256, (MAXL == 1 && SPH) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+// MODE: 0 = triangle-only scenes, 1 = general geometry (spheres and/or instances), 2 = general geometry + textures
+template <int MAXL, int MODE>
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+    constexpr bool SPH = MODE >= 1, TEX = MODE == 2;
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
@@ -717,7 +757,21 @@ __global__ __launch_bounds__(256, (MAXL == 1 && SPH) ? 2 : 1) PT_SHADE_ATTR void
                 PT_T(10);
                 Bsdf<MAXL> bsdf;
                 const uint32_t mi = s.prim_material[hp];
-                bool has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf);
+                bool has_bsdf = false;
+                if (TEX) {
+                    // compute_scattering_functions -> compute_differentials(ray) (interaction.rs:262-342): only the camera ray
+                    // carries differentials; every spawned ray has none
+                    RayDiff rdiff; rdiff.has = false;
+                    if (flags & PF_CAMERA_RAY) {
+                        P2 plens_u(0.0f, 0.0f);
+                        if (rc.lens_radius > 0.0f) plens_u = P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
+                        rdiff = camera_ray_differentials(rc, ps.pfilm_x[pid], ps.pfilm_y[pid], plens_u, ro, rd);
+                    }
+                    const TexCtx tctx = compute_differentials(si, rdiff);
+                    const TexMatEval E{s, tctx};
+                    has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, E);
+                } else has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, ConstMatEval());
+                flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
                     V3 o; spawn_ray(it, rd, o);
@@ -753,7 +807,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && SPH) ? 2 : 1) PT_SHADE_ATTR void
                             if (s.materials[mi].type == PT_MAT_SUBSURFACE && (sflags & BSDF_TRANSMISSION)) {
                                 const P2 s2 = smp.get_2d();
                                 const float s1 = smp.get_1d();
-                                DevBssrdf bss; bss.init_medium(s.materials[mi], s.bss_tables); bss.init_frame(si);
+                                DevBssrdf bss; bss.init_medium(s.materials[mi], s.bss_tables, rgb3(s.materials[mi].sigma_a), rgb3(s.materials[mi].sigma_s)); bss.init_frame(si);
                                 V3 start, target; float u1n = 0.0f;
                                 const BssSoA &bs = job.bs;
                                 if (!bss.probe_segment(s1, s2, start, target, u1n)) rr_kill = true;   // S is black: `break`
@@ -834,7 +888,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && SPH) ? 2 : 1) PT_SHADE_ATTR void
     counter_add(&job.counters->shade_bytes[job.cls], n_bytes);
 }
 #define PT_INST_SHADE(L, S) template __global__ void k_shade<L, S>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
-PT_INST_SHADE(1, false) PT_INST_SHADE(2, false) PT_INST_SHADE(5, false) PT_INST_SHADE(1, true) PT_INST_SHADE(2, true) PT_INST_SHADE(5, true)
+PT_INST_SHADE(1, 0) PT_INST_SHADE(2, 0) PT_INST_SHADE(5, 0) PT_INST_SHADE(1, 1) PT_INST_SHADE(2, 1) PT_INST_SHADE(5, 1) PT_INST_SHADE(1, 2) PT_INST_SHADE(2, 2) PT_INST_SHADE(5, 2)
 
 // ---- subsurface scattering: probe chains + exit-point vertex (path.rs:177-204, bssrdf.rs:334-410,559-574) --------------
 // One launch per wavefront iteration while any path walks a probe chain. Each queue entry is a path whose probe ray
@@ -925,7 +979,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
-                DevBssrdf bss; bss.init_medium(m, s.bss_tables);
+                DevBssrdf bss; bss.init_medium(m, s.bss_tables, rgb3(m.sigma_a), rgb3(m.sigma_s));   // textured sigma_a / sigma_s are rejected at scene creation
                 bss.ns = V3(bs.ns_x[pid], bs.ns_y[pid], bs.ns_z[pid]); bss.ss = V3(bs.ss_x[pid], bs.ss_y[pid], bs.ss_z[pid]);
                 bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
                 n_bytes += 36;

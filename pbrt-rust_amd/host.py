@@ -137,6 +137,9 @@ class SceneBuilder:
         self.area_light = None
         self.materials = []
         self.bssrdf_tables = []
+        self.textures = []            # PtTexture nodes; named maps as GraphicsState.float_textures / spectrum_textures (api.rs)
+        self.images = []              # prepared MIPMap pyramids (textures.prepare_image)
+        self.float_textures, self.spectrum_textures = {}, {}
         self.lights = []
         self.P, self.N, self.UV, self.S, self.idx, self.tri_flags = [], [], [], [], [], []
         self.nverts = 0
@@ -191,6 +194,23 @@ class SceneBuilder:
                             sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77)),
             kdsubsurface=dict(Kr=1.0, Kt=1.0, eta=1.33, uroughness=0.0, vroughness=0.0, scale=1.0, g=0.0, Kd=0.5, mfp=1.0))[kind]
         d.update(kw)
+        # a parameter given as a string names a texture ("texture Kd" "name"); the constant field then keeps the default
+        m.tex = (C.c_int32 * 16)(*([-1] * 16))
+        slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), opacity=(A.PT_MP_OPACITY, 0),
+                     eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0),
+                     sigma=(A.PT_MP_SIGMA, 1), roughness=(A.PT_MP_ROUGHNESS, 1), uroughness=(A.PT_MP_U_ROUGHNESS, 1),
+                     vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1))
+        for key in list(kw):
+            if isinstance(kw[key], str) and key in slots:
+                slot, is_float = slots[key]
+                table = self.float_textures if is_float else self.spectrum_textures
+                if kw[key] not in table: raise KeyError(f"texture {kw[key]!r} not declared ({'float' if is_float else 'spectrum'})")
+                if kind in ("kdsubsurface",) or (kind == "subsurface" and d.get("name")): raise NotImplementedError("textured kdsubsurface / named subsurface parameters")
+                m.tex[slot] = table[kw[key]]
+                d.pop(key)   # keep the create_*_material default in the constant field
+        if kind == "metal" and m.tex[A.PT_MP_ROUGHNESS] >= 0:   # metal.rs: uroughness/vroughness fall back to "roughness"
+            for sl in (A.PT_MP_U_ROUGHNESS, A.PT_MP_V_ROUGHNESS):
+                if m.tex[sl] < 0 and "uroughness" not in kw and "vroughness" not in kw: pass
         three = lambda v: (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
         m.kd = three(d.get("Kd", 0)); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", 0)); m.kt = three(d.get("Kt", 0))
         m.opacity = three(d.get("opacity", 1)); m.eta_rgb = three(d.get("eta_rgb", (0.2, 0.92, 1.1))); m.k_rgb = three(d.get("k", (3.9, 2.45, 2.14)))
@@ -223,6 +243,72 @@ class SceneBuilder:
                 self.bssrdf_tables.append(table); m.bssrdf_table = len(self.bssrdf_tables) - 1
         self.materials.append(m)
         self.material_id = len(self.materials) - 1
+
+    # -- textures (api.rs pbrt_texture; textures/*.rs create_* functions)
+    def _const_tex(self, value):
+        t = A.PtTexture(); t.type = A.PT_TEX_CONSTANT; t.child = (C.c_int32 * 3)(-1, -1, -1)
+        v = [float(value)] * 3 if np.isscalar(value) else [float(x) for x in value]
+        t.value = (C.c_float * 3)(*v)
+        self.textures.append(t); return len(self.textures) - 1
+
+    def _child(self, v, is_float):
+        if isinstance(v, str):
+            table = self.float_textures if is_float else self.spectrum_textures
+            return table[v]
+        return self._const_tex(v)
+
+    def _mapping(self, t, kw):   # get_mapping2d (texture.rs:439-466); texture-to-world = CTM at the Texture directive
+        kind = kw.get("mapping", "uv")
+        t.mapping = dict(uv=A.PT_MAP_UV, planar=A.PT_MAP_PLANAR, spherical=A.PT_MAP_SPHERICAL, cylindrical=A.PT_MAP_CYLINDRICAL)[kind]
+        t.su, t.sv = float(kw.get("uscale", 1.0)), float(kw.get("vscale", 1.0))
+        t.du, t.dv = float(kw.get("udelta", 0.0)), float(kw.get("vdelta", 0.0))
+        t.vs = (C.c_float * 3)(*[float(x) for x in kw.get("v1", (1, 0, 0))]); t.vt = (C.c_float * 3)(*[float(x) for x in kw.get("v2", (0, 1, 0))])
+        t.world_to_texture = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+
+    def texture(self, name, kind, cls, **kw):
+        """Texture "name" "color|spectrum|float" "class" params.  Image maps take `pixels` (h, w, 3; top row first, as
+        read_image returns) instead of a filename."""
+        is_float = kind == "float"
+        t = A.PtTexture(); t.child = (C.c_int32 * 3)(-1, -1, -1)
+        one = 1.0
+        if cls == "constant":
+            t.type = A.PT_TEX_CONSTANT
+            v = kw.get("value", 1.0); t.value = (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
+        elif cls == "scale":
+            t.type = A.PT_TEX_SCALE
+            t.child = (C.c_int32 * 3)(self._child(kw.get("tex1", one), is_float), self._child(kw.get("tex2", one), is_float), -1)
+        elif cls == "mix":
+            t.type = A.PT_TEX_MIX
+            t.child = (C.c_int32 * 3)(self._child(kw.get("tex1", 0.0), is_float), self._child(kw.get("tex2", 1.0), is_float), self._child(kw.get("amount", 0.5), True))
+        elif cls == "checkerboard":
+            dim = int(kw.get("dimension", 2))
+            t.child = (C.c_int32 * 3)(self._child(kw.get("tex1", 1.0), is_float), self._child(kw.get("tex2", 0.0), is_float), -1)
+            if dim == 2:
+                t.type = A.PT_TEX_CHECKERBOARD2D; self._mapping(t, kw)
+                t.aa_closedform = 0 if kw.get("aamode", "none") == "none" else 1
+            else:
+                t.type = A.PT_TEX_CHECKERBOARD3D; t.world_to_texture = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+        elif cls == "imagemap":
+            from . import textures as T
+            t.type = A.PT_TEX_IMAGEMAP; self._mapping(t, kw)
+            wrap = kw.get("wrap", "repeat")
+            img = T.prepare_image(kw["pixels"], scale=float(kw.get("scale", 1.0)), gamma=bool(kw.get("gamma", False)),
+                                  channels=1 if is_float else 3, wrap=wrap)
+            self.images.append(img); t.image = len(self.images) - 1
+            t.trilinear = 1 if kw.get("trilinear", False) else 0
+            t.max_anisotropy = float(kw.get("maxanisotropy", 8.0))
+            t.wrap = A.PT_WRAP_REPEAT if wrap == "repeat" else A.PT_WRAP_BLACK
+        elif cls == "uv":
+            if is_float: raise ValueError("uv textures are spectrum-only (textures/uv.rs:36-38)")
+            t.type = A.PT_TEX_UV; self._mapping(t, kw)
+        elif cls == "bilerp":
+            t.type = A.PT_TEX_BILERP; self._mapping(t, kw)
+            for nm, dv in (("v00", 0.0), ("v01", 1.0), ("v10", 0.0), ("v11", 1.0)):
+                v = kw.get(nm, dv); setattr(t, nm, (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v])))
+        else:
+            raise NotImplementedError(f"texture class {cls!r} (noise textures are not restated yet)")
+        self.textures.append(t)
+        (self.float_textures if is_float else self.spectrum_textures)[name] = len(self.textures) - 1
 
     def area_light_source(self, L=(1, 1, 1), twosided=False):
         self.area_light = dict(L=tuple(float(x) for x in L), twosided=twosided)
@@ -450,6 +536,19 @@ class SceneData:
         self.objects = (A.PtObject * max(1, self.n_objects))(*[A.PtObject(f, n) for _, f, n in b.object_list])
         self.instances = (A.PtInstance * max(1, self.n_instances))(*b.instances)
         self.top_refs = np.ascontiguousarray(np.concatenate(b.top_refs), dtype=np.uint32) if (b.instances and b.top_refs) else None
+        self.n_textures = len(b.textures)
+        self.textures = (A.PtTexture * max(1, self.n_textures))(*b.textures)
+        self.image_src = list(b.images)
+        self.images = (A.PtImage * max(1, len(self.image_src)))()
+        for i, im in enumerate(self.image_src):
+            e = self.images[i]
+            e.width, e.height, e.n_levels, e.channels = im["width"], im["height"], im["n_levels"], im["channels"]
+            e.texels = im["texels"].ctypes.data_as(A.fp)
+        if self.image_src:
+            from . import textures as T
+            self.ewa_lut = T.ewa_weight_lut()
+        else:
+            self.ewa_lut = None
         self.bssrdf_src = list(b.bssrdf_tables)
         self.bssrdf_tables = (A.PtBSSRDFTable * max(1, len(self.bssrdf_src)))()
         for i, t in enumerate(self.bssrdf_src):
@@ -484,4 +583,7 @@ class SceneData:
             d.n_objects = self.n_objects; d.objects = self.objects; d.n_instances = self.n_instances; d.instances = self.instances
             d.n_top = len(self.top_refs); d.top_refs = ptr(self.top_refs, A.u32p)
         d.n_bssrdf_tables = len(self.bssrdf_src); d.bssrdf_tables = self.bssrdf_tables
+        d.n_textures = self.n_textures; d.textures = self.textures
+        d.n_images = len(self.image_src); d.images = self.images
+        d.ewa_weight_lut = ptr(self.ewa_lut, A.fp)
         return d

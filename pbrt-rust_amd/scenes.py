@@ -248,3 +248,49 @@ def sphere_lights(xres=96, yres=64, spp=16, maxdepth=4):
     P, I, N = displaced_sphere(12, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
     b.attribute_begin(); b.material("glass", eta=1.5); b.translate(1.6, -0.4, 1.5); b.sphere(radius=0.6); b.attribute_end()
     return b
+
+
+def test_image(w=20, h=12, seed=5):
+    """A small procedural RGB image (top row first), non-power-of-two so that MIPMap resampling is exercised."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([0.5 + 0.5 * np.sin(x * 0.9) * np.cos(y * 0.7), 0.2 + 0.8 * ((x.astype(int) // 3 + y.astype(int) // 2) % 2), 0.15 + 0.8 * (y / h)], axis=-1)
+    rng = np.random.default_rng(seed)
+    return np.clip(img + 0.05 * rng.random((h, w, 3)), 0.0, 1.0).astype(F)
+
+
+def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False):
+    """image map (EWA or trilinear MIPMap, uv and planar mappings), checkerboard (closed-form and point
+    sampled, 2-D and 3-D), scale, mix, bilerp, uv, a float image texture driving a roughness, spherical + cylindrical
+    mappings; camera-ray differentials drive the filtering at the first hit, later bounces use zero-width lookups."""
+    from .host import SceneBuilder
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.2, 7.0), (0.0, 0.2, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.5, 0.55, 0.6))
+    b.attribute_begin(); b.area_light_source(L=(25.0, 22.0, 18.0))
+    P, I = quad((-1.5, 5.0, -1.0), (1.5, 5.0, -1.0), (1.5, 5.0, 1.5), (-1.5, 5.0, 1.5)); b.trianglemesh(P, I); b.attribute_end()
+    img = test_image()
+    b.texture("img", "color", "imagemap", pixels=img, gamma=True, trilinear=trilinear, uscale=4.0, vscale=4.0)
+    b.texture("imgplanar", "color", "imagemap", pixels=img, mapping="planar", v1=(0.25, 0.0, 0.0), v2=(0.0, 0.0, 0.25), trilinear=trilinear, maxanisotropy=4.0, wrap="black", scale=1.5)
+    b.texture("check", "color", "checkerboard", mapping="planar", v1=(1.0, 0.0, 0.0), v2=(0.0, 0.0, 1.0), aamode="closedform", tex1="imgplanar", tex2=(0.1, 0.1, 0.12))
+    b.texture("check3", "color", "checkerboard", dimension=3, tex1=(0.8, 0.3, 0.2), tex2="img")
+    b.texture("uvtex", "color", "uv", uscale=3.0, vscale=2.0)
+    b.texture("bil", "color", "bilerp", v00=(1, 0, 0), v01=(0, 1, 0), v10=(0, 0, 1), v11=(1, 1, 0))
+    b.texture("amount", "float", "checkerboard", uscale=6.0, vscale=6.0, tex1=0.2, tex2=0.9)
+    b.texture("mixed", "color", "mix", tex1="uvtex", tex2="bil", amount="amount")
+    b.texture("scaled", "color", "scale", tex1="img", tex2=(0.9, 0.6, 0.5))
+    b.texture("rough", "float", "imagemap", pixels=img, scale=0.3, uscale=2.0, vscale=2.0, trilinear=True)
+    b.texture("sph", "color", "imagemap", pixels=img, mapping="spherical")
+    b.texture("cyl", "color", "checkerboard", mapping="cylindrical", tex1=(0.9, 0.9, 0.2), tex2=(0.1, 0.2, 0.7), aamode="closedform")
+    b.material("matte", Kd="check")
+    P, I = quad((-8.0, -1.0, -8.0), (-8.0, -1.0, 8.0), (8.0, -1.0, 8.0), (8.0, -1.0, -8.0))
+    b.trianglemesh(P, I, UV=np.array([[0, 0], [0, 1], [1, 1], [1, 0]], dtype=F))
+    b.attribute_begin(); b.material("plastic", Kd="mixed", Ks=(0.3, 0.3, 0.3), roughness="rough"); b.translate(-2.0, 0.0, 0.5); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.material("matte", Kd="check3"); b.translate(0.3, -0.2, -0.5)
+    P, I, N = displaced_sphere(12, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
+    b.attribute_begin(); b.material("uber", Kd="scaled", Ks=(0.2, 0.2, 0.2), opacity=(1, 1, 1)); b.translate(2.3, 0.0, 0.8); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.translate(0.0, 1.8, -2.5); b.material("matte", Kd="sph"); b.sphere(radius=0.8); b.attribute_end()
+    b.attribute_begin(); b.translate(-3.2, 0.6, -2.0); b.material("matte", Kd="cyl"); b.sphere(radius=0.9); b.attribute_end()
+    return b

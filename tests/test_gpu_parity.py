@@ -279,3 +279,26 @@ def test_sphere_area_lights_match_oracle(pkg, gpu, oracle):
               "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den"):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("trilinear", [False, True])
+def test_textures_match_oracle(pkg, gpu, oracle, trilinear):
+    """image maps (EWA / trilinear MIPMap; uv, planar, spherical mappings; repeat and black wrap; RGB and float
+    memory), checkerboards (2-D closed form / point sampled over uv, planar and cylindrical mappings; 3-D), scale, mix,
+    bilerp, uv -- camera-ray differentials at the first vertex, zero-width lookups afterwards."""
+    sd, rp = pkg.scenes.textured(xres=96, yres=64, spp=8, trilinear=trilinear).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
+              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_textures_with_thin_lens(pkg, gpu, oracle):
+    """Lens branch of generate_ray_differential (perspective.rs:147-165): the auxiliary rays start on the lens sample."""
+    b = pkg.scenes.textured(xres=64, yres=40, spp=4)
+    b.cam.update(lensradius=0.05, focaldistance=7.0)
+    sd, rp = b.world_end()
+    _compare_render(pkg, gpu, oracle, sd, rp)
