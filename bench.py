@@ -125,8 +125,8 @@ def main():
         return None
     # Group the per-launch-kind statistics by kernel symbol (what rocprofv3 --stats reports) and take the
     # symbol with the largest total time as the dominant kernel.
-    SYMBOL = {"extend_camera": "k_trace<false, false>", "extend": "k_trace<false, false>", "extend_mis": "k_trace<false, false>",
-              "shadow": "k_trace<true, false>", "shade_matte": "k_shade<1, 0>", "shade_1lobe": "k_shade<1, 0>",
+    SYMBOL = {"extend_camera": "k_trace<false, 0>", "extend": "k_trace<false, 0>", "extend_mis": "k_trace<false, 0>",
+              "shadow": "k_trace<true, 0>", "shade_matte": "k_shade<1, 0>", "shade_1lobe": "k_shade<1, 0>",
               "shade_2lobe": "k_shade<2, 0>", "shade_uber": "k_shade<5, 0>"}  # names as rocprofv3 prints them (no spheres in S2)
     groups = {}
     for n, v in kstats.items():

@@ -267,6 +267,9 @@ typedef struct PtSceneDesc {
     uint32_t n_bssrdf_tables; const PtBSSRDFTable *bssrdf_tables;
 
     uint32_t n_textures; const PtTexture *textures;
+    /* alpha masks (TriangleMesh.alpha_mask / shadow_alpha_mask, triangle.rs:29-30,275-285,497-545): per triangle, the
+     * index of a float texture or -1; both arrays may be NULL. */
+    const int32_t *tri_alpha; const int32_t *tri_shadow_alpha;
     uint32_t n_images; const PtImage *images;
     const float *ewa_weight_lut;   /* [128] = exp(-2 r2) - exp(-2), r2 = i/127 (mipmap.rs:40-50); required with EWA image maps */
 } PtSceneDesc;

@@ -15,6 +15,18 @@ namespace ref {
 static RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
 static TRDist make_dist(Float ax, Float ay) { TRDist d; d.ax = fmax_(ax, 0.001f); d.ay = fmax_(ay, 0.001f); return d; }  // microfacet.rs:325-331
 
+bool ref::Scene::tri_alpha_rejects(uint32_t tri, const Float b[3], bool shadow) const {
+    // isectl = SurfaceInteraction::new(phit, 0, uvhit, -r.d, dpdu, dpdv, ..): no differentials (dudx.. = 0, dpdx = dpdy = 0)
+    uint32_t i0 = idx[3 * tri], i1 = idx[3 * tri + 1], i2 = idx[3 * tri + 2];
+    P2 uv[3]; tri_uvs(tri, uv);
+    TexCtx c; c.dpdx = V3(0, 0, 0); c.dpdy = V3(0, 0, 0);
+    c.p = P[i0] * b[0] + P[i1] * b[1] + P[i2] * b[2];
+    c.uv = P2(uv[0].x * b[0] + uv[1].x * b[1] + uv[2].x * b[2], uv[0].y * b[0] + uv[1].y * b[1] + uv[2].y * b[2]);
+    if (!tri_alpha.empty() && tri_alpha[tri] >= 0 && textures->eval(tri_alpha[tri], c).c[0] == 0.0f) return true;
+    if (shadow && !tri_shadow_alpha.empty() && tri_shadow_alpha[tri] >= 0 && textures->eval(tri_shadow_alpha[tri], c).c[0] == 0.0f) return true;
+    return false;
+}
+
 // Texture::evaluate of a material parameter: a ConstantTexture (the field) unless tex[slot] names a texture node.
 struct MatEval {
     const Scene &scene; const PtMaterial &m; const TexCtx *ctx;
@@ -563,6 +575,10 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
         }
         for (const PtMaterial &m : s.materials) for (int k = 0; k < 16; ++k) if (m.tex[k] >= (int32_t)d->n_textures) return PT_ERR_INVALID_ARG;
         s.textures = ts;
+        if (d->tri_alpha) s.tri_alpha.assign(d->tri_alpha, d->tri_alpha + d->n_triangles);
+        if (d->tri_shadow_alpha) s.tri_shadow_alpha.assign(d->tri_shadow_alpha, d->tri_shadow_alpha + d->n_triangles);
+        for (int32_t a : s.tri_alpha) if (a >= (int32_t)d->n_textures) return PT_ERR_INVALID_ARG;
+        for (int32_t a : s.tri_shadow_alpha) if (a >= (int32_t)d->n_textures) return PT_ERR_INVALID_ARG;
     }
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) if (s.lights[i].type == PT_LIGHT_INFINITE) s.infinite_lights.push_back(i);

@@ -89,6 +89,10 @@ struct Scene {
     std::vector<PtMaterial> materials;
     std::vector<BssrdfTable> bssrdf_tables;
     std::shared_ptr<struct TextureSet> textures;   // ref_texture.h (null: no textures)
+    std::vector<int32_t> tri_alpha, tri_shadow_alpha;   // per triangle: float texture index or -1 (empty: no masks)
+    // Triangle::intersect / intersect_p alpha tests (triangle.rs:275-285,497-545); defined in ref_render.cpp
+    bool tri_alpha_rejects(uint32_t tri, const Float b[3], bool shadow) const;
+    bool tri_has_alpha(uint32_t tri) const { return (!tri_alpha.empty() && tri_alpha[tri] >= 0) || (!tri_shadow_alpha.empty() && tri_shadow_alpha[tri] >= 0); }
     std::vector<PtLight> lights;
     std::vector<uint32_t> infinite_lights;
     uint32_t env_w = 0, env_h = 0;
@@ -295,6 +299,7 @@ inline bool Scene::prim_intersect(uint32_t prim, Ray &r, SurfaceInteraction &si,
         c.tri_tests++;
         Float t, b[3];
         if (!tri_intersect(i, r, t, b)) return false;
+        if (tri_has_alpha(i) && tri_alpha_rejects(i, b, false)) return false;   // triangle.rs:275-285 (test_alpha_texture = true)
         r.t_max = t;
         si.prim = prim; si.inst = PT_NONE; si.t = t; si.b[0] = b[0]; si.b[1] = b[1]; si.b[2] = b[2];
         return true;
@@ -312,7 +317,11 @@ inline bool Scene::prim_intersect_p(uint32_t prim, const Ray &r, Counters &c) co
     if (k == PT_SHAPE_TRIANGLE) {
         c.tri_tests++;
         Float t, b[3];
-        return tri_hit_params(i, r, t, b);  // no alpha masks: triangle.rs:497 branch not taken
+        if (!tri_hit_params(i, r, t, b)) return false;
+        if (!tri_has_alpha(i)) return true;              // triangle.rs:497 branch not taken
+        V3 dpdu, dpdv;
+        if (!tri_partials(i, dpdu, dpdv)) return false;  // :516-523: with an alpha mask intersect_p rejects degenerate triangles too
+        return !tri_alpha_rejects(i, b, true);
     }
     c.sphere_tests++;
     return sphere_intersect_p(i, r);

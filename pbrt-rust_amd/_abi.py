@@ -98,7 +98,7 @@ class PtSceneDesc(C.Structure):
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
                 ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable)),
-                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp)]
+                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("tri_alpha", i32p), ("tri_shadow_alpha", i32p), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp)]
 
 
 class PtRenderParams(C.Structure):

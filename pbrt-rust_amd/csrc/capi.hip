@@ -149,11 +149,11 @@ int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
     job.refill_min = g_refill_min[job.kind & 3]; job.leaf_quorum = g_leaf_quorum[job.kind & 3];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
-    const bool sph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;  // general kernels: spheres and/or instances
-    if (any && sph) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-    else if (any) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-    else if (sph) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? 1 : 0;  // kernels.hip: k_trace MODE
+    #define PT_LAUNCH_TRACE(A, M) hipLaunchKernelGGL((k_trace<A, M>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
+    if (any) { if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
+    else { if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
+    #undef PT_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -529,6 +529,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D) && (t.child[0] < 0 || t.child[1] < 0)) return fail(PT_ERR_INVALID_ARG, "texture node needs two children");
         if (t.type == PT_TEX_MIX && (t.child[0] < 0 || t.child[1] < 0 || t.child[2] < 0)) return fail(PT_ERR_INVALID_ARG, "mix texture needs three children");
     }
+    for (const int32_t *arr : {d->tri_alpha, d->tri_shadow_alpha})
+        if (arr) for (uint32_t i = 0; i < d->n_triangles; ++i) if (arr[i] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "alpha-mask texture index out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const PtMaterial &m = d->materials[i];
         for (int k = 0; k < 16; ++k) {
@@ -741,6 +743,9 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             }
             UP(images, imgs.data(), imgs.size());
             if (d->ewa_weight_lut) UP(ewa_lut, d->ewa_weight_lut, 128);
+            auto any_mask = [&](const int32_t *a) { if (!a) return false; for (uint32_t i = 0; i < d->n_triangles; ++i) if (a[i] >= 0) return true; return false; };
+            if (any_mask(d->tri_alpha)) UP(tri_alpha, d->tri_alpha, d->n_triangles);
+            if (any_mask(d->tri_shadow_alpha)) UP(tri_shadow_alpha, d->tri_shadow_alpha, d->n_triangles);
         }
         for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].type == PT_MAT_SUBSURFACE) sc->has_bssrdf = true;
         std::vector<uint32_t> inf;

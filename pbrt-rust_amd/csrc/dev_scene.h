@@ -18,7 +18,7 @@ struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads p
     float p1yz[2]; float p2xy[2];
     float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
 };
-enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
+enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11, TP_ALPHA = 1u << 12 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
 
 // Two-wide traversal record (64 B, four dwordx4 loads): one per INTERIOR node of the reference tree, holding the
 // bounds of both children, so that a ray fetches once per interior node it enters instead of once per node it tests.
@@ -68,6 +68,7 @@ struct DeviceScene {
     // textures (8f-1): nodes, one postfix program per node (tex_prog[tex_prog_offset[i] .. tex_prog_offset[i+1])), images
     const PtTexture *textures; uint32_t n_textures; const uint32_t *tex_prog_offset; const uint32_t *tex_prog;
     const DevImage *images; const float *ewa_lut;
+    const int32_t *tri_alpha; const int32_t *tri_shadow_alpha;   // per triangle float-texture index or -1 (NULL: no masks)
     // env map
     uint32_t env_w, env_h; const float *env_texels;
     const float *env_func; const float *env_cdf; const float *env_func_int;  // conditional rows (2h x 2w [+1]), marginal appended

@@ -100,6 +100,7 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
         p.p0[0] = p0.x; p.p0[1] = p0.y; p.p0[2] = p0.z; p.p1x = p1.x;
         p.p1yz[0] = p1.y; p.p1yz[1] = p1.z; p.p2xy[0] = p2.x; p.p2xy[1] = p2.y; p.p2z = p2.z;
         p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS);
+        if ((s.tri_alpha && s.tri_alpha[tri] >= 0) || (s.tri_shadow_alpha && s.tri_shadow_alpha[tri] >= 0)) p.flags |= TP_ALPHA;
     } else {
         p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
         p.flags = TP_SPHERE;
@@ -148,8 +149,10 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 // Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
 
 // GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
-template <bool ANY, bool SPH>
+// MODE: 0 = triangle-only scenes, 1 = general geometry (spheres, instances), 2 = general geometry + alpha-masked triangles
+template <bool ANY, int MODE>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
+    constexpr bool SPH = MODE >= 1, ALPHA = MODE == 2;
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -357,7 +360,22 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
                         V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
                         V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
                         float t, b0, b1, b2;
-                        if (tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2)) {
+                        bool hit = tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2);
+                        if constexpr (ALPHA) {
+                            // Triangle::intersect (triangle.rs:275-285) / intersect_p (:497-545) with an alpha mask: the hit is
+                            // discarded where the mask evaluates to 0; intersect_p then also rejects degenerate triangles
+                            if (hit && (fl & TP_ALPHA) && !(fl & TP_BOGUS)) {
+                                const uint32_t tri = q2.z & 0x3fffffffu;
+                                P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
+                                TexCtx c; c.dpdx = V3(0.0f, 0.0f, 0.0f); c.dpdy = V3(0.0f, 0.0f, 0.0f); c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
+                                c.p = p0 * b0 + p1 * b1 + p2 * b2;
+                                c.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
+                                const int32_t a = s.tri_alpha ? s.tri_alpha[tri] : -1;
+                                if (a >= 0 && tex_eval(s, a, c).r == 0.0f) hit = false;
+                                if (ANY && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
+                            } else if (ANY && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
+                        }
+                        if (hit) {
                             if (ANY) { found = true; last = true; state = ST_DONE; break; }
                             if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
                                 found = true; t_max = t;  // primitive.rs:137
@@ -382,10 +400,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob j
     counter_add(&job.counters->k_tris[job.kind], n_tris);
     counter_add(&job.counters->k_rays[job.kind], n_rays);
 }
-template __global__ void k_trace<false, false>(DeviceScene, TraceJob);
-template __global__ void k_trace<true, false>(DeviceScene, TraceJob);
-template __global__ void k_trace<false, true>(DeviceScene, TraceJob);
-template __global__ void k_trace<true, true>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, 0>(DeviceScene, TraceJob);
+template __global__ void k_trace<true, 0>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, 1>(DeviceScene, TraceJob);
+template __global__ void k_trace<true, 1>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, 2>(DeviceScene, TraceJob);
+template __global__ void k_trace<true, 2>(DeviceScene, TraceJob);
 
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit

@@ -140,6 +140,7 @@ class SceneBuilder:
         self.textures = []            # PtTexture nodes; named maps as GraphicsState.float_textures / spectrum_textures (api.rs)
         self.images = []              # prepared MIPMap pyramids (textures.prepare_image)
         self.float_textures, self.spectrum_textures = {}, {}
+        self.tri_alpha, self.tri_shadow_alpha = [], []
         self.lights = []
         self.P, self.N, self.UV, self.S, self.idx, self.tri_flags = [], [], [], [], [], []
         self.nverts = 0
@@ -364,7 +365,7 @@ class SceneBuilder:
         self.lights.append(l)
         return len(self.lights) - 1
 
-    def trianglemesh(self, P, indices, N=None, UV=None, S=None):
+    def trianglemesh(self, P, indices, N=None, UV=None, S=None, alpha=None, shadowalpha=None):
         """shapes/triangle.rs:21-73: vertices pre-transformed to world space, one primitive per triangle."""
         P = np.asarray(P, dtype=F).reshape(-1, 3); idx = np.asarray(indices, dtype=np.uint32).reshape(-1, 3)
         nv, nt = len(P), len(idx)
@@ -376,6 +377,12 @@ class SceneBuilder:
         fl = (A.PT_TRI_REVERSE_ORIENTATION if self.reverse_orientation else 0) | (A.PT_TRI_SWAPS_HANDEDNESS if self.ctm.swaps_handedness() else 0)
         fl |= (A.PT_TRI_HAS_N if N is not None else 0) | (A.PT_TRI_HAS_S if S is not None else 0) | (A.PT_TRI_HAS_UV if UV is not None else 0)
         self.tri_flags.append(np.full(nt, fl, dtype=np.uint8))
+        # "alpha" / "shadowalpha" (triangle.rs:727-756): a float texture name, or the constant 0 (=> ConstantTexture(0))
+        def mask(v):
+            if v is None: return -1
+            if isinstance(v, str): return self.float_textures[v]
+            return self._const_tex(0.0) if float(v) == 0.0 else -1
+        self.tri_alpha.append(np.full(nt, mask(alpha), dtype=np.int32)); self.tri_shadow_alpha.append(np.full(nt, mask(shadowalpha), dtype=np.int32))
         first_prim = self.nprims
         self.prim_shape.append((np.uint32(A.PT_SHAPE_TRIANGLE << 30) | (np.arange(nt, dtype=np.uint32) + np.uint32(self.ntris))).astype(np.uint32))
         mid = A.PT_NONE if self.material_id is None else self.material_id
@@ -536,6 +543,10 @@ class SceneData:
         self.objects = (A.PtObject * max(1, self.n_objects))(*[A.PtObject(f, n) for _, f, n in b.object_list])
         self.instances = (A.PtInstance * max(1, self.n_instances))(*b.instances)
         self.top_refs = np.ascontiguousarray(np.concatenate(b.top_refs), dtype=np.uint32) if (b.instances and b.top_refs) else None
+        ca = lambda parts: np.ascontiguousarray(np.concatenate(parts), dtype=np.int32) if parts else np.zeros(0, np.int32)
+        self.tri_alpha, self.tri_shadow_alpha = ca(b.tri_alpha), ca(b.tri_shadow_alpha)
+        if not (self.tri_alpha >= 0).any(): self.tri_alpha = None
+        if not (self.tri_shadow_alpha >= 0).any(): self.tri_shadow_alpha = None
         self.n_textures = len(b.textures)
         self.textures = (A.PtTexture * max(1, self.n_textures))(*b.textures)
         self.image_src = list(b.images)
@@ -584,6 +595,7 @@ class SceneData:
             d.n_top = len(self.top_refs); d.top_refs = ptr(self.top_refs, A.u32p)
         d.n_bssrdf_tables = len(self.bssrdf_src); d.bssrdf_tables = self.bssrdf_tables
         d.n_textures = self.n_textures; d.textures = self.textures
+        d.tri_alpha = ptr(self.tri_alpha, A.i32p); d.tri_shadow_alpha = ptr(self.tri_shadow_alpha, A.i32p)
         d.n_images = len(self.image_src); d.images = self.images
         d.ewa_weight_lut = ptr(self.ewa_lut, A.fp)
         return d

@@ -294,3 +294,45 @@ def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False):
     b.attribute_begin(); b.translate(0.0, 1.8, -2.5); b.material("matte", Kd="sph"); b.sphere(radius=0.8); b.attribute_end()
     b.attribute_begin(); b.translate(-3.2, 0.6, -2.0); b.material("matte", Kd="cyl"); b.sphere(radius=0.9); b.attribute_end()
     return b
+
+
+def alpha_foliage(xres=96, yres=64, spp=8, maxdepth=4, n_cards=40, seed=3, instanced=True):
+    """Alpha-masked geometry (SURVEY 8f-1, config C4's foliage): leaf cards whose `alpha` is a checkerboard / image float
+    texture (cut-outs seen by camera, bounce and shadow rays), one card with `shadowalpha` only (visible but casts
+    partially no shadow), a constant-zero alpha mesh (fully invisible), inside object instances and at top level."""
+    from .host import SceneBuilder
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.5, 8.0), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=42.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.35, 0.4, 0.5))
+    b.attribute_begin(); b.area_light_source(L=(30.0, 28.0, 24.0))
+    P, I = quad((-2.0, 6.0, -1.0), (2.0, 6.0, -1.0), (2.0, 6.0, 2.0), (-2.0, 6.0, 2.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.texture("holes", "float", "checkerboard", uscale=5.0, vscale=5.0, tex1=1.0, tex2=0.0)
+    img = test_image(16, 16, seed=9); img[(img[..., 1] < 0.5)] = 0.0
+    b.texture("leafmask", "float", "imagemap", pixels=img, trilinear=True)
+    b.texture("leafcol", "color", "imagemap", pixels=test_image(16, 16, seed=2), gamma=True)
+    b.material("matte", Kd=(0.5, 0.5, 0.45))
+    P, I = quad((-9.0, 0.0, -9.0), (-9.0, 0.0, 9.0), (9.0, 0.0, 9.0), (9.0, 0.0, -9.0)); b.trianglemesh(P, I)
+    uvq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=F)
+    card = quad((-0.5, 0.0, 0.0), (0.5, 0.0, 0.0), (0.5, 1.0, 0.0), (-0.5, 1.0, 0.0))
+    b.material("matte", Kd="leafcol")
+    if instanced:
+        b.object_begin("plant")
+        for k in range(3):
+            b.attribute_begin(); b.rotate(60.0 * k, 0, 1, 0); b.trianglemesh(card[0], card[1], UV=uvq, alpha="leafmask"); b.attribute_end()
+        b.object_end()
+    for _ in range(n_cards):
+        b.attribute_begin()
+        b.translate(float(rng.uniform(-4, 4)), 0.0, float(rng.uniform(-4, 3))); b.rotate(float(rng.uniform(0, 360)), 0, 1, 0)
+        sc = float(rng.uniform(0.6, 1.6)); b.scale(sc, sc, sc)
+        if instanced and rng.random() < 0.5: b.object_instance("plant")
+        else: b.trianglemesh(card[0], card[1], UV=uvq, alpha="holes")
+        b.attribute_end()
+    # visible card that only lets light through (shadowalpha), and a fully invisible blocker (alpha = 0)
+    b.attribute_begin(); b.material("matte", Kd=(0.8, 0.2, 0.2)); b.translate(0.0, 2.2, 1.0); b.rotate(-90.0, 1, 0, 0); b.scale(3.0, 3.0, 1.0)
+    b.trianglemesh(card[0], card[1], UV=uvq, shadowalpha="holes"); b.attribute_end()
+    b.attribute_begin(); b.translate(0.0, 0.5, 5.0); b.scale(6.0, 4.0, 1.0); b.trianglemesh(card[0], card[1], UV=uvq, alpha=0.0); b.attribute_end()
+    return b

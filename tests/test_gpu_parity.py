@@ -302,3 +302,19 @@ def test_textures_with_thin_lens(pkg, gpu, oracle):
     b.cam.update(lensradius=0.05, focaldistance=7.0)
     sd, rp = b.world_end()
     _compare_render(pkg, gpu, oracle, sd, rp)
+
+
+@pytest.mark.parametrize("instanced", [True, False])
+def test_alpha_masks_match_oracle(pkg, gpu, oracle, instanced):
+    """Alpha masks in Triangle::intersect / intersect_p (triangle.rs:275-285,497-545): cut-out cards (checkerboard and
+    image float textures), `shadowalpha`, constant-zero alpha, inside object instances and at top level; the traversal
+    kernels evaluate the mask texture at candidate hits. Closest-hit / any-hit records are compared as well."""
+    sd, rp = pkg.scenes.alpha_foliage(xres=96, yres=64, spp=8, instanced=instanced).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    _compare_render(pkg, gpu, oracle, sd, rp)
+    o, d = _random_rays(40000, 21)
+    o[:, 1] += 1.0; o *= np.float32(0.5)
+    tmax = np.full(len(o), np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(o, d, tmax); op, ot, ob = orc.trace_closest(o, d, tmax)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    assert np.array_equal(g.trace_any(o, d, np.full(len(o), 6.0, np.float32)), orc.trace_any(o, d, np.full(len(o), 6.0, np.float32)))

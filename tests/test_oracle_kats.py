@@ -467,3 +467,34 @@ def test_textured_scene_renders_and_filters(oracle, pkg):
         band = img[17:20, :, 1]                                # just below the horizon: many checks per pixel
         return float(np.abs(np.diff(band, axis=1)).mean())
     assert far_floor_roughness("closedform") < 0.5 * far_floor_roughness("none")
+
+
+def test_alpha_masks(oracle, pkg):
+    """A constant-zero alpha mesh is invisible to every ray; a checkerboard mask removes about half of a card's hits;
+    `shadowalpha` affects intersect_p only (triangle.rs:536-545)."""
+    b = pkg.host.SceneBuilder()
+    b.world_begin()
+    b.texture("holes", "float", "checkerboard", uscale=8.0, vscale=8.0, tex1=1.0, tex2=0.0)
+    uvq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    P, I = pkg.scenes.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0))
+    b.material("matte")
+    b.trianglemesh(P, I, UV=uvq, alpha="holes")                        # prims 0,1 at z = 0
+    b.translate(0, 0, -1); b.trianglemesh(P, I, UV=uvq, alpha=0.0)       # prims 2,3 at z = -1: invisible
+    b.translate(0, 0, -1); b.trianglemesh(P, I, UV=uvq, shadowalpha="holes")   # prims 4,5 at z = -2
+    sd, rp = b.world_end()
+    s = oracle.scene(sd)
+    rng = np.random.default_rng(4)
+    n = 20000
+    o = np.zeros((n, 3), np.float32); o[:, :2] = rng.uniform(-0.99, 0.99, (n, 2)); o[:, 2] = 1.0
+    d = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
+    prim, t, _ = s.trace_closest(o, d, np.full(n, np.inf, np.float32))
+    first = np.isin(prim, [0, 1]); third = np.isin(prim, [4, 5])
+    assert not np.isin(prim, [2, 3]).any() and (first | third).all()
+    assert abs(first.mean() - 0.5) < 0.03                              # half of the card is cut out
+    u, v = (o[:, 0] + 1) / 2, (o[:, 1] + 1) / 2
+    solid = ((np.floor(u * 8) + np.floor(v * 8)) % 2) == 0
+    assert np.array_equal(first, solid)
+    # intersect_p from behind the first card towards the third: blocked only where shadowalpha != 0
+    o2 = o.copy(); o2[:, 2] = -0.5
+    occ = s.trace_any(o2, d, np.full(n, 10.0, np.float32)).astype(bool)
+    assert np.array_equal(occ, solid)
