@@ -134,6 +134,7 @@ typedef enum PtMatParam {
     PT_MP_KD = 0, PT_MP_KS = 1, PT_MP_KR = 2, PT_MP_KT = 3, PT_MP_OPACITY = 4, PT_MP_ETA_RGB = 5, PT_MP_K_RGB = 6,
     PT_MP_SIGMA_A = 7, PT_MP_SIGMA_S = 8,
     PT_MP_SIGMA = 9, PT_MP_ROUGHNESS = 10, PT_MP_U_ROUGHNESS = 11, PT_MP_V_ROUGHNESS = 12, PT_MP_ETA = 13,
+    PT_MP_BUMP = 14,            /* "bumpmap" float texture (core/material.rs:46-87); -1 = none */
     PT_MP_COUNT = 16
 } PtMatParam;
 

@@ -40,13 +40,38 @@ struct MatEval {
     }
 };
 
+// bump() (core/material.rs:46-87): displacement texture `d` evaluated at the hit and at two shifted points; the shading
+// geometry is rebuilt with set_shading_geometry(.., false) (interaction.rs:228-249).
+static void bump_shading(const Scene &scene, int d, const TexCtx &ctx, SurfaceInteraction &si) {
+    TexCtx e = ctx;
+    Float du = 0.5f * (std::fabs(ctx.dudx) + std::fabs(ctx.dudy));
+    if (du == 0.0f) du = 0.0005f;
+    e.p = si.p + si.sh_dpdu * du; e.uv = P2(si.uv.x + du, si.uv.y + 0.0f);
+    Float udisplace = scene.textures->eval(d, e).c[0];
+    Float dv = 0.5f * (std::fabs(ctx.dvdx) + std::fabs(ctx.dvdy));
+    if (dv == 0.0f) dv = 0.0005f;
+    e.p = si.p + si.sh_dpdv * dv; e.uv = P2(si.uv.x + 0.0f, si.uv.y + dv);
+    Float vdisplace = scene.textures->eval(d, e).c[0];
+    Float displace = scene.textures->eval(d, ctx).c[0];
+    V3 dpdu = si.sh_dpdu + si.sh_n * ((udisplace - displace) / du) + si.sh_dndu * displace;
+    V3 dpdv = si.sh_dpdv + si.sh_n * ((vdisplace - displace) / dv) + si.sh_dndv * displace;
+    si.sh_n = normalize(cross(dpdu, dpdv));
+    if (si.has_shape) {
+        if (si.shape_flip) si.sh_n = -si.sh_n;
+        si.sh_n = face_forward(si.sh_n, si.n);   // orientation_is_authoritative = false
+    }
+    si.sh_dpdu = dpdu; si.sh_dpdv = dpdv;
+}
+
 // Returns false when the material leaves `si.bsdf == None` (null surface, path.rs:124-129).
-static bool compute_scattering_functions(const Scene &scene, const SurfaceInteraction &si, BSDF &bsdf,
+static bool compute_scattering_functions(const Scene &scene, SurfaceInteraction &si, BSDF &bsdf,
                                          TabulatedBSSRDF *bssrdf = nullptr, bool *has_bssrdf = nullptr, const TexCtx *tctx = nullptr) {
     uint32_t mi = scene.prim_material[si.prim];
     if (mi == PT_NONE) return false;  // primitive.rs:168-170: no material => no bsdf
     const PtMaterial &m = scene.materials[mi];
     const MatEval E{scene, m, tctx};
+    // bump() modifies the caller's interaction in place (shading.n is what path.rs / estimate_direct read afterwards)
+    if (tctx && scene.textures && m.tex[PT_MP_BUMP] >= 0) bump_shading(scene, m.tex[PT_MP_BUMP], *tctx, si);   // every material: `if let Some(map) = bumpmap { bump(map, si) }`
     switch (m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);

@@ -66,6 +66,9 @@ struct SurfaceInteraction {
     P2 uv;
     V3 dpdu, dpdv;
     V3 sh_n, sh_dpdu, sh_dpdv;
+    V3 sh_dndu, sh_dndv;       // shading.dndu / dndv (bump mapping only)
+    bool has_shape = false;    // SurfaceInteraction.shape is Some (triangles; None for spheres, App. A #6)
+    bool shape_flip = false;   // shape.reverse_orientation ^ shape.transform_swapshandedness
     uint32_t prim = PT_NONE;
     uint32_t inst = PT_NONE;   // instance (TransformedPrimitive) the hit went through
     Float t = 0;
@@ -213,9 +216,11 @@ struct Scene {
         si.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
         si.dpdu = dpdu; si.dpdv = dpdv;
         si.sh_dpdu = dpdu; si.sh_dpdv = dpdv;
+        si.sh_dndu = V3(0, 0, 0); si.sh_dndv = V3(0, 0, 0);
         si.t = t; si.b[0] = b0; si.b[1] = b1; si.b[2] = b2;
         uint8_t fl = tri_flags[tri];
         bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) ^ ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
+        si.has_shape = with_shape; si.shape_flip = flip;
         V3 nn = normalize(cross(dp02, dp12));
         si.n = nn; si.sh_n = nn;
         si.wo = -r.d;  // triangle.rs:296 (not normalised)
@@ -235,6 +240,19 @@ struct Scene {
             V3 ts = cross(ss, ns);
             if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
             else coordinate_system(ns, ss, ts);
+            if (fl & PT_TRI_HAS_N) {  // dndu / dndv, triangle.rs:349-386
+                Float duv02x = uv[0].x - uv[2].x, duv02y = uv[0].y - uv[2].y, duv12x = uv[1].x - uv[2].x, duv12y = uv[1].y - uv[2].y;
+                V3 dn1 = N[i0] - N[i2], dn2 = N[i1] - N[i2];
+                Float det = duv02x * duv12y - duv02y * duv12x;
+                if (std::fabs(det) < 1.0e-8f) {
+                    V3 dn = cross(N[i2] - N[i0], N[i1] - N[i0]);
+                    if (length_squared(dn) != 0.0f) coordinate_system(dn, si.sh_dndu, si.sh_dndv);
+                } else {
+                    Float invdet = 1.0f / det;
+                    si.sh_dndu = (dn1 * duv12y - dn2 * duv02y) * invdet;
+                    si.sh_dndv = (dn1 * -duv12x + dn2 * duv02x) * invdet;
+                }
+            }
             if (fl & PT_TRI_REVERSE_ORIENTATION) ts = -ts;
             // set_shading_geometry(ss, ts, dndu, dndv, true)  interaction.rs:228-249
             si.sh_n = normalize(cross(ss, ts));
@@ -405,6 +423,7 @@ inline bool Scene::intersect(Ray &r, SurfaceInteraction &si, Counters &c) const 
                 ret.dpdu = xf_vector(i2w, si.dpdu); ret.dpdv = xf_vector(i2w, si.dpdv);
                 ret.sh_n = normalize(xf_normal_inv(w2i, si.sh_n));
                 ret.sh_dpdu = xf_vector(i2w, si.sh_dpdu); ret.sh_dpdv = xf_vector(i2w, si.sh_dpdv);
+                ret.sh_dndu = xf_normal_inv(w2i, si.sh_dndu); ret.sh_dndv = xf_normal_inv(w2i, si.sh_dndv);
                 ret.sh_n = face_forward(ret.sh_n, ret.n);
                 si = ret;
             }

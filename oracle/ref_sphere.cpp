@@ -129,6 +129,16 @@ bool Scene::sphere_intersect(uint32_t si, const Ray &r, Float &thit, SurfaceInte
     Float cos_phi = p_hit.x * inv_radius, sin_phi = p_hit.y * inv_radius;
     V3 dpdu(-S.phi_max * p_hit.y, S.phi_max * p_hit.x, 0.0f);
     V3 dpdv = V3(p_hit.z * cos_phi, p_hit.z * sin_phi, -S.radius * dm_sinf(theta)) * (S.theta_max - S.theta_min);
+    // dndu / dndv from the fundamental forms (sphere.rs:165-184)
+    V3 d2pduu = V3(p_hit.x, p_hit.y, 0.0f) * -S.phi_max * S.phi_max;
+    V3 d2pduv = V3(-sin_phi, cos_phi, 0.0f) * (S.theta_max - S.theta_min) * p_hit.z * S.phi_max;
+    V3 d2pdvv = V3(p_hit.x, p_hit.y, p_hit.z) * -(S.theta_max - S.theta_min) * (S.theta_max - S.theta_min);
+    Float E = dot(dpdu, dpdu), Fm = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+    V3 Nn = normalize(cross(dpdu, dpdv));
+    Float e = dot(Nn, d2pduu), f = dot(Nn, d2pduv), g = dot(Nn, d2pdvv);
+    Float inv_EGF2 = 1.0f / (E * G - Fm * Fm);
+    V3 dndu = dpdu * (f * Fm - e * G) * inv_EGF2 + dpdv * (e * Fm - f * E) * inv_EGF2;
+    V3 dndv = dpdu * (g * Fm - f * G) * inv_EGF2 + dpdv * (f * Fm - g * E) * inv_EGF2;
     V3 p_error = vabs(p_hit) * gamma(5);
     // SurfaceInteraction::new(.., shape = None): n = normalize(dpdu x dpdv), wo = normalize(-ray.d) (interaction.rs:186-216)
     V3 n = normalize(cross(dpdu, dpdv));
@@ -143,6 +153,8 @@ bool Scene::sphere_intersect(uint32_t si, const Ray &r, Float &thit, SurfaceInte
     ret.dpdu = xf_vector(o2w, dpdu); ret.dpdv = xf_vector(o2w, dpdv);
     ret.sh_n = normalize(xf_normal_inv(w2o, n));
     ret.sh_dpdu = xf_vector(o2w, dpdu); ret.sh_dpdv = xf_vector(o2w, dpdv);
+    ret.sh_dndu = xf_normal_inv(w2o, dndu); ret.sh_dndv = xf_normal_inv(w2o, dndv);
+    ret.has_shape = false; ret.shape_flip = false;
     ret.sh_n = face_forward(ret.sh_n, ret.n);
     out = ret;
     thit = t;

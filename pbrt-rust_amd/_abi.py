@@ -69,7 +69,7 @@ PT_TOP_INSTANCE = 0x80000000
 PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_CYLINDRICAL = range(4)
 PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
 (PT_MP_KD, PT_MP_KS, PT_MP_KR, PT_MP_KT, PT_MP_OPACITY, PT_MP_ETA_RGB, PT_MP_K_RGB, PT_MP_SIGMA_A, PT_MP_SIGMA_S,
- PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA) = range(14)
+ PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA, PT_MP_BUMP) = range(15)
 
 
 class PtTexture(C.Structure):

@@ -163,6 +163,8 @@ struct SurfaceInteraction {
     V3 dpdu;             // == shading.dpdu unless the mesh has N/S
     V3 sh_n, sh_dpdu;
     V3 dpdv; P2 uv;      // read by texture evaluation only (dead code elsewhere)
+    V3 sh_dpdv, sh_dndu, sh_dndv;   // shading.dpdv / dndu / dndv: bump mapping only
+    bool has_shape, shape_flip;     // SurfaceInteraction.shape is Some (triangles) / its reverse_orientation ^ swaps_handedness
     uint32_t prim;
 };
 // `with_shape` = the `s: Option<Arc<Shapes>>` argument (None inside Shape::pdf_wi, shape.rs:72).
@@ -177,10 +179,12 @@ PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, 
     float zabs = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
     si.p_error = V3(xabs, yabs, zabs) * gammaf(7);
     si.p = p0 * b0 + p1 * b1 + p2 * b2;
-    si.dpdu = dpdu; si.sh_dpdu = dpdu; si.dpdv = dpdv;
+    si.dpdu = dpdu; si.sh_dpdu = dpdu; si.dpdv = dpdv; si.sh_dpdv = dpdv;
+    si.sh_dndu = V3(0.0f, 0.0f, 0.0f); si.sh_dndv = V3(0.0f, 0.0f, 0.0f);
     si.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);   // triangle.rs:266-268
     uint32_t fl = s.tri_flags[tri];
     bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
+    si.has_shape = with_shape; si.shape_flip = flip;
     V3 nn = normalize(cross(dp02, dp12));
     si.n = nn; si.sh_n = nn;
     si.wo = -ray_d;  // triangle.rs:296
@@ -199,13 +203,27 @@ PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, 
         V3 ts = cross(ss, ns);
         if (length_squared(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
         else coordinate_system(ns, ss, ts);
+        if (fl & PT_TRI_HAS_N) {  // dndu / dndv, triangle.rs:349-386 (read by bump mapping only)
+            const float duv02x = uv[0].x - uv[2].x, duv02y = uv[0].y - uv[2].y, duv12x = uv[1].x - uv[2].x, duv12y = uv[1].y - uv[2].y;
+            const V3 n0 = ld3(s.N, i0), n1 = ld3(s.N, i1), n2 = ld3(s.N, i2);
+            const V3 dn1 = n0 - n2, dn2 = n1 - n2;
+            const float det = duv02x * duv12y - duv02y * duv12x;
+            if (fabsf(det) < 1.0e-8f) {
+                const V3 dn = cross(n2 - n0, n1 - n0);
+                if (length_squared(dn) != 0.0f) coordinate_system(dn, si.sh_dndu, si.sh_dndv);
+            } else {
+                const float invdet = 1.0f / det;
+                si.sh_dndu = (dn1 * duv12y - dn2 * duv02y) * invdet;
+                si.sh_dndv = (dn1 * -duv12x + dn2 * duv02x) * invdet;
+            }
+        }
         if (fl & PT_TRI_REVERSE_ORIENTATION) ts = -ts;
         si.sh_n = normalize(cross(ss, ts));  // set_shading_geometry(.., true), interaction.rs:228-249
         if (with_shape) {
             if (flip) si.sh_n = -si.sh_n;
             si.n = face_forward(si.n, si.sh_n);
         }
-        si.sh_dpdu = ss;
+        si.sh_dpdu = ss; si.sh_dpdv = ts;
     }
 }
 PT_DEV float tri_area(V3 p0, V3 p1, V3 p2) { return 0.5f * length(cross(p1 - p0, p2 - p0)); }  // triangle.rs:550-554

@@ -122,6 +122,16 @@ PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceIn
     const float cos_phi = p_hit.x * inv_radius, sin_phi = p_hit.y * inv_radius;
     const V3 dpdu(-S.phi_max * p_hit.y, S.phi_max * p_hit.x, 0.0f);
     const V3 dpdv = V3(p_hit.z * cos_phi, p_hit.z * sin_phi, -S.radius * dm_sinf(theta)) * (S.theta_max - S.theta_min);
+    // dndu / dndv from the fundamental forms (sphere.rs:165-184); read by bump mapping only
+    const V3 d2pduu = V3(p_hit.x, p_hit.y, 0.0f) * -S.phi_max * S.phi_max;
+    const V3 d2pduv = V3(-sin_phi, cos_phi, 0.0f) * (S.theta_max - S.theta_min) * p_hit.z * S.phi_max;
+    const V3 d2pdvv = V3(p_hit.x, p_hit.y, p_hit.z) * -(S.theta_max - S.theta_min) * (S.theta_max - S.theta_min);
+    const float E = dot(dpdu, dpdu), Fm = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+    const V3 Nn = normalize(cross(dpdu, dpdv));
+    const float e = dot(Nn, d2pduu), f = dot(Nn, d2pduv), g = dot(Nn, d2pdvv);
+    const float inv_EGF2 = 1.0f / (E * G - Fm * Fm);
+    const V3 dndu = dpdu * (f * Fm - e * G) * inv_EGF2 + dpdv * (e * Fm - f * E) * inv_EGF2;
+    const V3 dndv = dpdu * (g * Fm - f * G) * inv_EGF2 + dpdv * (f * Fm - g * E) * inv_EGF2;
     const V3 p_error = vabs(p_hit) * gammaf(5);
     const V3 n = normalize(cross(dpdu, dpdv));
     const V3 wo = normalize(-d_obj);
@@ -131,7 +141,9 @@ PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceIn
     si.wo = normalize(xf_vector(o2w, wo));
     si.dpdu = xf_vector(o2w, dpdu); si.dpdv = xf_vector(o2w, dpdv);
     si.sh_n = face_forward(normalize(xf_normal_inv(w2o, n)), si.n);
-    si.sh_dpdu = si.dpdu;
+    si.sh_dpdu = si.dpdu; si.sh_dpdv = si.dpdv;
+    si.sh_dndu = xf_normal_inv(w2o, dndu); si.sh_dndv = xf_normal_inv(w2o, dndv);
+    si.has_shape = false; si.shape_flip = false;
     return true;
 }
 

@@ -543,7 +543,8 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
             si.wo = normalize(xf_vector(i2w, si.wo));
             si.dpdu = xf_vector(i2w, si.dpdu); si.dpdv = xf_vector(i2w, si.dpdv);
             si.sh_n = face_forward(normalize(xf_normal_inv(w2i, si.sh_n)), si.n);
-            si.sh_dpdu = xf_vector(i2w, si.sh_dpdu);
+            si.sh_dpdu = xf_vector(i2w, si.sh_dpdu); si.sh_dpdv = xf_vector(i2w, si.sh_dpdv);
+            si.sh_dndu = xf_normal_inv(w2i, si.sh_dndu); si.sh_dndv = xf_normal_inv(w2i, si.sh_dndv);
         }
         return;
     }
@@ -788,6 +789,24 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         rdiff = camera_ray_differentials(rc, ps.pfilm_x[pid], ps.pfilm_y[pid], plens_u, ro, rd);
                     }
                     const TexCtx tctx = compute_differentials(si, rdiff);
+                    if (mi != PT_NONE && s.materials[mi].tex[PT_MP_BUMP] >= 0) {   // bump() (core/material.rs:46-87)
+                        const int dtex = s.materials[mi].tex[PT_MP_BUMP];
+                        TexCtx e = tctx;
+                        float du = 0.5f * (fabsf(tctx.dudx) + fabsf(tctx.dudy));
+                        if (du == 0.0f) du = 0.0005f;
+                        e.p = si.p + si.sh_dpdu * du; e.uv = P2(si.uv.x + du, si.uv.y + 0.0f);
+                        const float udisplace = tex_eval(s, dtex, e).r;
+                        float dv = 0.5f * (fabsf(tctx.dvdx) + fabsf(tctx.dvdy));
+                        if (dv == 0.0f) dv = 0.0005f;
+                        e.p = si.p + si.sh_dpdv * dv; e.uv = P2(si.uv.x + 0.0f, si.uv.y + dv);
+                        const float vdisplace = tex_eval(s, dtex, e).r;
+                        const float displace = tex_eval(s, dtex, tctx).r;
+                        const V3 bdpdu = si.sh_dpdu + si.sh_n * ((udisplace - displace) / du) + si.sh_dndu * displace;
+                        const V3 bdpdv = si.sh_dpdv + si.sh_n * ((vdisplace - displace) / dv) + si.sh_dndv * displace;
+                        si.sh_n = normalize(cross(bdpdu, bdpdv));   // set_shading_geometry(.., false), interaction.rs:228-249
+                        if (si.has_shape) { if (si.shape_flip) si.sh_n = -si.sh_n; si.sh_n = face_forward(si.sh_n, si.n); }
+                        si.sh_dpdu = bdpdu; si.sh_dpdv = bdpdv;
+                    }
                     const TexMatEval E{s, tctx};
                     has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, E);
                 } else has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, ConstMatEval());

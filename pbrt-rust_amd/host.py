@@ -200,7 +200,7 @@ class SceneBuilder:
         slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), opacity=(A.PT_MP_OPACITY, 0),
                      eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0),
                      sigma=(A.PT_MP_SIGMA, 1), roughness=(A.PT_MP_ROUGHNESS, 1), uroughness=(A.PT_MP_U_ROUGHNESS, 1),
-                     vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1))
+                     vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1), bumpmap=(A.PT_MP_BUMP, 1))
         for key in list(kw):
             if isinstance(kw[key], str) and key in slots:
                 slot, is_float = slots[key]

@@ -258,7 +258,7 @@ def test_image(w=20, h=12, seed=5):
     return np.clip(img + 0.05 * rng.random((h, w, 3)), 0.0, 1.0).astype(F)
 
 
-def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False):
+def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False, bump=False):
     """image map (EWA or trilinear MIPMap, uv and planar mappings), checkerboard (closed-form and point
     sampled, 2-D and 3-D), scale, mix, bilerp, uv, a float image texture driving a roughness, spherical + cylindrical
     mappings; camera-ray differentials drive the filtering at the first hit, later bounces use zero-width lookups."""
@@ -284,13 +284,18 @@ def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False):
     b.texture("rough", "float", "imagemap", pixels=img, scale=0.3, uscale=2.0, vscale=2.0, trilinear=True)
     b.texture("sph", "color", "imagemap", pixels=img, mapping="spherical")
     b.texture("cyl", "color", "checkerboard", mapping="cylindrical", tex1=(0.9, 0.9, 0.2), tex2=(0.1, 0.2, 0.7), aamode="closedform")
-    b.material("matte", Kd="check")
+    bm = lambda name: dict(bumpmap=name) if bump else {}
+    if bump:   # displacement textures for bump() (core/material.rs:46-87)
+        b.texture("bumpimg", "float", "imagemap", pixels=img, scale=0.08, uscale=6.0, vscale=6.0, trilinear=True)
+        b.texture("bumpchk", "float", "checkerboard", mapping="planar", v1=(2.0, 0.0, 0.0), v2=(0.0, 0.0, 2.0), tex1=0.03, tex2=0.0, aamode="closedform")
+        b.texture("bumpmix", "float", "mix", tex1="bumpimg", tex2=0.02, amount=0.3)
+    b.material("matte", Kd="check", **bm("bumpchk"))
     P, I = quad((-8.0, -1.0, -8.0), (-8.0, -1.0, 8.0), (8.0, -1.0, 8.0), (8.0, -1.0, -8.0))
     b.trianglemesh(P, I, UV=np.array([[0, 0], [0, 1], [1, 1], [1, 0]], dtype=F))
-    b.attribute_begin(); b.material("plastic", Kd="mixed", Ks=(0.3, 0.3, 0.3), roughness="rough"); b.translate(-2.0, 0.0, 0.5); b.sphere(radius=1.0); b.attribute_end()
-    b.attribute_begin(); b.material("matte", Kd="check3"); b.translate(0.3, -0.2, -0.5)
+    b.attribute_begin(); b.material("plastic", Kd="mixed", Ks=(0.3, 0.3, 0.3), roughness="rough", **bm("bumpimg")); b.translate(-2.0, 0.0, 0.5); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.material("matte", Kd="check3", **bm("bumpmix")); b.translate(0.3, -0.2, -0.5)
     P, I, N = displaced_sphere(12, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
-    b.attribute_begin(); b.material("uber", Kd="scaled", Ks=(0.2, 0.2, 0.2), opacity=(1, 1, 1)); b.translate(2.3, 0.0, 0.8); b.sphere(radius=1.0); b.attribute_end()
+    b.attribute_begin(); b.material("uber", Kd="scaled", Ks=(0.2, 0.2, 0.2), opacity=(1, 1, 1), **bm("bumpimg")); b.translate(2.3, 0.0, 0.8); b.sphere(radius=1.0); b.attribute_end()
     b.attribute_begin(); b.translate(0.0, 1.8, -2.5); b.material("matte", Kd="sph"); b.sphere(radius=0.8); b.attribute_end()
     b.attribute_begin(); b.translate(-3.2, 0.6, -2.0); b.material("matte", Kd="cyl"); b.sphere(radius=0.9); b.attribute_end()
     return b
