@@ -86,8 +86,8 @@ typedef enum PtMaterialType {
 /* ---- textures (core/texture.rs, textures/*.rs, core/mipmap.rs) --------------------------------------
  * A texture is a node of a tree, exactly as the reference's Arc<Textures<..>> values: children are texture indices
  * (constants are ConstantTexture nodes, as TextureParams::get_*texture creates them, paramset.rs:500-600). Float-valued
- * textures use component 0. Not covered yet: noise textures (fbm, wrinkled, windy, marble, dots), bump maps, alpha masks,
- * ImageWrap::Clamp (the reference's texel() clamps to `u` instead of `u - 1`, mipmap.rs:305). */
+ * textures use component 0. Not covered: ImageWrap::Clamp (the reference's texel() clamps to `u` instead of `u - 1`,
+ * mipmap.rs:305). */
 typedef enum PtTextureType {
     PT_TEX_CONSTANT = 0,        /* textures/constant.rs                                  value[]                 */
     PT_TEX_SCALE = 1,           /* textures/scaled.rs:30-33    tex1 * tex2               child[0], child[1]      */
@@ -96,7 +96,12 @@ typedef enum PtTextureType {
     PT_TEX_CHECKERBOARD3D = 4,  /* textures/checkerboard.rs:87-100  world_to_texture     child[0], child[1]      */
     PT_TEX_IMAGEMAP = 5,        /* textures/imagemap.rs:167-176 + MIPMap::lookup2        mapping, image          */
     PT_TEX_UV = 6,              /* textures/uv.rs:21-33                                  mapping                 */
-    PT_TEX_BILERP = 7           /* textures/biler.rs:27-36                               mapping, v00..v11       */
+    PT_TEX_BILERP = 7,          /* textures/biler.rs:27-36                               mapping, v00..v11       */
+    PT_TEX_FBM = 8,             /* textures/fbm.rs:22-29        fbm(p, dpdx, dpdy, omega, octaves)   world_to_texture   */
+    PT_TEX_WRINKLED = 9,        /* textures/wrinkled.rs:22-29   turbulence(..)                       world_to_texture   */
+    PT_TEX_WINDY = 10,          /* textures/windy.rs:20-30      |fbm(.1p, 3 oct)| * fbm(p, 6 oct)    world_to_texture   */
+    PT_TEX_MARBLE = 11,         /* textures/marble.rs:36-65     spline(sin(p.y*scale + variation*fbm)) world_to_texture */
+    PT_TEX_DOTS = 12            /* textures/dots.rs:28-55       mapping; child[0] = outside, child[1] = inside           */
 } PtTextureType;
 typedef enum PtMappingType { PT_MAP_UV = 0, PT_MAP_PLANAR = 1, PT_MAP_SPHERICAL = 2, PT_MAP_CYLINDRICAL = 3 } PtMappingType;  /* core/texture.rs:112-270 */
 typedef enum PtImageWrap { PT_WRAP_REPEAT = 0, PT_WRAP_BLACK = 1 } PtImageWrap;                                             /* core/mipmap.rs:52 */
@@ -117,6 +122,8 @@ typedef struct PtTexture {
     uint32_t trilinear;         /* "trilinear" (false => EWA) */
     float max_anisotropy;       /* "maxanisotropy" (8) */
     uint32_t wrap;              /* PtImageWrap */
+    /* noise textures: "octaves" (8), "roughness" = omega (0.5); marble "scale" (1), "variation" (0.2) */
+    uint32_t octaves; float omega, marble_scale, variation;
 } PtTexture;
 
 /* MIPMap pyramid (core/mipmap.rs:75-198), built by the host exactly as MIPMap::new does (power-of-two resampling with the

@@ -8,6 +8,7 @@
 // log2 goes through the shared deterministic ln (dm_logf's double core) like every other transcendental.
 #pragma once
 #include "ref_scene.h"
+#include "../include/pt_noise_perm.h"
 
 namespace ref {
 
@@ -106,6 +107,55 @@ inline RGB mip_lookup2(const ImagePyramid &im, const PtTexture &T, const Float *
     return rgb_lerp(lod - (Float)ilod, mip_ewa(im, (int)T.wrap, lut, ilod, st, dst0, dst1), mip_ewa(im, (int)T.wrap, lut, ilod + 1, st, dst0, dst1));
 }
 
+// ---- Perlin noise (core/texture.rs:311-438). Quirks kept: `x.floor() as usize` saturates negative cells to 0 (so dx can be
+// negative), turbulence adds `o + |noise|` per octave, fbm uses ln(x) * 1.442695 while turbulence uses f32::log2.
+static const uint8_t kNoisePerm[512] = {PT_NOISE_PERM_VALUES};
+inline Float noise_grad(uint64_t x, uint64_t y, uint64_t z, Float dx, Float dy, Float dz) {
+    uint32_t h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15u;
+    Float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+    Float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+inline Float noise_weight(Float t) { Float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+inline Float flerp(Float t, Float a, Float b) { return (1.0f - t) * a + t * b; }
+inline Float noise3(Float x, Float y, Float z) {
+    uint64_t ix = f2u_sat(std::floor(x)), iy = f2u_sat(std::floor(y)), iz = f2u_sat(std::floor(z));
+    Float dx = x - (Float)ix, dy = y - (Float)iy, dz = z - (Float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    Float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    Float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    Float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    Float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    Float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    Float x00 = flerp(wx, w000, w100), x10 = flerp(wx, w010, w110), x01 = flerp(wx, w001, w101), x11 = flerp(wx, w011, w111);
+    Float y0 = flerp(wy, x00, x10), y1 = flerp(wy, x01, x11);
+    return flerp(wz, y0, y1);
+}
+inline Float smooth_step(Float mn, Float mx, Float value) { Float v = clampv((value - mn) / (mx - mn), 0.0f, 1.0f); return v * v * (-2.0f * v + 3.0f); }
+inline Float noise_fbm(V3 p, V3 dpdx, V3 dpdy, Float omega, uint32_t max_octaves) {
+    Float len2 = fmax_(length_squared(dpdx), length_squared(dpdy));
+    Float n = clampv(-1.0f - 0.5f * (dm_logf(len2) * 1.442695040888963387f), 0.0f, (Float)max_octaves);
+    uint64_t nint = f2u_sat(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint64_t i = 0; i < nint; ++i) { V3 q = p * lambda; sum += o * noise3(q.x, q.y, q.z); lambda *= 1.99f; o *= omega; }
+    Float npartial = n - (Float)nint;
+    V3 q = p * lambda;
+    sum += o * smooth_step(0.3f, 0.7f, npartial) * noise3(q.x, q.y, q.z);
+    return sum;
+}
+inline Float noise_turbulence(V3 p, V3 dpdx, V3 dpdy, Float omega, uint32_t max_octaves) {
+    Float len2 = fmax_(length_squared(dpdx), length_squared(dpdy));
+    Float n = clampv(-1.0f - 0.5f * dm_log2f(len2), 0.0f, (Float)max_octaves);
+    uint64_t nint = f2u_sat(std::floor(n));
+    Float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint64_t i = 0; i < nint; ++i) { V3 q = p * lambda; sum += o + std::fabs(noise3(q.x, q.y, q.z)); lambda *= 1.99f; o *= omega; }
+    Float npartial = n - (Float)nint;
+    V3 q = p * lambda;
+    sum += o + flerp(smooth_step(0.3f, 0.7f, npartial), 0.2f, std::fabs(noise3(q.x, q.y, q.z)));
+    for (uint64_t i = nint; i < max_octaves; ++i) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+
 struct TextureSet {
     std::vector<PtTexture> tex;
     std::vector<ImagePyramid> images;
@@ -183,6 +233,42 @@ struct TextureSet {
             P2 dstdx, dstdy;
             P2 st = map2d(T, c, dstdx, dstdy);
             return RGB(st.x - std::floor(st.x), st.y - std::floor(st.y), 0.0f);
+        }
+        case PT_TEX_FBM: case PT_TEX_WRINKLED: case PT_TEX_WINDY: case PT_TEX_MARBLE: {  // IdentityMapping3D (texture.rs:281-297)
+            M4 w2t = m4_from(T.world_to_texture);
+            V3 dpdx = xf_vector(w2t, c.dpdx), dpdy = xf_vector(w2t, c.dpdy), p = xf_point(w2t, c.p);
+            if (T.type == PT_TEX_FBM) return RGB(noise_fbm(p, dpdx, dpdy, T.omega, T.octaves));
+            if (T.type == PT_TEX_WRINKLED) return RGB(noise_turbulence(p, dpdx, dpdy, T.omega, T.octaves));
+            if (T.type == PT_TEX_WINDY) {
+                Float wstrength = noise_fbm(p * 0.1f, dpdx * 0.1f, dpdy * 0.1f, 0.5f, 3);
+                Float wheight = noise_fbm(p, dpdx, dpdy, 0.5f, 6);
+                return RGB(std::fabs(wstrength) * wheight);
+            }
+            static const Float Cm[9][3] = {{0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.5f, 0.5f, 0.5f}, {0.6f, 0.59f, 0.58f},
+                                           {0.58f, 0.58f, 0.6f}, {0.58f, 0.58f, 0.6f}, {0.2f, 0.2f, 0.33f}, {0.58f, 0.58f, 0.6f}};
+            p = p * T.marble_scale;
+            Float fb = noise_fbm(p, dpdx * T.marble_scale, dpdy * T.marble_scale, T.omega, T.octaves);
+            Float marble = p.y + T.variation * fb;
+            Float t = 0.5f + 0.5f * dm_sinf(marble);
+            uint64_t first = std::min<uint64_t>(5, f2u_sat(std::floor(t * 6.0f)));
+            RGB c0(Cm[first][0], Cm[first][1], Cm[first][2]), c1(Cm[first + 1][0], Cm[first + 1][1], Cm[first + 1][2]);
+            RGB c2(Cm[first + 2][0], Cm[first + 2][1], Cm[first + 2][2]), c3(Cm[first + 3][0], Cm[first + 3][1], Cm[first + 3][2]);
+            RGB s0 = c0 * (1.0f - t) + c1 * t, s1 = c1 * (1.0f - t) + c2 * t, s2 = c2 * (1.0f - t) + c3 * t;
+            s0 = s0 * (1.0f - t) + s1 * t; s1 = s1 * (1.0f - t) + s2 * t;
+            return (s0 * (1.0f - t) + s1 * t) * 1.5f;
+        }
+        case PT_TEX_DOTS: {
+            P2 dstdx, dstdy;
+            P2 st = map2d(T, c, dstdx, dstdy);
+            uint64_t scell = f2u_sat(std::floor(st.x + 0.5f)), tcell = f2u_sat(std::floor(st.y + 0.5f));
+            if (noise3((Float)scell + 0.5f, (Float)tcell + 0.5f, 0.5f) > 0.0f) {
+                const Float radius = 0.35f, max_shift = 0.5f - radius;
+                Float scenter = (Float)scell + max_shift * noise3((Float)scell + 1.5f, (Float)tcell + 2.8f, 0.5f);
+                Float tcenter = (Float)tcell + max_shift * noise3((Float)scell + 4.5f, (Float)tcell + 9.8f, 0.5f);
+                Float ds = st.x - scenter, dt = st.y - tcenter;
+                if (ds * ds + dt * dt < radius * radius) return eval(T.child[1], c);
+            }
+            return eval(T.child[0], c);
         }
         case PT_TEX_BILERP: {
             P2 dstdx, dstdy;

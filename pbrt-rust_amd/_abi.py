@@ -65,7 +65,8 @@ class PtInstance(C.Structure):
 PT_TOP_INSTANCE = 0x80000000
 
 
-(PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD2D, PT_TEX_CHECKERBOARD3D, PT_TEX_IMAGEMAP, PT_TEX_UV, PT_TEX_BILERP) = range(8)
+(PT_TEX_CONSTANT, PT_TEX_SCALE, PT_TEX_MIX, PT_TEX_CHECKERBOARD2D, PT_TEX_CHECKERBOARD3D, PT_TEX_IMAGEMAP, PT_TEX_UV, PT_TEX_BILERP,
+ PT_TEX_FBM, PT_TEX_WRINKLED, PT_TEX_WINDY, PT_TEX_MARBLE, PT_TEX_DOTS) = range(13)
 PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_CYLINDRICAL = range(4)
 PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
 (PT_MP_KD, PT_MP_KS, PT_MP_KR, PT_MP_KT, PT_MP_OPACITY, PT_MP_ETA_RGB, PT_MP_K_RGB, PT_MP_SIGMA_A, PT_MP_SIGMA_S,
@@ -75,7 +76,8 @@ PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
 class PtTexture(C.Structure):
     _fields_ = [("type", u32), ("child", C.c_int32 * 3), ("value", f32 * 3), ("v00", f32 * 3), ("v01", f32 * 3), ("v10", f32 * 3), ("v11", f32 * 3),
                 ("mapping", u32), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32), ("vs", f32 * 3), ("vt", f32 * 3),
-                ("world_to_texture", f32 * 16), ("aa_closedform", u32), ("image", u32), ("trilinear", u32), ("max_anisotropy", f32), ("wrap", u32)]
+                ("world_to_texture", f32 * 16), ("aa_closedform", u32), ("image", u32), ("trilinear", u32), ("max_anisotropy", f32), ("wrap", u32),
+                ("octaves", u32), ("omega", f32), ("marble_scale", f32), ("variation", f32)]
 
 
 class PtImage(C.Structure):

@@ -515,7 +515,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     }
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const PtTexture &t = d->textures[i];
-        if (t.type > PT_TEX_BILERP) return fail(PT_ERR_UNSUPPORTED, "texture type not implemented");
+        if (t.type > PT_TEX_DOTS) return fail(PT_ERR_UNSUPPORTED, "texture type not implemented");
         for (int k = 0; k < 3; ++k) if (t.child[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "texture child index out of range");
         if (t.type == PT_TEX_IMAGEMAP) {
             if (!d->images || t.image >= d->n_images) return fail(PT_ERR_INVALID_ARG, "image texture without an image");
@@ -526,7 +526,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if (t.wrap > PT_WRAP_BLACK) return fail(PT_ERR_UNSUPPORTED, "ImageWrap::Clamp is not implemented");
             if (!t.trilinear && !d->ewa_weight_lut) return fail(PT_ERR_INVALID_ARG, "EWA image texture without ewa_weight_lut");
         }
-        if ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D) && (t.child[0] < 0 || t.child[1] < 0)) return fail(PT_ERR_INVALID_ARG, "texture node needs two children");
+        if ((t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D || t.type == PT_TEX_DOTS) && (t.child[0] < 0 || t.child[1] < 0)) return fail(PT_ERR_INVALID_ARG, "texture node needs two children");
         if (t.type == PT_TEX_MIX && (t.child[0] < 0 || t.child[1] < 0 || t.child[2] < 0)) return fail(PT_ERR_INVALID_ARG, "mix texture needs three children");
     }
     for (const int32_t *arr : {d->tri_alpha, d->tri_shadow_alpha})
@@ -722,7 +722,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
                 while (!st.empty()) {
                     Fr &f = st.back();
                     const PtTexture &t = d->textures[f.node];
-                    const int nchild = (t.type == PT_TEX_MIX) ? 3 : (t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D) ? 2 : 0;
+                    const int nchild = (t.type == PT_TEX_MIX) ? 3 : (t.type == PT_TEX_SCALE || t.type == PT_TEX_CHECKERBOARD2D || t.type == PT_TEX_CHECKERBOARD3D || t.type == PT_TEX_DOTS) ? 2 : 0;
                     if (f.next < nchild) { const int c = t.child[f.next++]; st.push_back({c, 0}); if (++guard > 4096 || st.size() > 64) return bail(fail(PT_ERR_INVALID_ARG, "texture graph too deep or cyclic")); continue; }
                     prog.push_back((uint32_t)f.node);
                     depth += 1 - nchild; max_depth = std::max(max_depth, depth + nchild);

@@ -7,6 +7,7 @@
 // evaluates all of its children and selects/blends afterwards (textures are pure functions, so the value is identical).
 #pragma once
 #include "dev_scene.h"
+#include "../../include/pt_noise_perm.h"
 
 namespace ptd {
 
@@ -137,6 +138,57 @@ PT_DEV P2 tex_map2d(const PtTexture &T, const TexCtx &c, P2 &dstdx, P2 &dstdy) {
     if (dstdy.y > 0.5f) dstdy.y = 1.0f - dstdy.y; else if (dstdy.y < -0.5f) dstdy.y = -(dstdy.y + 1.0f);
     return st;
 }
+// ---- Perlin noise (core/texture.rs:311-438); quirks as in the oracle: saturating `floor() as usize`, turbulence's `o + |n|`,
+// fbm's ln(x) * 1.442695 vs turbulence's f32::log2.
+__device__ const uint8_t kNoisePerm[512] = {PT_NOISE_PERM_VALUES};
+PT_DEV float noise_grad(uint32_t x, uint32_t y, uint32_t z, float dx, float dy, float dz) {
+    const uint32_t h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z] & 15u;
+    const float u = (h < 8u || h == 12u || h == 13u) ? dx : dy;
+    const float v = (h < 4u || h == 12u || h == 13u) ? dy : dz;
+    return ((h & 1u) ? -u : u) + ((h & 2u) ? -v : v);
+}
+PT_DEV float noise_weight(float t) { const float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }
+PT_DEV float flerp(float t, float a, float b) { return (1.0f - t) * a + t * b; }
+PT_DEV uint64_t f2u64_sat(float f) { if (!(f > 0.0f)) return 0ull; if (f >= 18446744073709551616.0f) return ~0ull; return (uint64_t)f; }
+__device__ __noinline__ float noise3(float x, float y, float z) {
+    const uint64_t ux = f2u64_sat(floorf(x)), uy = f2u64_sat(floorf(y)), uz = f2u64_sat(floorf(z));
+    const float dx = x - (float)ux, dy = y - (float)uy, dz = z - (float)uz;
+    const uint32_t ix = (uint32_t)(ux & 255ull), iy = (uint32_t)(uy & 255ull), iz = (uint32_t)(uz & 255ull);
+    const float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    const float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    const float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    const float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    const float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+    const float x00 = flerp(wx, w000, w100), x10 = flerp(wx, w010, w110), x01 = flerp(wx, w001, w101), x11 = flerp(wx, w011, w111);
+    const float y0 = flerp(wy, x00, x10), y1 = flerp(wy, x01, x11);
+    return flerp(wz, y0, y1);
+}
+PT_DEV float pclamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // pbrt.rs clamp (NaN passes through)
+PT_DEV float smooth_step(float mn, float mx, float value) { const float v = pclamp((value - mn) / (mx - mn), 0.0f, 1.0f); return v * v * (-2.0f * v + 3.0f); }
+PT_DEV float noise_fbm(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves) {
+    const float len2 = maxf(length_squared(dpdx), length_squared(dpdy));
+    const float n = pclamp(-1.0f - 0.5f * (dm_logf(len2) * 1.442695040888963387f), 0.0f, (float)max_octaves);
+    const uint64_t nint = f2u64_sat(floorf(n));
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint64_t i = 0; i < nint; ++i) { const V3 q = p * lambda; sum += o * noise3(q.x, q.y, q.z); lambda *= 1.99f; o *= omega; }
+    const float npartial = n - (float)nint;
+    const V3 q = p * lambda;
+    sum += o * smooth_step(0.3f, 0.7f, npartial) * noise3(q.x, q.y, q.z);
+    return sum;
+}
+PT_DEV float noise_turbulence(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves) {
+    const float len2 = maxf(length_squared(dpdx), length_squared(dpdy));
+    const float n = pclamp(-1.0f - 0.5f * dm_log2f(len2), 0.0f, (float)max_octaves);
+    const uint64_t nint = f2u64_sat(floorf(n));
+    float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+    for (uint64_t i = 0; i < nint; ++i) { const V3 q = p * lambda; sum += o + fabsf(noise3(q.x, q.y, q.z)); lambda *= 1.99f; o *= omega; }
+    const float npartial = n - (float)nint;
+    const V3 q = p * lambda;
+    sum += o + flerp(smooth_step(0.3f, 0.7f, npartial), 0.2f, fabsf(noise3(q.x, q.y, q.z)));
+    for (uint64_t i = nint; i < (uint64_t)max_octaves; ++i) { sum += o * 0.2f; o *= omega; }
+    return sum;
+}
+
 PT_DEV bool tex_even_sum(float a, float b) { return ((f2i_sat(floorf(a)) + f2i_sat(floorf(b))) % 2) == 0; }   // isize % 2 == 0
 
 // Evaluate texture `root` (an index into s.textures) at the interaction. A real function (not inlined): build_bsdf
@@ -190,6 +242,49 @@ __device__ __noinline__ RGB tex_eval(const DeviceScene &s, int root, const TexCt
             P2 dstdx, dstdy;
             const P2 st = tex_map2d(T, c, dstdx, dstdy);
             v = RGB(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);
+            break;
+        }
+        case PT_TEX_FBM: case PT_TEX_WRINKLED: case PT_TEX_WINDY: case PT_TEX_MARBLE: {  // IdentityMapping3D (texture.rs:281-297)
+            M4 w2t; for (int i = 0; i < 16; ++i) w2t.m[i] = T.world_to_texture[i];
+            const V3 dpdx = xf_vector(w2t, c.dpdx), dpdy = xf_vector(w2t, c.dpdy);
+            V3 p = xf_point(w2t, c.p);
+            if (T.type == PT_TEX_FBM) v = RGB(noise_fbm(p, dpdx, dpdy, T.omega, T.octaves));
+            else if (T.type == PT_TEX_WRINKLED) v = RGB(noise_turbulence(p, dpdx, dpdy, T.omega, T.octaves));
+            else if (T.type == PT_TEX_WINDY) {
+                const float wstrength = noise_fbm(p * 0.1f, dpdx * 0.1f, dpdy * 0.1f, 0.5f, 3u);
+                const float wheight = noise_fbm(p, dpdx, dpdy, 0.5f, 6u);
+                v = RGB(fabsf(wstrength) * wheight);
+            } else {
+                p = p * T.marble_scale;
+                const float fb = noise_fbm(p, dpdx * T.marble_scale, dpdy * T.marble_scale, T.omega, T.octaves);
+                const float marble = p.y + T.variation * fb;
+                const float t = 0.5f + 0.5f * dm_sinf(marble);
+                const uint64_t f6 = f2u64_sat(floorf(t * 6.0f));
+                const int first = (int)(f6 < 5ull ? f6 : 5ull);
+                auto Cm = [](int i) -> RGB {   // marble.rs:10-14
+                    return (i == 3) ? RGB(0.5f, 0.5f, 0.5f) : (i == 4) ? RGB(0.6f, 0.59f, 0.58f) : (i == 7) ? RGB(0.2f, 0.2f, 0.33f) : RGB(0.58f, 0.58f, 0.6f);
+                };
+                const RGB c0 = Cm(first), c1 = Cm(first + 1), c2 = Cm(first + 2), c3 = Cm(first + 3);
+                RGB s0 = c0 * (1.0f - t) + c1 * t, s1 = c1 * (1.0f - t) + c2 * t;
+                const RGB s2 = c2 * (1.0f - t) + c3 * t;
+                s0 = s0 * (1.0f - t) + s1 * t; s1 = s1 * (1.0f - t) + s2 * t;
+                v = (s0 * (1.0f - t) + s1 * t) * 1.5f;
+            }
+            break;
+        }
+        case PT_TEX_DOTS: {
+            const RGB inside = stk[--sp], outside = stk[--sp];
+            P2 dstdx, dstdy;
+            const P2 st = tex_map2d(T, c, dstdx, dstdy);
+            const uint64_t scell = f2u64_sat(floorf(st.x + 0.5f)), tcell = f2u64_sat(floorf(st.y + 0.5f));
+            v = outside;
+            if (noise3((float)scell + 0.5f, (float)tcell + 0.5f, 0.5f) > 0.0f) {
+                const float radius = 0.35f, max_shift = 0.5f - radius;
+                const float scenter = (float)scell + max_shift * noise3((float)scell + 1.5f, (float)tcell + 2.8f, 0.5f);
+                const float tcenter = (float)tcell + max_shift * noise3((float)scell + 4.5f, (float)tcell + 9.8f, 0.5f);
+                const float ds = st.x - scenter, dt = st.y - tcenter;
+                if (ds * ds + dt * dt < radius * radius) v = inside;
+            }
             break;
         }
         default: {  // PT_TEX_BILERP

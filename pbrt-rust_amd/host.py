@@ -306,8 +306,17 @@ class SceneBuilder:
             t.type = A.PT_TEX_BILERP; self._mapping(t, kw)
             for nm, dv in (("v00", 0.0), ("v01", 1.0), ("v10", 0.0), ("v11", 1.0)):
                 v = kw.get(nm, dv); setattr(t, nm, (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v])))
+        elif cls in ("fbm", "wrinkled", "windy", "marble"):   # IdentityMapping3D(texture-to-world CTM)
+            if cls == "marble" and is_float: raise ValueError("marble textures are spectrum-only (textures/marble.rs:68-70)")
+            t.type = dict(fbm=A.PT_TEX_FBM, wrinkled=A.PT_TEX_WRINKLED, windy=A.PT_TEX_WINDY, marble=A.PT_TEX_MARBLE)[cls]
+            t.world_to_texture = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+            t.octaves = int(kw.get("octaves", 8)); t.omega = float(kw.get("roughness", 0.5))
+            t.marble_scale = float(kw.get("scale", 1.0)); t.variation = float(kw.get("variation", 0.2))
+        elif cls == "dots":
+            t.type = A.PT_TEX_DOTS; self._mapping(t, kw)
+            t.child = (C.c_int32 * 3)(self._child(kw.get("outside", 0.0), is_float), self._child(kw.get("inside", 1.0), is_float), -1)
         else:
-            raise NotImplementedError(f"texture class {cls!r} (noise textures are not restated yet)")
+            raise NotImplementedError(f"texture class {cls!r}")
         self.textures.append(t)
         (self.float_textures if is_float else self.spectrum_textures)[name] = len(self.textures) - 1
 

@@ -258,7 +258,7 @@ def test_image(w=20, h=12, seed=5):
     return np.clip(img + 0.05 * rng.random((h, w, 3)), 0.0, 1.0).astype(F)
 
 
-def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False, bump=False):
+def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False, bump=False, noise=False):
     """image map (EWA or trilinear MIPMap, uv and planar mappings), checkerboard (closed-form and point
     sampled, 2-D and 3-D), scale, mix, bilerp, uv, a float image texture driving a roughness, spherical + cylindrical
     mappings; camera-ray differentials drive the filtering at the first hit, later bounces use zero-width lookups."""
@@ -298,6 +298,22 @@ def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False, bump=False):
     b.attribute_begin(); b.material("uber", Kd="scaled", Ks=(0.2, 0.2, 0.2), opacity=(1, 1, 1), **bm("bumpimg")); b.translate(2.3, 0.0, 0.8); b.sphere(radius=1.0); b.attribute_end()
     b.attribute_begin(); b.translate(0.0, 1.8, -2.5); b.material("matte", Kd="sph"); b.sphere(radius=0.8); b.attribute_end()
     b.attribute_begin(); b.translate(-3.2, 0.6, -2.0); b.material("matte", Kd="cyl"); b.sphere(radius=0.9); b.attribute_end()
+    if noise:   # Perlin-noise textures (fbm, wrinkled, windy, marble, dots), as colours, a float roughness and a bump map
+        # texture space is shifted so that coordinates stay positive: the reference's noise() saturates negative lattice
+        # cells to 0 (`x.floor() as usize`), which makes the interpolation weights explode for negative inputs
+        b.attribute_begin(); b.translate(-20.0, -20.0, -20.0); b.scale(0.5, 0.5, 0.5)
+        b.texture("marb", "color", "marble", scale=2.0, variation=0.4, octaves=6)
+        b.texture("fbmf", "float", "fbm", octaves=5, roughness=0.6)
+        b.texture("wrk", "color", "wrinkled", octaves=4)
+        b.texture("wind", "float", "windy")
+        b.attribute_end()
+        b.texture("dots", "color", "dots", uscale=8.0, vscale=6.0, inside=(0.9, 0.1, 0.1), outside="marb")
+        b.texture("windbump", "float", "scale", tex1="wind", tex2=0.2)
+        b.texture("wrkscaled", "color", "scale", tex1="wrk", tex2=(0.35, 0.3, 0.25))
+        b.attribute_begin(); b.material("matte", Kd="marb"); b.translate(-1.0, 0.0, 2.6); b.sphere(radius=0.7); b.attribute_end()
+        b.attribute_begin(); b.material("plastic", Kd="dots", Ks=(0.2, 0.2, 0.2), roughness=0.2, bumpmap="windbump"); b.translate(1.0, -0.3, 2.8); b.sphere(radius=0.7); b.attribute_end()
+        b.attribute_begin(); b.material("matte", Kd="wrkscaled", sigma="fbmf"); b.translate(3.6, 0.2, -1.5)
+        P, I, N = displaced_sphere(10, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
     return b
 
 

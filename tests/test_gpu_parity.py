@@ -281,14 +281,15 @@ def test_sphere_area_lights_match_oracle(pkg, gpu, oracle):
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("trilinear,bump", [(False, False), (True, False), (False, True)])
-def test_textures_match_oracle(pkg, gpu, oracle, trilinear, bump):
+@pytest.mark.parametrize("trilinear,bump,noise", [(False, False, False), (True, False, False), (False, True, False), (True, False, True)])
+def test_textures_match_oracle(pkg, gpu, oracle, trilinear, bump, noise):
     """image maps (EWA / trilinear MIPMap; uv, planar, spherical mappings; repeat and black wrap; RGB and float
     memory), checkerboards (2-D closed form / point sampled over uv, planar and cylindrical mappings; 3-D), scale, mix,
     bilerp, uv -- camera-ray differentials at the first vertex, zero-width lookups afterwards."""
     # bump=True adds `bumpmap` float textures (image, closed-form checkerboard, mix) on a sphere, a mesh with shading
     # normals (dndu/dndv path) and the floor: bump() + set_shading_geometry (material.rs:46-87, interaction.rs:228-249)
-    sd, rp = pkg.scenes.textured(xres=96, yres=64, spp=8, trilinear=trilinear, bump=bump).world_end()
+    # noise=True adds the Perlin-noise textures: marble, fbm (as Oren-Nayar sigma), wrinkled, windy (as a bump map), dots
+    sd, rp = pkg.scenes.textured(xres=96, yres=64, spp=8, trilinear=trilinear, bump=bump, noise=noise).world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
