@@ -12,13 +12,13 @@ echo "== bench (headline config, unprofiled)"
 python3 $REPO/bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.json
 echo "== rocprofv3 --kernel-trace --stats (spp $PSPP)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PSPP --cpu-seconds 0 > $OUT/stats_bench.json 2> $OUT/stats.err
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PSPP --cpu-seconds 0 > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "== rocprofv3 --pmc FETCH_SIZE (spp $PPASS = one pass)"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 echo "== rocprofv3 --pmc WRITE_SIZE (spp $PPASS = one pass)"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
 echo "== rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum (spp $PPASS = one pass)"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_l2_bench.json 2> $OUT/pmc_l2.err
+timeout -k 5 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_l2_bench.json 2> $OUT/pmc_l2.err
 python3 $REPO/tools/summarize_profile.py $OUT $PPASS > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep the merged-back payload small: drop the raw traces, keep stats + summaries
