@@ -258,6 +258,9 @@ typedef struct PtSceneDesc {
     uint32_t env_width, env_height;
     const float *env_texels;       /* 3*env_width*env_height       */
     const float *env_importance;   /* (2*env_width)*(2*env_height) */
+    /* InfiniteAreaLight::power (infinite.rs:103-109) reads `map.lookup((.5,.5), .5)`: MIPMap level `levels - 2`, a host-side
+     * pyramid value (the texel itself for a 1x1 map). Used by the "power" light sample strategy only. */
+    float env_power_lookup[3];
 
     /* Accelerator: either prebuilt by the caller (reference order) or NULL => the
      * library builds the same SAH tree (accelerators/bvh.rs:200-375,662-693). */

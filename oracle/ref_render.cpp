@@ -608,6 +608,7 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
     if (d->n_lights) s.lights.assign(d->lights, d->lights + d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) if (s.lights[i].type == PT_LIGHT_INFINITE) s.infinite_lights.push_back(i);
     if (d->env_texels) {
+        s.env_power_lookup = RGB(d->env_power_lookup[0], d->env_power_lookup[1], d->env_power_lookup[2]);
         s.env_w = d->env_width; s.env_h = d->env_height;
         s.env_texels.resize((size_t)s.env_w * s.env_h);
         for (size_t i = 0; i < s.env_texels.size(); ++i) s.env_texels[i] = RGB(d->env_texels[3 * i], d->env_texels[3 * i + 1], d->env_texels[3 * i + 2]);

@@ -101,6 +101,7 @@ struct Scene {
     uint32_t env_w = 0, env_h = 0;
     std::vector<RGB> env_texels;
     std::vector<Float> env_importance;
+    RGB env_power_lookup;
     uint32_t max_node_prims = 4;
     std::vector<PtBVHNode> nodes;       // top-level accelerator
     std::vector<uint32_t> ordered;      // positions in the top-level list (see top_ref)

@@ -281,7 +281,7 @@ RGB LightSampler::power(uint32_t li) const {
     case PT_LIGHT_POINT: return c * 4.0f * PI;                            // point.rs:44-46
     case PT_LIGHT_SPOT: return c * 2.0f * PI * (1.0f - 0.5f * (L.cos_falloff_start + L.cos_total_width));  // spot.rs:64-66
     case PT_LIGHT_INFINITE: {                                             // infinite.rs:103-109 (lookup width .5 => top level)
-        RGB v = env_lookup(P2(0.5f, 0.5f));  // NOTE: exact only for 1x1 maps (top MIP level == the texel)
+        RGB v = scene->env_power_lookup;   // map.lookup((.5,.5), .5): MIP level `levels - 2`, computed by the host
         return v * world_radius * world_radius * PI;
     }
     }

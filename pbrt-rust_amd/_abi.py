@@ -96,7 +96,7 @@ class PtSceneDesc(C.Structure):
                 ("n_prims", u32), ("prim_shape", u32p), ("prim_material", u32p), ("prim_light", u32p),
                 ("n_materials", u32), ("materials", C.POINTER(PtMaterial)),
                 ("n_lights", u32), ("lights", C.POINTER(PtLight)),
-                ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp),
+                ("env_width", u32), ("env_height", u32), ("env_texels", fp), ("env_importance", fp), ("env_power_lookup", f32 * 3),
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
                 ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable)),

@@ -242,8 +242,7 @@ int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
                 case PT_LIGHT_POINT: p = c * 4.0f * kPi; break;                                           // point.rs:44-46
                 case PT_LIGHT_SPOT: p = c * 2.0f * kPi * (1.0f - 0.5f * (L.cos_falloff_start + L.cos_total_width)); break;  // spot.rs:64-66
                 case PT_LIGHT_INFINITE: {                                                                  // infinite.rs:103-109
-                    if (sc->env_w != 1 || sc->env_h != 1) return fail(PT_ERR_UNSUPPORTED, "power light distribution with an image environment map");
-                    p = RGB(sc->env_texel0[0], sc->env_texel0[1], sc->env_texel0[2]) * wr * wr * kPi; break;
+                    p = RGB(sc->env_texel0[0], sc->env_texel0[1], sc->env_texel0[2]) * wr * wr * kPi; break;   // env_texel0 = PtSceneDesc.env_power_lookup
                 }
                 default: break;
                 }
@@ -692,7 +691,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     UP(spheres, d->spheres, d->n_spheres); ds.n_spheres = d->n_spheres;
     UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
     if (d->n_lights) sc->host_lights.assign(d->lights, d->lights + d->n_lights);
-    if (d->env_texels) { sc->env_w = d->env_width; sc->env_h = d->env_height; for (int k = 0; k < 3; ++k) sc->env_texel0[k] = d->env_texels[k]; }
+    if (d->env_texels) { sc->env_w = d->env_width; sc->env_h = d->env_height; for (int k = 0; k < 3; ++k) sc->env_texel0[k] = d->env_power_lookup[k]; }
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
         for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }

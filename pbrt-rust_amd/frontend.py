@@ -1,0 +1,72 @@
+"""ctypes binding of libmi355front.so, the compiled .pbrt scene-file front end (include/mi355front.h)."""
+import ctypes as C
+import os
+import subprocess
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "frontend", "libmi355front.so")
+CLI_PATH = os.path.join(_HERE, "frontend", "mi355pbrt")
+
+
+def build(verbose=False):
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "frontend")], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-3000:]); print(r.stderr[-3000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libmi355front.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.ptf_parse_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ptf_parse_string.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ptf_last_error.restype = C.c_char_p
+        L.ptf_scene_desc.restype = C.POINTER(A.PtSceneDesc); L.ptf_scene_desc.argtypes = [C.c_void_p]
+        L.ptf_render_params.restype = C.POINTER(A.PtRenderParams); L.ptf_render_params.argtypes = [C.c_void_p]
+        L.ptf_output_filename.restype = C.c_char_p; L.ptf_output_filename.argtypes = [C.c_void_p]
+        L.ptf_scene_destroy.argtypes = [C.c_void_p]
+        L.ptf_write_pfm.argtypes = [C.c_char_p, C.c_int, C.c_int, A.fp]
+        _lib = L
+    return _lib
+
+
+class FrontScene:
+    """A parsed .pbrt scene; quacks like host.SceneData (desc()) so that runtime.Scene / the oracle binding accept it."""
+
+    def __init__(self, path=None, text=None, base_dir=None):
+        L = lib()
+        self.h = C.c_void_p()
+        if path is not None:
+            st = L.ptf_parse_file(os.fsencode(path), C.byref(self.h))
+        else:
+            st = L.ptf_parse_string(text.encode(), os.fsencode(base_dir) if base_dir else None, C.byref(self.h))
+        if st != A.PT_OK:
+            raise ValueError(L.ptf_last_error().decode(errors="replace"))
+
+    def desc(self):
+        return lib().ptf_scene_desc(self.h).contents
+
+    def render_params(self):
+        rp = A.PtRenderParams()
+        C.memmove(C.byref(rp), lib().ptf_render_params(self.h), C.sizeof(A.PtRenderParams))
+        return rp
+
+    def output_filename(self):
+        return lib().ptf_output_filename(self.h).decode()
+
+    def close(self):
+        if self.h:
+            lib().ptf_scene_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass

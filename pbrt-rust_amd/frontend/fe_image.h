@@ -1,0 +1,157 @@
+// fe_image.h -- image I/O and texture preparation of the .pbrt front end.
+//   PFM read / write (core/imageio.rs:288-328 write_image_pfm; reading restated from the same format)
+//   MIPMap::new (core/mipmap.rs:75-198): power-of-two resampling with Lanczos weights (:264-291) + 2x2 box levels
+//   ImageTexture::get_texture (textures/imagemap.rs:141-157): y flip, scale, inverse gamma (pbrt.rs:218-222)
+//   InfiniteAreaLight importance image (lights/infinite.rs:62-81) ; EWA weight table (mipmap.rs:40-50)
+// The same work is done by the Python host in pbrt-rust_amd/textures.py; this is the compiled-host version.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace fe {
+
+struct Image { int w = 0, h = 0; std::vector<float> rgb; };   // top row first, 3 floats per pixel (as read_image returns)
+
+inline Image read_pfm(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("image \"" + path + "\" not found");
+    std::string magic; int w = 0, h = 0; float scale = 0;
+    f >> magic >> w >> h >> scale; f.get();
+    const int nc = magic == "PF" ? 3 : (magic == "Pf" ? 1 : 0);
+    if (!nc || w <= 0 || h <= 0) throw std::runtime_error("\"" + path + "\": only PFM images can be read by this front end");
+    std::vector<float> raw((size_t)w * h * nc);
+    f.read((char *)raw.data(), (std::streamsize)(raw.size() * 4));
+    if (!f) throw std::runtime_error("PFM \"" + path + "\" is truncated");
+    if (scale > 0) for (float &v : raw) { unsigned char *b = (unsigned char *)&v; std::swap(b[0], b[3]); std::swap(b[1], b[2]); }   // big endian file
+    const float s = std::fabs(scale);
+    Image im; im.w = w; im.h = h; im.rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y)      // PFM rows are bottom-to-top
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) im.rgb[((size_t)(h - 1 - y) * w + x) * 3 + c] = raw[((size_t)y * w + x) * nc + (nc == 3 ? c : 0)] * s;
+    return im;
+}
+inline void write_pfm(const std::string &path, int w, int h, const float *rgb_top_first) {
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("cannot write \"" + path + "\"");
+    std::fprintf(fp, "PF\n%d %d\n-1\n", w, h);
+    for (int y = h - 1; y >= 0; --y) std::fwrite(rgb_top_first + (size_t)y * w * 3, 4, (size_t)w * 3, fp);
+    std::fclose(fp);
+}
+
+inline float inverse_gamma_correct(float v) { return v <= 0.04045f ? v * 1.0f / 12.92f : std::pow((v + 0.055f) * 1.0f / 1.055f, 2.4f); }
+inline float lanczos(float x, float tau) {  // texture.rs:311-321
+    x = std::fabs(x);
+    if (x < 1.0e-5f) return 1.0f;
+    if (x > 1.0f) return 0.0f;
+    x *= 3.14159265358979323846f;
+    const float s = std::sin(x * tau) / (x * tau);
+    return s * (std::sin(x) / x);
+}
+struct ResampleWeight { long first = 0; float w[4] = {0, 0, 0, 0}; };
+inline std::vector<ResampleWeight> resample_weights(int oldres, int newres) {  // mipmap.rs:264-291
+    std::vector<ResampleWeight> wt((size_t)newres);
+    const float fw = 2.0f;
+    for (int i = 0; i < newres; ++i) {
+        const float center = ((float)i + 0.5f) * (float)oldres / (float)newres;
+        wt[i].first = (long)std::floor((center - fw) + 0.5f);
+        for (int j = 0; j < 4; ++j) { const float pos = (float)wt[i].first + (float)j + 0.5f; wt[i].w[j] = lanczos((pos - center) / fw, 2.0f); }
+        const float inv = 1.0f / (wt[i].w[0] + wt[i].w[1] + wt[i].w[2] + wt[i].w[3]);
+        for (int j = 0; j < 4; ++j) wt[i].w[j] *= inv;
+    }
+    return wt;
+}
+
+struct Pyramid { int width = 0, height = 0, n_levels = 0, channels = 3; std::vector<float> texels; };
+
+// texels: (h, w, c) rows = t after the y flip. wrap: 0 repeat, 1 black.
+inline Pyramid build_mipmap(std::vector<float> img, int w, int h, int c, int wrap) {
+    auto pow2 = [](int n) { return n > 0 && (n & (n - 1)) == 0; };
+    auto up2 = [](int n) { int v = 1; while (v < n) v <<= 1; return v; };
+    if (!pow2(w) || !pow2(h)) {
+        const int W = up2(w), H = up2(h);
+        std::vector<float> res((size_t)W * H * c, 0.0f), out((size_t)W * H * c, 0.0f);
+        const auto ws = resample_weights(w, W);
+        for (int t = 0; t < h; ++t)
+            for (int s = 0; s < W; ++s)
+                for (int j = 0; j < 4; ++j) {
+                    long o = ws[s].first + j;
+                    if (wrap == 0) { o %= w; if (o < 0) o += w; }
+                    if (o >= 0 && o < w) for (int k = 0; k < c; ++k) res[((size_t)t * W + s) * c + k] += img[((size_t)t * w + o) * c + k] * ws[s].w[j];
+                }
+        const auto wt = resample_weights(h, H);
+        for (int s = 0; s < W; ++s)
+            for (int t = 0; t < H; ++t) {
+                float acc[3] = {0, 0, 0};
+                for (int j = 0; j < 4; ++j) {
+                    long o = wt[t].first + j;
+                    if (wrap == 0) { o %= h; if (o < 0) o += h; }
+                    if (o >= 0 && o < h) for (int k = 0; k < c; ++k) acc[k] += res[((size_t)o * W + s) * c + k] * wt[t].w[j];
+                }
+                for (int k = 0; k < c; ++k) out[((size_t)t * W + s) * c + k] = acc[k] < 0.0f ? 0.0f : acc[k];   // Clampable::clamp(.., 0, inf)
+            }
+        img.swap(out); w = W; h = H;
+    }
+    Pyramid p; p.width = w; p.height = h; p.channels = c;
+    p.n_levels = 1 + (int)std::log2((float)std::max(w, h));
+    p.texels = img;
+    std::vector<float> prev = img; int pw = w, ph = h;
+    for (int l = 1; l < p.n_levels; ++l) {
+        const int sres = std::max(1, pw / 2), tres = std::max(1, ph / 2);
+        std::vector<float> d((size_t)sres * tres * c);
+        auto texel = [&](long s, long t, int k) -> float {
+            if (wrap == 0) { s %= pw; if (s < 0) s += pw; t %= ph; if (t < 0) t += ph; }
+            else if (s < 0 || s >= pw || t < 0 || t >= ph) return 0.0f;
+            return prev[((size_t)t * pw + s) * c + k];
+        };
+        for (int t = 0; t < tres; ++t)
+            for (int s = 0; s < sres; ++s)
+                for (int k = 0; k < c; ++k)
+                    d[((size_t)t * sres + s) * c + k] = (texel(2 * s, 2 * t, k) + texel(2 * s + 1, 2 * t, k) + texel(2 * s, 2 * t + 1, k) + texel(2 * s + 1, 2 * t + 1, k)) * 0.25f;
+        p.texels.insert(p.texels.end(), d.begin(), d.end());
+        prev.swap(d); pw = sres; ph = tres;
+    }
+    return p;
+}
+// imagemap.rs:141-157 for an image as read (top row first)
+inline Pyramid prepare_image(const Image &im, float scale, bool gamma, int channels, int wrap) {
+    std::vector<float> px((size_t)im.w * im.h * channels);
+    for (int y = 0; y < im.h; ++y)
+        for (int x = 0; x < im.w; ++x) {
+            const float *s = &im.rgb[((size_t)(im.h - 1 - y) * im.w + x) * 3];
+            if (channels == 1) { const float yv = 0.212671f * s[0] + 0.715160f * s[1] + 0.072169f * s[2]; px[(size_t)y * im.w + x] = scale * (gamma ? inverse_gamma_correct(yv) : yv); }
+            else for (int k = 0; k < 3; ++k) px[((size_t)y * im.w + x) * 3 + k] = (gamma ? inverse_gamma_correct(s[k]) : s[k]) * scale;
+        }
+    return build_mipmap(std::move(px), im.w, im.h, channels, wrap);
+}
+inline std::vector<float> ewa_weight_lut() { std::vector<float> l(128); for (int i = 0; i < 128; ++i) { const float r2 = (float)i / 127.0f; l[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); } return l; }
+
+// lights/infinite.rs:62-81 for power-of-two maps with aspect <= 2:1 (level-0 bilinear lookup; see host.py _env_importance)
+inline std::vector<float> env_importance(const std::vector<float> &tex, int w, int h) {
+    auto pow2 = [](int n) { return n > 0 && (n & (n - 1)) == 0; };
+    if (!(pow2(w) && pow2(h) && std::max(w, h) <= 2 * std::min(w, h))) throw std::runtime_error("environment maps must be power-of-two sized with aspect <= 2:1");
+    const int W = 2 * w, H = 2 * h;
+    std::vector<float> img((size_t)W * H);
+    auto tx = [&](long s, long t, int k) { s %= w; if (s < 0) s += w; t %= h; if (t < 0) t += h; return tex[((size_t)t * w + s) * 3 + k]; };
+    for (int v = 0; v < H; ++v) {
+        const float vp = ((float)v + 0.5f) / (float)H;
+        const float sin_theta = std::sin(3.14159265358979323846f * ((float)v + 0.5f) / (float)H);
+        for (int u = 0; u < W; ++u) {
+            const float up = ((float)u + 0.5f) / (float)W;
+            const float s = up * (float)w - 0.5f, t = vp * (float)h - 0.5f;
+            const long s0 = (long)std::floor(s), t0 = (long)std::floor(t);
+            const float ds = s - (float)s0, dt = t - (float)t0;
+            float rgb[3];
+            for (int k = 0; k < 3; ++k)
+                rgb[k] = tx(s0, t0, k) * ((1.0f - ds) * (1.0f - dt)) + tx(s0, t0 + 1, k) * ((1.0f - ds) * dt) + tx(s0 + 1, t0, k) * (ds * (1.0f - dt)) + tx(s0 + 1, t0 + 1, k) * (ds * dt);
+            img[(size_t)v * W + u] = (0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2]) * sin_theta;
+        }
+    }
+    return img;
+}
+
+}  // namespace fe

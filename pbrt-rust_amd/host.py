@@ -361,7 +361,7 @@ class SceneBuilder:
             else:
                 tex = (np.asarray(tex, dtype=F) * L.reshape(1, 1, 3)).astype(F)   # infinite.rs:46-50: texels *= L * scale
             tex = np.ascontiguousarray(tex, dtype=F)
-            self.env = dict(texels=tex, importance=_env_importance(tex))
+            self.env = dict(texels=tex, importance=_env_importance(tex), power_lookup=_env_power_lookup(tex))
         else:
             raise ValueError(kind)
         self.lights.append(l)
@@ -492,6 +492,22 @@ class SceneBuilder:
         return rp
 
 
+def _env_power_lookup(tex):
+    """`map.lookup((.5, .5), .5)` of InfiniteAreaLight::power (infinite.rs:103-109): MIPMap::lookup with width 0.5 is
+    level = levels - 2 (exactly, delta = 0) -> `triangle(levels - 2, st)`; the texel for a 1x1 map (mipmap.rs:202-223)."""
+    from . import textures as T
+    levels, w, h = T.build_mipmap(tex, "repeat")
+    n = len(levels)
+    if n == 1: return levels[0][0, 0].astype(F)
+    lv = levels[n - 2]; lh, lw, _ = lv.shape
+    s = F(F(0.5) * F(lw) - F(0.5)); t = F(F(0.5) * F(lh) - F(0.5))
+    s0, t0 = int(math.floor(s)), int(math.floor(t)); ds, dt = F(s - F(s0)), F(t - F(t0))
+    tx = lambda a, b: lv[b % lh, a % lw].astype(F)
+    r = (tx(s0, t0) * F(F(1 - ds) * F(1 - dt)) + tx(s0, t0 + 1) * F(F(1 - ds) * dt)).astype(F)
+    r = (r + tx(s0 + 1, t0) * F(ds * F(1 - dt))).astype(F)
+    return (r + tx(s0 + 1, t0 + 1) * F(ds * dt)).astype(F)
+
+
 def _env_importance(tex):
     """lights/infinite.rs:62-81 importance image (2w x 2h): `map.lookup(st, fwidth).y() * sin(theta)` with
     fwidth = 0.5 / min(2w, 2h).  MIPMap::lookup (mipmap.rs:202-223) picks level = levels - 1 + log2(fwidth)
@@ -596,6 +612,7 @@ class SceneData:
             t = self.env["texels"]
             d.env_height, d.env_width = t.shape[0], t.shape[1]
             d.env_texels = ptr(t, A.fp); d.env_importance = ptr(self.env["importance"], A.fp)
+            d.env_power_lookup = (C.c_float * 3)(*[float(x) for x in self.env["power_lookup"]])
         d.max_node_prims = self.max_node_prims
         if self.nodes is not None:
             d.n_nodes = len(self.nodes); d.nodes = self.nodes; d.ordered_prims = ptr(self.ordered, A.u32p)

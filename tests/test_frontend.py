@@ -1,0 +1,278 @@
+"""The compiled .pbrt front end (pbrt-rust_amd/frontend/, include/mi355front.h): tokenizer, parameter
+lists, graphics-state semantics, PLY / PFM readers -- checked against the independent Python mirror of core/api.rs
+(pbrt_rust_amd.host.SceneBuilder) and, through the oracle, end to end."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _arr(p, n):
+    return np.ctypeslib.as_array(p, (n,)).copy() if p and n else np.zeros(0)
+
+
+def _write_pfm(path, img):          # img: (h, w, 3), top row first
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1\n" % (w, h)); f.write(np.ascontiguousarray(img[::-1], dtype="<f4").tobytes())
+
+
+def _write_ply(path, P, N, UV, faces, binary):
+    with open(path, "wb") as f:
+        hdr = ["ply", "format %s 1.0" % ("binary_little_endian" if binary else "ascii"), "element vertex %d" % len(P)]
+        hdr += ["property float x", "property float y", "property float z", "property float nx", "property float ny", "property float nz", "property float u", "property float v"]
+        hdr += ["element face %d" % len(faces), "property list uint8 int vertex_indices", "end_header"]
+        f.write(("\n".join(hdr) + "\n").encode())
+        if binary:
+            for p, n, uv in zip(P, N, UV): f.write(struct.pack("<8f", *p, *n, *uv))
+            for fc in faces: f.write(struct.pack("<B%di" % len(fc), len(fc), *fc))
+        else:
+            for p, n, uv in zip(P, N, UV): f.write((" ".join(repr(float(x)) for x in (*p, *n, *uv)) + "\n").encode())
+            for fc in faces: f.write(("%d %s\n" % (len(fc), " ".join(str(i) for i in fc))).encode())
+
+
+def test_c1_scene_file_equals_python_builder(pkg):
+    fs = pkg.frontend.FrontScene(path=os.path.join(HERE, "scenes", "spheres_c1.pbrt"))
+    d, rp = fs.desc(), fs.render_params()
+    sd, rp2 = pkg.scenes.spheres_c1(xres=96, yres=96, spp=8).world_end()
+    d2 = sd.desc()
+    for f in ("n_vertices", "n_triangles", "n_spheres", "n_prims", "n_materials", "n_lights", "max_node_prims", "n_instances", "n_textures"):
+        assert getattr(d, f) == getattr(d2, f), f
+    assert np.array_equal(_arr(d.P, 3 * d.n_vertices), _arr(d2.P, 3 * d2.n_vertices))
+    assert np.array_equal(_arr(d.indices, 3 * d.n_triangles), _arr(d2.indices, 3 * d2.n_triangles))
+    for f in ("prim_shape", "prim_material", "prim_light"):
+        assert np.array_equal(_arr(getattr(d, f), d.n_prims), _arr(getattr(d2, f), d2.n_prims)), f
+    for i in range(d.n_spheres):
+        for f in ("object_to_world", "world_to_object"):
+            assert np.allclose(list(getattr(d.spheres[i], f)), list(getattr(d2.spheres[i], f)), atol=1e-6)
+        for f in ("radius", "z_min", "z_max", "theta_min", "theta_max", "phi_max", "reverse_orientation", "transform_swaps_handedness"):
+            assert getattr(d.spheres[i], f) == getattr(d2.spheres[i], f), f
+    for i in range(d.n_lights):
+        for f in ("type", "two_sided", "prim"): assert getattr(d.lights[i], f) == getattr(d2.lights[i], f)
+        assert np.allclose(list(d.lights[i].L), list(d2.lights[i].L)) and np.allclose(list(d.lights[i].dir), list(d2.lights[i].dir))
+    for i in range(d.n_materials):
+        for f in ("type", "sigma", "eta", "roughness", "u_roughness", "v_roughness", "remap_roughness"): assert getattr(d.materials[i], f) == getattr(d2.materials[i], f), (i, f)
+        for f in ("kd", "ks", "kr", "kt", "opacity", "tex"): assert list(getattr(d.materials[i], f)) == list(getattr(d2.materials[i], f)), (i, f)
+    for f in ("full_resolution", "cropped_pixel_bounds", "sample_bounds", "pixel_bounds", "filter_table", "filter_radius"):
+        assert list(getattr(rp, f)) == list(getattr(rp2, f)), f
+    # Matrix4x4::inverse is restated in f32 (Gauss-Jordan, transform.rs:78-145); the Python mirror inverts in f64
+    assert np.allclose(list(rp.raster_to_camera), list(rp2.raster_to_camera), rtol=1e-5, atol=1e-5)
+    assert np.allclose(list(rp.camera_to_world), list(rp2.camera_to_world), atol=1e-6)
+    assert (rp.spp, rp.max_depth, rp.light_strategy, rp.rr_threshold) == (rp2.spp, rp2.max_depth, rp2.light_strategy, rp2.rr_threshold)
+    assert fs.output_filename() == "spheres_c1.exr"
+
+
+FEATURES = r"""
+# exercises: comments, Include, named materials, textures, instancing, PLY (binary + ascii, a quad face), PFM images,
+# CoordinateSystem / CoordSysTransform, TransformBegin/End, ReverseOrientation, cropwindow, gaussian filter, spot/point/infinite
+Scale -1 1 1   # flips handedness like the reference's sss-dragon scene
+LookAt 0 2.5 7   0 0.4 0   0 1 0
+Camera "perspective" "float fov" [42] "float lensradius" [0.02] "float focaldistance" [7]
+Film "image" "integer xresolution" [80] "integer yresolution" [48] "float cropwindow" [0.1 0.95 0 0.9] "float scale" 1.5
+Sampler "sobol" "integer pixelsamples" [4]
+PixelFilter "gaussian" "float xwidth" [1.5] "float ywidth" [1.5] "float alpha" [1.2]
+Integrator "path" "integer maxdepth" [3] "string lightsamplestrategy" "power"
+Accelerator "bvh" "integer maxnodeprims" [2]
+WorldBegin
+AttributeBegin
+  Rotate -90 1 0 0
+  LightSource "infinite" "rgb L" [0.5 0.5 0.5] "string mapname" ["sky.pfm"] "float scale" 2
+AttributeEnd
+LightSource "spot" "point from" [1 3 2] "point to" [0 0 0] "rgb I" [40 40 30] "float coneangle" 25 "float conedeltaangle" 8
+LightSource "point" "point from" [-2 2 1] "rgb I" [5 5 9]
+CoordinateSystem "lightspot"
+Texture "img" "color" "imagemap" "string filename" "tex.pfm" "float uscale" [4] "float vscale" [4] "bool trilinear" ["true"]
+Texture "chk" "spectrum" "checkerboard" "string mapping" "planar" "vector v1" [1 0 0] "vector v2" [0 0 1] "string aamode" "closedform"
+        "texture tex1" "img" "rgb tex2" [0.1 0.1 0.12]
+Texture "rough" "float" "imagemap" "string filename" "tex.pfm" "float scale" [0.3]
+Texture "holes" "float" "checkerboard" "float uscale" [5] "float vscale" [5] "float tex1" 1 "float tex2" 0
+MakeNamedMaterial "floor" "string type" "matte" "texture Kd" "chk"
+MakeNamedMaterial "shiny" "string type" "plastic" "rgb Kd" [0.5 0.2 0.2] "texture roughness" "rough" "bool remaproughness" "false"
+NamedMaterial "floor"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-8 -1 -8  -8 -1 8  8 -1 8  8 -1 -8] "float st" [0 0 0 1 1 1 1 0]
+Include "objects.pbrtinc"
+TransformBegin
+  Translate 0 0 -2
+  ObjectInstance "card"
+  Translate 1.5 0 0.5
+  Rotate 40 0 1 0
+  ObjectInstance "card"
+TransformEnd
+AttributeBegin
+  NamedMaterial "shiny"
+  Translate -1.6 0 0.4
+  Shape "plymesh" "string filename" "blob_bin.ply"
+AttributeEnd
+AttributeBegin
+  Material "uber" "rgb Kd" [0.2 0.4 0.7] "rgb Ks" [0.3 0.3 0.3] "float index" [1.3]
+  CoordSysTransform "lightspot"
+  Translate 1.8 0 1
+  ReverseOrientation
+  Shape "plymesh" "string filename" "blob_ascii.ply" "float shadowalpha" 1
+AttributeEnd
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [6 6 5] "bool twosided" "true" "float scale" 2
+  Translate 0 3.5 0
+  Shape "sphere" "float radius" 0.4
+AttributeEnd
+WorldEnd
+"""
+
+OBJECTS_INC = r"""
+ObjectBegin "card"
+  Material "matte" "texture Kd" "img"
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-0.5 0 0  0.5 0 0  0.5 1 0  -0.5 1 0] "float uv" [0 0 1 0 1 1 0 1] "texture alpha" "holes"
+ObjectEnd
+"""
+
+
+def _feature_files(pkg, tmp_path):
+    _write_pfm(tmp_path / "sky.pfm", pkg.scenes.sky_env(16, 8))
+    _write_pfm(tmp_path / "tex.pfm", pkg.scenes.test_image(20, 12))
+    P, I, N = pkg.scenes.displaced_sphere(8, with_normals=True)
+    P = (P * 0.6).astype(np.float32)
+    UV = np.stack([np.arctan2(P[:, 1], P[:, 0]) / (2 * np.pi) + 0.5, P[:, 2] * 0.5 + 0.5], axis=1).astype(np.float32)
+    faces = [list(map(int, t)) for t in I]
+    _write_ply(tmp_path / "blob_bin.ply", P, N, UV, faces, binary=True)
+    _write_ply(tmp_path / "blob_ascii.ply", P, N, UV, faces, binary=False)
+    (tmp_path / "objects.pbrtinc").write_text(OBJECTS_INC)
+    (tmp_path / "features.pbrt").write_text(FEATURES)
+    return P, I, N, UV
+
+
+def _python_twin(pkg, P, I, N, UV):
+    """The same scene through the Python mirror of api.rs."""
+    b = pkg.host.SceneBuilder()
+    b.scale(-1, 1, 1); b.look_at((0, 2.5, 7), (0, 0.4, 0), (0, 1, 0)); b.camera(fov=42.0, lensradius=0.02, focaldistance=7.0)
+    b.film.update(xres=80, yres=48, crop=(0.1, 0.95, 0.0, 0.9), scale=1.5); b.spp = 4
+    b.filter.update(kind="gaussian", radius=(1.5, 1.5), alpha=1.2)
+    b.integ.update(maxdepth=3, strategy="power"); b.max_node_prims = 2
+    b.world_begin()
+    b.attribute_begin(); b.rotate(-90, 1, 0, 0); b.light_source("infinite", L=(0.5, 0.5, 0.5), texels=pkg.scenes.sky_env(16, 8), scale=2.0); b.attribute_end()
+    b.light_source("spot", from_=(1, 3, 2), to=(0, 0, 0), I=(40, 40, 30), coneangle=25.0, conedeltaangle=8.0)
+    b.light_source("point", from_=(-2, 2, 1), I=(5, 5, 9))
+    img = pkg.scenes.test_image(20, 12)
+    b.texture("img", "color", "imagemap", pixels=img, uscale=4.0, vscale=4.0, trilinear=True)
+    b.texture("chk", "spectrum", "checkerboard", mapping="planar", v1=(1, 0, 0), v2=(0, 0, 1), aamode="closedform", tex1="img", tex2=(0.1, 0.1, 0.12))
+    b.texture("rough", "float", "imagemap", pixels=img, scale=0.3)
+    b.texture("holes", "float", "checkerboard", uscale=5.0, vscale=5.0, tex1=1.0, tex2=0.0)
+    b.material("matte", Kd="chk"); floor = b.material_id
+    b.material("plastic", Kd=(0.5, 0.2, 0.2), roughness="rough", remaproughness=False); shiny = b.material_id
+    b.material_id = floor
+    Pq, Iq = pkg.scenes.quad((-8, -1, -8), (-8, -1, 8), (8, -1, 8), (8, -1, -8))
+    b.trianglemesh(Pq, Iq, UV=np.array([[0, 0], [0, 1], [1, 1], [1, 0]], dtype=np.float32))
+    b.object_begin("card"); b.material("matte", Kd="img")
+    Pc, Ic = pkg.scenes.quad((-0.5, 0, 0), (0.5, 0, 0), (0.5, 1, 0), (-0.5, 1, 0))
+    b.trianglemesh(Pc, Ic, UV=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32), alpha="holes"); b.object_end()
+    saved = b.ctm
+    b.translate(0, 0, -2); b.object_instance("card"); b.translate(1.5, 0, 0.5); b.rotate(40, 0, 1, 0); b.object_instance("card")
+    b.ctm = saved
+    b.attribute_begin(); b.material_id = shiny; b.translate(-1.6, 0, 0.4); b.trianglemesh(P, I, N=N, UV=UV); b.attribute_end()
+    b.attribute_begin(); b.material("uber", Kd=(0.2, 0.4, 0.7), Ks=(0.3, 0.3, 0.3), eta=1.3); b.ctm = saved; b.translate(1.8, 0, 1)
+    b.reverse_orientation = not b.reverse_orientation; b.trianglemesh(P, I, N=N, UV=UV); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(12, 12, 10), twosided=True); b.translate(0, 3.5, 0); b.sphere(radius=0.4); b.attribute_end()
+    return b.world_end()
+
+
+def test_feature_scene_matches_python_builder_and_renders(pkg, oracle, tmp_path):
+    P, I, N, UV = _feature_files(pkg, tmp_path)
+    fs = pkg.frontend.FrontScene(path=str(tmp_path / "features.pbrt"))
+    d, rp = fs.desc(), fs.render_params()
+    sd, rp2 = _python_twin(pkg, P, I, N, UV)
+    d2 = sd.desc()
+    for f in ("n_vertices", "n_triangles", "n_spheres", "n_prims", "n_lights", "max_node_prims", "n_objects", "n_instances", "n_top", "n_images", "env_width", "env_height"):
+        assert getattr(d, f) == getattr(d2, f), f
+    assert np.array_equal(_arr(d.indices, 3 * d.n_triangles), _arr(d2.indices, 3 * d2.n_triangles))
+    assert np.array_equal(_arr(d.tri_flags, d.n_triangles), _arr(d2.tri_flags, d2.n_triangles))
+    assert np.array_equal(_arr(d.top_refs, d.n_top), _arr(d2.top_refs, d2.n_top))
+    assert np.array_equal(_arr(d.prim_shape, d.n_prims), _arr(d2.prim_shape, d2.n_prims)) and np.array_equal(_arr(d.prim_light, d.n_prims), _arr(d2.prim_light, d2.n_prims))
+    assert np.allclose(_arr(d.P, 3 * d.n_vertices), _arr(d2.P, 3 * d2.n_vertices), atol=1e-5)
+    assert np.allclose(_arr(d.N, 3 * d.n_vertices), _arr(d2.N, 3 * d2.n_vertices), atol=1e-5)
+    assert np.array_equal(_arr(d.UV, 2 * d.n_vertices), _arr(d2.UV, 2 * d2.n_vertices))
+    assert np.array_equal(_arr(d.tri_alpha, d.n_triangles) >= 0, _arr(d2.tri_alpha, d2.n_triangles) >= 0)
+    # the MIPMap pyramid, the environment importance image and the filter table are built by two independent
+    # implementations (C++ / numpy) of the same reference code
+    for i in range(d.n_images):
+        a, b = d.images[i], d2.images[i]
+        assert (a.width, a.height, a.n_levels, a.channels) == (b.width, b.height, b.n_levels, b.channels)
+        n = sum(max(1, a.width >> l) * max(1, a.height >> l) for l in range(a.n_levels)) * a.channels
+        assert np.allclose(_arr(a.texels, n), _arr(b.texels, n), rtol=2e-5, atol=2e-6)
+    assert np.allclose(_arr(d.env_importance, 4 * d.env_width * d.env_height), _arr(d2.env_importance, 4 * d2.env_width * d2.env_height), rtol=1e-5)
+    assert np.allclose(list(d.env_power_lookup), list(d2.env_power_lookup), rtol=1e-5) and d.env_power_lookup[0] > 0
+    assert np.allclose(list(rp.filter_table), list(rp2.filter_table), rtol=1e-5, atol=1e-7)
+    for f in ("cropped_pixel_bounds", "sample_bounds", "pixel_bounds", "full_resolution"): assert list(getattr(rp, f)) == list(getattr(rp2, f)), f
+    assert (rp.spp, rp.max_depth, rp.light_strategy, rp.lens_radius, rp.focal_distance, rp.scale) == (rp2.spp, rp2.max_depth, rp2.light_strategy, rp2.lens_radius, rp2.focal_distance, rp2.scale)
+    for i in range(d.n_lights):
+        assert d.lights[i].type == d2.lights[i].type
+        assert np.allclose(list(d.lights[i].L), list(d2.lights[i].L), rtol=1e-6) and np.allclose(list(d.lights[i].pos), list(d2.lights[i].pos), atol=1e-5)
+    # end to end through the oracle: same image up to the float differences of the two hosts' matrix inverses
+    a = oracle.scene(fs); b = oracle.scene(sd)
+    ia = a.resolve(a.render(rp, nthreads=4), scale=rp.scale); ib = b.resolve(b.render(rp2, nthreads=4), scale=rp2.scale)
+    assert np.isfinite(ia).all() and ia.mean() > 0.05
+    diff = np.abs(ia - ib)
+    assert (diff.max(axis=2) > 0.05).mean() < 0.02 and diff.mean() < 2e-3
+
+
+@pytest.mark.parametrize("text,needle", [
+    ("WorldBegin\nFrobnicate 1 2 3\n", "line 2: unknown directive Frobnicate"),
+    ('Sampler "halton" "integer pixelsamples" 4\nWorldBegin WorldEnd', "only \"sobol\""),
+    ('Integrator "bdpt"\n', "only \"path\""),
+    ('WorldBegin\nShape "cone"\n', "shape \"cone\""),
+    ('WorldBegin\nMaterial "matte" "blackbody Kd" [5500 1]\n', "blackbody"),
+    ('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 5] "point P" [0 0 0 1 0 0 0 1 0]\n', "out of-bounds vertex index"),
+    ('WorldBegin\nNamedMaterial "nope"\n', "not defined"),
+    ('WorldBegin\nAttributeEnd\n', "unmatched AttributeEnd"),
+    ('WorldBegin\nMaterial "matte" "texture Kd" "missing"\n', "not declared"),
+])
+def test_front_end_errors_name_the_problem(pkg, text, needle):
+    with pytest.raises(ValueError) as e:
+        pkg.frontend.FrontScene(text=text)
+    assert needle in str(e.value)
+
+
+def test_tokenizer_and_parameter_forms(pkg):
+    """Numbers (lexer.rs NUMBER: sign, fraction, exponent, leading dot), bare and bracketed single values, `integer`/`int`,
+    `color`/`rgb`, `point`/`point3`, comments at line ends, Transform's column-major matrix, excess array values dropped."""
+    fs = pkg.frontend.FrontScene(text='''
+Film "image" "int xresolution" 32 "integer yresolution" [ 16 ]   # trailing comment
+Sampler "sobol" "integer pixelsamples" [2]
+WorldBegin
+Transform [1 0 0 0  0 1 0 0  0 0 1 0  .5 -1.5e0 +2E0 1]
+Material "matte" "color Kd" [.25 0.5 7.5e-1 99]
+Shape "trianglemesh" "integer indices" [0 1 2] "point3 P" [0 0 0  1 0 0  0 1 0  ]
+ConcatTransform [2 0 0 0  0 2 0 0  0 0 2 0  0 0 0 1]
+Shape "sphere" "float radius" .5
+WorldEnd''')
+    d, rp = fs.desc(), fs.render_params()
+    assert list(rp.full_resolution) == [32, 16] and rp.spp == 2
+    assert np.allclose(_arr(d.P, 9), [0.5, -1.5, 2.0, 1.5, -1.5, 2.0, 0.5, -0.5, 2.0])
+    assert np.allclose(list(d.materials[1].kd), [0.25, 0.5, 0.75])
+    o2w = np.array(list(d.spheres[0].object_to_world)).reshape(4, 4)
+    assert np.allclose(o2w, [[2, 0, 0, 0.5], [0, 2, 0, -1.5], [0, 0, 2, 2.0], [0, 0, 0, 1]])
+
+
+@pytest.mark.gpu
+def test_front_end_scene_renders_on_gpu_like_the_oracle(pkg, gpu, oracle, tmp_path):
+    _feature_files(pkg, tmp_path)
+    fs = pkg.frontend.FrontScene(path=str(tmp_path / "features.pbrt"))
+    rp = fs.render_params()
+    g = pkg.Scene(gpu, fs); orc = oracle.scene(fs)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    # gaussian filter: overlapping splats are summed by float atomics in a different order
+    np.testing.assert_allclose(film, ref, rtol=2e-4, atol=2e-6)
+    # the command-line renderer produces the same picture as the library path
+    out = tmp_path / "out.pfm"
+    r = subprocess.run([pkg.frontend.CLI_PATH, str(tmp_path / "features.pbrt"), "--outfile", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n"; w, h = map(int, f.readline().split()); f.readline()
+        img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]
+    np.testing.assert_allclose(img, g.resolve(film, scale=rp.scale), rtol=2e-4, atol=2e-5)
