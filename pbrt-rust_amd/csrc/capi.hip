@@ -22,6 +22,7 @@ int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {8, 8, 8, 20};
+uint32_t g_trace_waves_per_cu = 20;               // persistent trace waves per CU = 5 per SIMD, the occupancy of k_trace<*, 0> (env PT_TRACE_WAVES_PER_CU)
 SobolTables g_tabs = {nullptr, nullptr, nullptr};
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
@@ -164,7 +165,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         int st;
         if ((st = sc->dalloc(&sc->qc, 1))) return st;
         if ((st = sc->dalloc(&sc->dc, 1))) return st;
-        sc->spill_waves = (uint32_t)g_num_cus * 16u;  // 16 waves per CU resident at most (LDS: 6 KB per wave)
+        sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 6 KB per wave)
         if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * (kMaxStack - kLdsStack)))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
     }
@@ -486,6 +487,7 @@ int pt_init(int device_ordinal) {
     if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr}; }
     g_device = device_ordinal;
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; } }
+    if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
     return upload_tables();
 }

@@ -149,9 +149,13 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 // Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
 
 // GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
+#ifndef PT_TRACE_ATTR
+#define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
+                        // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
+#endif
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres, instances), 2 = general geometry + alpha-masked triangles
 template <bool ANY, int MODE>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     constexpr bool SPH = MODE >= 1, ALPHA = MODE == 2;
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
     const uint32_t lane = lane_id();
