@@ -127,7 +127,7 @@ def main():
     # symbol with the largest total time as the dominant kernel.
     SYMBOL = {"extend_camera": "k_trace<false, 0>", "extend": "k_trace<false, 0>", "extend_mis": "k_trace<false, 0>",
               "shadow": "k_trace<true, 0>", "shade_matte": "k_shade<1, 0>", "shade_1lobe": "k_shade<1, 0>",
-              "shade_2lobe": "k_shade<2, 0>", "shade_uber": "k_shade<5, 0>"}  # names as rocprofv3 prints them (no spheres in S2)
+              "shade_2lobe": "k_shade<2, 0>", "shade_uber": "k_shade<5, 0>", "shade_miss": "k_shade_miss<false>"}  # names as rocprofv3 prints them (no spheres in S2)
     groups = {}
     for n, v in kstats.items():
         ab = algo_bytes(n, v)

@@ -64,7 +64,7 @@ struct pt_scene {
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
-    bool class_used[kNumClasses] = {true, false, false, false};
+    bool class_used[kNumClasses] = {true, false, false, false, true};   // matte (default material) and the miss class always exist
     bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
     void *bss_slab = nullptr; BssSoA bs{};
     uint32_t n_lights = 0;
@@ -338,13 +338,13 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * 16u)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
-    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber"};
+    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss"};
     for (int iter = 0; iter < 4096; ++iter) {
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
         if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : "Sobol dimension overflow (>= 1024)");
-        const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][0], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
+        const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
         if (n_ext == 0 && n_resolve == 0 && n_probe == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
@@ -366,7 +366,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sc->begin("route", n_ext);
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], (const uint32_t *)ps.hit_prim, &qc->shade[cur][0],
-                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3]);
+                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4]);
             sc->end();
         }
         // MIS rays of the previous vertex (closest hit, integrator.rs:215)
@@ -402,7 +402,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
             bj.probe_next = sc->q.probe[1 - cur]; bj.probe_next_count = &qc->probe[1 - cur];
             bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
-            bj.shade_next0 = sc->q.shade[1 - cur][0]; bj.shade_next0_count = &qc->shade[1 - cur][0];
+            bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
             bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
             const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * 8u);
@@ -424,12 +424,17 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             ShadeJob sj{};
             sj.queue = sc->q.shade[cur][c]; sj.count = &qc->shade[cur][c];
             sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
-            sj.shade_next0 = sc->q.shade[1 - cur][0]; sj.shade_next0_count = &qc->shade[1 - cur][0];
+            sj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; sj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
             if (c == 3 && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
-            if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
+            if (c == kMissClass) {
+                const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 16u);
+                if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade_miss<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
+                else hipLaunchKernelGGL((k_shade_miss<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
+            }
+            else if (c <= 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
             else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
             sc->end();
@@ -456,7 +461,7 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
-    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber"};
+    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }

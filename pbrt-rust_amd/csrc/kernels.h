@@ -7,7 +7,8 @@
 
 namespace ptd {
 
-constexpr int kNumClasses = 4;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber
+constexpr int kNumClasses = 5;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
+constexpr int kMissClass = 4;       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
 constexpr int kLdsStack = 12;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
@@ -116,7 +117,7 @@ struct TraceJob {
 struct ShadeJob {
     const uint32_t *queue; const uint32_t *count;
     uint32_t *ext_next, *ext_next_count;
-    uint32_t *shade_next0, *shade_next0_count;   // resolve-only paths go to class 0 of the next iteration
+    uint32_t *shade_next0, *shade_next0_count;   // resolve-only paths go to the miss class (kMissClass) of the next iteration
     uint32_t *shadow, *shadow_count, *mis, *mis_count;
     uint32_t *error;
     DevCounters *counters;

@@ -413,29 +413,31 @@ template __global__ void k_trace<true, 2>(DeviceScene, TraceJob);
 
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
-// material's class (misses -> class 0). Block-level staged appends: one global atomic per ~1000 entries per class.
+// material's class (escaped rays -> the miss class). Block-level staged appends: one global atomic per ~1000 entries per class.
 __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *hit_prim,
-                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3) {
-    __shared__ LdsQueue<1024> q0, q1, q2, q3;
-    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3);
+                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4) {
+    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4;
+    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4);
     __syncthreads();
     const uint32_t count = *count_ptr;
     const uint32_t rounded = (count + 255u) & ~255u;
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
         const bool valid = qi < count;
-        uint32_t pid = 0, cls = 0;
+        uint32_t pid = 0, cls = (uint32_t)kMissClass;   // escaped rays: their own light kernel (k_shade_miss)
         if (valid) {
             pid = queue[qi];
             const uint32_t hp = hit_prim[pid];
             if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
-        lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u);
+        lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
         lq_sync_flush(q0, class_count + 0, c0, 256u, false); lq_sync_flush(q1, class_count + 1, c1, 256u, false);
         lq_sync_flush(q2, class_count + 2, c2, 256u, false); lq_sync_flush(q3, class_count + 3, c3, 256u, false);
+        lq_sync_flush(q4, class_count + 4, c4, 256u, false);
     }
     lq_sync_flush(q0, class_count + 0, c0, 0u, true); lq_sync_flush(q1, class_count + 1, c1, 0u, true);
     lq_sync_flush(q2, class_count + 2, c2, 0u, true); lq_sync_flush(q3, class_count + 3, c3, 0u, true);
+    lq_sync_flush(q4, class_count + 4, c4, 0u, true);
 }
 
 // ---- camera rays -------------------------------------------------------------------------------------
@@ -932,6 +934,46 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
 }
 #define PT_INST_SHADE(L, S) template __global__ void k_shade<L, S>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
 PT_INST_SHADE(1, 0) PT_INST_SHADE(2, 0) PT_INST_SHADE(5, 0) PT_INST_SHADE(1, 1) PT_INST_SHADE(2, 1) PT_INST_SHADE(5, 1) PT_INST_SHADE(1, 2) PT_INST_SHADE(2, 2) PT_INST_SHADE(5, 2)
+
+// ---- escaped rays and dead paths (class kMissClass) -------------------------------------------------------------------
+// More than half of the vertices of an open scene are rays that left it (S2: 54 %). They only need the previous vertex's
+// NEE resolved, the environment's Le where path.rs:106-117 adds it, and the path-length histogram entry -- none of the
+// BSDF / light-sampling code. Keeping them out of k_shade leaves its waves full of real surface hits.
+template <bool SPH>
+__global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job) {
+    __shared__ uint32_t s_hist[16];
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t count = *job.count;
+    unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < count; qi += gridDim.x * blockDim.x) {
+        n_valid++;
+        n_bytes += 4 + 4 + 12 + 12 + /* write back */ 12 + 4;
+        const uint32_t pid = job.queue[qi];
+        const uint32_t meta = ps.meta[pid];
+        uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
+        RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
+        if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
+            n_bytes += 12 + 12;
+            const RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+            const V3 rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+            for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
+        }
+        ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
+        ps.meta[pid] = (meta & 0x00ffffffu) | ((flags & ~PF_CAMERA_RAY) << 24);
+        atomicAdd(&s_hist[bounces > 15u ? 15u : bounces], 1u);   // path.rs:219
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->stages, n_valid);
+    counter_add(&job.counters->shade_items[kMissClass], n_valid);
+    counter_add(&job.counters->shade_bytes[kMissClass], n_bytes);
+    (void)rc;
+}
+template __global__ void k_shade_miss<false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
+template __global__ void k_shade_miss<true>(DeviceScene, RenderConst, PathSoA, ShadeJob);
 
 // ---- subsurface scattering: probe chains + exit-point vertex (path.rs:177-204, bssrdf.rs:334-410,559-574) --------------
 // One launch per wavefront iteration while any path walks a probe chain. Each queue entry is a path whose probe ray
