@@ -126,8 +126,8 @@ def main():
     # Group the per-launch-kind statistics by kernel symbol (what rocprofv3 --stats reports) and take the
     # symbol with the largest total time as the dominant kernel.
     SYMBOL = {"extend_camera": "k_trace<false, 0>", "extend": "k_trace<false, 0>", "extend_mis": "k_trace<false, 0>",
-              "shadow": "k_trace<true, 0>", "shade_matte": "k_shade<1, 0>", "shade_1lobe": "k_shade<1, 0>",
-              "shade_2lobe": "k_shade<2, 0>", "shade_uber": "k_shade<5, 0>", "shade_miss": "k_shade_miss<false>"}  # names as rocprofv3 prints them (no spheres in S2)
+              "shadow": "k_trace<true, 0>", "shade_matte": "k_shade<1, 0, true>", "shade_1lobe": "k_shade<1, 0, false>",
+              "shade_2lobe": "k_shade<2, 0, false>", "shade_uber": "k_shade<5, 0, false>", "shade_miss": "k_shade_miss<false>"}  # names as rocprofv3 prints them (no spheres in S2)
     groups = {}
     for n, v in kstats.items():
         ab = algo_bytes(n, v)

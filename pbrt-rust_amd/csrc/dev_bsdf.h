@@ -161,8 +161,12 @@ PT_DEV V3 tr_sample_wh(float ax, float ay, V3 wo, P2 u) {  // microfacet.rs:293-
 
 PT_DEV float pow5(float v) { return (v * v) * (v * v) * v; }
 
-PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
-    switch (b.kind) {
+// DIFF = the material class holds diffuse lobes only (class 0, matte): the value range of `kind` is narrowed so that the
+// compiler drops every specular / microfacet case from the matte shade kernel (smaller code, fewer registers).
+template <bool DIFF> PT_DEV uint8_t lobe_kind(const Lobe &b) { return DIFF ? (b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R) : b.kind; }
+
+template <bool DIFF = false> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
+    switch (lobe_kind<DIFF>(b)) {
     case LB_LAMBERT_R: return b.r * kInvPi;
     case LB_LAMBERT_T: return b.t * kInvPi;
     case LB_OREN_NAYAR: {  // reflection.rs:926-952
@@ -217,8 +221,8 @@ PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
     }
 }
 
-PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
-    switch (b.kind) {
+template <bool DIFF = false> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
+    switch (lobe_kind<DIFF>(b)) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_FRESNEL_SPEC:  // reflection.rs:439-445, :788-794
         return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f;
     case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) : 0.0f;  // :886-892
@@ -246,19 +250,19 @@ PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
     }
 }
 
-PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
-    switch (b.kind) {
+template <bool DIFF = false> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
+    switch (lobe_kind<DIFF>(b)) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: {
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf<DIFF>(b, wo, wi);
+        return lobe_f<DIFF>(b, wo, wi);
     }
     case LB_LAMBERT_T: {
         wi = cosine_sample_hemisphere(u);
         if (wo.z > 0.0f) wi.z *= -1.0f;
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf<DIFF>(b, wo, wi);
+        return lobe_f<DIFF>(b, wo, wi);
     }
     case LB_SPEC_R: {
         wi = V3(-wo.x, -wo.y, wo.z);
@@ -298,7 +302,7 @@ PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sa
         wi = reflect(wo, wh);
         if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         pdf = tr_pdf(b.ax, b.ay, wo, wh) / (4.0f * dot(wo, wh));
-        return lobe_f(b, wo, wi);
+        return lobe_f<DIFF>(b, wo, wi);
     }
     case LB_MICRO_T: {
         if (wo.z == 0.0f) return RGB(0.0f);
@@ -306,8 +310,8 @@ PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sa
         if (dot(wo, wh) < 0.0f) return RGB(0.0f);
         float eta = (cos_theta(wo) > 0.0f) ? b.etaa / b.etab : b.etab / b.etaa;
         if (!refract(wo, wh, eta, wi)) return RGB(0.0f);
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf<DIFF>(b, wo, wi);
+        return lobe_f<DIFF>(b, wo, wi);
     }
     default: {  // LB_FRESNEL_BLEND
         P2 uu = u;
@@ -321,14 +325,14 @@ PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sa
             wi = reflect(wo, wh);
             if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         }
-        pdf = lobe_pdf(b, wo, wi);
-        return lobe_f(b, wo, wi);
+        pdf = lobe_pdf<DIFF>(b, wo, wi);
+        return lobe_f<DIFF>(b, wo, wi);
     }
     }
 }
 
 // ---- BSDF (reflection.rs:1495-1689). MAXL = compile-time lobe capacity of the shade-queue class -----------
-template <int MAXL> struct Bsdf {
+template <int MAXL, bool DIFF = false> struct Bsdf {
     float eta;
     V3 ns, ng, ss, ts;
     int n;
@@ -350,7 +354,7 @@ template <int MAXL> struct Bsdf {
         RGB res(0.0f);
         for (int i = 0; i < MAXL; ++i)
             if (i < n && l[i].matches(flags) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                res = res + lobe_f(l[i], wo, wi);
+                res = res + lobe_f<DIFF>(l[i], wo, wi);
         return res;
     }
     PT_DEV float pdf(V3 wow, V3 wiw, int flags) const {
@@ -358,7 +362,7 @@ template <int MAXL> struct Bsdf {
         V3 wo = to_local(wow), wi = to_local(wiw);
         if (wo.z == 0.0f) return 0.0f;
         float p = 0.0f; int matching = 0;
-        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf(l[i], wo, wi); }
+        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf<DIFF>(l[i], wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
     // `pdf` must hold the caller's previous value on entry (it is left untouched on the wo.z == 0 exit,
@@ -381,18 +385,18 @@ template <int MAXL> struct Bsdf {
         RGB fv(0.0f);
         int btype = 0;
         // select the lobe without dynamic register-array indexing
-        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = lobe_sample_f(l[i], wo, wi, ur, pdf, sampled); }
+        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = lobe_sample_f<DIFF>(l[i], wo, wi, ur, pdf, sampled); }
         if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
         wiw = to_world(wi);
         if (!(btype & BSDF_SPECULAR) && matching > 1)
-            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf(l[i], wo, wi);
+            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf<DIFF>(l[i], wo, wi);
         if (matching > 1) pdf /= (float)matching;
         if (!(btype & BSDF_SPECULAR)) {
             bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
             fv = RGB(0.0f);
             for (int i = 0; i < MAXL; ++i)
                 if (i < n && l[i].matches(ty) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                    fv = fv + lobe_f(l[i], wo, wi);
+                    fv = fv + lobe_f<DIFF>(l[i], wo, wi);
         }
         return fv;
     }
@@ -411,8 +415,8 @@ struct ConstMatEval {
 
 // Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None. `E` evaluates the
 // (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
-template <int MAXL, class ME> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL> &bsdf, const ME &E) {
-    switch (m.type) {
+template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
+    switch (DIFF ? (uint32_t)PT_MAT_MATTE : m.type) {   // class 0 holds matte materials only
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
         RGB r = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);

@@ -716,7 +716,8 @@ PT_DEV RayDiff camera_ray_differentials(const RenderConst &rc, float pfx, float 
 #define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
 #endif
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres and/or instances), 2 = general geometry + textures
-template <int MAXL, int MODE>
+// DIFF: the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only)
+template <int MAXL, int MODE, bool DIFF>
 __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE == 2;
     __shared__ uint32_t s_sobol[kSobolLdsWords];
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 PT_T(4);
                 smp.load_window();
                 PT_T(10);
-                Bsdf<MAXL> bsdf;
+                Bsdf<MAXL, DIFF> bsdf;
                 const uint32_t mi = s.prim_material[hp];
                 bool has_bsdf = false;
                 if (TEX) {
@@ -814,8 +815,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         si.sh_dpdu = bdpdu; si.sh_dpdv = bdpdv;
                     }
                     const TexMatEval E{s, tctx};
-                    has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, E);
-                } else has_bsdf = (mi != PT_NONE) && build_bsdf<MAXL>(s.materials[mi], si, bsdf, ConstMatEval());
+                    has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E);
+                } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval());
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
@@ -932,8 +933,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
     counter_add(&job.counters->shade_items[job.cls], n_valid);
     counter_add(&job.counters->shade_bytes[job.cls], n_bytes);
 }
-#define PT_INST_SHADE(L, S) template __global__ void k_shade<L, S>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
-PT_INST_SHADE(1, 0) PT_INST_SHADE(2, 0) PT_INST_SHADE(5, 0) PT_INST_SHADE(1, 1) PT_INST_SHADE(2, 1) PT_INST_SHADE(5, 1) PT_INST_SHADE(1, 2) PT_INST_SHADE(2, 2) PT_INST_SHADE(5, 2)
+#define PT_INST_SHADE(L, S, D) template __global__ void k_shade<L, S, D>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+PT_INST_SHADE(1, 0, true) PT_INST_SHADE(1, 0, false) PT_INST_SHADE(2, 0, false) PT_INST_SHADE(5, 0, false)
+PT_INST_SHADE(1, 1, true) PT_INST_SHADE(1, 1, false) PT_INST_SHADE(2, 1, false) PT_INST_SHADE(5, 1, false)
+PT_INST_SHADE(1, 2, true) PT_INST_SHADE(1, 2, false) PT_INST_SHADE(2, 2, false) PT_INST_SHADE(5, 2, false)
 
 // ---- escaped rays and dead paths (class kMissClass) -------------------------------------------------------------------
 // More than half of the vertices of an open scene are rays that left it (S2: 54 %). They only need the previous vertex's
@@ -943,6 +946,11 @@ template <bool SPH>
 __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_hist[16];
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};   // not reported: the region table is k_shade's
+#endif
     __syncthreads();
     const uint32_t count = *job.count;
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
         const uint32_t meta = ps.meta[pid];
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
         RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
-        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes);
+        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
         if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
             n_bytes += 12 + 12;
             const RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
