@@ -1169,6 +1169,15 @@ __global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const 
         int64_t tb2 = min(f2i_sat(floorf((float)tx1 - 0.5f + rc.filter_radius[0])) + 1, (int64_t)rc.crop[2]);
         int64_t tb3 = min(f2i_sat(floorf((float)ty1 - 0.5f + rc.filter_radius[1])) + 1, (int64_t)rc.crop[3]);
         const float invrx = 1.0f / rc.filter_radius[0], invry = 1.0f / rc.filter_radius[1];
+        // Splats onto this thread's own pixel are accumulated in registers, seeded with the pixel's current value, and written
+        // back once: the additions happen in sample order exactly as before (and as FilmTile::add_sample does), without one
+        // L2 atomic per channel per sample. Splats onto other pixels (wide filters; for the box filter only the pfilm == px
+        // edge case) still use atomics; should one of them land on this pixel meanwhile, the final compare-and-swap fails
+        // and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
+        const bool own_ok = px >= tb0 && px < tb2 && py >= tb1 && py < tb3;
+        float *own = film_rgbw + 4 * ((size_t)(py - rc.crop[1]) * rc.film_w + (size_t)(px - rc.crop[0]));
+        float seed[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
         for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
             const uint32_t pid = sl * rc.n_pix_slots + slot;
             RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
@@ -1188,11 +1197,19 @@ __global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const 
                     const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
                     const float fw = filter_table[iy * 16 + ix];
                     const RGB c = L * RGB(1.0f) * RGB(fw);
-                    float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
-                    atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                    if (own_ok && x == (int64_t)px && y == (int64_t)py) { acc[0] += c.r; acc[1] += c.g; acc[2] += c.b; acc[3] += fw; }
+                    else {
+                        float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
+                        atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                    }
                     splats++;
                 }
             }
+        }
+        if (own_ok) for (int k = 0; k < 4; ++k) {
+            if (__float_as_uint(acc[k]) == __float_as_uint(seed[k])) continue;
+            const uint32_t old = atomicCAS((uint32_t *)(own + k), __float_as_uint(seed[k]), __float_as_uint(acc[k]));
+            if (old != __float_as_uint(seed[k])) atomicAdd(own + k, acc[k] - seed[k]);
         }
     }
     counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
