@@ -74,6 +74,20 @@ template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount,
 // atomics made every producer slower; with 768-entry buffers k_shade still lost 10 % -- the barriers keep the four waves of
 // a block in lockstep through a 150 KB kernel, which evidently helps instruction fetch.)
 
+// Several queues per kernel: one barrier makes the pushes visible, each queue that is nearly full flushes (block-uniform
+// decision, rare), one barrier closes the round -- instead of two barriers per queue per iteration.
+template <int CAP> PT_DEV void lq_flush_nosync(LdsQueue<CAP> &q, uint32_t *gcount, uint32_t *gbuf, uint32_t reserve, bool force) {
+    const uint32_t n = q.count;   // the caller's barrier precedes this read
+    if (n != 0 && (force || n + reserve > (uint32_t)CAP)) {
+        if (threadIdx.x == 0) q.base = atomicAdd(gcount, n);
+        __syncthreads();
+        const uint32_t b = q.base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gbuf[b + i] = q.buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) q.count = 0;
+    }
+}
+
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
 // (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
@@ -431,13 +445,15 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
         lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
-        lq_sync_flush(q0, class_count + 0, c0, 256u, false); lq_sync_flush(q1, class_count + 1, c1, 256u, false);
-        lq_sync_flush(q2, class_count + 2, c2, 256u, false); lq_sync_flush(q3, class_count + 3, c3, 256u, false);
-        lq_sync_flush(q4, class_count + 4, c4, 256u, false);
+        __syncthreads();
+        lq_flush_nosync(q0, class_count + 0, c0, 256u, false); lq_flush_nosync(q1, class_count + 1, c1, 256u, false);
+        lq_flush_nosync(q2, class_count + 2, c2, 256u, false); lq_flush_nosync(q3, class_count + 3, c3, 256u, false);
+        lq_flush_nosync(q4, class_count + 4, c4, 256u, false);
+        __syncthreads();
     }
-    lq_sync_flush(q0, class_count + 0, c0, 0u, true); lq_sync_flush(q1, class_count + 1, c1, 0u, true);
-    lq_sync_flush(q2, class_count + 2, c2, 0u, true); lq_sync_flush(q3, class_count + 3, c3, 0u, true);
-    lq_sync_flush(q4, class_count + 4, c4, 0u, true);
+    lq_flush_nosync(q0, class_count + 0, c0, 0u, true); lq_flush_nosync(q1, class_count + 1, c1, 0u, true);
+    lq_flush_nosync(q2, class_count + 2, c2, 0u, true); lq_flush_nosync(q3, class_count + 3, c3, 0u, true);
+    lq_flush_nosync(q4, class_count + 4, c4, 0u, true);
 }
 
 // ---- camera rays -------------------------------------------------------------------------------------
@@ -909,17 +925,21 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)
-    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 256u, false);
-    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
-    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 256u, false);
-    lq_sync_flush(s_qmis, job.mis_count, job.mis, 256u, false);
-    if constexpr (MAXL == 5) if (job.probe_next) { lq_push(s_qprobe, pid, push_probe); lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 256u, false); }
+    if constexpr (MAXL == 5) if (job.probe_next) lq_push(s_qprobe, pid, push_probe);
+    __syncthreads();
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    __syncthreads();
     }  // persistent loop over the queue
-    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 0u, true);
-    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
-    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
-    lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
-    if constexpr (MAXL == 5) if (job.probe_next) lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    __syncthreads();
     __syncthreads();   // s_hist complete
 #ifdef PT_REGION_PROFILE
     PT_T(14);
@@ -1131,17 +1151,20 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
-    lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
-    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 256u, false);
-    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
-    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 256u, false);
-    lq_sync_flush(s_qmis, job.mis_count, job.mis, 256u, false);
+    __syncthreads();
+    lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+    __syncthreads();
     }
-    lq_sync_flush(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
-    lq_sync_flush(s_qext, job.ext_next_count, job.ext_next, 0u, true);
-    lq_sync_flush(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
-    lq_sync_flush(s_qsh, job.shadow_count, job.shadow, 0u, true);
-    lq_sync_flush(s_qmis, job.mis_count, job.mis, 0u, true);
+    lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    __syncthreads();
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->stages, n_valid);
