@@ -88,11 +88,13 @@ def test_host_sah_builder_equals_oracle_builder(pkg, oracle):
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "hb.cpp"), "w").write(src)
         so = os.path.join(td, "hb.so")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", here, "-o", so,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-I", here, "-o", so,
                                os.path.join(td, "hb.cpp"), os.path.join(here, "host_bvh.cpp")])
         hb = C.CDLL(so)
         A = pkg._abi
-        for n, kw in ((20, {}), (48, dict(with_normals=True))):
+        # n = 200 -> 80 004 triangles: above the 65 536-primitive threshold of the multi-threaded build (subtrees on worker
+        # threads, identical tree); add -pthread when linking
+        for n, kw in ((20, {}), (48, dict(with_normals=True)), (200, {})):
             sd, _ = pkg.scenes.ganesha_scale(n=n, xres=16, yres=16, spp=1, **kw).world_end()
             P, idx = sd.P, sd.idx
             tri = P[idx]  # (nt, 3, 3)
