@@ -194,6 +194,7 @@ typedef struct PtLight {
 
 /* accelerators/bvh.rs:89-95 LinearBVHNode: left child at index+1, right child at `offset`
  * for interior nodes (n_prims == 0); leaves index `ordered_prims[offset .. offset+n_prims]`. */
+typedef enum PtSplitMethod { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1 } PtSplitMethod;
 typedef struct PtBVHNode {
     float bmin[3];
     float bmax[3];
@@ -283,6 +284,10 @@ typedef struct PtSceneDesc {
     const int32_t *tri_alpha; const int32_t *tri_shadow_alpha;
     uint32_t n_images; const PtImage *images;
     const float *ewa_weight_lut;   /* [128] = exp(-2 r2) - exp(-2), r2 = i/127 (mipmap.rs:40-50); required with EWA image maps */
+    /* bvh "splitmethod" (api.rs make_accelerator -> bvh.rs:918-940) for every accelerator the library builds (ignored for
+     * an adopted one). PT_SPLIT_SAH: host SAH builder = the reference's tree. PT_SPLIT_HLBVH: built on the GPU
+     * (Morton sort + LBVH treelets + SAH upper levels, bvh.rs:377-660; see csrc/gpu_bvh.hip for the exact tree). */
+    uint32_t split_method;
 } PtSceneDesc;
 
 /* ---- render parameters ---------------------------------------------------------------- */

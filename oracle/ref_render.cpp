@@ -5,6 +5,7 @@
 //   integrators/path.rs:79-222; cameras/perspective.rs:120-179; core/film.rs:104-161,217-258,292-331.
 #include "ref_bssrdf.h"
 #include "ref_texture.h"
+#include "ref_hlbvh.h"
 #include <thread>
 #include <atomic>
 #include <chrono>
@@ -615,6 +616,7 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
         s.env_importance.assign(d->env_importance, d->env_importance + (size_t)4 * s.env_w * s.env_h);
     }
     s.max_node_prims = d->max_node_prims ? d->max_node_prims : 4;
+    s.split_method = d->split_method;
     if (d->n_instances && d->top_refs) {
         s.objects.assign(d->objects, d->objects + d->n_objects);
         s.instances.assign(d->instances, d->instances + d->n_instances);

@@ -102,7 +102,7 @@ struct Scene {
     std::vector<RGB> env_texels;
     std::vector<Float> env_importance;
     RGB env_power_lookup;
-    uint32_t max_node_prims = 4;
+    uint32_t max_node_prims = 4, split_method = PT_SPLIT_SAH;
     std::vector<PtBVHNode> nodes;       // top-level accelerator
     std::vector<uint32_t> ordered;      // positions in the top-level list (see top_ref)
     struct Accel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };
@@ -572,8 +572,10 @@ struct Builder {
 };
 }  // namespace bvhbuild
 
+namespace hlbvh { void build(const std::vector<Bounds3> &bounds, uint32_t max_node_prims, std::vector<PtBVHNode> &nodes, std::vector<uint32_t> &ordered); }  // ref_hlbvh.h
 // BVHAccel::new over `bounds[i]` (item i keeps number i): fills nodes + ordered item numbers
-inline void build_accel(const std::vector<Bounds3> &bounds, uint32_t max_node_prims, std::vector<PtBVHNode> &nodes, std::vector<uint32_t> &ordered) {
+inline void build_accel(const std::vector<Bounds3> &bounds, uint32_t max_node_prims, std::vector<PtBVHNode> &nodes, std::vector<uint32_t> &ordered, uint32_t split_method = PT_SPLIT_SAH) {
+    if (split_method == PT_SPLIT_HLBVH) { hlbvh::build(bounds, max_node_prims, nodes, ordered); return; }
     nodes.clear(); ordered.clear();
     size_t n = bounds.size();
     if (n == 0) return;
@@ -615,7 +617,7 @@ inline void Scene::build_object_accels() {  // api.rs:1692-1700: one BVH per obj
         if (O.n_prims <= 1) continue;
         std::vector<Bounds3> bb(O.n_prims);
         for (uint32_t i = 0; i < O.n_prims; ++i) bb[i] = prim_world_bound(O.first_prim + i);
-        build_accel(bb, max_node_prims, obj_accel[o].nodes, obj_accel[o].ordered);
+        build_accel(bb, max_node_prims, obj_accel[o].nodes, obj_accel[o].ordered, split_method);
         for (auto &e : obj_accel[o].ordered) e += O.first_prim;  // item number -> primitive index
     }
 }
@@ -623,7 +625,7 @@ inline void Scene::build_bvh() {
     size_t n = n_top();
     std::vector<Bounds3> bb(n);
     for (size_t i = 0; i < n; ++i) bb[i] = ref_world_bound(top_ref((uint32_t)i));
-    build_accel(bb, max_node_prims, nodes, ordered);
+    build_accel(bb, max_node_prims, nodes, ordered, split_method);
 }
 
 }  // namespace ref

@@ -21,6 +21,7 @@ PT_NONE = 0xFFFFFFFF
 PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE = range(8)
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
+PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
 
 
 def shape_ref(kind, index):
@@ -100,7 +101,7 @@ class PtSceneDesc(C.Structure):
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
                 ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable)),
-                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("tri_alpha", i32p), ("tri_shadow_alpha", i32p), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp)]
+                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("tri_alpha", i32p), ("tri_shadow_alpha", i32p), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp), ("split_method", u32)]
 
 
 class PtRenderParams(C.Structure):

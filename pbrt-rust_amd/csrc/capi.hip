@@ -578,6 +578,14 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         for (int k = 0; k < 3; ++k) { out.lo[k] = std::fmin(std::fmin(a[k], b[k]), c[k]); out.hi[k] = std::fmax(std::fmax(a[k], b[k]), c[k]); }
     };
     const uint32_t maxp = d->max_node_prims ? d->max_node_prims : 4;
+    if (d->split_method > PT_SPLIT_HLBVH) return bail(fail(PT_ERR_INVALID_ARG, "unknown split_method"));
+    // BVHAccel::new (bvh.rs:145-198): SAH on the host (the reference's tree) or HLBVH on the device (gpu_bvh.hip)
+    auto build_accel = [&](const std::vector<pth::PrimBound> &pb, std::vector<PtBVHNode> &nodes, std::vector<uint32_t> &ordered) -> int {
+        if (d->split_method != PT_SPLIT_HLBVH) { pth::build_sah_bvh(pb, maxp, nodes, ordered); return PT_OK; }
+        const char *msg = "HLBVH build failed";
+        if (pth::build_hlbvh_gpu(pb, maxp, nodes, ordered, &msg)) return fail(PT_ERR_HIP, msg);
+        return PT_OK;
+    };
     struct ObjAccel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };
     std::vector<ObjAccel> obj(instanced ? d->n_objects : 0);
     if (instanced) {
@@ -587,7 +595,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if (O.n_prims == 1) continue;
             std::vector<pth::PrimBound> pb(O.n_prims);
             for (uint32_t i = 0; i < O.n_prims; ++i) prim_bound(O.first_prim + i, pb[i]);
-            pth::build_sah_bvh(pb, maxp, obj[o].nodes, obj[o].ordered);
+            if ((st = build_accel(pb, obj[o].nodes, obj[o].ordered))) return bail(st);
             for (auto &e : obj[o].ordered) e += O.first_prim;
         }
         for (uint32_t i = 0; i < d->n_instances; ++i) if (d->instances[i].object >= d->n_objects) return bail(fail(PT_ERR_INVALID_ARG, "instance object index out of range"));
@@ -625,7 +633,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
                 for (int k = 0; k < 3; ++k) { pb[i].lo[k] = c ? std::fmin(pb[i].lo[k], pc[k]) : pc[k]; pb[i].hi[k] = c ? std::fmax(pb[i].hi[k], pc[k]) : pc[k]; }
             }
         }
-        pth::build_sah_bvh(pb, maxp, sc->nodes, sc->ordered);
+        if ((st = build_accel(pb, sc->nodes, sc->ordered))) return bail(st);
     }
     // uploads
 #define UP(field, src, count) if ((st = sc->upload(&ds.field, src, (size_t)(count)))) return bail(st)

@@ -52,7 +52,7 @@ struct Scene {
     ParamSet camera_params; Transform camera_to_world; std::string camera_name = "perspective";
     int spp = 16; std::string sampler = "sobol";
     int maxdepth = 5; float rr_threshold = 1.0f; std::string strategy = "spatial"; bool has_pixel_bounds = false; int pixel_bounds[4] = {0, 0, 0, 0};
-    uint32_t max_node_prims = 4;
+    uint32_t max_node_prims = 4, split_method = PT_SPLIT_SAH;
     PtSceneDesc desc{}; PtRenderParams rp{};
     std::string base_dir;
 };
@@ -114,7 +114,7 @@ private:
         else if (w == "PixelFilter") { sc.filter = str_arg(lx, d); sc.filter_params = read_params(lx); }
         else if (w == "Integrator") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); integrator(d, n, p); }
         else if (w == "Accelerator") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); if (n != "bvh") fail(d, "only the bvh accelerator is supported");
-                                       if (p.one_string("splitmethod", "sah") != "sah") fail(d, "only splitmethod \"sah\" is supported"); sc.max_node_prims = (uint32_t)p.one_int("maxnodeprims", 4); }
+                                       { const std::string sm = p.one_string("splitmethod", "sah"); if (sm == "hlbvh") sc.split_method = PT_SPLIT_HLBVH; else if (sm != "sah") fail(d, "splitmethod \"" + sm + "\" is not supported (sah, hlbvh)"); } sc.max_node_prims = (uint32_t)p.one_int("maxnodeprims", 4); }
         else if (w == "WorldBegin") { in_world = true; gs.ctm = Transform(); named_cs["world"] = gs.ctm; }
         else if (w == "WorldEnd") in_world = false;
         else if (w == "Material") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.material = new_material(n, p); }
@@ -469,7 +469,7 @@ static void finish(Scene &sc, const Api &api) {
     d.n_materials = (uint32_t)sc.materials.size(); d.materials = sc.materials.data();
     d.n_lights = (uint32_t)sc.lights.size(); d.lights = sc.lights.data();
     if (sc.env_w) { d.env_width = sc.env_w; d.env_height = sc.env_h; d.env_texels = sc.env_texels.data(); d.env_importance = sc.env_importance.data(); for (int k = 0; k < 3; ++k) d.env_power_lookup[k] = sc.env_power_lookup[k]; }
-    d.max_node_prims = sc.max_node_prims;
+    d.max_node_prims = sc.max_node_prims; d.split_method = sc.split_method;
     if (!sc.instances.empty()) { d.n_objects = (uint32_t)sc.objects.size(); d.objects = sc.objects.data(); d.n_instances = (uint32_t)sc.instances.size(); d.instances = sc.instances.data(); d.n_top = (uint32_t)sc.top_refs.size(); d.top_refs = sc.top_refs.data(); }
     for (auto &t : sc.bss_tables) { PtBSSRDFTable e{}; e.n_rho = (uint32_t)t->n_rho; e.n_radius = (uint32_t)t->n_radius; e.rho_samples = t->rho_samples.data(); e.radius_samples = t->radius_samples.data(); e.profile = t->profile.data(); e.rhoeff = t->rhoeff.data(); e.profile_cdf = t->profile_cdf.data(); sc.bss_desc.push_back(e); }
     d.n_bssrdf_tables = (uint32_t)sc.bss_desc.size(); d.bssrdf_tables = sc.bss_desc.data();

@@ -161,6 +161,7 @@ class SceneBuilder:
         self.spp = 16
         self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None)
         self.max_node_prims = 4
+        self.split_method = "sah"   # accelerator "bvh" "string splitmethod": "sah" | "hlbvh" (bvh.rs:918-940)
         self.material("matte")  # api.rs:345-361 default material matte Kd .5
 
     # -- transforms / attributes (api.rs:941-1010,1268-1327)
@@ -563,6 +564,7 @@ class SceneData:
         self.n_materials, self.n_lights, self.n_spheres = len(b.materials), len(b.lights), len(b.spheres)
         self.env = b.env
         self.max_node_prims = b.max_node_prims
+        self.split_method = {"sah": A.PT_SPLIT_SAH, "hlbvh": A.PT_SPLIT_HLBVH}[b.split_method]
         self.nodes = None; self.ordered = None
         self.n_objects, self.n_instances = len(b.object_list), len(b.instances)
         self.objects = (A.PtObject * max(1, self.n_objects))(*[A.PtObject(f, n) for _, f, n in b.object_list])
@@ -614,6 +616,7 @@ class SceneData:
             d.env_texels = ptr(t, A.fp); d.env_importance = ptr(self.env["importance"], A.fp)
             d.env_power_lookup = (C.c_float * 3)(*[float(x) for x in self.env["power_lookup"]])
         d.max_node_prims = self.max_node_prims
+        d.split_method = self.split_method
         if self.nodes is not None:
             d.n_nodes = len(self.nodes); d.nodes = self.nodes; d.ordered_prims = ptr(self.ordered, A.u32p)
         if self.top_refs is not None:
