@@ -21,7 +21,7 @@ int g_device = -1;
 int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
-uint32_t g_leaf_quorum[4] = {8, 8, 8, 20};
+uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
 uint32_t g_trace_waves_per_cu = 20;               // persistent trace waves per CU = 5 per SIMD, the occupancy of k_trace<*, 0> (env PT_TRACE_WAVES_PER_CU)
 SobolTables g_tabs = {nullptr, nullptr, nullptr};
 
@@ -467,6 +467,11 @@ void read_counters(pt_scene *sc) {
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
     for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
+#ifdef PT_TRACE_UTIL
+    for (int k = 0; k < 4; ++k)
+        fprintf(stderr, "[trace-util] %-14s node phase: %.3e wave iterations, %.1f %% lanes active; leaf phase: %.3e iterations, %.1f %% lanes active\n", kn[k], (double)d.regions[4 * k],
+                d.regions[4 * k] ? 100.0 * (double)d.regions[4 * k + 1] / (64.0 * (double)d.regions[4 * k]) : 0.0, (double)d.regions[4 * k + 2], d.regions[4 * k + 2] ? 100.0 * (double)d.regions[4 * k + 3] / (64.0 * (double)d.regions[4 * k + 2]) : 0.0);
+#endif
 #ifdef PT_REGION_PROFILE
     {
         static const char *rn[16] = {"0 loop/queue read", "1 resolve", "2 resolve env le", "3 load ray/hit + fill_hit + Le", "4 sobol window", "5 light choice",

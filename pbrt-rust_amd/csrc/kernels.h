@@ -111,7 +111,7 @@ struct TraceJob {
     DevCounters *counters;
     uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera (per-kind work counters)
     uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)
-    uint32_t leaf_quorum;    // leave the node phase once this many lanes wait at a leaf
+    uint32_t leaf_quorum;    // lanes waiting at a leaf join the record fetch once this many wait (or no lane is at a node)
 };
 
 struct ShadeJob {

@@ -180,6 +180,12 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
+#ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
+    uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0;
+#define PT_UTIL(it, act, pred) do { const unsigned long long m_ = __ballot(pred); if (pred) { act++; it += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } } while (0)
+#else
+#define PT_UTIL(it, act, pred) do { } while (0)
+#endif
 
     // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
@@ -282,13 +288,20 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
         }
         if (__ballot(state != ST_IDLE) == 0ull) break;   // queue drained and every lane retired
 
-        // ---- phase 1: enter interior nodes
-        for (;;) {
-            const unsigned long long em = __ballot(state == ST_ENTER);
-            if (em == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(state == ST_LEAF)) >= job.leaf_quorum) break;
-            if (state == ST_ENTER) {
-                const uint4 q0 = wide4[4 * (size_t)cur], q1 = wide4[4 * (size_t)cur + 1], q2 = wide4[4 * (size_t)cur + 2], q3 = wide4[4 * (size_t)cur + 3];
+        // ---- one record per lane and iteration: a lane at an interior node fetches its 64-byte two-wide record, a lane at a leaf
+        //      its next 48-byte packet; both kinds of fetch are in flight together and nobody waits for a phase change
+        // lanes at a leaf join in once `leaf_quorum` of them wait (or no lane is at a node), so the triangle test is not
+        // executed for a handful of lanes in every iteration
+        const bool at_node = state == ST_ENTER;
+        const unsigned long long leaf_m = __ballot(state == ST_LEAF);
+        const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || __ballot(at_node) == 0ull);
+        PT_UTIL(u_it1, u_act1, at_node || at_leaf);
+        PT_UTIL(u_it2, u_act2, at_leaf);
+        if (at_node || at_leaf) {
+            const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
+            bool need_pop = false;
+            if (at_node) {
                 const float lmin[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
                 const float lmax[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
                 const float rmin[3] = {__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
@@ -315,100 +328,89 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                 if (geo_near && tmin_near < t_max) {
                     cur = near_ref & kRefMask;
                     state = (near_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
-                } else pop_next();
-            }
-        }
-
-        // ---- phase 2: leaf packets in ordered_prims order, two at a time (both loads in flight together)
-        if (state == ST_LEAF) {
-            bool last = false, entered_instance = false;
-            uint32_t li = cur;
-            while (!last) {
-                const uint4 a0 = leaf4[3 * (size_t)li], a1 = leaf4[3 * (size_t)li + 1], a2 = leaf4[3 * (size_t)li + 2];
-                const uint4 c0 = leaf4[3 * (size_t)li + 3], c1 = leaf4[3 * (size_t)li + 4], c2 = leaf4[3 * (size_t)li + 5];  // array is padded by one packet
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint4 q0 = k ? c0 : a0, q1 = k ? c1 : a1, q2 = k ? c2 : a2;
-                    const uint32_t fl = q2.w;
-                    if (fl & TP_INSTANCE) {
-                        if constexpr (SPH) {  // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
-                            const DevInstance &I = s.instances[q2.z];
-                            // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
-                            const M4 w2i = ldm4g(I.world_to_instance);
-                            V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
-                            const float l2 = length_squared(d2);
-                            float tm2 = t_max;
-                            if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
-                            const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
-                            const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
-                            bool enter = true;
-                            if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
-                            if (enter) {
-                                // remember where to resume: the rest of this leaf (if any) and the outer skip count
-                                const bool more = !(fl & TP_LAST);
-                                const uint32_t w0 = (more ? (kLeafBit | ((li + (uint32_t)k + 1u) & kRefMask)) : 0u) | (pending << 25);
-                                if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
-                                else {
-                                    if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
-                                    else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = kMarker; }
-                                    sp++; pending = 0;
-                                    t_max_world = t_max; in_inst = q2.z; inst_hit = false;
-                                    ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
-                                    cur = I.root_ref & kRefMask;
-                                    state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
-                                    last = true; entered_instance = true;
-                                    break;
-                                }
+                } else need_pop = true;
+            } else {
+                // leaf packets in ordered_prims order
+                const uint32_t fl = q2.w, li = cur;
+                bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
+                if (fl & TP_INSTANCE) {
+                    if constexpr (SPH) {  // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
+                        const DevInstance &I = s.instances[q2.z];
+                        // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
+                        const M4 w2i = ldm4g(I.world_to_instance);
+                        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+                        const float l2 = length_squared(d2);
+                        float tm2 = t_max;
+                        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
+                        const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
+                        const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
+                        bool enter = true;
+                        if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+                        if (enter) {
+                            // remember where to resume: the rest of this leaf (if any) and the outer skip count
+                            const bool more = !(fl & TP_LAST);
+                            const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
+                            if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                            else {
+                                if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
+                                else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = kMarker; }
+                                sp++; pending = 0;
+                                t_max_world = t_max; in_inst = q2.z; inst_hit = false;
+                                ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
+                                cur = I.root_ref & kRefMask;
+                                state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                                advance = false;
                             }
                         }
-                    } else if (fl & TP_SPHERE) {
-                        if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
-                            n_sph++;
-                            float t, phi; V3 ph, dobj;
-                            if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, ANY, t, ph, phi, dobj)) {
-                                if (ANY) { found = true; last = true; state = ST_DONE; break; }
-                                found = true; t_max = t;
+                    }
+                } else if (fl & TP_SPHERE) {
+                    if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
+                        n_sph++;
+                        float t, phi; V3 ph, dobj;
+                        if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, ANY, t, ph, phi, dobj)) {
+                            found = true;
+                            if (ANY) { state = ST_DONE; advance = false; }
+                            else {
+                                t_max = t;
                                 hit_prim = q2.y; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
                                 hit_inst = in_inst; inst_hit = in_inst != PT_NONE;
                             }
                         }
-                    } else {
-                        n_tris++;
-                        V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-                        V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-                        V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
-                        float t, b0, b1, b2;
-                        bool hit = tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2);
-                        if constexpr (ALPHA) {
-                            // Triangle::intersect (triangle.rs:275-285) / intersect_p (:497-545) with an alpha mask: the hit is
-                            // discarded where the mask evaluates to 0; intersect_p then also rejects degenerate triangles
-                            if (hit && (fl & TP_ALPHA) && !(fl & TP_BOGUS)) {
-                                const uint32_t tri = q2.z & 0x3fffffffu;
-                                P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
-                                TexCtx c; c.dpdx = V3(0.0f, 0.0f, 0.0f); c.dpdy = V3(0.0f, 0.0f, 0.0f); c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
-                                c.p = p0 * b0 + p1 * b1 + p2 * b2;
-                                c.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
-                                const int32_t a = s.tri_alpha ? s.tri_alpha[tri] : -1;
-                                if (a >= 0 && tex_eval(s, a, c).r == 0.0f) hit = false;
-                                if (ANY && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
-                            } else if (ANY && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
-                        }
-                        if (hit) {
-                            if (ANY) { found = true; last = true; state = ST_DONE; break; }
-                            if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
-                                found = true; t_max = t;  // primitive.rs:137
-                                hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
-                                if (SPH) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
-                            }
+                    }
+                } else {
+                    n_tris++;
+                    V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                    V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+                    V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+                    float t, b0, b1, b2;
+                    bool hit = tri_hit_params(p0, p1, p2, ro, rd, t_max, t, b0, b1, b2);
+                    if constexpr (ALPHA) {
+                        // Triangle::intersect (triangle.rs:275-285) / intersect_p (:497-545) with an alpha mask: the hit is
+                        // discarded where the mask evaluates to 0; intersect_p then also rejects degenerate triangles
+                        if (hit && (fl & TP_ALPHA) && !(fl & TP_BOGUS)) {
+                            const uint32_t tri = q2.z & 0x3fffffffu;
+                            P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
+                            TexCtx c; c.dpdx = V3(0.0f, 0.0f, 0.0f); c.dpdy = V3(0.0f, 0.0f, 0.0f); c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
+                            c.p = p0 * b0 + p1 * b1 + p2 * b2;
+                            c.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
+                            const int32_t a = s.tri_alpha ? s.tri_alpha[tri] : -1;
+                            if (a >= 0 && tex_eval(s, a, c).r == 0.0f) hit = false;
+                            if (ANY && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
+                        } else if (ANY && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
+                    }
+                    if (hit) {
+                        if (ANY) { found = true; state = ST_DONE; advance = false; }
+                        else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
+                            found = true; t_max = t;  // primitive.rs:137
+                            hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                            if (SPH) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
                         }
                     }
-                    if (fl & TP_LAST) { last = true; break; }
                 }
-                li += 2;
+                if (advance) { if (fl & TP_LAST) need_pop = true; else cur = li + 1u; }
             }
-            if (state == ST_LEAF && !entered_instance) pop_next();
+            if (need_pop) pop_next();
         }
-
     }
     counter_add(&job.counters->nodes, n_nodes);
     counter_add(&job.counters->tri_tests, n_tris);
@@ -417,6 +419,13 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
     counter_add(&job.counters->k_nodes[job.kind], n_nodes);
     counter_add(&job.counters->k_tris[job.kind], n_tris);
     counter_add(&job.counters->k_rays[job.kind], n_rays);
+#ifdef PT_TRACE_UTIL
+    for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
+    if (lane == 0) {
+        atomicAdd(&job.counters->regions[4 * job.kind + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * job.kind + 1], (unsigned long long)u_act1);
+        atomicAdd(&job.counters->regions[4 * job.kind + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * job.kind + 3], (unsigned long long)u_act2);
+    }
+#endif
 }
 template __global__ void k_trace<false, 0>(DeviceScene, TraceJob);
 template __global__ void k_trace<true, 0>(DeviceScene, TraceJob);
