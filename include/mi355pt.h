@@ -292,6 +292,7 @@ typedef struct PtSceneDesc {
 
 /* ---- render parameters ---------------------------------------------------------------- */
 
+typedef enum PtSamplerType { PT_SAMPLER_SOBOL = 0, PT_SAMPLER_HALTON = 1 } PtSamplerType;
 typedef enum PtLightStrategy { PT_LS_UNIFORM = 0, PT_LS_POWER = 1, PT_LS_SPATIAL = 2 } PtLightStrategy;
 
 typedef struct PtRenderParams {
@@ -324,6 +325,10 @@ typedef struct PtRenderParams {
     /* 1 => record per-kernel HIP-event timings (see pt_get_kernel_stats); 2 => also exact per-class launch sizes
      * (one extra host sync per iteration). */
     uint32_t profile;
+    /* Sampler (api.rs make_sampler): PT_SAMPLER_SOBOL (samplers/sobol.rs) or PT_SAMPLER_HALTON (samplers/halton.rs, the
+     * reference's default when a scene names no sampler, api.rs:215-241); "samplepixelcenter" (halton.rs:226). */
+    uint32_t sampler_type;
+    uint32_t sample_at_pixel_center;
 } PtRenderParams;
 
 /* Device-side work counters: mirrors of the reference's stat counters
@@ -395,6 +400,9 @@ int pt_trace_any(pt_scene *scene, uint32_t n, const float *origins, const float 
  * consecutive sample_dimension() values starting at dimension 0 (samplers/sobol.rs:68-86). */
 int pt_sobol_samples(const int32_t sample_bounds[4], uint32_t n, const int32_t *pixel_xy,
                      const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index);
+/* HaltonSampler (samplers/halton.rs:122-165): same contract, dimensions 0/1 are the offsets inside the pixel. */
+int pt_halton_samples(const int32_t sample_bounds[4], uint32_t sample_at_pixel_center, uint32_t n, const int32_t *pixel_xy,
+                      const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index);
 /* PerspectiveCamera::generate_ray_differential main ray for n camera samples
  * (pfilm.xy, time, plens.xy) -> origin, direction (cameras/perspective.rs:120-179). */
 int pt_camera_rays(const PtRenderParams *params, uint32_t n, const float *camera_samples,

@@ -27,7 +27,7 @@ class Oracle:
         lib = C.CDLL(LIB_PATH)
         table = {k.replace("pt_", "orc_", 1): v for k, v in A.ENTRY_POINTS.items()
                  if k in ("pt_scene_create", "pt_scene_destroy", "pt_scene_bvh_info", "pt_scene_bvh_read", "pt_get_counters",
-                          "pt_trace_closest", "pt_trace_any", "pt_sobol_samples", "pt_camera_rays")}
+                          "pt_trace_closest", "pt_trace_any", "pt_sobol_samples", "pt_halton_samples", "pt_camera_rays")}
         for name, (res, args) in table.items():
             fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
         lib.orc_render.restype = C.c_int
@@ -38,6 +38,8 @@ class Oracle:
         f = C.c_float
         lib.orc_sobol_sample_float.restype = f; lib.orc_sobol_sample_float.argtypes = [C.c_uint64, C.c_int, C.c_uint32]
         lib.orc_radical_inverse.restype = f; lib.orc_radical_inverse.argtypes = [C.c_int, C.c_uint64]
+        lib.orc_radical_inverse_any.restype = f; lib.orc_radical_inverse_any.argtypes = [C.c_uint32, C.c_uint64]
+        lib.orc_halton_permutation.restype = C.c_uint32; lib.orc_halton_permutation.argtypes = [C.c_uint32, C.POINTER(C.c_uint16)]
         for n in ("orc_next_float_up", "orc_next_float_down", "orc_dm_sin", "orc_dm_cos", "orc_dm_acos", "orc_dm_log"):
             getattr(lib, n).restype = f; getattr(lib, n).argtypes = [f]
         lib.orc_dm_atan2.restype = f; lib.orc_dm_atan2.argtypes = [f, f]

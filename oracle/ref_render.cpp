@@ -502,7 +502,7 @@ static void render_tiles(const RenderJob &job, float *film_xyzw, int nthreads, C
             int64_t tx = t % ntx, ty = t / ntx;
             int64_t tb[4] = {sb[0] + tx * 16, sb[1] + ty * 16, 0, 0};
             tb[2] = std::min<int64_t>(tb[0] + 16, sb[2]); tb[3] = std::min<int64_t>(tb[1] + 16, sb[3]);
-            SobolSampler sampler(rp.spp, rp.sample_bounds);
+            SobolSampler sampler(rp.spp, rp.sample_bounds, rp.sampler_type, rp.sample_at_pixel_center != 0);
             FilmTile tile(job.fp, tb);
             for (int64_t y = tb[1]; y < tb[3]; ++y)
                 for (int64_t x = tb[0]; x < tb[2]; ++x) {
@@ -717,6 +717,27 @@ int orc_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, 
         for (uint32_t k = 0; k < n_dims; ++k) out[(size_t)i * n_dims + k] = s.sample_dimension(s.interval_sample_index, (int)k);
     }
     return PT_OK;
+}
+int orc_halton_samples(const int32_t sb[4], uint32_t at_center, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    SobolSampler s(1u << 30, sb, PT_SAMPLER_HALTON, at_center != 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        s.start_pixel(pixel_xy[2 * i], pixel_xy[2 * i + 1]);
+        s.set_sample_number(sample_num[i]);
+        if (out_index) out_index[i] = s.interval_sample_index;
+        for (uint32_t k = 0; k < n_dims; ++k) out[(size_t)i * n_dims + k] = s.sample_dimension(s.interval_sample_index, (int)k);
+    }
+    return PT_OK;
+}
+// KAT hooks: radical_inverse(base_index, n) (pbrt_macros:92-111) and the Halton digit permutation of a dimension
+float orc_radical_inverse_any(uint32_t base_index, uint64_t n) {
+    if (base_index == 0) return (float)reverse_bits64_h(n) * 0x1.0p-64f;
+    return radical_inverse_base(halton_tables().primes[base_index], n);
+}
+uint32_t orc_halton_permutation(uint32_t dim, uint16_t *out) {
+    const HaltonTables &T = halton_tables();
+    if (dim >= 1000) return 0;
+    for (uint32_t j = 0; j < T.primes[dim]; ++j) out[j] = T.perm[T.sums[dim] + j];
+    return T.primes[dim];
 }
 int orc_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float *out_o, float *out_d) {
     Camera cam;

@@ -22,6 +22,7 @@ PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
+PT_SAMPLER_SOBOL, PT_SAMPLER_HALTON = range(2)
 
 
 def shape_ref(kind, index):
@@ -111,7 +112,7 @@ class PtRenderParams(C.Structure):
                 ("raster_to_camera", f32 * 16), ("camera_to_world", f32 * 16), ("lens_radius", f32),
                 ("focal_distance", f32), ("shutter_open", f32), ("shutter_close", f32),
                 ("max_depth", u32), ("rr_threshold", f32), ("pixel_bounds", i32 * 4), ("light_strategy", u32),
-                ("tile_rank", u32), ("tile_world", u32), ("spp_per_pass", u32), ("profile", u32)]
+                ("tile_rank", u32), ("tile_world", u32), ("spp_per_pass", u32), ("profile", u32), ("sampler_type", u32), ("sample_at_pixel_center", u32)]
 
 
 class PtCounters(C.Structure):
@@ -149,6 +150,7 @@ ENTRY_POINTS = {
     "pt_trace_closest": (C.c_int, [VP, u32, fp, fp, fp, u32p, fp, fp]),
     "pt_trace_any": (C.c_int, [VP, u32, fp, fp, fp, u8p]),
     "pt_sobol_samples": (C.c_int, [i32p, u32, i32p, u32p, u32, fp, u64p]),
+    "pt_halton_samples": (C.c_int, [i32p, u32, u32, i32p, u32p, u32, fp, u64p]),
     "pt_camera_rays": (C.c_int, [C.POINTER(PtRenderParams), u32, fp, fp, fp]),
 }
 

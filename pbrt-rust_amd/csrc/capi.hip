@@ -23,7 +23,7 @@ int g_num_cus = 256;
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
 uint32_t g_trace_waves_per_cu = 20;               // persistent trace waves per CU = 5 per SIMD, the occupancy of k_trace<*, 0> (env PT_TRACE_WAVES_PER_CU)
-SobolTables g_tabs = {nullptr, nullptr, nullptr};
+SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
 #define HIP_TRY(expr)                                                                                         \
@@ -51,6 +51,35 @@ int upload_tables() {
     g_tabs.m32 = (const uint32_t *)d;
     g_tabs.vdc = (const uint64_t *)((const char *)d + 1024 * 52 * 4);
     g_tabs.vdc_inv = g_tabs.vdc + 25 * 52;
+    // Halton: the first 1000 primes (PRIMES / PRIME_SUMS, lowdiscrepancy.rs:9-192: here sieved, not tabulated) and the digit
+    // permutations of compute_radical_inverse_permutations(&mut RNG::default()) (lowdiscrepancy.rs:359-378): per base the
+    // identity permutation shuffled by `shuffle` (sampling.rs:178-186) with PCG32 (rng.rs:17-58), one RNG for all bases.
+    {
+        std::vector<uint32_t> primes, sums;
+        for (uint32_t c = 2; primes.size() < kHaltonMaxDims; ++c) { bool pr = true; for (uint32_t q : primes) { if (q * q > c) break; if (c % q == 0) { pr = false; break; } } if (pr) primes.push_back(c); }
+        uint32_t total = 0;
+        for (uint32_t q : primes) { sums.push_back(total); total += q; }
+        std::vector<uint16_t> perm(total);
+        uint64_t state = 0x853c49e6748fea9bull; const uint64_t inc = 0xda3e39cb94b95bdbull;
+        auto uniform_u32 = [&]() {
+            const uint64_t old = state;
+            state = old * 0x5851f42d4c957f2dull + inc;
+            const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27), rot = (uint32_t)(old >> 59);
+            return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+        };
+        auto uniform_below = [&](uint32_t b) { const uint32_t threshold = (~b + 1u) % b; for (;;) { const uint32_t r = uniform_u32(); if (r >= threshold) return r % b; } };
+        for (size_t i = 0; i < primes.size(); ++i) {
+            uint16_t *pp = perm.data() + sums[i];
+            for (uint32_t j = 0; j < primes[i]; ++j) pp[j] = (uint16_t)j;
+            for (uint32_t j = 0; j < primes[i]; ++j) { const uint32_t other = j + uniform_below(primes[i] - j); std::swap(pp[j], pp[other]); }
+        }
+        void *dp = nullptr, *ds = nullptr, *dm = nullptr;
+        HIP_TRY(hipMalloc(&dp, primes.size() * 4)); HIP_TRY(hipMalloc(&ds, sums.size() * 4)); HIP_TRY(hipMalloc(&dm, perm.size() * 2));
+        HIP_TRY(hipMemcpy(dp, primes.data(), primes.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ds, sums.data(), sums.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dm, perm.data(), perm.size() * 2, hipMemcpyHostToDevice));
+        g_tabs.prime = (const uint32_t *)dp; g_tabs.prime_sum = (const uint32_t *)ds; g_tabs.perm = (const uint16_t *)dm;
+    }
     return PT_OK;
 }
 
@@ -293,6 +322,24 @@ void fill_render_const(const PtRenderParams *rp, RenderConst &rc) {
     int32_t v = std::max(dx, dy); v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
     rc.sobol.resolution = v; rc.sobol.log2_resolution = 31 - __builtin_clz((uint32_t)v);
     rc.sobol.sb_min[0] = rp->sample_bounds[0]; rc.sobol.sb_min[1] = rp->sample_bounds[1];
+    if (rp->sampler_type == PT_SAMPLER_HALTON) {   // HaltonSampler::new (halton.rs:62-110), kMaxResolution = 128
+        rc.halton.enabled = 1; rc.halton.at_center = rp->sample_at_pixel_center ? 1u : 0u;
+        const int32_t res[2] = {dx, dy};
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t base = i == 0 ? 2u : 3u;
+            uint32_t scale = 1, e = 0;
+            while ((int64_t)scale < (int64_t)std::min(res[i], 128)) { scale *= base; e++; }
+            rc.halton.base_scale[i] = scale; rc.halton.base_exp[i] = e;
+        }
+        rc.halton.stride = rc.halton.base_scale[0] * rc.halton.base_scale[1];
+        auto mult_inverse = [](int64_t a, int64_t n) {   // extended_gcd + mod_ (halton.rs:19-35)
+            int64_t x0 = 1, x1 = 0, aa = a, bb = n;      // iterative form of the same recurrence: x with a*x = gcd (mod n)
+            while (bb != 0) { const int64_t q = aa / bb; int64_t t = aa - q * bb; aa = bb; bb = t; t = x0 - q * x1; x0 = x1; x1 = t; }
+            return ((x0 % n) + n) % n;
+        };
+        rc.halton.mult_inv[0] = (uint32_t)mult_inverse(rc.halton.base_scale[1], rc.halton.base_scale[0]);
+        rc.halton.mult_inv[1] = (uint32_t)mult_inverse(rc.halton.base_scale[0], rc.halton.base_scale[1]);
+    }
     std::memcpy(rc.raster_to_camera.m, rp->raster_to_camera, 64);
     std::memcpy(rc.camera_to_world.m, rp->camera_to_world, 64);
     rc.lens_radius = rp->lens_radius; rc.focal_distance = rp->focal_distance;
@@ -326,7 +373,7 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 template <int MAXL, bool DIFF = false> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
     if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
-    else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
@@ -495,7 +542,7 @@ int pt_init(int device_ordinal) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr}; }
+    if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
     g_device = device_ordinal;
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; } }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
@@ -872,6 +919,8 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->film_rgbw, 0, film_px * 16, sc->stream));
         HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
+        // Halton scenes shade with the general kernels, which read the instance of a hit; the triangle-only traversal never writes it
+        if (rc.halton.enabled && sc->ds.n_spheres == 0 && sc->ds.n_instances == 0) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
@@ -999,6 +1048,26 @@ int pt_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, c
     HIP_TRY(hipMemcpy(dxy, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dsn, sample_num, (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_sobol_samples, dim3((n + 255) / 256), dim3(256), 0, 0, g_tabs, rc.sobol, n, dxy, dsn, n_dims, dout, didx);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * n_dims * 4, hipMemcpyDeviceToHost));
+    if (out_index) HIP_TRY(hipMemcpy(out_index, didx, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipFree(dxy); hipFree(dsn); hipFree(dout); hipFree(didx);
+    return PT_OK;
+}
+
+int pt_halton_samples(const int32_t sb[4], uint32_t sample_at_pixel_center, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    if (!sb || !pixel_xy || !sample_num || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (n_dims > kHaltonMaxDims) return fail(PT_ERR_SOBOL_DIMENSIONS, "HaltonSampler can only sample 1000 dimensions");
+    int st = ensure_device();
+    if (st || n == 0) return st;
+    PtRenderParams rp{}; std::memcpy(rp.sample_bounds, sb, 16); rp.sampler_type = PT_SAMPLER_HALTON; rp.sample_at_pixel_center = sample_at_pixel_center;
+    RenderConst rc; fill_render_const(&rp, rc);
+    int32_t *dxy; uint32_t *dsn; float *dout; uint64_t *didx;
+    HIP_TRY(hipMalloc((void **)&dxy, (size_t)n * 8)); HIP_TRY(hipMalloc((void **)&dsn, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(hipMalloc((void **)&didx, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dxy, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsn, sample_num, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_halton_samples, dim3((n + 255) / 256), dim3(256), 0, 0, g_tabs, rc.halton, n, dxy, dsn, n_dims, dout, didx);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, (size_t)n * n_dims * 4, hipMemcpyDeviceToHost));
     if (out_index) HIP_TRY(hipMemcpy(out_index, didx, (size_t)n * 8, hipMemcpyDeviceToHost));

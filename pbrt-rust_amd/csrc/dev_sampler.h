@@ -1,4 +1,6 @@
-// dev_sampler.h -- Sobol' sampler on device.
+// dev_sampler.h -- Sobol' and Halton samplers on device (both are GlobalSamplers: one global index per (pixel, sample),
+// one value per dimension; only get_index_for_sample / sample_dimension differ).
+//   samplers/halton.rs:19-35,62-110,112-165; core/lowdiscrepancy.rs:359-426,469-484 (Halton)
 //   samplers/sobol.rs:61-86; core/sampler.rs:170-180,322-354 (dimension bookkeeping);
 //   core/lowdiscrepancy.rs:512-569 (interval-to-index, sample_float), :399-414 + pbrt_macros:92-111 (radical inverse).
 // Tables are DATA (core/sobolmatrices.rs) uploaded from data/sobol_tables.bin.
@@ -11,6 +13,19 @@ struct SobolTables {
     const uint32_t *m32;      // [1024][52]
     const uint64_t *vdc;      // [25][52]
     const uint64_t *vdc_inv;  // [26][52]
+    // Halton: the first 1000 primes, their running sums and the digit permutations (compute_radical_inverse_permutations
+    // with the default RNG, lowdiscrepancy.rs:359-378), built once on the host by capi.hip
+    const uint32_t *prime;     // [1000]
+    const uint32_t *prime_sum; // [1000]
+    const uint16_t *perm;      // [sum of the first 1000 primes]
+};
+
+struct HaltonParams {          // HaltonSampler::new (halton.rs:62-110)
+    uint32_t enabled;          // PtRenderParams.sampler_type == PT_SAMPLER_HALTON
+    uint32_t base_scale[2], base_exp[2];
+    uint32_t stride;           // sample_stride = base_scale[0] * base_scale[1]
+    uint32_t mult_inv[2];
+    uint32_t at_center;        // "samplepixelcenter"
 };
 
 struct SobolParams {
@@ -52,13 +67,60 @@ PT_DEV void sobol_stage_lds(uint32_t *lds, const uint32_t *m32, uint32_t tid, ui
     for (uint32_t i = tid; i < kSobolLdsWords; i += nthreads) lds[i] = m32[i];
 }
 
-// Per-path sampler state: the global Sobol' index of this (pixel, sample) and the running dimension.
+constexpr uint32_t kHaltonMaxDims = 1000;  // PRIME_TABLE_SIZE: permutation_for_dimension panics beyond (halton.rs:113-119)
+
+// inverse_radical_inverse::<BASE> (lowdiscrepancy.rs:416-426)
+PT_DEV uint64_t halton_inverse_radical_inverse(uint32_t base, uint64_t inverse, uint32_t ndigits) {
+    uint64_t index = 0;
+    for (uint32_t i = 0; i < ndigits; ++i) { const uint64_t digit = inverse % base; inverse /= base; index = index * base + digit; }
+    return index;
+}
+// HaltonSampler::get_index_for_sample (halton.rs:122-155); mod_ is the non-negative remainder (pbrt.rs)
+PT_DEV uint64_t halton_index_for_sample(const HaltonParams &hp, int32_t px, int32_t py, uint64_t sample_num) {
+    uint64_t offset = 0;
+    if (hp.stride > 1) {
+        const int32_t pm[2] = {((px % 128) + 128) % 128, ((py % 128) + 128) % 128};
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t dim_offset = halton_inverse_radical_inverse(i == 0 ? 2u : 3u, (uint64_t)pm[i], hp.base_exp[i]);
+            offset += dim_offset * (uint64_t)(hp.stride / hp.base_scale[i]) * (uint64_t)hp.mult_inv[i];
+        }
+        offset %= (uint64_t)hp.stride;
+    }
+    return offset + sample_num * (uint64_t)hp.stride;
+}
+// radical_inverse_specialized::<BASE> (lowdiscrepancy.rs:399-414); 32-bit digits loop when the value fits (same digits)
+PT_DEV float halton_radical_inverse(uint32_t base, uint64_t n) {
+    const float inv_base = 1.0f / (float)base;
+    uint64_t rev = 0; float inv_base_n = 1.0f;
+    if ((n >> 32) == 0) { uint32_t a = (uint32_t)n; while (a != 0) { const uint32_t next = a / base; rev = rev * base + (a - next * base); inv_base_n *= inv_base; a = next; } }
+    else while (n != 0) { const uint64_t next = n / base; rev = rev * base + (n - next * base); inv_base_n *= inv_base; n = next; }
+    return minf((float)rev * inv_base_n, kOneMinusEps);
+}
+// scranmbled_radical_inverse_specialized::<BASE> (lowdiscrepancy.rs:469-484)
+PT_DEV float halton_scrambled_radical_inverse(uint32_t base, const uint16_t *perm, uint64_t n) {
+    const float inv_base = 1.0f / (float)base;
+    uint64_t rev = 0; float inv_base_n = 1.0f;
+    if ((n >> 32) == 0) { uint32_t a = (uint32_t)n; while (a != 0) { const uint32_t next = a / base; rev = rev * base + perm[a - next * base]; inv_base_n *= inv_base; a = next; } }
+    else while (n != 0) { const uint64_t next = n / base; rev = rev * base + perm[n - next * base]; inv_base_n *= inv_base; n = next; }
+    return minf(inv_base_n * ((float)rev + inv_base * (float)perm[0] / (1.0f - inv_base)), kOneMinusEps);
+}
+// HaltonSampler::sample_dimension (halton.rs:157-165); dim < kHaltonMaxDims
+PT_DEV float halton_sample_dimension(const SobolTables &T, const HaltonParams &hp, uint64_t index, uint32_t dim) {
+    if (hp.at_center && dim < 2) return 0.5f;
+    if (dim == 0) return (float)__brevll(index >> hp.base_exp[0]) * 0x1.0p-64f;   // radical_inverse(0, ..): no clamp (pbrt_macros:101)
+    if (dim == 1) return halton_radical_inverse(3u, index / hp.base_scale[1]);
+    return halton_scrambled_radical_inverse(T.prime[dim], T.perm + T.prime_sum[dim], index);
+}
+
+// Per-path sampler state: the global sample index of this (pixel, sample) and the running dimension.
 struct Sampler {
     uint64_t index;
     uint32_t dim;
     const uint32_t *m32;      // full table in HBM
     const uint32_t *lds;      // first kSobolLdsDims rows in LDS
     bool overflow;
+    bool halton;              // wave-uniform: Halton instead of Sobol' (the window then holds float bits)
+    const uint32_t *prime, *prime_sum; const uint16_t *perm;
     uint32_t base;            // window of 8 consecutive dimensions evaluated in one pass over the index bits
     uint32_t w0, w1, w2, w3, w4, w5, w6, w7;
     // A path vertex consumes at most 8 dimensions (1 light choice + 2 + 2 + 2 BSDF + 1 roulette, path.rs /
@@ -66,6 +128,13 @@ struct Sampler {
     PT_DEV void load_window() {
         base = dim;
         w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0;
+        if (halton) {
+            if (base + 8 > kHaltonMaxDims) { base = 0xffffffffu; return; }
+            uint32_t w[8];
+            for (int k = 0; k < 8; ++k) w[k] = __float_as_uint(halton_scrambled_radical_inverse(prime[base + k], perm + prime_sum[base + k], index));
+            w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3]; w4 = w[4]; w5 = w[5]; w6 = w[6]; w7 = w[7];
+            return;
+        }
 #ifdef PT_ABL_SOBOL   // timing ablation only: a cheap hash instead of the generator-matrix products (results differ)
         { uint32_t h = (uint32_t)index * 0x9E3779B9u ^ (uint32_t)(index >> 32) ^ (base * 0x85EBCA6Bu);
           w0 = h; w1 = h * 3u; w2 = h * 5u; w3 = h * 7u; w4 = h * 11u; w5 = h * 13u; w6 = h * 17u; w7 = h * 19u; return; }
@@ -80,13 +149,14 @@ struct Sampler {
             }
         } else base = 0xffffffffu;  // beyond the staged rows: evaluate on demand from HBM
     }
-    PT_DEV float sample_dimension(uint32_t d) {  // sobol.rs:68-86 for dim >= 2
-        if (d >= 1024) { overflow = true; return 0.0f; }  // the reference panics here
+    PT_DEV float sample_dimension(uint32_t d) {  // sobol.rs:68-86 / halton.rs:157-165 for dim >= 2
+        if (d >= (halton ? kHaltonMaxDims : 1024u)) { overflow = true; return 0.0f; }  // the reference panics here
         const uint32_t k = d - base;
         if (base != 0xffffffffu && k < 8u) {
             const uint32_t v = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : k == 4 ? w4 : k == 5 ? w5 : k == 6 ? w6 : w7;
-            return sobol_to_float(v);
+            return halton ? __uint_as_float(v) : sobol_to_float(v);
         }
+        if (halton) return halton_scrambled_radical_inverse(prime[d], perm + prime_sum[d], index);
         return sobol_sample_float(d < kSobolLdsDims ? lds : m32, index, d);
     }
     PT_DEV float get_1d() { float r = sample_dimension(dim); dim += 1; return r; }  // sampler.rs:322-333 (array_end_dim == 5)

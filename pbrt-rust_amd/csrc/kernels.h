@@ -83,6 +83,7 @@ struct RenderConst {
     uint32_t n_pix_slots;             // n_tile_slots * 256
     int32_t sample_bounds[4], pixel_bounds[4], crop[4];
     SobolParams sobol;
+    HaltonParams halton;
     M4 raster_to_camera, camera_to_world;
     float lens_radius, focal_distance, shutter_open, shutter_close;
     float dx_camera[3], dy_camera[3];  // perspective.rs:64-70

@@ -520,6 +520,24 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
             int32_t px, py;
             if (slot_to_pixel(rc, slot, px, py)) {
                 const uint64_t sample = rc.s_begin + sl;
+                if (rc.halton.enabled) {   // HaltonSampler: same GlobalSampler bookkeeping, its own index and dimensions (halton.rs:122-165)
+                    const uint64_t index = halton_index_for_sample(rc.halton, px, py, sample);
+                    const float fx = halton_sample_dimension(tabs, rc.halton, index, 0u), fy = halton_sample_dimension(tabs, rc.halton, index, 1u);
+                    const float pfx = (float)px + fx, pfy = (float)py + fy;   // get_camera_sample: p_film = pixel + get_2d() (sampler.rs:170-180)
+                    const float tm = halton_sample_dimension(tabs, rc.halton, index, 2u);
+                    const P2 pl(halton_sample_dimension(tabs, rc.halton, index, 3u), halton_sample_dimension(tabs, rc.halton, index, 4u));
+                    V3 o, d;
+                    camera_ray(rc, pfx, pfy, tm, pl, o, d);
+                    ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
+                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                    ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
+                    ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
+                    ps.etascale[pid] = 1.0f;
+                    ps.sobol_index[pid] = index;
+                    ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);
+                    alive = true;
+                } else {
                 const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
                 // get_camera_sample (sampler.rs:170-180): pfilm = get_2d, time = get_1d, plens = get_2d; one pass over the index bits
                 uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 ps.sobol_index[pid] = index;
                 ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
                 alive = true;
+                }
             }
         }
         lq_push(s_q, pid, alive);
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         pid = job.queue[qi];
         uint32_t meta = ps.meta[pid];
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
         smp.base = 0xffffffffu;
         RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
         RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
@@ -817,7 +836,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                     RayDiff rdiff; rdiff.has = false;
                     if (flags & PF_CAMERA_RAY) {
                         P2 plens_u(0.0f, 0.0f);
-                        if (rc.lens_radius > 0.0f) plens_u = P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
+                        if (rc.lens_radius > 0.0f) plens_u = rc.halton.enabled ? P2(halton_sample_dimension(tabs, rc.halton, smp.index, 3u), halton_sample_dimension(tabs, rc.halton, smp.index, 4u))
+                                                                              : P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
                         rdiff = camera_ray_differentials(rc, ps.pfilm_x[pid], ps.pfilm_y[pid], plens_u, ro, rd);
                     }
                     const TexCtx tctx = compute_differentials(si, rdiff);
@@ -1091,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
         if (at_exit || dead) {
             uint32_t meta = ps.meta[pid];
             uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
             smp.base = 0xffffffffu;
             RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
             RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
@@ -1301,6 +1321,15 @@ __global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, si
 }
 
 // ---- parity helpers -------------------------------------------------------------------------------------------
+__global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
+                                 uint32_t n_dims, float *out, uint64_t *out_index) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t index = halton_index_for_sample(hp, pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_num[i]);
+    if (out_index) out_index[i] = index;
+    for (uint32_t d = 0; d < n_dims; ++d) out[(size_t)i * n_dims + d] = halton_sample_dimension(tabs, hp, index, d);
+}
+
 __global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
                                 uint32_t n_dims, float *out, uint64_t *out_index) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

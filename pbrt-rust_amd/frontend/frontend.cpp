@@ -7,7 +7,7 @@
 //   :1630-1713 (ObjectBegin/End/Instance), :1715-1748 (WorldEnd), core/paramset.rs:500-600 (texture-or-constant lookups),
 //   cameras/perspective.rs:40-86,298-356, core/film.rs:55-112,364-398, filters/*.rs, lights/*.rs create_* functions,
 //   materials/*.rs create_* functions, shapes/{triangle.rs:700-760, sphere.rs:424-431, plymesh.rs}.
-// Out of scope here (an error names the directive): other cameras / samplers / integrators than perspective / sobol / path,
+// Out of scope here (an error names the directive): other cameras / samplers / integrators than perspective / sobol, halton / path,
 // participating media, spectral (non-RGB) parameters, image formats other than PFM, per-shape material parameter
 // overrides, animated transforms (ActiveTransform / TransformTimes are accepted and ignored for static scenes).
 #include "../../include/mi355pt.h"
@@ -50,7 +50,8 @@ struct Scene {
     int xres = 1280, yres = 720; float crop[4] = {0, 1, 0, 1}; float film_scale = 1.0f, max_lum = INFINITY; std::string filename = "pbrt.pfm";
     std::string filter = "box"; ParamSet filter_params;
     ParamSet camera_params; Transform camera_to_world; std::string camera_name = "perspective";
-    int spp = 16; std::string sampler = "sobol";
+    int spp = 16; std::string sampler = "halton";   // RenderOptions::default (api.rs:215-241)
+    bool sample_at_center = false;
     int maxdepth = 5; float rr_threshold = 1.0f; std::string strategy = "spatial"; bool has_pixel_bounds = false; int pixel_bounds[4] = {0, 0, 0, 0};
     uint32_t max_node_prims = 4, split_method = PT_SPLIT_SAH;
     PtSceneDesc desc{}; PtRenderParams rp{};
@@ -110,7 +111,7 @@ private:
         else if (w == "ReverseOrientation") gs.reverse = !gs.reverse;
         else if (w == "Camera") { sc.camera_name = str_arg(lx, d); sc.camera_params = read_params(lx); sc.camera_to_world = gs.ctm.inverse(); named_cs["camera"] = sc.camera_to_world; }
         else if (w == "Film") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); film(d, n, p); }
-        else if (w == "Sampler") { sc.sampler = str_arg(lx, d); ParamSet p = read_params(lx); sc.spp = p.one_int("pixelsamples", 16); }
+        else if (w == "Sampler") { sc.sampler = str_arg(lx, d); ParamSet p = read_params(lx); sc.spp = p.one_int("pixelsamples", 16); sc.sample_at_center = p.one_bool("samplepixelcenter", false); }
         else if (w == "PixelFilter") { sc.filter = str_arg(lx, d); sc.filter_params = read_params(lx); }
         else if (w == "Integrator") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); integrator(d, n, p); }
         else if (w == "Accelerator") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); if (n != "bvh") fail(d, "only the bvh accelerator is supported");
@@ -459,7 +460,7 @@ static void filter_table(const std::string &name, const ParamSet &p, float radiu
 
 static void finish(Scene &sc, const Api &api) {
     if (sc.camera_name != "perspective") throw std::runtime_error("camera \"" + sc.camera_name + "\": only \"perspective\" runs on this back end");
-    if (sc.sampler != "sobol") throw std::runtime_error("sampler \"" + sc.sampler + "\": only \"sobol\" runs on this back end (the path depends on its dimension bookkeeping)");
+    if (sc.sampler != "sobol" && sc.sampler != "halton") throw std::runtime_error("sampler \"" + sc.sampler + "\": only \"sobol\" and \"halton\" run on this back end (the path depends on the GlobalSampler dimension bookkeeping)");
     PtSceneDesc &d = sc.desc; d = PtSceneDesc{};
     d.n_vertices = (uint32_t)(sc.P.size() / 3); d.P = sc.P.data();
     d.N = api.any_n ? sc.N.data() : nullptr; d.S = api.any_s ? sc.S.data() : nullptr; d.UV = api.any_uv ? sc.UV.data() : nullptr;
@@ -509,6 +510,7 @@ static void finish(Scene &sc, const Api &api) {
     else { const int *pb = sc.pixel_bounds; rp.pixel_bounds[0] = std::max(pb[0], sb[0]); rp.pixel_bounds[1] = std::max(pb[2], sb[1]); rp.pixel_bounds[2] = std::min(pb[1], sb[2]); rp.pixel_bounds[3] = std::min(pb[3], sb[3]); }   // path.rs:233-246
     rp.light_strategy = sc.strategy == "uniform" ? PT_LS_UNIFORM : sc.strategy == "power" ? PT_LS_POWER : PT_LS_SPATIAL;
     rp.tile_rank = 0; rp.tile_world = 1; rp.spp_per_pass = 0; rp.profile = 0;
+    rp.sampler_type = sc.sampler == "halton" ? PT_SAMPLER_HALTON : PT_SAMPLER_SOBOL; rp.sample_at_pixel_center = (sc.sampler == "halton" && sc.sample_at_center) ? 1u : 0u;
 }
 
 }  // namespace fe

@@ -159,6 +159,8 @@ class SceneBuilder:
         self.filter = dict(kind="box", radius=(0.5, 0.5), alpha=2.0)
         self.cam = dict(fov=90.0, lensradius=0.0, focaldistance=1e6, shutteropen=0.0, shutterclose=1.0, c2w=Transform())
         self.spp = 16
+        self.sampler = "sobol"          # "sobol" | "halton" (Sampler directive; the reference's default is halton, api.rs:215-241)
+        self.sample_at_pixel_center = False
         self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None)
         self.max_node_prims = 4
         self.split_method = "sah"   # accelerator "bvh" "string splitmethod": "sah" | "hlbvh" (bvh.rs:918-940)
@@ -468,6 +470,8 @@ class SceneBuilder:
         rp.filter_table = (C.c_float * 256)(*table)
         rp.max_sample_luminance = self.film["max_lum"]; rp.scale = self.film["scale"]
         rp.spp = self.spp
+        rp.sampler_type = {"sobol": A.PT_SAMPLER_SOBOL, "halton": A.PT_SAMPLER_HALTON}[self.sampler]
+        rp.sample_at_pixel_center = 1 if self.sample_at_pixel_center else 0
         sb = [math.floor(F(crop[0]) + F(0.5) - F(rx)), math.floor(F(crop[1]) + F(0.5) - F(ry)),
               math.ceil(F(crop[2]) - F(0.5) + F(rx)), math.ceil(F(crop[3]) - F(0.5) + F(ry))]  # film.rs:104-112
         rp.sample_bounds = (C.c_int32 * 4)(*sb)

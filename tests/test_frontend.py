@@ -220,7 +220,7 @@ def test_feature_scene_matches_python_builder_and_renders(pkg, oracle, tmp_path)
 
 @pytest.mark.parametrize("text,needle", [
     ("WorldBegin\nFrobnicate 1 2 3\n", "line 2: unknown directive Frobnicate"),
-    ('Sampler "halton" "integer pixelsamples" 4\nWorldBegin WorldEnd', "only \"sobol\""),
+    ('Sampler "stratified" "integer xsamples" 4\nWorldBegin WorldEnd', "only \"sobol\" and \"halton\""),
     ('Integrator "bdpt"\n', "only \"path\""),
     ('WorldBegin\nShape "cone"\n', "shape \"cone\""),
     ('WorldBegin\nMaterial "matte" "blackbody Kd" [5500 1]\n', "blackbody"),
