@@ -83,7 +83,7 @@ typedef enum PtMaterialType {
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
 } PtMaterialType;
 
-/* ---- textures (core/texture.rs, textures/*.rs, core/mipmap.rs) --------------------------------------
+/* ---- textures (core/texture.rs, textures/, core/mipmap.rs) --------------------------------------
  * A texture is a node of a tree, exactly as the reference's Arc<Textures<..>> values: children are texture indices
  * (constants are ConstantTexture nodes, as TextureParams::get_*texture creates them, paramset.rs:500-600). Float-valued
  * textures use component 0. Not covered: ImageWrap::Clamp (the reference's texel() clamps to `u` instead of `u - 1`,

@@ -5,5 +5,5 @@ include/mi355pt.h).  The product is csrc/ -> libmi355pt.so (hand-written HIP for
 The directory name contains a '-', so import it through `import_pkg()` in the repo-root
 `_pkg.py` (module name `pbrt_rust_amd`).
 """
-from . import _abi, host, scenes, frontend  # noqa: F401
+from . import _abi, host, scenes, frontend, textures, bssrdf  # noqa: F401
 from .runtime import Library, Scene, load_library, build_library  # noqa: F401

@@ -23,7 +23,7 @@ inline Image read_pfm(const std::string &path) {
     std::string magic; int w = 0, h = 0; float scale = 0;
     f >> magic >> w >> h >> scale; f.get();
     const int nc = magic == "PF" ? 3 : (magic == "Pf" ? 1 : 0);
-    if (!nc || w <= 0 || h <= 0) throw std::runtime_error("\"" + path + "\": only PFM images can be read by this front end");
+    if (!nc || w <= 0 || h <= 0) throw std::runtime_error("\"" + path + "\": not a PFM image");
     std::vector<float> raw((size_t)w * h * nc);
     f.read((char *)raw.data(), (std::streamsize)(raw.size() * 4));
     if (!f) throw std::runtime_error("PFM \"" + path + "\" is truncated");

@@ -13,6 +13,7 @@
 #include "../../include/mi355pt.h"
 #include "fe_bssrdf.h"
 #include "fe_image.h"
+#include "fe_imageio.h"
 #include "fe_math.h"
 #include "fe_params.h"
 #include "fe_ply.h"
@@ -202,7 +203,7 @@ private:
             std::string fn = p.one_string("filename", ""), wrap = p.one_string("wrap", "repeat");
             if (wrap == "clamp") fail(d, "imagemap wrap \"clamp\" is not supported");
             const bool is_png = fn.size() > 4 && (fn.substr(fn.size() - 4) == ".png" || fn.substr(fn.size() - 4) == ".tga");
-            Image im = read_pfm(sc.base_dir + fn);
+            Image im = read_image(sc.base_dir + fn);
             sc.pyramids.push_back(prepare_image(im, p.one_float("scale", 1.0f), p.one_bool("gamma", is_png), is_float ? 1 : 3, wrap == "black" ? 1 : 0));
             t.image = (uint32_t)sc.pyramids.size() - 1; t.trilinear = p.one_bool("trilinear", false) ? 1u : 0u;
             t.max_anisotropy = p.one_float("maxanisotropy", 8.0f); t.wrap = wrap == "black" ? PT_WRAP_BLACK : PT_WRAP_REPEAT;
@@ -334,7 +335,7 @@ private:
             l.type = PT_LIGHT_INFINITE;
             if (map.empty()) { sc.env_w = sc.env_h = 1; sc.env_texels.assign(L, L + 3); }
             else {
-                Image im = read_pfm(sc.base_dir + map);
+                Image im = read_image(sc.base_dir + map);
                 sc.env_w = (uint32_t)im.w; sc.env_h = (uint32_t)im.h; sc.env_texels.resize(im.rgb.size());
                 for (size_t i = 0; i < im.rgb.size(); ++i) sc.env_texels[i] = im.rgb[i] * L[i % 3];   // infinite.rs:46-50
             }

@@ -276,3 +276,119 @@ def test_front_end_scene_renders_on_gpu_like_the_oracle(pkg, gpu, oracle, tmp_pa
         assert f.readline() == b"PF\n"; w, h = map(int, f.readline().split()); f.readline()
         img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]
     np.testing.assert_allclose(img, g.resolve(film, scale=rp.scale), rtol=2e-4, atol=2e-5)
+
+
+# ---- image readers (core/imageio.rs:18-40 read_image: pfm, hdr, png, tga) ------------------------------------------------
+
+def _hdr_bytes(rgbe, rle=True):   # rgbe: (h, w, 4) uint8
+    h, w, _ = rgbe.shape
+    out = bytearray(b"#?RADIANCE\n# test\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+    for y in range(h):
+        if not (rle and 8 <= w < 32768):
+            out += rgbe[y].tobytes(); continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row = rgbe[y, :, c].tolist(); x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]: run += 1
+                if run >= 3: out += bytes([128 + run, row[x]]); x += run
+                else:
+                    lit = [row[x]]; x += 1
+                    while x < w and len(lit) < 128 and not (x + 2 < w and row[x] == row[x + 1] == row[x + 2]): lit.append(row[x]); x += 1
+                    out += bytes([len(lit)] + lit)
+    return bytes(out)
+
+
+def _png_bytes(img, ctype, depth=8, palette=None):   # img: (h, w, nch) integer samples
+    import struct, zlib
+    h, w = img.shape[:2]
+    raw = img.astype(">u2" if depth == 16 else np.uint8).reshape(h, -1).view(np.uint8).reshape(h, -1)
+    bpp = max(1, raw.shape[1] // w)
+    lines = bytearray(); prev = np.zeros(raw.shape[1], np.int32)
+    for y in range(h):
+        cur = raw[y].astype(np.int32); ft = y % 5
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]); c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]); b = prev
+        if ft == 0: pred = 0
+        elif ft == 1: pred = a
+        elif ft == 2: pred = b
+        elif ft == 3: pred = (a + b) // 2
+        else:
+            pa, pb, pc = np.abs(b - c), np.abs(a - c), np.abs(a + b - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        lines += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes(); prev = cur
+    def chunk(t, body): return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    z = zlib.compress(bytes(lines)); half = len(z) // 2
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None: out += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+def _level0(fs, i=0):
+    d = fs.desc(); im = d.images[i]
+    return np.ctypeslib.as_array(im.texels, shape=(im.height * im.width * im.channels,)).reshape(im.height, im.width, im.channels).copy()
+
+
+def _tex_scene(name, extra=""):
+    return 'WorldBegin\nTexture "t" "color" "imagemap" "string filename" "%s" "bool gamma" "false" %s\nMaterial "matte" "texture Kd" "t"\nShape "sphere"\nWorldEnd\n' % (name, extra)
+
+
+@pytest.mark.parametrize("w", [8, 4])
+def test_hdr_reader_rle_and_flat(pkg, tmp_path, w):
+    """Radiance .hdr (imageio.rs:142-166 -> image crate HdrDecoder, Rgbe8Pixel::to_hdr = c * 2^(e-136), zero when e == 0):
+    run-length coded scanlines (width >= 8) and flat ones; the decoded image equals the same floats stored as PFM."""
+    rng = np.random.default_rng(w)
+    rgbe = rng.integers(0, 256, (4, w, 4)).astype(np.uint8)
+    rgbe[0, :, 0] = 77; rgbe[1, 1:7 if w == 8 else 3, 3] = 130; rgbe[2, 0, 3] = 0   # runs in a plane, a zero-exponent pixel
+    (tmp_path / "a.hdr").write_bytes(_hdr_bytes(rgbe))
+    expect = rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:4].astype(np.float32) - 136.0).astype(np.float32)
+    expect[rgbe[..., 3] == 0] = 0
+    _write_pfm(tmp_path / "a.pfm", expect)
+    a = _level0(pkg.frontend.FrontScene(text=_tex_scene("a.hdr"), base_dir=str(tmp_path)))
+    b = _level0(pkg.frontend.FrontScene(text=_tex_scene("a.pfm"), base_dir=str(tmp_path)))
+    assert a.shape == (4, w, 3) and np.array_equal(a, b)
+    assert np.array_equal(a, expect[::-1])   # ImageTexture flips y (imagemap.rs:141-157)
+
+
+def test_png_and_tga_readers(pkg, tmp_path):
+    """PNG / TGA (imageio.rs:338-357): 8-bit RGB = v / 255; grey, grey+alpha, RGBA, palette and 16-bit variants reduce to it.
+    All five scanline filters and a split IDAT stream are exercised."""
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (8, 8, 3))
+    def load(name): return _level0(pkg.frontend.FrontScene(text=_tex_scene(name), base_dir=str(tmp_path)))
+    (tmp_path / "rgb.png").write_bytes(_png_bytes(rgb, 2))
+    want = (rgb.astype(np.float32) / np.float32(255.0))[::-1]
+    assert np.array_equal(load("rgb.png"), want)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (8, 8, 1))], axis=2)
+    (tmp_path / "rgba.png").write_bytes(_png_bytes(rgba, 6)); assert np.array_equal(load("rgba.png"), want)
+    grey = rgb[..., :1]
+    (tmp_path / "g.png").write_bytes(_png_bytes(grey, 0)); assert np.array_equal(load("g.png"), np.repeat(want[..., :1], 3, axis=2))
+    (tmp_path / "g16.png").write_bytes(_png_bytes(grey * 257, 0, depth=16)); assert np.array_equal(load("g16.png"), np.repeat(want[..., :1], 3, axis=2))
+    pal = rng.integers(0, 256, (256, 3)); idx = rng.integers(0, 256, (8, 8, 1))
+    (tmp_path / "p.png").write_bytes(_png_bytes(idx, 3, palette=pal))
+    assert np.array_equal(load("p.png"), (pal[idx[..., 0]].astype(np.float32) / np.float32(255.0))[::-1])
+    # inverse gamma is the default for 8-bit formats (imagemap.rs "gamma" default = has an 8-bit extension)
+    g = _level0(pkg.frontend.FrontScene(text=_tex_scene("rgb.png").replace('"bool gamma" "false"', ""), base_dir=str(tmp_path)))
+    assert np.allclose(g, pkg.textures.inverse_gamma_correct(want), rtol=1e-6)
+    # TGA: uncompressed 24-bit, bottom-left origin, BGR
+    hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 8, 0, 24, 0])
+    (tmp_path / "t.tga").write_bytes(hdr + rgb[::-1, :, ::-1].astype(np.uint8).tobytes())
+    assert np.array_equal(load("t.tga"), want)
+    (tmp_path / "x.exr").write_bytes(b"v/1\x01")
+    with pytest.raises(Exception, match="OpenEXR"): load("x.exr")
+    (tmp_path / "bad.png").write_bytes(b"not a png")
+    with pytest.raises(Exception, match="not a PNG"): load("bad.png")
+
+
+def test_hdr_environment_map(pkg, tmp_path):
+    """LightSource "infinite" "string mapname" "*.hdr" (lights/infinite.rs:43-60): same light as the PFM of the decoded floats."""
+    rng = np.random.default_rng(9)
+    rgbe = np.concatenate([rng.integers(1, 256, (8, 16, 3)), rng.integers(126, 132, (8, 16, 1))], axis=2).astype(np.uint8)
+    (tmp_path / "sky.hdr").write_bytes(_hdr_bytes(rgbe))
+    _write_pfm(tmp_path / "sky.pfm", rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:4].astype(np.float32) - 136.0).astype(np.float32))
+    scene = 'WorldBegin\nLightSource "infinite" "string mapname" "%s"\nShape "sphere"\nWorldEnd\n'
+    a = pkg.frontend.FrontScene(text=scene % "sky.hdr", base_dir=str(tmp_path)).desc()
+    b = pkg.frontend.FrontScene(text=scene % "sky.pfm", base_dir=str(tmp_path)).desc()
+    assert (a.env_width, a.env_height) == (16, 8)
+    n = 16 * 8 * 3
+    assert np.array_equal(np.ctypeslib.as_array(a.env_texels, shape=(n,)), np.ctypeslib.as_array(b.env_texels, shape=(n,)))
