@@ -7,6 +7,7 @@
  * Supported subset and the directives that are rejected: see pbrt-rust_amd/frontend/frontend.cpp header. */
 #ifndef MI355FRONT_H
 #define MI355FRONT_H
+#include <stddef.h>
 #include "mi355pt.h"
 #ifdef __cplusplus
 extern "C" {
@@ -23,6 +24,12 @@ const char *ptf_output_filename(const ptf_scene *scene);   /* Film "string filen
 void ptf_scene_destroy(ptf_scene *scene);
 /* Film::write_image's PFM branch (core/imageio.rs:288-328): rgb = width*height*3 floats, top row first. */
 int ptf_write_pfm(const char *path, int width, int height, const float *rgb);
+/* write_image (core/imageio.rs:42-60): by extension -- exr (three FLOAT channels, uncompressed), png / tga (8-bit, gamma
+ * encoded, imageio.rs:359-381), pfm. */
+int ptf_write_image(const char *path, int width, int height, const float *rgb);
+/* read_image (core/imageio.rs:18-40): pfm, hdr, png, tga, exr (scan-line, NO/ZIPS/ZIP). Call with rgb == NULL to get the
+ * size, then with a buffer of width*height*3 floats (top row first). */
+int ptf_read_image(const char *path, int *width, int *height, float *rgb, size_t capacity_floats);
 #ifdef __cplusplus
 }
 #endif

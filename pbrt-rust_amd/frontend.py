@@ -35,6 +35,8 @@ def lib():
         L.ptf_output_filename.restype = C.c_char_p; L.ptf_output_filename.argtypes = [C.c_void_p]
         L.ptf_scene_destroy.argtypes = [C.c_void_p]
         L.ptf_write_pfm.argtypes = [C.c_char_p, C.c_int, C.c_int, A.fp]
+        L.ptf_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, A.fp]
+        L.ptf_read_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), A.fp, C.c_size_t]
         _lib = L
     return _lib
 
@@ -70,3 +72,21 @@ class FrontScene:
     def __del__(self):
         try: self.close()
         except Exception: pass
+
+
+def read_image(path):
+    """read_image (core/imageio.rs:18-40) through the compiled front end: (h, w, 3) float32, top row first."""
+    import numpy as np
+    L = lib(); w, h = C.c_int(), C.c_int()
+    if L.ptf_read_image(os.fsencode(path), C.byref(w), C.byref(h), None, 0) != 0: raise ValueError(L.ptf_last_error().decode(errors="replace"))
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    if L.ptf_read_image(os.fsencode(path), None, None, out.ctypes.data_as(A.fp), out.size) != 0: raise ValueError(L.ptf_last_error().decode(errors="replace"))
+    return out
+
+
+def write_image(path, rgb):
+    """write_image (core/imageio.rs:42-60): rgb = (h, w, 3) float32, top row first; format by extension (exr, png, tga, pfm)."""
+    import numpy as np
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    L = lib()
+    if L.ptf_write_image(os.fsencode(path), rgb.shape[1], rgb.shape[0], rgb.ctypes.data_as(A.fp)) != 0: raise ValueError(L.ptf_last_error().decode(errors="replace"))

@@ -6,7 +6,8 @@
 //        no +0.5 as in Ward's original); new-style RLE, old-style repeat pixels and flat scanlines.
 //   PNG / TGA (imageio.rs:338-357): to_rgb8 then v / 255 per channel (grey replicated, alpha dropped, palette expanded,
 //        16-bit samples reduced to their high byte's rounding v * 255 / 65535).
-//   EXR: refused with a message (the exr crate's codecs are not restated).
+//   EXR  (imageio.rs:68-114, `exr` crate 1.0.0): scan-line files, uncompressed / ZIPS / ZIP, HALF / FLOAT / UINT channels are
+//        read; three uncompressed FLOAT channels are written.
 // zlib (system library, -lz) inflates PNG IDAT streams.
 #pragma once
 #include <cstdint>
@@ -159,6 +160,156 @@ inline Image read_tga(const std::string &path) {
     return im;
 }
 
+
+// ---- OpenEXR (scan-line files; the `exr` crate 1.0.0 of Cargo.lock is not vendored: the published file layout is restated) ----
+inline float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) { if (m == 0) bits = sign; else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; sh++; } bits = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13); } }
+    else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+// read_image_exr (imageio.rs:68-97): R, G, B channels (HALF / FLOAT / UINT) of a single-part scan-line file with NO, ZIPS or
+// ZIP compression -- what `envmap.exr` of the reference's scenes uses; tiled, deep, PIZ/PXR24/B44/DWA files are refused by name.
+inline Image read_exr(const std::string &path) {
+    const std::vector<unsigned char> d = read_file(path);
+    auto need = [&](size_t p, size_t n) { if (p + n > d.size()) throw std::runtime_error("EXR \"" + path + "\" is truncated"); };
+    auto i32 = [&](size_t p) { need(p, 4); int32_t v; std::memcpy(&v, d.data() + p, 4); return v; };
+    need(0, 8);
+    if (i32(0) != 20000630) throw std::runtime_error("\"" + path + "\": not an OpenEXR file");
+    const int32_t version = i32(4);
+    if (version & 0x1a00) throw std::runtime_error("EXR \"" + path + "\": tiled, deep and multi-part files are not supported");
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans; int compression = -1, line_order = 0; int32_t win[4] = {0, 0, -1, -1};
+    size_t p = 8;
+    for (;;) {
+        need(p, 1);
+        if (d[p] == 0) { p++; break; }
+        auto cstr = [&]() { std::string t; while (true) { need(p, 1); if (!d[p]) { p++; break; } t.push_back((char)d[p++]); } return t; };
+        const std::string name = cstr(), type = cstr(); const int32_t size = i32(p); p += 4; need(p, (size_t)size);
+        if (name == "channels") { size_t q = p; while (d[q]) { Chan c; while (d[q]) c.name.push_back((char)d[q++]); q++; c.type = i32(q); if (i32(q + 8) != 1 || i32(q + 12) != 1) throw std::runtime_error("EXR \"" + path + "\": subsampled channels are not supported"); q += 16; chans.push_back(c); } }
+        else if (name == "compression") compression = d[p];
+        else if (name == "dataWindow") for (int k = 0; k < 4; ++k) win[k] = i32(p + 4 * k);
+        else if (name == "lineOrder") line_order = d[p];
+        (void)type; p += (size_t)size;
+    }
+    (void)line_order;
+    const int w = win[2] - win[0] + 1, h = win[3] - win[1] + 1;
+    if (w <= 0 || h <= 0 || chans.empty()) throw std::runtime_error("EXR \"" + path + "\": missing dataWindow / channels");
+    if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error("EXR \"" + path + "\": only uncompressed, ZIPS and ZIP files are supported (compression " + std::to_string(compression) + ")");
+    const int lines_per_block = compression == 3 ? 16 : 1, n_blocks = (h + lines_per_block - 1) / lines_per_block;
+    size_t line_bytes = 0; std::vector<size_t> chan_off;
+    for (auto &c : chans) { chan_off.push_back(line_bytes); line_bytes += (size_t)w * (c.type == 1 ? 2 : 4); }
+    int idx[3] = {-1, -1, -1};
+    for (size_t c = 0; c < chans.size(); ++c) { if (chans[c].name == "R") idx[0] = (int)c; else if (chans[c].name == "G") idx[1] = (int)c; else if (chans[c].name == "B") idx[2] = (int)c; else if (chans[c].name == "Y" && idx[0] < 0) idx[0] = idx[1] = idx[2] = (int)c; }
+    if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) throw std::runtime_error("EXR \"" + path + "\": no R, G, B (or Y) channels");
+    Image im; im.w = w; im.h = h; im.rgb.assign((size_t)w * h * 3, 0.0f);
+    const size_t table = p;
+    std::vector<unsigned char> raw, tmp;
+    for (int b = 0; b < n_blocks; ++b) {
+        need(table + 8 * (size_t)b, 8);
+        uint64_t off; std::memcpy(&off, d.data() + table + 8 * (size_t)b, 8);
+        const int y0 = i32((size_t)off) - win[1]; const int32_t packed = i32((size_t)off + 4);
+        if (y0 < 0 || y0 >= h || packed < 0) throw std::runtime_error("EXR \"" + path + "\": bad scan-line block");
+        need((size_t)off + 8, (size_t)packed);
+        const int nl = std::min(lines_per_block, h - y0); const size_t want = line_bytes * (size_t)nl;
+        raw.resize(want);
+        if (compression == 0 || (size_t)packed == want) std::memcpy(raw.data(), d.data() + off + 8, std::min<size_t>(want, (size_t)packed));
+        else {
+            tmp.resize(want); uLongf n = (uLongf)want;
+            if (uncompress(tmp.data(), &n, d.data() + off + 8, (uLong)packed) != Z_OK || n != want) throw std::runtime_error("EXR \"" + path + "\": corrupt ZIP block");
+            for (size_t i = 1; i < want; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);     // undo the byte predictor
+            const size_t half = (want + 1) / 2;                                                           // undo the even/odd split
+            for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+        }
+        for (int l = 0; l < nl; ++l)
+            for (int c = 0; c < 3; ++c) {
+                const Chan &ch = chans[idx[c]]; const unsigned char *src = raw.data() + line_bytes * (size_t)l + chan_off[idx[c]];
+                for (int x = 0; x < w; ++x) {
+                    float v;
+                    if (ch.type == 1) { uint16_t hv; std::memcpy(&hv, src + 2 * x, 2); v = half_to_float(hv); }
+                    else if (ch.type == 2) std::memcpy(&v, src + 4 * x, 4);
+                    else { uint32_t u; std::memcpy(&u, src + 4 * x, 4); v = (float)u; }
+                    im.rgb[((size_t)(y0 + l) * w + x) * 3 + c] = v;
+                }
+            }
+    }
+    return im;
+}
+// write_image_exr (imageio.rs:99-114, `write_rgb_f32_file`): three FLOAT channels, scan lines, no compression
+inline void write_exr(const std::string &path, int w, int h, const float *rgb_top_first) {
+    std::vector<unsigned char> o;
+    auto put = [&](const void *q, size_t n) { o.insert(o.end(), (const unsigned char *)q, (const unsigned char *)q + n); };
+    auto i32 = [&](int32_t v) { put(&v, 4); };
+    auto str = [&](const char *t) { put(t, std::strlen(t) + 1); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+    i32(20000630); i32(2);
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char *c : {"B", "G", "R"}) { str(c); i32(2); i32(0); i32(1); i32(1); }
+    o.push_back(0);
+    attr("compression", "compression", 1); o.push_back(0);
+    attr("dataWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("lineOrder", "lineOrder", 1); o.push_back(0);
+    const float one = 1.0f, zero = 0.0f;
+    attr("pixelAspectRatio", "float", 4); put(&one, 4);
+    attr("screenWindowCenter", "v2f", 8); put(&zero, 4); put(&zero, 4);
+    attr("screenWindowWidth", "float", 4); put(&one, 4);
+    o.push_back(0);
+    const size_t line = 8 + (size_t)w * 12; uint64_t off = o.size() + 8 * (uint64_t)h;
+    for (int y = 0; y < h; ++y) { put(&off, 8); off += line; }
+    std::vector<float> plane((size_t)w);
+    for (int y = 0; y < h; ++y) {
+        i32(y); i32((int32_t)((size_t)w * 12));
+        for (int c = 2; c >= 0; --c) { for (int x = 0; x < w; ++x) plane[x] = rgb_top_first[((size_t)y * w + x) * 3 + c]; put(plane.data(), (size_t)w * 4); }   // B, G, R
+    }
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp || std::fwrite(o.data(), 1, o.size(), fp) != o.size()) { if (fp) std::fclose(fp); throw std::runtime_error("cannot write \"" + path + "\""); }
+    std::fclose(fp);
+}
+
+// write_image_png_tga (imageio.rs:359-381): clamp(255 * gamma_correct(v) + 0.5, 0, 255) as u8 (pbrt.rs:210-216)
+inline unsigned char to_byte(float v) {
+    const float g = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+    const float s = 255.0f * g + 0.5f;
+    return (unsigned char)(s < 0.0f || s != s ? 0.0f : (s > 255.0f ? 255.0f : s));
+}
+inline void write_png(const std::string &path, int w, int h, const float *rgb_top_first) {
+    std::vector<unsigned char> lines(((size_t)w * 3 + 1) * h);
+    for (int y = 0; y < h; ++y) { unsigned char *row = lines.data() + ((size_t)w * 3 + 1) * y; row[0] = 0; for (int i = 0; i < w * 3; ++i) row[1 + i] = to_byte(rgb_top_first[(size_t)y * w * 3 + i]); }
+    uLongf zn = compressBound((uLong)lines.size()); std::vector<unsigned char> z(zn);
+    if (compress2(z.data(), &zn, lines.data(), (uLong)lines.size(), 6) != Z_OK) throw std::runtime_error("cannot compress \"" + path + "\"");
+    std::vector<unsigned char> o = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    auto be32 = [&](uint32_t v) { for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s)); };
+    auto chunk = [&](const char *type, const unsigned char *body, size_t n) {
+        be32((uint32_t)n); const size_t start = o.size(); o.insert(o.end(), type, type + 4); o.insert(o.end(), body, body + n);
+        be32((uint32_t)crc32(0L, o.data() + start, (uInt)(n + 4)));
+    };
+    unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w, (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h, 8, 2, 0, 0, 0};
+    chunk("IHDR", ihdr, 13); chunk("IDAT", z.data(), zn); chunk("IEND", nullptr, 0);
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp || std::fwrite(o.data(), 1, o.size(), fp) != o.size()) { if (fp) std::fclose(fp); throw std::runtime_error("cannot write \"" + path + "\""); }
+    std::fclose(fp);
+}
+inline void write_tga(const std::string &path, int w, int h, const float *rgb_top_first) {
+    std::vector<unsigned char> o = {0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, (unsigned char)w, (unsigned char)(w >> 8), (unsigned char)h, (unsigned char)(h >> 8), 24, 0x20};   // top-left origin
+    for (size_t i = 0; i < (size_t)w * h; ++i) for (int c = 2; c >= 0; --c) o.push_back(to_byte(rgb_top_first[i * 3 + c]));
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp || std::fwrite(o.data(), 1, o.size(), fp) != o.size()) { if (fp) std::fclose(fp); throw std::runtime_error("cannot write \"" + path + "\""); }
+    std::fclose(fp);
+}
+// write_image (imageio.rs:42-60): by extension
+inline void write_image(const std::string &path, int w, int h, const float *rgb_top_first) {
+    const size_t dot = path.find_last_of('.');
+    const std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+    if (ext == "png") write_png(path, w, h, rgb_top_first);
+    else if (ext == "tga") write_tga(path, w, h, rgb_top_first);
+    else if (ext == "exr") write_exr(path, w, h, rgb_top_first);
+    else if (ext == "pfm") write_pfm(path, w, h, rgb_top_first);
+    else throw std::runtime_error("Unsupported file format \"" + ext + "\"");
+}
+
 // core/imageio.rs:18-40: dispatch on the file name extension
 inline Image read_image(const std::string &path) {
     const size_t dot = path.find_last_of('.');
@@ -167,7 +318,7 @@ inline Image read_image(const std::string &path) {
     if (ext == "hdr") return read_hdr(path);
     if (ext == "png" || ext == "PNG") return read_png(path);
     if (ext == "tga" || ext == "TGA") return read_tga(path);
-    if (ext == "exr" || ext == "EXR") throw std::runtime_error("\"" + path + "\": OpenEXR files are not read by this front end (convert to .pfm or .hdr)");
+    if (ext == "exr" || ext == "EXR") return read_exr(path);
     throw std::runtime_error("\"" + path + "\": unable to load image with this extension (imageio.rs:33-37)");
 }
 

@@ -48,7 +48,7 @@ struct Scene {
     std::vector<PtObject> objects; std::vector<std::string> object_names; std::vector<PtInstance> instances; std::vector<uint32_t> top_refs;
     std::map<std::string, std::pair<uint32_t, uint32_t>> object_ranges; std::string current_object; bool in_object = false;
     // options
-    int xres = 1280, yres = 720; float crop[4] = {0, 1, 0, 1}; float film_scale = 1.0f, max_lum = INFINITY; std::string filename = "pbrt.pfm";
+    int xres = 1280, yres = 720; float crop[4] = {0, 1, 0, 1}; float film_scale = 1.0f, max_lum = INFINITY; std::string filename = "pbrt.exr";   // film.rs:371
     std::string filter = "box"; ParamSet filter_params;
     ParamSet camera_params; Transform camera_to_world; std::string camera_name = "perspective";
     int spp = 16; std::string sampler = "halton";   // RenderOptions::default (api.rs:215-241)
@@ -554,6 +554,18 @@ void ptf_scene_destroy(ptf_scene *s) { delete s; }
 // rgb: width * height * 3 floats, top row first (the layout pt_film_resolve produces)
 int ptf_write_pfm(const char *path, int width, int height, const float *rgb) {
     try { fe::write_pfm(path, width, height, rgb); } catch (const std::exception &e) { fe::g_error = e.what(); return PT_ERR_INVALID_ARG; }
+    return PT_OK;
+}
+int ptf_write_image(const char *path, int width, int height, const float *rgb) {
+    try { fe::write_image(path, width, height, rgb); } catch (const std::exception &e) { fe::g_error = e.what(); return PT_ERR_INVALID_ARG; }
+    return PT_OK;
+}
+int ptf_read_image(const char *path, int *width, int *height, float *rgb, size_t capacity_floats) {
+    try {
+        const fe::Image im = fe::read_image(path);
+        if (width) *width = im.w; if (height) *height = im.h;
+        if (rgb) { if (capacity_floats < im.rgb.size()) { fe::g_error = "buffer too small"; return PT_ERR_INVALID_ARG; } std::memcpy(rgb, im.rgb.data(), im.rgb.size() * 4); }
+    } catch (const std::exception &e) { fe::g_error = e.what(); return PT_ERR_INVALID_ARG; }
     return PT_OK;
 }
 }

@@ -1,7 +1,7 @@
 // mi355pbrt -- command-line renderer: the drop-in for `pbrt-rust scene.pbrt` on this back end (main.rs + api.rs:1715-1748).
 //   mi355pbrt scene.pbrt [--outfile out.pfm] [--device N] [--spp N] [--quiet]
-// Parses with libmi355front.so, renders with libmi355pt.so (HIP), writes the film as PFM (the reference's EXR / PNG writers
-// depend on crates that are not available here).
+// Parses with libmi355front.so, renders with libmi355pt.so (HIP), writes the film in the format the Film's "filename"
+// extension names (exr -- the reference's default "pbrt.exr" -- png, tga, pfm: core/imageio.rs:42-60).
 #include "../../include/mi355front.h"
 #include <chrono>
 #include <cstdio>
@@ -27,7 +27,6 @@ int main(int argc, char **argv) {
     if (spp > 0) rp.spp = (uint32_t)spp;
     if (outfile.empty()) {
         outfile = ptf_output_filename(fs);
-        size_t dot = outfile.find_last_of('.'); outfile = (dot == std::string::npos ? outfile : outfile.substr(0, dot)) + ".pfm";
     }
     if (pt_init(device) != PT_OK) { std::fprintf(stderr, "mi355pbrt: %s\n", pt_last_error()); return 1; }
     const auto t0 = std::chrono::steady_clock::now();
@@ -39,7 +38,7 @@ int main(int argc, char **argv) {
     if (pt_render(sc, &rp, film.data(), 0) != PT_OK) { std::fprintf(stderr, "mi355pbrt: %s\n", pt_last_error()); return 1; }
     const auto t2 = std::chrono::steady_clock::now();
     pt_film_resolve(film.data(), (uint32_t)(w * h), rp.scale, rgb.data());
-    if (ptf_write_pfm(outfile.c_str(), w, h, rgb.data()) != PT_OK) { std::fprintf(stderr, "mi355pbrt: %s\n", ptf_last_error()); return 1; }
+    if (ptf_write_image(outfile.c_str(), w, h, rgb.data()) != PT_OK) { std::fprintf(stderr, "mi355pbrt: %s\n", ptf_last_error()); return 1; }
     if (!quiet) {
         PtCounters c; pt_get_counters(sc, &c);
         const double ts = std::chrono::duration<double>(t1 - t0).count(), tr = std::chrono::duration<double>(t2 - t1).count();

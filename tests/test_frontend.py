@@ -374,8 +374,8 @@ def test_png_and_tga_readers(pkg, tmp_path):
     hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 0, 8, 0, 24, 0])
     (tmp_path / "t.tga").write_bytes(hdr + rgb[::-1, :, ::-1].astype(np.uint8).tobytes())
     assert np.array_equal(load("t.tga"), want)
-    (tmp_path / "x.exr").write_bytes(b"v/1\x01")
-    with pytest.raises(Exception, match="OpenEXR"): load("x.exr")
+    (tmp_path / "x.exr").write_bytes(b"12345678")
+    with pytest.raises(Exception, match="not an OpenEXR"): load("x.exr")
     (tmp_path / "bad.png").write_bytes(b"not a png")
     with pytest.raises(Exception, match="not a PNG"): load("bad.png")
 
@@ -392,3 +392,48 @@ def test_hdr_environment_map(pkg, tmp_path):
     assert (a.env_width, a.env_height) == (16, 8)
     n = 16 * 8 * 3
     assert np.array_equal(np.ctypeslib.as_array(a.env_texels, shape=(n,)), np.ctypeslib.as_array(b.env_texels, shape=(n,)))
+
+
+def _exr_zip_half(img):   # (h, w, 3) float -> scan-line EXR, ZIP (16 lines per block), HALF channels B, G, R
+    import struct, zlib
+    h, w, _ = img.shape
+    def attr(name, typ, body): return name + b"\0" + typ + b"\0" + struct.pack("<i", len(body)) + body
+    chl = b"".join(c + b"\0" + struct.pack("<iiii", 1, 0, 1, 1) for c in (b"B", b"G", b"R")) + b"\0"
+    hdr = struct.pack("<ii", 20000630, 2) + attr(b"channels", b"chlist", chl) + attr(b"compression", b"compression", b"\x03") + \
+        attr(b"dataWindow", b"box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr(b"displayWindow", b"box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + \
+        attr(b"lineOrder", b"lineOrder", b"\0") + attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1)) + \
+        attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0, 0)) + attr(b"screenWindowWidth", b"float", struct.pack("<f", 1)) + b"\0"
+    blocks = []
+    for y0 in range(0, h, 16):
+        raw = b"".join(img[y, :, c].astype(np.float16).tobytes() for y in range(y0, min(h, y0 + 16)) for c in (2, 1, 0))
+        a = np.frombuffer(raw, np.uint8); t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+        t[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+        z = zlib.compress(t.astype(np.uint8).tobytes())
+        blocks.append(struct.pack("<ii", y0, len(z)) + z)
+    off = len(hdr) + 8 * len(blocks); table = b""
+    for b in blocks: table += struct.pack("<Q", off); off += len(b)
+    return hdr + table + b"".join(blocks)
+
+
+def test_exr_png_pfm_writers_and_exr_reader(pkg, tmp_path):
+    """write_image / read_image (core/imageio.rs:18-60): EXR written as three uncompressed FLOAT channels reads back exactly;
+    a ZIP-compressed HALF file (the layout of the reference's scenes/textures/envmap.exr) decodes to the half values; PNG is
+    the 8-bit gamma encoding of imageio.rs:359-381."""
+    F = pkg.frontend
+    rng = np.random.default_rng(11)
+    img = (rng.random((21, 13, 3)) * 4).astype(np.float32); img[0, 0] = (0, 1e-8, 65000.0)
+    F.write_image(str(tmp_path / "a.exr"), img)
+    assert np.array_equal(F.read_image(str(tmp_path / "a.exr")), img)
+    F.write_image(str(tmp_path / "a.pfm"), img)
+    assert np.array_equal(F.read_image(str(tmp_path / "a.pfm")), img)
+    big = (rng.random((37, 19, 3)) * 3).astype(np.float32)
+    (tmp_path / "z.exr").write_bytes(_exr_zip_half(big))
+    assert np.array_equal(F.read_image(str(tmp_path / "z.exr")), big.astype(np.float16).astype(np.float32))
+    lin = rng.random((9, 7, 3)).astype(np.float32); lin[0, 0] = (-1, 2, 0.001)
+    F.write_image(str(tmp_path / "a.png"), lin); F.write_image(str(tmp_path / "a.tga"), lin)
+    g = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0), 1 / 2.4) - 0.055)
+    want = np.clip(255.0 * g + 0.5, 0, 255).astype(np.uint8).astype(np.float32) / np.float32(255.0)
+    assert np.abs(F.read_image(str(tmp_path / "a.png")) - want).max() <= 1.01 / 255   # pow() rounding may move a value across .5
+    assert np.array_equal(F.read_image(str(tmp_path / "a.png")), F.read_image(str(tmp_path / "a.tga")))
+    with pytest.raises(Exception, match="Unsupported file format"): F.write_image(str(tmp_path / "a.jpg"), lin)
+    assert F.FrontScene(text='WorldBegin\nShape "sphere"\nWorldEnd\n').output_filename() == "pbrt.exr"   # film.rs default
