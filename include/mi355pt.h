@@ -79,7 +79,7 @@ typedef enum PtMaterialType {
     PT_MAT_METAL = 4,      /* materials/metal.rs      */
     PT_MAT_UBER = 5,       /* materials/uber.rs       */
     PT_MAT_SUBSTRATE = 6,  /* materials/substrate.rs  */
-    PT_MAT_SUBSURFACE = 7  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
+    PT_MAT_SUBSURFACE = 7, PT_MAT_TRANSLUCENT = 8 /* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
 } PtMaterialType;
 

@@ -121,6 +121,32 @@ static bool compute_scattering_functions(const Scene &scene, SurfaceInteraction 
         }
         return true;
     }
+    case PT_MAT_TRANSLUCENT: {  // translucent.rs:36-78
+        const Float eta = 1.5f;
+        bsdf.init(si, eta);
+        RGB r = E.spec(PT_MP_KR, m.kr).clamps(0.0f, INF), t = E.spec(PT_MP_KT, m.kt).clamps(0.0f, INF);   // "reflect", "transmit"
+        if (r.is_black() && t.is_black()) return false;  // App. A #14
+        RGB kd = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);
+        if (!kd.is_black()) {
+            if (!r.is_black()) { Bxdf b; b.kind = BX_LAMBERT_R; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = r * kd; bsdf.add(b); }
+            if (!t.is_black()) { Bxdf b; b.kind = BX_LAMBERT_T; b.type = BSDF_TRANSMISSION | BSDF_DIFFUSE; b.t = t * kd; bsdf.add(b); }
+        }
+        RGB ks = E.spec(PT_MP_KS, m.ks).clamps(0.0f, INF);
+        if (!ks.is_black() && (!r.is_black() || !t.is_black())) {
+            Float rough = E.flt(PT_MP_ROUGHNESS, m.roughness);
+            if (m.remap_roughness) rough = TRDist::roughness_to_alpha(rough);
+            TRDist d = make_dist(rough, rough);
+            if (!r.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = r * ks; b.dist = d;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+            if (!t.is_black()) {
+                Bxdf b; b.kind = BX_MICRO_T; b.type = BSDF_TRANSMISSION | BSDF_GLOSSY; b.t = t * ks; b.dist = d; b.etaa = 1.0f; b.etab = eta;
+                b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = eta; bsdf.add(b);
+            }
+        }
+        return true;
+    }
     case PT_MAT_PLASTIC: {  // plastic.rs:34-70
         bsdf.init(si, 1.0f);
         RGB kd = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);

@@ -18,7 +18,7 @@ PT_TRI_HAS_UV = 16
 PT_SHAPE_TRIANGLE, PT_SHAPE_SPHERE = 0, 1
 PT_NONE = 0xFFFFFFFF
 
-PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE = range(8)
+PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE, PT_MAT_TRANSLUCENT = range(9)
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)

@@ -592,6 +592,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (arr) for (uint32_t i = 0; i < d->n_triangles; ++i) if (arr[i] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "alpha-mask texture index out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const PtMaterial &m = d->materials[i];
+        if (m.type > PT_MAT_TRANSLUCENT) return fail(PT_ERR_INVALID_ARG, "unknown material type");
         for (int k = 0; k < 16; ++k) {
             if (d->n_textures == 0 && m.tex[k] > 0) return fail(PT_ERR_INVALID_ARG, "material references a texture but the scene has none");
             if (d->n_textures && m.tex[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "material texture index out of range");

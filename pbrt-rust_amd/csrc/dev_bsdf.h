@@ -513,6 +513,31 @@ template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial
         if (!kt.is_black()) { Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = kt; b.etaa = 1.0f; b.etab = e; bsdf.add(b); }
         return true;
     }
+    case PT_MAT_TRANSLUCENT: {  // translucent.rs:36-78 (kr = "reflect", kt = "transmit")
+        const float eta = 1.5f;
+        bsdf.init(si, eta);
+        RGB r = E.spec(m, PT_MP_KR, m.kr).clamps(0.0f, PT_INF), t = E.spec(m, PT_MP_KT, m.kt).clamps(0.0f, PT_INF);
+        if (r.is_black() && t.is_black()) return false;
+        RGB kd = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
+        if (!kd.is_black()) {
+            if (!r.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_R, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = r * kd; bsdf.add(b); }
+            if (!t.is_black()) { Lobe b = mk_lobe(LB_LAMBERT_T, BSDF_TRANSMISSION | BSDF_DIFFUSE); b.t = t * kd; bsdf.add(b); }
+        }
+        RGB ks = E.spec(m, PT_MP_KS, m.ks).clamps(0.0f, PT_INF);
+        if (!ks.is_black() && (!r.is_black() || !t.is_black())) {
+            float rough = E.flt(m, PT_MP_ROUGHNESS, m.roughness);
+            if (m.remap_roughness) rough = roughness_to_alpha(rough);
+            if (!r.is_black()) {
+                Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = r * ks; set_dist(b, rough, rough);
+                b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+            }
+            if (!t.is_black()) {
+                Lobe b = mk_lobe(LB_MICRO_T, BSDF_TRANSMISSION | BSDF_GLOSSY); b.t = t * ks; set_dist(b, rough, rough);
+                b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
+            }
+        }
+        return true;
+    }
     default: {  // PT_MAT_SUBSTRATE, substrate.rs:34-60
         bsdf.init(si, 1.0f);
         RGB d = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF), s = E.spec(m, PT_MP_KS, m.ks).clamps(0.0f, PT_INF);

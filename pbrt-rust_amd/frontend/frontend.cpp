@@ -268,6 +268,10 @@ private:
             m.u_roughness = has("uroughness") ? flt("uroughness", PT_MP_U_ROUGHNESS, -1.0f) : -1.0f; m.v_roughness = has("vroughness") ? flt("vroughness", PT_MP_V_ROUGHNESS, -1.0f) : -1.0f;
             m.eta = has("eta") ? flt("eta", PT_MP_ETA, 1.5f) : flt("index", PT_MP_ETA, 1.5f);
         }
+        else if (kind == "translucent") {   // translucent.rs:82-92
+            m.type = PT_MAT_TRANSLUCENT; spec("Kd", PT_MP_KD, m.kd, 0.25f); spec("Ks", PT_MP_KS, m.ks, 0.25f);
+            spec("reflect", PT_MP_KR, m.kr, 0.5f); spec("transmit", PT_MP_KT, m.kt, 0.5f); m.roughness = flt("roughness", PT_MP_ROUGHNESS, 0.1f);
+        }
         else if (kind == "substrate") { m.type = PT_MAT_SUBSTRATE; spec("Kd", PT_MP_KD, m.kd, 0.5f); spec("Ks", PT_MP_KS, m.ks, 0.5f);
                                         m.u_roughness = flt("uroughness", PT_MP_U_ROUGHNESS, 0.1f); m.v_roughness = flt("vroughness", PT_MP_V_ROUGHNESS, 0.1f); }
         else if (kind == "subsurface" || kind == "kdsubsurface") {

@@ -357,3 +357,34 @@ def alpha_foliage(xres=96, yres=64, spp=8, maxdepth=4, n_cards=40, seed=3, insta
     b.trianglemesh(card[0], card[1], UV=uvq, shadowalpha="holes"); b.attribute_end()
     b.attribute_begin(); b.translate(0.0, 0.5, 5.0); b.scale(6.0, 4.0, 1.0); b.trianglemesh(card[0], card[1], UV=uvq, alpha=0.0); b.attribute_end()
     return b
+
+
+def translucent_panels(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
+    """materials/translucent.rs: thin translucent sheets (diffuse + glossy reflection and transmission) between an area
+    light and a matte floor, one of them lit from behind only; a textured variant drives reflect / transmit / roughness."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 1.6, 5.5), (0.0, 0.6, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.08, 0.08, 0.1))
+    b.attribute_begin(); b.area_light_source(L=(20.0, 18.0, 15.0))
+    P, I = quad((-0.8, 3.5, -2.5), (0.8, 3.5, -2.5), (0.8, 3.5, -1.0), (-0.8, 3.5, -1.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("point", from_=(0.0, 1.0, -3.0), I=(30.0, 30.0, 40.0))
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=F)
+    if textured:
+        b.texture("chk", "spectrum", "checkerboard", uscale=4.0, vscale=4.0, tex1=(0.9, 0.2, 0.2), tex2=(0.1, 0.6, 0.9))
+        b.texture("rough", "float", "checkerboard", uscale=2.0, vscale=2.0, tex1=0.05, tex2=0.4)
+        b.material("translucent", Kd=(0.5, 0.5, 0.5), Ks=(0.4, 0.4, 0.4), reflect="chk", transmit="chk", roughness="rough")
+    else:
+        b.material("translucent", Kd=(0.6, 0.5, 0.3), Ks=(0.3, 0.3, 0.3), reflect=(0.4, 0.4, 0.4), transmit=(0.7, 0.7, 0.7), roughness=0.2)
+    P, I = quad((-2.2, -0.5, -1.5), (-0.4, -0.5, -1.5), (-0.4, 2.0, -1.5), (-2.2, 2.0, -1.5)); b.trianglemesh(P, I, UV=uv)
+    b.material("translucent", Kd=(0.0, 0.0, 0.0), Ks=(0.8, 0.8, 0.8), reflect=(0.0, 0.0, 0.0), transmit=(0.9, 0.9, 0.9), roughness=0.05, remaproughness=False)
+    P, I = quad((0.4, -0.5, -1.5), (2.2, -0.5, -1.5), (2.2, 2.0, -1.5), (0.4, 2.0, -1.5)); b.trianglemesh(P, I, UV=uv)
+    b.material("translucent", reflect=(0.0, 0.0, 0.0), transmit=(0.0, 0.0, 0.0))   # no BSDF at all: skipped like a null surface
+    P, I = quad((-0.3, -0.5, 0.5), (0.3, -0.5, 0.5), (0.3, 0.6, 0.5), (-0.3, 0.6, 0.5)); b.trianglemesh(P, I)
+    b.material("translucent", transmit=(0.0, 0.0, 0.0))                              # reflection only
+    b.attribute_begin(); b.translate(0.0, 0.1, 1.2); b.sphere(radius=0.5); b.attribute_end()
+    return b

@@ -321,3 +321,12 @@ def test_alpha_masks_match_oracle(pkg, gpu, oracle, instanced):
     gp, gt, gb = g.trace_closest(o, d, tmax); op, ot, ob = orc.trace_closest(o, d, tmax)
     assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
     assert np.array_equal(g.trace_any(o, d, np.full(len(o), 6.0, np.float32)), orc.trace_any(o, d, np.full(len(o), 6.0, np.float32)))
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_translucent_material_matches_oracle(pkg, gpu, oracle, textured):
+    """materials/translucent.rs: Lambertian reflection + transmission and microfacet reflection + transmission scaled by
+    `reflect` / `transmit`; a sheet with neither has no BSDF and is passed through (App. A #14)."""
+    sd, rp = pkg.scenes.translucent_panels(textured=textured).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5 if textured else 2e-6, atol=1e-6 if textured else 1e-7)
+    assert film[..., :3].sum() > 0

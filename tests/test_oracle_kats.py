@@ -498,3 +498,46 @@ def test_alpha_masks(oracle, pkg):
     o2 = o.copy(); o2[:, 2] = -0.5
     occ = s.trace_any(o2, d, np.full(n, 10.0, np.float32)).astype(bool)
     assert np.array_equal(occ, solid)
+
+
+def test_quad_light_over_lambertian_plane_closed_form(oracle, pkg):
+    """Analytic check independent of any implementation: a one-sided diffuse rectangle 2a x 2b at height h
+    over a Lambertian plane. At the point under its centre the irradiance is
+    E = 2 L [ a/sqrt(a^2+h^2) atan(b/sqrt(a^2+h^2)) + b/sqrt(b^2+h^2) atan(a/sqrt(b^2+h^2)) ] and, with maxdepth 1 (direct
+    lighting only: NEE + BSDF sampling under MIS), the camera sees L_o = rho E / pi."""
+    a, bb, h, rho = 1.0, 1.5, 4.0, 0.6
+    Le = np.array([17.0, 12.0, 4.0])
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=8, yres=8); b.spp = 1024
+    b.integ.update(maxdepth=1)
+    b.look_at((0.0, 3.0, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=0.5)
+    b.world_begin()
+    b.attribute_begin(); b.area_light_source(L=tuple(Le))
+    P, I = pkg.scenes.quad((-a, h, -bb), (a, h, -bb), (a, h, bb), (-a, h, bb)); b.trianglemesh(P, I); b.attribute_end()   # normal faces -y
+    b.material("matte", Kd=(rho, rho, rho))
+    P, I = pkg.scenes.quad((-10.0, 0.0, -10.0), (-10.0, 0.0, 10.0), (10.0, 0.0, 10.0), (10.0, 0.0, -10.0)); b.trianglemesh(P, I)
+    sd, rp = b.world_end()
+    s = oracle.scene(sd)
+    rgb = s.resolve(s.render(rp, nthreads=8)).reshape(-1, 3).mean(axis=0)
+    ra, rb = np.hypot(a, h), np.hypot(bb, h)
+    E = 2.0 * Le * (a / ra * np.arctan(bb / ra) + bb / rb * np.arctan(a / rb))
+    want = rho * E / np.pi
+    assert np.all(np.abs(rgb - want) < 0.01 * want), (rgb, want)
+
+
+@pytest.mark.parametrize("pixel", [(0, 0), (5, 3), (37, 22)])
+def test_sobol_pixel_samples_are_a_02_net(oracle, pkg, pixel):
+    """Analytic check: the first 2^k film samples of a pixel form a (0,2)-net in base 2 inside that pixel -- every
+    dyadic box of area 2^-k holds exactly one of them (sobol.rs:61-86 + lowdiscrepancy.rs:512-543)."""
+    A = pkg._abi
+    sb = (C.c_int32 * 4)(0, 0, 64, 48)
+    for k in (4, 6):
+        n = 1 << k
+        xy = np.tile(np.array(pixel, np.int32), (n, 1)); sn = np.arange(n, dtype=np.uint32)
+        out = np.zeros((n, 2), np.float32)
+        assert oracle.lib.orc_sobol_samples(sb, n, xy.ctypes.data_as(A.i32p), sn.ctypes.data_as(A.u32p), 2, out.ctypes.data_as(A.fp), None) == 0
+        assert (out >= 0).all() and (out < 1).all()
+        for kx in range(k + 1):
+            nx, ny = 1 << kx, 1 << (k - kx)
+            cell = np.floor(out[:, 0] * nx).astype(int) * ny + np.floor(out[:, 1] * ny).astype(int)
+            assert sorted(cell.tolist()) == list(range(n)), (k, kx)
