@@ -79,7 +79,8 @@ typedef enum PtMaterialType {
     PT_MAT_METAL = 4,      /* materials/metal.rs      */
     PT_MAT_UBER = 5,       /* materials/uber.rs       */
     PT_MAT_SUBSTRATE = 6,  /* materials/substrate.rs  */
-    PT_MAT_SUBSURFACE = 7, PT_MAT_TRANSLUCENT = 8 /* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
+    PT_MAT_SUBSURFACE = 7, PT_MAT_TRANSLUCENT = 8 /* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */,
+    PT_MAT_MIX = 9 /* materials/mix.rs: kd = "amount", mix[0] / mix[1] = the two named materials */  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
 } PtMaterialType;
 
@@ -169,6 +170,10 @@ typedef struct PtMaterial {
     float scale;
     uint32_t bssrdf_table;
     int32_t tex[16];        /* PtMatParam slot -> texture index, -1 = constant (a zeroed struct must set these to -1) */
+    /* mix (materials/mix.rs:25-50): indices of "namedmaterial1" / "namedmaterial2" in the materials array (not mix or
+     * subsurface materials; at most 5 lobes together); "amount" is kd / tex[PT_MP_KD]; tex[PT_MP_BUMP] = material 1's bump map
+     * (material 2's bump map only perturbs a copy of the interaction that the reference then discards). */
+    uint32_t mix[2];
 } PtMaterial;
 
 typedef enum PtLightType {

@@ -65,10 +65,31 @@ static void bump_shading(const Scene &scene, int d, const TexCtx &ctx, SurfaceIn
 }
 
 // Returns false when the material leaves `si.bsdf == None` (null surface, path.rs:124-129).
+static bool material_scattering_functions(const Scene &scene, uint32_t mi, SurfaceInteraction &si, BSDF &bsdf,
+                                          TabulatedBSSRDF *bssrdf, bool *has_bssrdf, const TexCtx *tctx);
 static bool compute_scattering_functions(const Scene &scene, SurfaceInteraction &si, BSDF &bsdf,
                                          TabulatedBSSRDF *bssrdf = nullptr, bool *has_bssrdf = nullptr, const TexCtx *tctx = nullptr) {
     uint32_t mi = scene.prim_material[si.prim];
     if (mi == PT_NONE) return false;  // primitive.rs:168-170: no material => no bsdf
+    const PtMaterial &m = scene.materials[mi];
+    if (m.type == PT_MAT_MIX) {   // MixMaterial::compute_scattering_functions (mix.rs:25-50)
+        const MatEval E{scene, m, tctx};
+        RGB s1 = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);   // "amount"
+        RGB s2 = (RGB(1.0f) - s1).clamps(0.0f, INF);
+        SurfaceInteraction si2 = si;                          // a fresh interaction: same point and uv, no ray differentials;
+        TexCtx plain; const TexCtx *tctx2 = nullptr;          // its own shading frame is discarded with its BSDF
+        if (tctx) { plain = *tctx; plain.dpdx = plain.dpdy = V3(0.0f, 0.0f, 0.0f); plain.dudx = plain.dvdx = plain.dudy = plain.dvdy = 0.0f; tctx2 = &plain; }
+        if (!material_scattering_functions(scene, m.mix[0], si, bsdf, nullptr, nullptr, tctx)) return false;   // the reference unwraps
+        BSDF b2;
+        bool ok2 = material_scattering_functions(scene, m.mix[1], si2, b2, nullptr, nullptr, tctx2);
+        for (int i = 0; i < bsdf.n; ++i) { bsdf.b[i].scaled = true; bsdf.b[i].scale = s1; }
+        if (ok2) for (int i = 0; i < b2.n; ++i) { Bxdf x = b2.b[i]; x.scaled = true; x.scale = s2; bsdf.add(x); }
+        return true;
+    }
+    return material_scattering_functions(scene, mi, si, bsdf, bssrdf, has_bssrdf, tctx);
+}
+static bool material_scattering_functions(const Scene &scene, uint32_t mi, SurfaceInteraction &si, BSDF &bsdf,
+                                          TabulatedBSSRDF *bssrdf, bool *has_bssrdf, const TexCtx *tctx) {
     const PtMaterial &m = scene.materials[mi];
     const MatEval E{scene, m, tctx};
     // bump() modifies the caller's interaction in place (shading.n is what path.rs / estimate_direct read afterwards)

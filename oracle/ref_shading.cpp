@@ -11,7 +11,9 @@ static Float default_pdf(V3 wo, V3 wi) {  // reflection.rs:439-445
 }
 static inline Float pow5(Float v) { return (v * v) * (v * v) * v; }
 
-RGB bxdf_f(const Bxdf &b, V3 wo, V3 wi) {
+static RGB bxdf_f_unscaled(const Bxdf &b, V3 wo, V3 wi);
+RGB bxdf_f(const Bxdf &b, V3 wo, V3 wi) { RGB f = bxdf_f_unscaled(b, wo, wi); return b.scaled ? b.scale * f : f; }
+static RGB bxdf_f_unscaled(const Bxdf &b, V3 wo, V3 wi) {
     switch (b.kind) {
     case BX_LAMBERT_R: return b.r * INV_PI;  // reflection.rs:822-824
     case BX_BSSRDF: return RGB(bssrdf_sw(b.etab, wi)) * (b.etab * b.etab);  // bssrdf.rs:594-602 (mode == Radiance)
@@ -99,19 +101,21 @@ Float bxdf_pdf(const Bxdf &b, V3 wo, V3 wi) {
     return 0.0f;
 }
 
-RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) {
+static RGB bxdf_sample_f_unscaled(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled);
+RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) { RGB f = bxdf_sample_f_unscaled(b, wo, wi, u, pdf, sampled); return b.scaled ? b.scale * f : f; }
+static RGB bxdf_sample_f_unscaled(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) {
     switch (b.kind) {
     case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_BSSRDF: {  // default BxDF::sample_f :392-403
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;
         pdf = bxdf_pdf(b, wo, wi);
-        return bxdf_f(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
     }
     case BX_LAMBERT_T: {  // :865-876
         wi = cosine_sample_hemisphere(u);
         if (wo.z > 0.0f) wi.z *= -1.0f;
         pdf = bxdf_pdf(b, wo, wi);
-        return bxdf_f(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
     }
     case BX_SPEC_R: {  // :636-643
         wi = V3(-wo.x, -wo.y, wo.z);
@@ -151,7 +155,7 @@ RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) 
         wi = reflect(wo, wh);
         if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         pdf = b.dist.pdf(wo, wh) / (4.0f * dot(wo, wh));
-        return bxdf_f(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
     }
     case BX_MICRO_T: {  // :1094-1110
         if (wo.z == 0.0f) return RGB(0.0f);
@@ -160,7 +164,7 @@ RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) 
         Float eta = (cos_theta(wo) > 0.0f) ? b.etaa / b.etab : b.etab / b.etaa;
         if (!refract(wo, wh, eta, wi)) return RGB(0.0f);
         pdf = bxdf_pdf(b, wo, wi);
-        return bxdf_f(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
     }
     case BX_FRESNEL_BLEND: {  // :1184-1208
         P2 uu = u;
@@ -175,7 +179,7 @@ RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) 
             if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         }
         pdf = bxdf_pdf(b, wo, wi);
-        return bxdf_f(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
     }
     }
     return RGB(0.0f);

@@ -243,6 +243,7 @@ struct Bxdf {
     Float etaa = 1, etab = 1;
     Fresnel fresnel;
     TRDist dist;
+    bool scaled = false; RGB scale;   // ScaledBxDF (reflection.rs:466-517): f and sample_f times `scale`, pdf unchanged
     bool matches(int flags) const { return (type & flags) == type; }
 };
 

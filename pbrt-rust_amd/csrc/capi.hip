@@ -592,7 +592,18 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (arr) for (uint32_t i = 0; i < d->n_triangles; ++i) if (arr[i] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "alpha-mask texture index out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const PtMaterial &m = d->materials[i];
-        if (m.type > PT_MAT_TRANSLUCENT) return fail(PT_ERR_INVALID_ARG, "unknown material type");
+        if (m.type > PT_MAT_MIX) return fail(PT_ERR_INVALID_ARG, "unknown material type");
+        if (m.type == PT_MAT_MIX) {   // mix.rs:25-50: two plain materials whose lobes fit the five-lobe shade class together
+            auto lobes = [](const PtMaterial &q) { switch (q.type) { case PT_MAT_GLASS: return 2; case PT_MAT_PLASTIC: return 2; case PT_MAT_UBER: return 5; case PT_MAT_TRANSLUCENT: return 4; default: return 1; } };
+            int total = 0;
+            for (int k = 0; k < 2; ++k) {
+                if (m.mix[k] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "mix material index out of range");
+                const PtMaterial &q = d->materials[m.mix[k]];
+                if (q.type == PT_MAT_MIX || q.type == PT_MAT_SUBSURFACE) return fail(PT_ERR_UNSUPPORTED, "mix of mix / subsurface materials");
+                total += lobes(q);
+            }
+            if (total > 5) return fail(PT_ERR_UNSUPPORTED, "mix material with more than 5 BxDFs");
+        }
         for (int k = 0; k < 16; ++k) {
             if (d->n_textures == 0 && m.tex[k] > 0) return fail(PT_ERR_INVALID_ARG, "material references a texture but the scene has none");
             if (d->n_textures && m.tex[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "material texture index out of range");

@@ -337,10 +337,16 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
     V3 ns, ng, ss, ts;
     int n;
     Lobe l[MAXL];
+    // MixMaterial (mix.rs:25-50): lobes [0, n1) are ScaledBxDFs with scale s1, lobes [n1, n) with scale s2 (reflection.rs:466-517);
+    // only the five-lobe class carries this. `frozen`: the second material's init() must not reset the frame / eta / lobes.
+    static constexpr bool MIX = MAXL == 5;
+    int n1; RGB s1, s2; bool frozen;
 
     PT_DEV void init(const SurfaceInteraction &si, float eta_) {
+        if (MIX && frozen) return;
         eta = eta_; ns = si.sh_n; ss = normalize(si.sh_dpdu); ng = si.n; ts = cross(ns, ss); n = 0;
     }
+    PT_DEV RGB scaled(int i, RGB v) const { if (MIX && n1 >= 0) return (i < n1 ? s1 : s2) * v; return v; }
     PT_DEV void add(const Lobe &x) { if (n < MAXL) l[n++] = x; }
     PT_DEV int num_components(int flags) const { int c = 0; for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) ++c; return c; }
     PT_DEV V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
@@ -354,7 +360,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         RGB res(0.0f);
         for (int i = 0; i < MAXL; ++i)
             if (i < n && l[i].matches(flags) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                res = res + lobe_f<DIFF>(l[i], wo, wi);
+                res = res + scaled(i, lobe_f<DIFF>(l[i], wo, wi));
         return res;
     }
     PT_DEV float pdf(V3 wow, V3 wiw, int flags) const {
@@ -385,7 +391,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         RGB fv(0.0f);
         int btype = 0;
         // select the lobe without dynamic register-array indexing
-        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = lobe_sample_f<DIFF>(l[i], wo, wi, ur, pdf, sampled); }
+        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = scaled(i, lobe_sample_f<DIFF>(l[i], wo, wi, ur, pdf, sampled)); }
         if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
         wiw = to_world(wi);
         if (!(btype & BSDF_SPECULAR) && matching > 1)
@@ -396,7 +402,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
             fv = RGB(0.0f);
             for (int i = 0; i < MAXL; ++i)
                 if (i < n && l[i].matches(ty) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                    fv = fv + lobe_f<DIFF>(l[i], wo, wi);
+                    fv = fv + scaled(i, lobe_f<DIFF>(l[i], wo, wi));
         }
         return fv;
     }
@@ -411,11 +417,12 @@ struct ConstMatEval {
     PT_DEV RGB spec(const PtMaterial &, int, const float *field) const { return RGB(field[0], field[1], field[2]); }
     PT_DEV float flt(const PtMaterial &, int, float field) const { return field; }
     PT_DEV bool bound(const PtMaterial &, int) const { return false; }
+    PT_DEV ConstMatEval plain() const { return *this; }
 };
 
 // Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None. `E` evaluates the
 // (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
-template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
+template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf_leaf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
     switch (DIFF ? (uint32_t)PT_MAT_MATTE : m.type) {   // class 0 holds matte materials only
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
@@ -551,6 +558,26 @@ template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial
         return false;
     }
     }
+}
+
+// Material::compute_scattering_functions incl. MixMaterial (mix.rs:25-50): both materials' BxDFs in one BSDF (frame and eta of
+// the first), wrapped in ScaledBxDFs with scale = "amount" and 1 - "amount". `mats` = the scene's material array.
+template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E, const PtMaterial *mats) {
+    if constexpr (MAXL == 5) {
+        bsdf.n1 = -1; bsdf.frozen = false;
+        if (m.type == PT_MAT_MIX) {
+            const RGB a = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
+            const RGB c = RGB(1.0f - a.r, 1.0f - a.g, 1.0f - a.b).clamps(0.0f, PT_INF);
+            if (!build_bsdf_leaf(mats[m.mix[0]], si, bsdf, E)) return false;   // the reference unwraps si.bsdf here
+            const int first = bsdf.n;
+            bsdf.frozen = true;
+            build_bsdf_leaf(mats[m.mix[1]], si, bsdf, E.plain());   // evaluated on the reference's `si2`: no ray differentials
+            bsdf.frozen = false;
+            bsdf.n1 = first; bsdf.s1 = a; bsdf.s2 = c;
+            return true;
+        }
+    }
+    return build_bsdf_leaf(m, si, bsdf, E);
 }
 
 }  // namespace ptd

@@ -722,6 +722,14 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
 // ---- textured material parameters (8f-1) ---------------------------------------------------------------------
 struct TexMatEval {
     const DeviceScene &s; const TexCtx &c;
+    // MixMaterial evaluates its second material on a fresh SurfaceInteraction (mix.rs:31-36): same p / uv, no differentials
+    struct Plain {
+        const DeviceScene &s; TexCtx c;
+        PT_DEV bool bound(const PtMaterial &m, int slot) const { return m.tex[slot] >= 0; }
+        PT_DEV RGB spec(const PtMaterial &m, int slot, const float *field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c) : RGB(field[0], field[1], field[2]); }
+        PT_DEV float flt(const PtMaterial &m, int slot, float field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c).r : field; }
+    };
+    PT_DEV Plain plain() const { Plain q{s, c}; q.c.dpdx = V3(0.0f, 0.0f, 0.0f); q.c.dpdy = V3(0.0f, 0.0f, 0.0f); q.c.dudx = q.c.dvdx = q.c.dudy = q.c.dvdy = 0.0f; return q; }
     PT_DEV bool bound(const PtMaterial &m, int slot) const { return m.tex[slot] >= 0; }
     PT_DEV RGB spec(const PtMaterial &m, int slot, const float *field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c) : RGB(field[0], field[1], field[2]); }
     PT_DEV float flt(const PtMaterial &m, int slot, float field) const { return m.tex[slot] >= 0 ? tex_eval(s, m.tex[slot], c).r : field; }
@@ -860,8 +868,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         si.sh_dpdu = bdpdu; si.sh_dpdv = bdpdv;
                     }
                     const TexMatEval E{s, tctx};
-                    has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E);
-                } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval());
+                    has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E, s.materials);
+                } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged

@@ -295,6 +295,17 @@ private:
             }
             copy3(m.sigma_a, siga); copy3(m.sigma_s, sigs);
         }
+        else if (kind == "mix") {   // api.rs:615-640 + mix.rs:52-56: an undefined named material falls back to a matte made from these parameters
+            m.type = PT_MAT_MIX; spec("amount", PT_MP_KD, m.kd, 0.5f);
+            for (int k = 0; k < 2; ++k) {
+                const std::string nm = p.one_string(k ? "namedmaterial2" : "namedmaterial1", "");
+                auto it = gs.named_materials.find(nm);
+                m.mix[k] = (uint32_t)(it != gs.named_materials.end() ? it->second : new_material("matte", p));
+                const uint32_t ty = sc.materials[m.mix[k]].type;
+                if (ty == PT_MAT_MIX || ty == PT_MAT_SUBSURFACE) throw std::runtime_error("mix of \"mix\" / subsurface materials is not supported");
+            }
+            m.tex[PT_MP_BUMP] = sc.materials[m.mix[0]].tex[PT_MP_BUMP];   // only the first material's bump map survives (mix.rs:31-45)
+        }
         else throw std::runtime_error("material \"" + kind + "\" is not implemented on this back end");
         sc.materials.push_back(m);
         return (int)sc.materials.size() - 1;

@@ -186,14 +186,16 @@ class SceneBuilder:
         m = A.PtMaterial()
         kinds = dict(matte=A.PT_MAT_MATTE, mirror=A.PT_MAT_MIRROR, glass=A.PT_MAT_GLASS, plastic=A.PT_MAT_PLASTIC,
                      metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE,
-                     subsurface=A.PT_MAT_SUBSURFACE, kdsubsurface=A.PT_MAT_SUBSURFACE, translucent=A.PT_MAT_TRANSLUCENT)
+                     subsurface=A.PT_MAT_SUBSURFACE, kdsubsurface=A.PT_MAT_SUBSURFACE, translucent=A.PT_MAT_TRANSLUCENT, mix=A.PT_MAT_MIX)
         m.type = kinds[kind]
         d = dict(  # create_*_material defaults
             matte=dict(Kd=0.5, sigma=0.0), mirror=dict(Kr=0.9), glass=dict(Kr=1.0, Kt=1.0, eta=1.5, uroughness=0.0, vroughness=0.0),
             plastic=dict(Kd=0.25, Ks=0.25, roughness=0.1), metal=dict(roughness=0.01, uroughness=-1.0, vroughness=-1.0),
             uber=dict(Kd=0.25, Ks=0.25, Kr=0.0, Kt=0.0, roughness=0.1, uroughness=-1.0, vroughness=-1.0, opacity=1.0, eta=1.5),
             substrate=dict(Kd=0.5, Ks=0.5, uroughness=0.1, vroughness=0.1),
-            translucent=dict(Kd=0.25, Ks=0.25, reflect=0.5, transmit=0.5, roughness=0.1),   # translucent.rs:82-92 (reflect -> kr, transmit -> kt)
+            translucent=dict(Kd=0.25, Ks=0.25, reflect=0.5, transmit=0.5, roughness=0.1),
+            mix=dict(amount=0.5, namedmaterial1=None, namedmaterial2=None),   # mix.rs:52-56; the two materials are given as material ids
+   # translucent.rs:82-92 (reflect -> kr, transmit -> kt)
             # subsurface.rs:108-139 / kdsubsurface.rs:106-126
             subsurface=dict(Kr=1.0, Kt=1.0, eta=1.33, uroughness=0.0, vroughness=0.0, scale=1.0, g=0.0, name="",
                             sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77)),
@@ -201,7 +203,7 @@ class SceneBuilder:
         d.update(kw)
         # a parameter given as a string names a texture ("texture Kd" "name"); the constant field then keeps the default
         m.tex = (C.c_int32 * 16)(*([-1] * 16))
-        slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), reflect=(A.PT_MP_KR, 0), transmit=(A.PT_MP_KT, 0), opacity=(A.PT_MP_OPACITY, 0),
+        slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), reflect=(A.PT_MP_KR, 0), transmit=(A.PT_MP_KT, 0), amount=(A.PT_MP_KD, 0), opacity=(A.PT_MP_OPACITY, 0),
                      eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0),
                      sigma=(A.PT_MP_SIGMA, 1), roughness=(A.PT_MP_ROUGHNESS, 1), uroughness=(A.PT_MP_U_ROUGHNESS, 1),
                      vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1), bumpmap=(A.PT_MP_BUMP, 1))
@@ -217,7 +219,7 @@ class SceneBuilder:
             for sl in (A.PT_MP_U_ROUGHNESS, A.PT_MP_V_ROUGHNESS):
                 if m.tex[sl] < 0 and "uroughness" not in kw and "vroughness" not in kw: pass
         three = lambda v: (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
-        m.kd = three(d.get("Kd", 0)); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", d.get("reflect", 0))); m.kt = three(d.get("Kt", d.get("transmit", 0)))
+        m.kd = three(d.get("Kd", d.get("amount", 0))); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", d.get("reflect", 0))); m.kt = three(d.get("Kt", d.get("transmit", 0)))
         m.opacity = three(d.get("opacity", 1)); m.eta_rgb = three(d.get("eta_rgb", (0.2, 0.92, 1.1))); m.k_rgb = three(d.get("k", (3.9, 2.45, 2.14)))
         m.sigma = d.get("sigma", 0.0); m.eta = d.get("eta", 1.5); m.roughness = d.get("roughness", 0.1)
         m.u_roughness = d.get("uroughness", -1.0); m.v_roughness = d.get("vroughness", -1.0)
@@ -246,6 +248,12 @@ class SceneBuilder:
                 if t is table: m.bssrdf_table = i; break
             else:
                 self.bssrdf_tables.append(table); m.bssrdf_table = len(self.bssrdf_tables) - 1
+        if kind == "mix":
+            ids = (d["namedmaterial1"], d["namedmaterial2"])
+            for i in ids:
+                if not isinstance(i, int) or not (0 <= i < len(self.materials)) or self.materials[i].type in (A.PT_MAT_MIX, A.PT_MAT_SUBSURFACE): raise ValueError("mix needs the ids of two plain materials")
+            m.mix = (C.c_uint32 * 2)(*ids)
+            m.tex[A.PT_MP_BUMP] = self.materials[ids[0]].tex[A.PT_MP_BUMP]   # mix.rs:31-45: only material 1's bump map survives
         self.materials.append(m)
         self.material_id = len(self.materials) - 1
 

@@ -388,3 +388,41 @@ def translucent_panels(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
     b.material("translucent", transmit=(0.0, 0.0, 0.0))                              # reflection only
     b.attribute_begin(); b.translate(0.0, 0.1, 1.2); b.sphere(radius=0.5); b.attribute_end()
     return b
+
+
+def mix_materials(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
+    """materials/mix.rs: ScaledBxDF blends -- matte + mirror, plastic + rough glass, metal + translucent (1 + 4 lobes) -- with a
+    constant or (textured variant) checkerboard "amount"; in the textured variant both sub-materials and a bump map are textured,
+    so the second material's textures are evaluated without ray differentials as in the reference."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.0, 6.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=36.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.3, 0.35, 0.45))
+    b.attribute_begin(); b.area_light_source(L=(18.0, 16.0, 14.0))
+    P, I = quad((-1.0, 4.0, -1.0), (1.0, 4.0, -1.0), (1.0, 4.0, 1.0), (-1.0, 4.0, 1.0)); b.trianglemesh(P, I); b.attribute_end()
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=F)
+    amount = (0.3, 0.5, 0.7)
+    if textured:
+        b.texture("amt", "spectrum", "checkerboard", uscale=3.0, vscale=3.0, tex1=(0.9, 0.9, 0.9), tex2=(0.1, 0.2, 0.3))
+        b.texture("img", "spectrum", "imagemap", pixels=test_image(16, 16), uscale=2.0, vscale=2.0, trilinear=True)
+        b.texture("bumps", "float", "checkerboard", uscale=6.0, vscale=6.0, tex1=0.02, tex2=0.0)
+        amount = "amt"
+    b.material("matte", Kd=("img" if textured else (0.7, 0.3, 0.2)), **({"bumpmap": "bumps"} if textured else {})); m_matte = b.material_id
+    b.material("mirror", Kr=(0.9, 0.9, 0.9)); m_mirror = b.material_id
+    b.material("plastic", Kd=(0.1, 0.4, 0.1), Ks=(0.5, 0.5, 0.5), roughness=0.15); m_plastic = b.material_id
+    b.material("glass", Kr=(0.8, 0.8, 0.8), Kt=(0.9, 0.9, 0.9), uroughness=0.2, vroughness=0.3); m_glass = b.material_id
+    b.material("metal", roughness=0.05); m_metal = b.material_id
+    b.material("translucent", Kd=("img" if textured else (0.5, 0.5, 0.6)), reflect=(0.5, 0.5, 0.5), transmit=(0.6, 0.6, 0.6)); m_trans = b.material_id
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I, UV=uv * 8)
+    b.material("mix", amount=amount, namedmaterial1=m_matte, namedmaterial2=m_mirror)
+    b.attribute_begin(); b.translate(-1.7, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("mix", amount=amount, namedmaterial1=m_plastic, namedmaterial2=m_glass)
+    P, I = quad((-0.7, -0.5, 0.3), (0.7, -0.5, 0.3), (0.7, 1.2, -0.3), (-0.7, 1.2, -0.3)); b.trianglemesh(P, I, UV=uv)
+    b.material("mix", amount=0.4, namedmaterial1=m_metal, namedmaterial2=m_trans)
+    b.attribute_begin(); b.translate(1.7, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("mix", amount=amount, namedmaterial1=m_trans, namedmaterial2=m_matte)   # textured second material: no differentials
+    P, I = quad((-2.6, -0.5, -2.0), (2.6, -0.5, -2.0), (2.6, 1.6, -2.0), (-2.6, 1.6, -2.0)); b.trianglemesh(P, I, UV=uv * 2)
+    return b

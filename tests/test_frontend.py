@@ -437,3 +437,29 @@ def test_exr_png_pfm_writers_and_exr_reader(pkg, tmp_path):
     assert np.array_equal(F.read_image(str(tmp_path / "a.png")), F.read_image(str(tmp_path / "a.tga")))
     with pytest.raises(Exception, match="Unsupported file format"): F.write_image(str(tmp_path / "a.jpg"), lin)
     assert F.FrontScene(text='WorldBegin\nShape "sphere"\nWorldEnd\n').output_filename() == "pbrt.exr"   # film.rs default
+
+
+def test_mix_and_translucent_materials_from_a_scene_file(pkg):
+    """api.rs:615-640 + mix.rs / translucent.rs parameter names; an undefined named material falls back to a matte."""
+    A = pkg._abi
+    fs = pkg.frontend.FrontScene(text='''WorldBegin
+Texture "bmp" "float" "checkerboard"
+MakeNamedMaterial "a" "string type" "plastic" "rgb Kd" [.1 .2 .3] "texture bumpmap" "bmp"
+MakeNamedMaterial "b" "string type" "translucent" "rgb reflect" [.2 .2 .2] "rgb transmit" [.7 .6 .5] "float roughness" .3
+Material "mix" "string namedmaterial1" "a" "string namedmaterial2" "b" "rgb amount" [.25 .5 .75]
+Shape "sphere"
+Material "mix" "string namedmaterial1" "nope" "string namedmaterial2" "a" "rgb Kd" [.9 .8 .7]
+Shape "sphere"
+WorldEnd
+''')
+    d = fs.desc()
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    mixes = [m for m in mats if m.type == A.PT_MAT_MIX]
+    assert len(mixes) == 2
+    m = mixes[0]
+    assert mats[m.mix[0]].type == A.PT_MAT_PLASTIC and mats[m.mix[1]].type == A.PT_MAT_TRANSLUCENT
+    assert list(m.kd) == pytest.approx([.25, .5, .75]) and m.tex[A.PT_MP_BUMP] == mats[m.mix[0]].tex[A.PT_MP_BUMP] >= 0
+    t = mats[m.mix[1]]
+    assert list(t.kr) == pytest.approx([.2, .2, .2]) and list(t.kt) == pytest.approx([.7, .6, .5]) and t.roughness == pytest.approx(.3) and list(t.kd) == pytest.approx([.25] * 3)
+    fb = mats[mixes[1].mix[0]]
+    assert fb.type == A.PT_MAT_MATTE and list(fb.kd) == pytest.approx([.9, .8, .7]) and list(mixes[1].kd) == pytest.approx([.5] * 3)

@@ -330,3 +330,22 @@ def test_translucent_material_matches_oracle(pkg, gpu, oracle, textured):
     sd, rp = pkg.scenes.translucent_panels(textured=textured).world_end()
     film, ref = _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5 if textured else 2e-6, atol=1e-6 if textured else 1e-7)
     assert film[..., :3].sum() > 0
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_mix_material_matches_oracle(pkg, gpu, oracle, textured):
+    """materials/mix.rs: both materials' BxDFs as ScaledBxDFs (amount, 1 - amount) in the first material's frame; the second
+    material's textures are evaluated on an interaction without differentials; only the first material's bump map acts."""
+    sd, rp = pkg.scenes.mix_materials(textured=textured).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5 if textured else 2e-6, atol=1e-6 if textured else 1e-7)
+    assert film[..., :3].sum() > 0
+
+
+def test_mix_material_limits_are_reported(pkg, gpu):
+    b = pkg.scenes.mix_materials()
+    b.material("uber"); u = b.material_id
+    b.material("plastic"); p2 = b.material_id
+    b.material("mix", namedmaterial1=u, namedmaterial2=p2)   # 5 + 2 BxDFs
+    P, I = pkg.scenes.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)); b.trianglemesh(P, I)
+    sd, rp = b.world_end()
+    with pytest.raises(Exception, match="more than 5 BxDFs"): pkg.Scene(gpu, sd)
