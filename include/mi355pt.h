@@ -79,9 +79,11 @@ typedef enum PtMaterialType {
     PT_MAT_METAL = 4,      /* materials/metal.rs      */
     PT_MAT_UBER = 5,       /* materials/uber.rs       */
     PT_MAT_SUBSTRATE = 6,  /* materials/substrate.rs  */
-    PT_MAT_SUBSURFACE = 7, PT_MAT_TRANSLUCENT = 8 /* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */,
-    PT_MAT_MIX = 9 /* materials/mix.rs: kd = "amount", mix[0] / mix[1] = the two named materials */  /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
+    PT_MAT_SUBSURFACE = 7, /* materials/subsurface.rs (kdsubsurface: the host converts Kd/mfp with
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
+    PT_MAT_TRANSLUCENT = 8,/* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */
+    PT_MAT_MIX = 9,        /* materials/mix.rs: kd = "amount", mix[0] / mix[1] = the two named materials */
+    PT_MAT_DISNEY = 10     /* materials/disney.rs: kd = "color", eta, roughness + disney[] / disney_thin; scatterdistance must be 0 */
 } PtMaterialType;
 
 /* ---- textures (core/texture.rs, textures/, core/mipmap.rs) --------------------------------------
@@ -146,6 +148,11 @@ typedef enum PtMatParam {
     PT_MP_COUNT = 16
 } PtMatParam;
 
+typedef enum PtDisneyParam {
+    PT_DS_METALLIC = 0, PT_DS_SPECULARTINT = 1, PT_DS_ANISOTROPIC = 2, PT_DS_SHEEN = 3, PT_DS_SHEENTINT = 4, PT_DS_CLEARCOAT = 5,
+    PT_DS_CLEARCOATGLOSS = 6, PT_DS_SPECTRANS = 7, PT_DS_FLATNESS = 8, PT_DS_DIFFTRANS = 9
+} PtDisneyParam;
+
 /* Material parameters. Field use per type follows the reference's create_*_material parameter names; every field is the
  * value of a ConstantTexture unless tex[slot] names a texture. */
 typedef struct PtMaterial {
@@ -174,6 +181,10 @@ typedef struct PtMaterial {
      * subsurface materials; at most 5 lobes together); "amount" is kd / tex[PT_MP_KD]; tex[PT_MP_BUMP] = material 1's bump map
      * (material 2's bump map only perturbs a copy of the interaction that the reference then discards). */
     uint32_t mix[2];
+    /* disney (materials/disney.rs:842-887): the float parameters that are constants here, indexed by PtDisneyParam;
+     * "color" = kd / tex[PT_MP_KD], "eta" = eta / tex[PT_MP_ETA], "roughness" = roughness / tex[PT_MP_ROUGHNESS] may be textured. */
+    float disney[10];
+    uint32_t disney_thin;
 } PtMaterial;
 
 typedef enum PtLightType {

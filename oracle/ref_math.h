@@ -187,11 +187,7 @@ inline float dm_acosf(float xf) {
     double s = std::sqrt((1.0 - x) * (1.0 + x));
     return (float)dm_atan2d(s, x);
 }
-inline float dm_logf(float xf) {
-    if (xf != xf || xf < 0.0f) return std::numeric_limits<float>::quiet_NaN();
-    if (xf == 0.0f) return -INF;
-    if (std::isinf(xf)) return xf;
-    double x = xf;
+inline double dm_logd_pos(double x) {
     uint64_t bits; std::memcpy(&bits, &x, 8);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
@@ -210,8 +206,44 @@ inline float dm_logf(float xf) {
     p = p * s2 + 2.0 / 5.0;
     p = p * s2 + 2.0 / 3.0;
     p = p * s2 + 2.0;
-    return (float)((double)e * DM_LN2 + s * p);
+    return (double)e * DM_LN2 + s * p;
 }
+inline float dm_logf(float xf) {
+    if (xf != xf || xf < 0.0f) return std::numeric_limits<float>::quiet_NaN();
+    if (xf == 0.0f) return -INF;
+    if (std::isinf(xf)) return xf;
+    return (float)dm_logd_pos((double)xf);
+}
+// e^y in f64 (same scheme as dev_math.h: k ln2 + r, degree-14 Taylor series, 2^k scale) -> f32::powf / exp stand-ins
+inline double dm_expd(double y) {
+    if (y > 700.0) y = 700.0;
+    if (y < -700.0) y = -700.0;
+    const double kf = std::floor(y * (1.0 / DM_LN2) + 0.5);
+    const double r = y - kf * DM_LN2;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const uint64_t bits = (uint64_t)((int64_t)kf + 1023) << 52;
+    double sc; std::memcpy(&sc, &bits, 8);
+    return p * sc;
+}
+inline float dm_powf(float a, float b) {
+    if (!(a > 0.0f)) return (a == 0.0f) ? (b == 0.0f ? 1.0f : 0.0f) : std::numeric_limits<float>::quiet_NaN();
+    return (float)dm_expd((double)b * dm_logd_pos((double)a));
+}
+
 
 // ---- vectors ---------------------------------------------------------------------------------
 struct V3 {

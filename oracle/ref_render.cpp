@@ -223,6 +223,50 @@ static bool material_scattering_functions(const Scene &scene, uint32_t mi, Surfa
         }
         return true;
     }
+    case PT_MAT_DISNEY: {  // disney.rs:719-840; "scatterdistance" is zero here (the BSSRDF branch is refused at scene creation)
+        bsdf.init(si, 1.0f);
+        RGB c = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF);   // "color"
+        Float mweight = m.disney[PT_DS_METALLIC], e = E.flt(PT_MP_ETA, m.eta), strans = m.disney[PT_DS_SPECTRANS];
+        Float dweight = (1.0f - mweight) * (1.0f - strans);
+        Float dt = m.disney[PT_DS_DIFFTRANS] / 2.0f;
+        Float rough = E.flt(PT_MP_ROUGHNESS, m.roughness);
+        Float lum = 0.212671f * c.c[0] + 0.715160f * c.c[1] + 0.072169f * c.c[2];
+        RGB ctint = lum > 0.0f ? c / lum : RGB(1.0f);
+        Float sheen_weight = m.disney[PT_DS_SHEEN];
+        RGB csheen(0.0f);
+        if (sheen_weight > 0.0f) csheen = lerp_t(m.disney[PT_DS_SHEENTINT], RGB(1.0f), ctint);
+        bool thin = m.disney_thin != 0;
+        if (dweight > 0.0f) {
+            if (thin) {
+                Float flat = m.disney[PT_DS_FLATNESS];
+                { Bxdf b; b.kind = BX_DISNEY_DIFFUSE; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight * flat * (1.0f - dt); bsdf.add(b); }
+                { Bxdf b; b.kind = BX_DISNEY_FAKESS; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * (1.0f - dt) * flat * dweight; b.A = rough; bsdf.add(b); }
+            } else { Bxdf b; b.kind = BX_DISNEY_DIFFUSE; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight; bsdf.add(b); }
+            { Bxdf b; b.kind = BX_DISNEY_RETRO; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight; b.A = rough; bsdf.add(b); }
+            if (sheen_weight > 0.0f) { Bxdf b; b.kind = BX_DISNEY_SHEEN; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = csheen * sheen_weight * dweight; bsdf.add(b); }
+        }
+        Float aspect = std::sqrt(1.0f - m.disney[PT_DS_ANISOTROPIC] * 0.9f);
+        TRDist dis; dis.ax = fmax_(rough * rough / aspect, 0.001f); dis.ay = fmax_(rough * rough * aspect, 0.001f); dis.separable = true;
+        RGB cspec0 = lerp_t(mweight, lerp_t(m.disney[PT_DS_SPECULARTINT], RGB(1.0f) * (((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f))), ctint), c);
+        {
+            Bxdf b; b.kind = BX_MICRO_R; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.r = RGB(1.0f); b.dist = dis;
+            b.fresnel.kind = FR_DISNEY; b.fresnel.r0 = cspec0; b.fresnel.metallic = mweight; b.fresnel.etat = e; bsdf.add(b);
+        }
+        Float cc = m.disney[PT_DS_CLEARCOAT];
+        if (cc > 0.0f) { Bxdf b; b.kind = BX_DISNEY_CLEARCOAT; b.type = BSDF_REFLECTION | BSDF_GLOSSY; b.B = cc; b.A = lerp_t(m.disney[PT_DS_CLEARCOATGLOSS], 0.1f, 0.001f); bsdf.add(b); }
+        if (strans > 0.0f) {
+            RGB T = sqrt_rgb(c) * strans;
+            Bxdf b; b.kind = BX_MICRO_T; b.type = BSDF_TRANSMISSION | BSDF_GLOSSY; b.t = T; b.etaa = 1.0f; b.etab = e;
+            b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e;
+            if (thin) {
+                Float rscaled = (0.65f * e - 0.35f) * rough;
+                b.dist.ax = fmax_(rscaled * rscaled / aspect, 0.001f); b.dist.ay = fmax_(rscaled * rscaled * aspect, 0.001f);
+            } else b.dist = dis;
+            bsdf.add(b);
+        }
+        if (thin) { Bxdf b; b.kind = BX_LAMBERT_T; b.type = BSDF_TRANSMISSION | BSDF_DIFFUSE; b.t = c * dt; bsdf.add(b); }
+        return true;
+    }
     case PT_MAT_SUBSTRATE: {  // substrate.rs:34-60
         bsdf.init(si, 1.0f);
         RGB d = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF), s = E.spec(PT_MP_KS, m.ks).clamps(0.0f, INF);

@@ -10,6 +10,14 @@ static Float default_pdf(V3 wo, V3 wi) {  // reflection.rs:439-445
     return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * INV_PI : 0.0f;
 }
 static inline Float pow5(Float v) { return (v * v) * (v * v) * v; }
+static inline Float disney_gtr1(Float c, Float alpha) {   // disney.rs:222-226
+    Float a2 = alpha * alpha;
+    return (a2 - 1.0f) / (PI * dm_logf(a2) * (1.0f + (a2 - 1.0f) * c * c));
+}
+static inline Float disney_smithg_ggx(Float c, Float alpha) {   // disney.rs:228-233: no square root there
+    Float a2 = alpha * alpha, c2 = c * c;
+    return 1.0f / (c + (a2 + c2 - a2 * c2));
+}
 
 static RGB bxdf_f_unscaled(const Bxdf &b, V3 wo, V3 wi);
 RGB bxdf_f(const Bxdf &b, V3 wo, V3 wi) { RGB f = bxdf_f_unscaled(b, wo, wi); return b.scaled ? b.scale * f : f; }
@@ -30,6 +38,45 @@ static RGB bxdf_f_unscaled(const Bxdf &b, V3 wo, V3 wi) {
         if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sin_o; tan_beta = sin_i / abs_cos_theta(wi); }
         else { sin_alpha = sin_i; tan_beta = sin_o / abs_cos_theta(wo); }
         return b.r * INV_PI * (b.A + b.B * max_cos * sin_alpha * tan_beta);
+    }
+    case BX_DISNEY_DIFFUSE: {                // disney.rs:66-74
+        Float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        return b.r * INV_PI * (1.0f - fo / 2.0f) * (1.0f - fi / 2.0f);
+    }
+    case BX_DISNEY_FAKESS: {                 // disney.rs:104-124
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        Float cos_d = dot(wi, wh);
+        Float fss90 = cos_d * cos_d * b.A;
+        Float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        Float fss = lerp_t(fo, 1.0f, fss90) * lerp_t(fi, 1.0f, fss90);
+        Float ss = 1.25f * (fss * (1.0f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - 0.5f) + 0.5f);
+        return b.r / INV_PI * ss;            // `/ INV_PI` as written at disney.rs:123
+    }
+    case BX_DISNEY_RETRO: {                  // disney.rs:158-172
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        Float cos_d = dot(wi, wh);
+        Float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        Float rr = 2.0f * b.A * cos_d * cos_d;
+        return b.r * INV_PI * rr * (fo + fi + fo * fi * (rr - 1.0f));
+    }
+    case BX_DISNEY_SHEEN: {                  // disney.rs:202-210
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        return b.r * schlick_weight(dot(wi, wh));
+    }
+    case BX_DISNEY_CLEARCOAT: {              // disney.rs:238-255 (A = gloss, B = weight)
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        Float dr = disney_gtr1(abs_cos_theta(wh), b.A);
+        Float fr = fr_schlick(0.04f, dot(wo, wh));
+        Float gr = disney_smithg_ggx(abs_cos_theta(wo), 0.25f) * disney_smithg_ggx(abs_cos_theta(wi), 0.25f);
+        return RGB(fr * b.B * gr * dr / 4.0f);
     }
     case BX_SPEC_R: case BX_SPEC_T: return RGB(0.0f);
     case BX_FRESNEL_SPEC: return RGB(1.0f);  // App. A #9, reflection.rs:745-747
@@ -75,6 +122,15 @@ static RGB bxdf_f_unscaled(const Bxdf &b, V3 wo, V3 wi) {
 Float bxdf_pdf(const Bxdf &b, V3 wo, V3 wi) {
     switch (b.kind) {
     case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_FRESNEL_SPEC: case BX_BSSRDF: return default_pdf(wo, wi);  // FresnelSpecular: :788-794
+    case BX_DISNEY_DIFFUSE: case BX_DISNEY_FAKESS: case BX_DISNEY_RETRO: case BX_DISNEY_SHEEN: return default_pdf(wo, wi);
+    case BX_DISNEY_CLEARCOAT: {  // disney.rs:276-292 (`wh = wi + wi` as written there)
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = wi + wi;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+        wh = normalize(wh);
+        Float dr = disney_gtr1(abs_cos_theta(wh), b.A);
+        return dr * abs_cos_theta(wh) / (4.0f * dot(wo, wh));
+    }
     case BX_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) : 0.0f;              // :886-892 (no INV_PI, App. A #10)
     case BX_SPEC_R: case BX_SPEC_T: return 0.0f;
     case BX_MICRO_R: {  // :1021-1027
@@ -105,6 +161,20 @@ static RGB bxdf_sample_f_unscaled(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf
 RGB bxdf_sample_f(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) { RGB f = bxdf_sample_f_unscaled(b, wo, wi, u, pdf, sampled); return b.scaled ? b.scale * f : f; }
 static RGB bxdf_sample_f_unscaled(const Bxdf &b, V3 wo, V3 &wi, P2 u, Float &pdf, int &sampled) {
     switch (b.kind) {
+    case BX_DISNEY_CLEARCOAT: {  // disney.rs:257-274
+        if (wo.z == 0.0f) return RGB(0.0f);
+        Float a2 = b.A * b.A;
+        Float ct = std::sqrt(fmax_((1.0f - dm_powf(a2, 1.0f - u.x)) / (1.0f - a2), 0.0f));
+        Float st = std::sqrt(fmax_(1.0f - ct * ct, 0.0f));
+        Float phi = 2.0f * PI * u.y;
+        V3 wh(st * dm_cosf(phi), st * dm_sinf(phi), ct);   // spherical_direction (geometry.rs:27-33)
+        if (!same_hemisphere(wo, wh)) wh = -wh;
+        wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, wh)) return RGB(0.0f);
+        pdf = bxdf_pdf(b, wo, wi);
+        return bxdf_f_unscaled(b, wo, wi);
+    }
+    case BX_DISNEY_DIFFUSE: case BX_DISNEY_FAKESS: case BX_DISNEY_RETRO: case BX_DISNEY_SHEEN:
     case BX_LAMBERT_R: case BX_OREN_NAYAR: case BX_BSSRDF: {  // default BxDF::sample_f :392-403
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;

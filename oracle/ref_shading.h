@@ -96,8 +96,9 @@ inline Float power_heuristic(int nf, Float fpdf, int ng, Float gpdf) {  // sampl
 
 // ---- BxDFs (core/reflection.rs) ---------------------------------------------------------------
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum BxdfKind { BX_LAMBERT_R, BX_LAMBERT_T, BX_OREN_NAYAR, BX_SPEC_R, BX_SPEC_T, BX_FRESNEL_SPEC, BX_MICRO_R, BX_MICRO_T, BX_FRESNEL_BLEND, BX_BSSRDF };
-enum FresnelKind { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR };
+enum BxdfKind { BX_LAMBERT_R, BX_LAMBERT_T, BX_OREN_NAYAR, BX_SPEC_R, BX_SPEC_T, BX_FRESNEL_SPEC, BX_MICRO_R, BX_MICRO_T, BX_FRESNEL_BLEND, BX_BSSRDF,
+                BX_DISNEY_DIFFUSE, BX_DISNEY_FAKESS, BX_DISNEY_RETRO, BX_DISNEY_SHEEN, BX_DISNEY_CLEARCOAT };   // materials/disney.rs
+enum FresnelKind { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR, FR_DISNEY };
 
 inline Float cos_theta(V3 w) { return w.z; }
 inline Float cos2_theta(V3 w) { return w.z * w.z; }
@@ -153,12 +154,21 @@ inline RGB fr_conductor(Float cos_thetai, RGB etai, RGB etat, RGB k) {
     return (rp + rs) * 0.5f;
 }
 
+// materials/disney.rs:31-52
+inline Float schlick_weight(Float c) { Float m = clampv(1.0f - c, 0.0f, 1.0f); return (m * m) * (m * m) * m; }
+inline Float lerp_t(Float t, Float x, Float y) { return x * (1.0f - t) + y * t; }   // pbrt.rs:136-144
+inline RGB lerp_t(Float t, RGB x, RGB y) { return x * (1.0f - t) + y * t; }
+inline Float fr_schlick(Float r0, Float c) { return lerp_t(schlick_weight(c), r0, 1.0f); }
+inline RGB fr_schlicks(RGB r0, Float c) { return lerp_t(schlick_weight(c), r0, RGB(1.0f)); }
+
 struct Fresnel {
     int kind = FR_NOOP;
     Float etai = 1, etat = 1;
     RGB ci, ct, k;
+    RGB r0; Float metallic = 0;   // DisneyFresnel (disney.rs:283-303), eta in `etat`
     RGB evaluate(Float cosi) const {
         if (kind == FR_NOOP) return RGB(1.0f);
+        if (kind == FR_DISNEY) return lerp_t(metallic, RGB(fr_dielectric(cosi, 1.0f, etat)), fr_schlicks(r0, cosi));
         if (kind == FR_DIELECTRIC) return RGB(fr_dielectric(cosi, etai, etat));
         return fr_conductor(std::fabs(cosi), ci, ct, k);
     }
@@ -187,7 +197,8 @@ struct TRDist {
         return (-1.0f + std::sqrt(1.0f + a2t2)) / 2.0f;
     }
     Float g1(V3 w) const { return 1.0f / (1.0f + lambda(w)); }
-    Float g(V3 wo, V3 wi) const { return 1.0f / (1.0f + lambda(wo) + lambda(wi)); }
+    bool separable = false;   // DisneyMicrofacetDistribution::g (disney.rs:376-379)
+    Float g(V3 wo, V3 wi) const { return separable ? g1(wo) * g1(wi) : 1.0f / (1.0f + lambda(wo) + lambda(wi)); }
     Float pdf(V3 wo, V3 wh) const {  // microfacet.rs:120-131 (samplevis)
         return d(wh) * g1(wo) * abs_dot(wo, wh) / abs_cos_theta(wo);
     }

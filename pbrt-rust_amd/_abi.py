@@ -18,7 +18,9 @@ PT_TRI_HAS_UV = 16
 PT_SHAPE_TRIANGLE, PT_SHAPE_SPHERE = 0, 1
 PT_NONE = 0xFFFFFFFF
 
-PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE, PT_MAT_TRANSLUCENT, PT_MAT_MIX = range(10)
+PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_UBER, PT_MAT_SUBSTRATE, PT_MAT_SUBSURFACE, PT_MAT_TRANSLUCENT, PT_MAT_MIX, PT_MAT_DISNEY = range(11)
+(PT_DS_METALLIC, PT_DS_SPECULARTINT, PT_DS_ANISOTROPIC, PT_DS_SHEEN, PT_DS_SHEENTINT, PT_DS_CLEARCOAT, PT_DS_CLEARCOATGLOSS, PT_DS_SPECTRANS,
+ PT_DS_FLATNESS, PT_DS_DIFFTRANS) = range(10)
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
@@ -43,7 +45,7 @@ class PtMaterial(C.Structure):
     _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
                 ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
-                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2)]
+                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32)]
 
 
 class PtLight(C.Structure):

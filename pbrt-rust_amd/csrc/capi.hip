@@ -592,9 +592,16 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (arr) for (uint32_t i = 0; i < d->n_triangles; ++i) if (arr[i] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "alpha-mask texture index out of range");
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const PtMaterial &m = d->materials[i];
-        if (m.type > PT_MAT_MIX) return fail(PT_ERR_INVALID_ARG, "unknown material type");
+        if (m.type > PT_MAT_DISNEY) return fail(PT_ERR_INVALID_ARG, "unknown material type");
+        if (m.type == PT_MAT_DISNEY) {   // disney.rs:741-836: BxDFs the parameters can produce; the shade class holds five
+            const bool thin = m.disney_thin != 0;
+            const float dw = (1.0f - m.disney[PT_DS_METALLIC]) * (1.0f - m.disney[PT_DS_SPECTRANS]);
+            int n = 1 + (m.disney[PT_DS_CLEARCOAT] > 0.0f) + (m.disney[PT_DS_SPECTRANS] > 0.0f) + (thin ? 1 : 0);
+            if (dw > 0.0f) n += (thin ? 2 : 1) + 1 + (m.disney[PT_DS_SHEEN] > 0.0f);
+            if (n > 5) return fail(PT_ERR_UNSUPPORTED, "disney material with more than 5 BxDFs");
+        }
         if (m.type == PT_MAT_MIX) {   // mix.rs:25-50: two plain materials whose lobes fit the five-lobe shade class together
-            auto lobes = [](const PtMaterial &q) { switch (q.type) { case PT_MAT_GLASS: return 2; case PT_MAT_PLASTIC: return 2; case PT_MAT_UBER: return 5; case PT_MAT_TRANSLUCENT: return 4; default: return 1; } };
+            auto lobes = [](const PtMaterial &q) { switch (q.type) { case PT_MAT_GLASS: return 2; case PT_MAT_PLASTIC: return 2; case PT_MAT_UBER: return 5; case PT_MAT_TRANSLUCENT: return 4; case PT_MAT_DISNEY: return 5; default: return 1; } };
             int total = 0;
             for (int k = 0; k < 2; ++k) {
                 if (m.mix[k] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "mix material index out of range");

@@ -8,8 +8,9 @@
 namespace ptd {
 
 enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };
-enum LobeKind : uint8_t { LB_LAMBERT_R, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_MICRO_R, LB_MICRO_T, LB_FRESNEL_BLEND };
-enum FresnelKind : uint8_t { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR };
+enum LobeKind : uint8_t { LB_LAMBERT_R, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_MICRO_R, LB_MICRO_T, LB_FRESNEL_BLEND,
+                          LB_DISNEY_DIFFUSE, LB_DISNEY_FAKESS, LB_DISNEY_RETRO, LB_DISNEY_SHEEN, LB_DISNEY_CLEARCOAT };   // materials/disney.rs
+enum FresnelKind : uint8_t { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR, FR_DISNEY };
 
 // sampling.rs:153-176
 PT_DEV P2 concentric_sample_disk(P2 u) {
@@ -83,16 +84,33 @@ PT_DEV RGB fr_conductor(float cos_i, RGB etai, RGB etat, RGB k) {  // reflection
 
 struct Lobe {
     uint8_t kind, type, fresnel;
+    uint8_t sepg;    // DisneyMicrofacetDistribution: separable masking-shadowing G = G1(wo) G1(wi) (disney.rs:376-379)
     RGB r, t;        // R | T | Rd ; FresnelBlend: t = Rs ; conductor: r=1, t unused
     float ax, ay;    // Trowbridge-Reitz alphas
     float etaa, etab;  // dielectric etas (etai/etat of the Fresnel term, or lobe etaA/etaB)
     RGB ck, ce;      // conductor k, eta
-    float A, B;      // Oren-Nayar
+    float A, B;      // Oren-Nayar; Disney: A = roughness (fake-ss, retro) / clearcoat gloss / Fresnel metallic, B = clearcoat weight
     PT_DEV bool matches(int flags) const { return (type & flags) == type; }
 };
 
-PT_DEV RGB fresnel_eval(const Lobe &l, float cosi, float fi, float ft) {
+// ---- materials/disney.rs:31-52 helpers
+PT_DEV float schlick_weight(float c) { const float m = clampf(1.0f - c, 0.0f, 1.0f); return (m * m) * (m * m) * m; }
+PT_DEV float lerp_t(float t, float x, float y) { return x * (1.0f - t) + y * t; }                       // pbrt.rs:136-144
+PT_DEV RGB lerp_rgb(float t, RGB x, RGB y) { return x * (1.0f - t) + y * t; }
+PT_DEV float fr_schlick(float r0, float c) { return lerp_t(schlick_weight(c), r0, 1.0f); }
+PT_DEV RGB fr_schlicks(RGB r0, float c) { return lerp_rgb(schlick_weight(c), r0, RGB(1.0f)); }
+PT_DEV float gtr1(float c, float alpha) {       // disney.rs:222-226
+    const float a2 = alpha * alpha;
+    return (a2 - 1.0f) / (kPi * dm_logf(a2) * (1.0f + (a2 - 1.0f) * c * c));
+}
+PT_DEV float smithg_ggx(float c, float alpha) {  // disney.rs:228-233 (no square root, as written there)
+    const float a2 = alpha * alpha, c2 = c * c;
+    return 1.0f / (c + (a2 + c2 - a2 * c2));
+}
+
+template <bool FULL = true> PT_DEV RGB fresnel_eval(const Lobe &l, float cosi, float fi, float ft) {
     if (l.fresnel == FR_NOOP) return RGB(1.0f);
+    if (FULL && l.fresnel == FR_DISNEY) return lerp_rgb(l.A, RGB(fr_dielectric(cosi, 1.0f, l.etab)), fr_schlicks(l.ce, cosi));   // DisneyFresnel (disney.rs:296-303)
     if (l.fresnel == FR_DIELECTRIC) return RGB(fr_dielectric(cosi, fi, ft));
     return fr_conductor(fabsf(cosi), RGB(1.0f), l.ce, l.ck);
 }
@@ -163,10 +181,17 @@ PT_DEV float pow5(float v) { return (v * v) * (v * v) * v; }
 
 // DIFF = the material class holds diffuse lobes only (class 0, matte): the value range of `kind` is narrowed so that the
 // compiler drops every specular / microfacet case from the matte shade kernel (smaller code, fewer registers).
-template <bool DIFF> PT_DEV uint8_t lobe_kind(const Lobe &b) { return DIFF ? (b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R) : b.kind; }
+template <bool FULL = true> PT_DEV float lobe_g(const Lobe &b, V3 wo, V3 wi) { return (FULL && b.sepg) ? tr_g1(b.ax, b.ay, wo) * tr_g1(b.ax, b.ay, wi) : tr_g(b.ax, b.ay, wo, wi); }
 
-template <bool DIFF = false> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
-    switch (lobe_kind<DIFF>(b)) {
+// FULL = the five-lobe class, the only one that can hold the Disney lobes (uber, subsurface, translucent, mix, disney materials): the
+// one- and two-lobe kernels narrow `kind` to the classic lobes so that they carry none of the Disney code.
+template <bool DIFF, bool FULL> PT_DEV uint8_t lobe_kind(const Lobe &b) {
+    if (DIFF) return b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R;
+    return FULL ? b.kind : (b.kind > LB_FRESNEL_BLEND ? (uint8_t)LB_FRESNEL_BLEND : b.kind);
+}
+
+template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
+    switch (lobe_kind<DIFF, FULL>(b)) {
     case LB_LAMBERT_R: return b.r * kInvPi;
     case LB_LAMBERT_T: return b.t * kInvPi;
     case LB_OREN_NAYAR: {  // reflection.rs:926-952
@@ -189,8 +214,8 @@ template <bool DIFF = false> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
         if (cos_i == 0.0f || cos_o == 0.0f) return RGB(0.0f);
         if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
         wh = normalize(wh);
-        RGB F = fresnel_eval(b, dot(wi, wh), b.etaa, b.etab);
-        float d = tr_d(b.ax, b.ay, wh), g = tr_g(b.ax, b.ay, wo, wi);
+        RGB F = fresnel_eval<FULL>(b, dot(wi, wh), b.etaa, b.etab);
+        float d = tr_d(b.ax, b.ay, wh), g = lobe_g<FULL>(b, wo, wi);
         return b.r * d * g * F / (4.0f * cos_i * cos_o);
     }
     case LB_MICRO_T: {  // reflection.rs:1059-1092
@@ -204,9 +229,38 @@ template <bool DIFF = false> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
         RGB f = RGB(fr_dielectric(dot(wo, wh), b.etaa, b.etab));
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1.0f / eta;
-        float s = tr_d(b.ax, b.ay, wh) * tr_g(b.ax, b.ay, wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor /
+        float s = tr_d(b.ax, b.ay, wh) * lobe_g<FULL>(b, wo, wi) * eta * eta * abs_dot(wi, wh) * abs_dot(wo, wh) * factor * factor /
                   (cos_i * cos_o * sqrt_denom * sqrt_denom);
         return (RGB(1.0f) - f) * b.t * fabsf(s);
+    }
+    case LB_DISNEY_DIFFUSE: {  // disney.rs:66-74
+        const float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        return b.r * kInvPi * (1.0f - fo / 2.0f) * (1.0f - fi / 2.0f);
+    }
+    case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: {  // disney.rs:104-124, :158-172, :202-210
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        const float cos_d = dot(wi, wh);
+        if (b.kind == LB_DISNEY_SHEEN) return b.r * schlick_weight(cos_d);
+        const float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        if (b.kind == LB_DISNEY_RETRO) {
+            const float rr = 2.0f * b.A * cos_d * cos_d;
+            return b.r * kInvPi * rr * (fo + fi + fo * fi * (rr - 1.0f));
+        }
+        const float fss90 = cos_d * cos_d * b.A;
+        const float fss = lerp_t(fo, 1.0f, fss90) * lerp_t(fi, 1.0f, fss90);
+        const float ss = 1.25f * (fss * (1.0f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - 0.5f) + 0.5f);
+        return b.r / kInvPi * ss;   // divides by INV_PI, as the reference does (disney.rs:123)
+    }
+    case LB_DISNEY_CLEARCOAT: {  // disney.rs:238-255
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return RGB(0.0f);
+        wh = normalize(wh);
+        const float dr = gtr1(abs_cos_theta(wh), b.A);
+        const float fr = fr_schlick(0.04f, dot(wo, wh));
+        const float gr = smithg_ggx(abs_cos_theta(wo), 0.25f) * smithg_ggx(abs_cos_theta(wi), 0.25f);
+        return RGB(fr * b.B * gr * dr / 4.0f);
     }
     default: {  // LB_FRESNEL_BLEND, reflection.rs:1165-1182 (r = Rd, t = Rs)
         RGB diffuse = b.r * (RGB(1.0f) - b.t) * (28.0f / (23.0f * kPi)) * (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wi))) *
@@ -221,10 +275,19 @@ template <bool DIFF = false> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
     }
 }
 
-template <bool DIFF = false> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
-    switch (lobe_kind<DIFF>(b)) {
+template <bool DIFF = false, bool FULL = true> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
+    switch (lobe_kind<DIFF, FULL>(b)) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_FRESNEL_SPEC:  // reflection.rs:439-445, :788-794
+    case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN:   // BxDF::pdf default
         return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f;
+    case LB_DISNEY_CLEARCOAT: {  // disney.rs:276-292: the half vector is built from `wi + wi`, as written there
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = wi + wi;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+        wh = normalize(wh);
+        const float dr = gtr1(abs_cos_theta(wh), b.A);
+        return dr * abs_cos_theta(wh) / (4.0f * dot(wo, wh));
+    }
     case LB_LAMBERT_T: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) : 0.0f;  // :886-892
     case LB_SPEC_R: case LB_SPEC_T: return 0.0f;
     case LB_MICRO_R: {
@@ -250,24 +313,38 @@ template <bool DIFF = false> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) 
     }
 }
 
-template <bool DIFF = false> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
-    switch (lobe_kind<DIFF>(b)) {
-    case LB_LAMBERT_R: case LB_OREN_NAYAR: {
+template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
+    switch (lobe_kind<DIFF, FULL>(b)) {
+    case LB_DISNEY_CLEARCOAT: {  // disney.rs:257-274
+        if (wo.z == 0.0f) return RGB(0.0f);
+        const float a2 = b.A * b.A;
+        const float ct = sqrtf(maxf((1.0f - dm_powf(a2, 1.0f - u.x)) / (1.0f - a2), 0.0f));
+        const float st = sqrtf(maxf(1.0f - ct * ct, 0.0f));
+        const float phi = 2.0f * kPi * u.y;
+        float sp, cp; dm_sincosf(phi, sp, cp);
+        V3 wh(st * cp, st * sp, ct);
+        if (!same_hemisphere(wo, wh)) wh = -wh;
+        wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, wh)) return RGB(0.0f);
+        pdf = lobe_pdf<DIFF, FULL>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
+    }
+    case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: {   // BxDF::sample_f default
         wi = cosine_sample_hemisphere(u);
         if (wo.z < 0.0f) wi.z *= -1.0f;
-        pdf = lobe_pdf<DIFF>(b, wo, wi);
-        return lobe_f<DIFF>(b, wo, wi);
+        pdf = lobe_pdf<DIFF, FULL>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
     }
     case LB_LAMBERT_T: {
         wi = cosine_sample_hemisphere(u);
         if (wo.z > 0.0f) wi.z *= -1.0f;
-        pdf = lobe_pdf<DIFF>(b, wo, wi);
-        return lobe_f<DIFF>(b, wo, wi);
+        pdf = lobe_pdf<DIFF, FULL>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
     }
     case LB_SPEC_R: {
         wi = V3(-wo.x, -wo.y, wo.z);
         pdf = 1.0f;
-        return fresnel_eval(b, cos_theta(wi), b.etaa, b.etab) * b.r / abs_cos_theta(wi);
+        return fresnel_eval<FULL>(b, cos_theta(wi), b.etaa, b.etab) * b.r / abs_cos_theta(wi);
     }
     case LB_SPEC_T: {
         float etai, etat;
@@ -302,7 +379,7 @@ template <bool DIFF = false> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &
         wi = reflect(wo, wh);
         if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         pdf = tr_pdf(b.ax, b.ay, wo, wh) / (4.0f * dot(wo, wh));
-        return lobe_f<DIFF>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
     }
     case LB_MICRO_T: {
         if (wo.z == 0.0f) return RGB(0.0f);
@@ -310,8 +387,8 @@ template <bool DIFF = false> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &
         if (dot(wo, wh) < 0.0f) return RGB(0.0f);
         float eta = (cos_theta(wo) > 0.0f) ? b.etaa / b.etab : b.etab / b.etaa;
         if (!refract(wo, wh, eta, wi)) return RGB(0.0f);
-        pdf = lobe_pdf<DIFF>(b, wo, wi);
-        return lobe_f<DIFF>(b, wo, wi);
+        pdf = lobe_pdf<DIFF, FULL>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
     }
     default: {  // LB_FRESNEL_BLEND
         P2 uu = u;
@@ -325,8 +402,8 @@ template <bool DIFF = false> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &
             wi = reflect(wo, wh);
             if (!same_hemisphere(wo, wi)) return RGB(0.0f);
         }
-        pdf = lobe_pdf<DIFF>(b, wo, wi);
-        return lobe_f<DIFF>(b, wo, wi);
+        pdf = lobe_pdf<DIFF, FULL>(b, wo, wi);
+        return lobe_f<DIFF, FULL>(b, wo, wi);
     }
     }
 }
@@ -339,7 +416,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
     Lobe l[MAXL];
     // MixMaterial (mix.rs:25-50): lobes [0, n1) are ScaledBxDFs with scale s1, lobes [n1, n) with scale s2 (reflection.rs:466-517);
     // only the five-lobe class carries this. `frozen`: the second material's init() must not reset the frame / eta / lobes.
-    static constexpr bool MIX = MAXL == 5;
+    static constexpr bool MIX = MAXL == 5, FULL = MAXL == 5;
     int n1; RGB s1, s2; bool frozen;
 
     PT_DEV void init(const SurfaceInteraction &si, float eta_) {
@@ -360,7 +437,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         RGB res(0.0f);
         for (int i = 0; i < MAXL; ++i)
             if (i < n && l[i].matches(flags) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                res = res + scaled(i, lobe_f<DIFF>(l[i], wo, wi));
+                res = res + scaled(i, lobe_f<DIFF, FULL>(l[i], wo, wi));
         return res;
     }
     PT_DEV float pdf(V3 wow, V3 wiw, int flags) const {
@@ -368,7 +445,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         V3 wo = to_local(wow), wi = to_local(wiw);
         if (wo.z == 0.0f) return 0.0f;
         float p = 0.0f; int matching = 0;
-        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf<DIFF>(l[i], wo, wi); }
+        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf<DIFF, FULL>(l[i], wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
     // `pdf` must hold the caller's previous value on entry (it is left untouched on the wo.z == 0 exit,
@@ -391,25 +468,25 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         RGB fv(0.0f);
         int btype = 0;
         // select the lobe without dynamic register-array indexing
-        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = scaled(i, lobe_sample_f<DIFF>(l[i], wo, wi, ur, pdf, sampled)); }
+        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = scaled(i, lobe_sample_f<DIFF, FULL>(l[i], wo, wi, ur, pdf, sampled)); }
         if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
         wiw = to_world(wi);
         if (!(btype & BSDF_SPECULAR) && matching > 1)
-            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf<DIFF>(l[i], wo, wi);
+            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf<DIFF, FULL>(l[i], wo, wi);
         if (matching > 1) pdf /= (float)matching;
         if (!(btype & BSDF_SPECULAR)) {
             bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
             fv = RGB(0.0f);
             for (int i = 0; i < MAXL; ++i)
                 if (i < n && l[i].matches(ty) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                    fv = fv + scaled(i, lobe_f<DIFF>(l[i], wo, wi));
+                    fv = fv + scaled(i, lobe_f<DIFF, FULL>(l[i], wo, wi));
         }
         return fv;
     }
 };
 
 PT_DEV RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
-PT_DEV Lobe mk_lobe(uint8_t kind, uint8_t type) { Lobe b; b.kind = kind; b.type = type; b.fresnel = FR_NOOP; b.ax = b.ay = 0.001f; b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; return b; }
+PT_DEV Lobe mk_lobe(uint8_t kind, uint8_t type) { Lobe b; b.kind = kind; b.type = type; b.fresnel = FR_NOOP; b.sepg = 0; b.ax = b.ay = 0.001f; b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; return b; }
 PT_DEV void set_dist(Lobe &b, float ax, float ay) { b.ax = maxf(ax, 0.001f); b.ay = maxf(ay, 0.001f); }  // microfacet.rs:325-331
 
 // Texture::evaluate of a material parameter when no texture can be bound (scenes without textures): the constant field.
@@ -543,6 +620,49 @@ template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf_leaf(const PtMat
                 b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = eta; bsdf.add(b);
             }
         }
+        return true;
+    }
+    case PT_MAT_DISNEY: {  // disney.rs:719-840 (scatterdistance == 0: the BSSRDF branch is refused at scene creation)
+        bsdf.init(si, 1.0f);
+        const RGB c = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);   // "color"
+        const float metallic = m.disney[PT_DS_METALLIC], e = E.flt(m, PT_MP_ETA, m.eta), strans = m.disney[PT_DS_SPECTRANS];
+        const float dweight = (1.0f - metallic) * (1.0f - strans);
+        const float dt = m.disney[PT_DS_DIFFTRANS] / 2.0f;
+        const float rough = E.flt(m, PT_MP_ROUGHNESS, m.roughness);
+        const float lum = 0.212671f * c.r + 0.715160f * c.g + 0.072169f * c.b;   // Spectrum::y (spectrum.rs:123-127)
+        const RGB ctint = lum > 0.0f ? c / lum : RGB(1.0f);
+        const float sheen_weight = m.disney[PT_DS_SHEEN];
+        RGB csheen(0.0f);
+        if (sheen_weight > 0.0f) csheen = lerp_rgb(m.disney[PT_DS_SHEENTINT], RGB(1.0f), ctint);
+        const bool thin = m.disney_thin != 0;
+        if (dweight > 0.0f) {
+            if (thin) {
+                const float flat = m.disney[PT_DS_FLATNESS];
+                { Lobe b = mk_lobe(LB_DISNEY_DIFFUSE, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight * flat * (1.0f - dt); bsdf.add(b); }   // `flat`, not 1 - flat (disney.rs:759)
+                { Lobe b = mk_lobe(LB_DISNEY_FAKESS, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * (1.0f - dt) * flat * dweight; b.A = rough; bsdf.add(b); }
+            } else { Lobe b = mk_lobe(LB_DISNEY_DIFFUSE, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight; bsdf.add(b); }
+            { Lobe b = mk_lobe(LB_DISNEY_RETRO, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight; b.A = rough; bsdf.add(b); }
+            if (sheen_weight > 0.0f) { Lobe b = mk_lobe(LB_DISNEY_SHEEN, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = csheen * sheen_weight * dweight; bsdf.add(b); }
+        }
+        const float aspect = sqrtf(1.0f - m.disney[PT_DS_ANISOTROPIC] * 0.9f);
+        const float ax = maxf(rough * rough / aspect, 0.001f), ay = maxf(rough * rough * aspect, 0.001f);
+        const RGB cspec0 = lerp_rgb(metallic, lerp_rgb(m.disney[PT_DS_SPECULARTINT], RGB(1.0f) * (((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f))), ctint), c);
+        {
+            Lobe b = mk_lobe(LB_MICRO_R, BSDF_REFLECTION | BSDF_GLOSSY); b.r = RGB(1.0f); b.ax = ax; b.ay = ay; b.sepg = 1;
+            b.fresnel = FR_DISNEY; b.ce = cspec0; b.A = metallic; b.etaa = 1.0f; b.etab = e; bsdf.add(b);
+        }
+        const float cc = m.disney[PT_DS_CLEARCOAT];
+        if (cc > 0.0f) { Lobe b = mk_lobe(LB_DISNEY_CLEARCOAT, BSDF_REFLECTION | BSDF_GLOSSY); b.B = cc; b.A = lerp_t(m.disney[PT_DS_CLEARCOATGLOSS], 0.1f, 0.001f); bsdf.add(b); }
+        if (strans > 0.0f) {
+            const RGB T = sqrt_rgb(c) * strans;
+            Lobe b = mk_lobe(LB_MICRO_T, BSDF_TRANSMISSION | BSDF_GLOSSY); b.t = T; b.fresnel = FR_DIELECTRIC; b.etaa = 1.0f; b.etab = e;
+            if (thin) {   // a Trowbridge-Reitz distribution with the roughness scaled by the index (disney.rs:812-821)
+                const float rscaled = (0.65f * e - 0.35f) * rough;
+                b.ax = maxf(rscaled * rscaled / aspect, 0.001f); b.ay = maxf(rscaled * rscaled * aspect, 0.001f);
+            } else { b.ax = ax; b.ay = ay; b.sepg = 1; }
+            bsdf.add(b);
+        }
+        if (thin) { Lobe b = mk_lobe(LB_LAMBERT_T, BSDF_TRANSMISSION | BSDF_DIFFUSE); b.t = c * dt; bsdf.add(b); }
         return true;
     }
     default: {  // PT_MAT_SUBSTRATE, substrate.rs:34-60

@@ -175,11 +175,8 @@ PT_HD float dm_acosf(float xf) {
     double s = __builtin_sqrt((1.0 - x) * (1.0 + x));
     return (float)dm_atan2d(s, x);
 }
-PT_HD float dm_logf(float xf) {
-    if (xf != xf || xf < 0.0f) return __builtin_nanf("");
-    if (xf == 0.0f) return -PT_INF;
-    if (__builtin_isinf(xf)) return xf;
-    double x = xf;
+// ln of a positive finite double (the core of dm_logf, also used by dm_powf)
+PT_HD double dm_logd_pos(double x) {
     uint64_t bits = __builtin_bit_cast(uint64_t, x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
@@ -198,8 +195,44 @@ PT_HD float dm_logf(float xf) {
     p = p * s2 + 2.0 / 5.0;
     p = p * s2 + 2.0 / 3.0;
     p = p * s2 + 2.0;
-    return (float)((double)e * kDmLn2 + s * p);
+    return (double)e * kDmLn2 + s * p;
 }
+PT_HD float dm_logf(float xf) {
+    if (xf != xf || xf < 0.0f) return __builtin_nanf("");
+    if (xf == 0.0f) return -PT_INF;
+    if (__builtin_isinf(xf)) return xf;
+    return (float)dm_logd_pos((double)xf);
+}
+// e^y for |y| <= 700 in f64: y = k ln2 + r, Taylor series of e^r (|r| <= 0.35, degree 14), scaled by 2^k. Shared with the
+// oracle (ref_math.h) so that f32::powf / f32::exp call sites (materials/disney.rs) are bit-identical on both sides.
+PT_HD double dm_expd(double y) {
+    if (y > 700.0) y = 700.0;
+    if (y < -700.0) y = -700.0;
+    const double kf = __builtin_floor(y * (1.0 / kDmLn2) + 0.5);
+    const double r = y - kf * kDmLn2;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const uint64_t bits = (uint64_t)((int64_t)kf + 1023) << 52;
+    return p * __builtin_bit_cast(double, bits);
+}
+PT_HD float dm_powf(float a, float b) {   // a > 0 (f32::powf call sites on the path have a positive base)
+    if (!(a > 0.0f)) return (a == 0.0f) ? (b == 0.0f ? 1.0f : 0.0f) : __builtin_nanf("");
+    return (float)dm_expd((double)b * dm_logd_pos((double)a));
+}
+
 
 // ---- vectors ---------------------------------------------------------------------------------
 struct V3 {

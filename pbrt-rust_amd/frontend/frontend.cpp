@@ -295,6 +295,18 @@ private:
             }
             copy3(m.sigma_a, siga); copy3(m.sigma_s, sigs);
         }
+        else if (kind == "disney") {   // disney.rs:842-887
+            m.type = PT_MAT_DISNEY; spec("color", PT_MP_KD, m.kd, 0.5f); m.eta = flt("eta", PT_MP_ETA, 1.5f); m.roughness = flt("roughness", PT_MP_ROUGHNESS, 0.5f);
+            static const struct { const char *name; float dflt; } ds[10] = {{"metallic", 0.0f}, {"speculartint", 0.0f}, {"anisotropic", 0.0f}, {"sheen", 0.0f}, {"sheentint", 0.5f},
+                {"clearcoat", 0.0f}, {"clearcoatgloss", 1.0f}, {"spectrans", 0.0f}, {"flatness", 0.0f}, {"difftrans", 0.0f}};
+            for (int k = 0; k < 10; ++k) {
+                if (!p.texture(ds[k].name).empty()) throw std::runtime_error(std::string("disney: a textured \"") + ds[k].name + "\" is not supported (color, eta and roughness may be textured)");
+                m.disney[k] = p.one_float(ds[k].name, ds[k].dflt);
+            }
+            float sd[3] = {0.0f, 0.0f, 0.0f}; p.rgb("scatterdistance", sd);
+            if (!p.texture("scatterdistance").empty() || sd[0] != 0.0f || sd[1] != 0.0f || sd[2] != 0.0f) throw std::runtime_error("disney: scatterdistance (DisneyBSSRDF) is not supported");
+            m.disney_thin = p.one_bool("thin", false) ? 1u : 0u;
+        }
         else if (kind == "mix") {   // api.rs:615-640 + mix.rs:52-56: an undefined named material falls back to a matte made from these parameters
             m.type = PT_MAT_MIX; spec("amount", PT_MP_KD, m.kd, 0.5f);
             for (int k = 0; k < 2; ++k) {

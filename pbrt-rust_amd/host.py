@@ -186,7 +186,7 @@ class SceneBuilder:
         m = A.PtMaterial()
         kinds = dict(matte=A.PT_MAT_MATTE, mirror=A.PT_MAT_MIRROR, glass=A.PT_MAT_GLASS, plastic=A.PT_MAT_PLASTIC,
                      metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE,
-                     subsurface=A.PT_MAT_SUBSURFACE, kdsubsurface=A.PT_MAT_SUBSURFACE, translucent=A.PT_MAT_TRANSLUCENT, mix=A.PT_MAT_MIX)
+                     subsurface=A.PT_MAT_SUBSURFACE, kdsubsurface=A.PT_MAT_SUBSURFACE, translucent=A.PT_MAT_TRANSLUCENT, mix=A.PT_MAT_MIX, disney=A.PT_MAT_DISNEY)
         m.type = kinds[kind]
         d = dict(  # create_*_material defaults
             matte=dict(Kd=0.5, sigma=0.0), mirror=dict(Kr=0.9), glass=dict(Kr=1.0, Kt=1.0, eta=1.5, uroughness=0.0, vroughness=0.0),
@@ -194,7 +194,10 @@ class SceneBuilder:
             uber=dict(Kd=0.25, Ks=0.25, Kr=0.0, Kt=0.0, roughness=0.1, uroughness=-1.0, vroughness=-1.0, opacity=1.0, eta=1.5),
             substrate=dict(Kd=0.5, Ks=0.5, uroughness=0.1, vroughness=0.1),
             translucent=dict(Kd=0.25, Ks=0.25, reflect=0.5, transmit=0.5, roughness=0.1),
-            mix=dict(amount=0.5, namedmaterial1=None, namedmaterial2=None),   # mix.rs:52-56; the two materials are given as material ids
+            mix=dict(amount=0.5, namedmaterial1=None, namedmaterial2=None),
+            # disney.rs:842-887
+            disney=dict(color=0.5, metallic=0.0, eta=1.5, roughness=0.5, speculartint=0.0, anisotropic=0.0, sheen=0.0, sheentint=0.5, clearcoat=0.0,
+                        clearcoatgloss=1.0, spectrans=0.0, scatterdistance=0.0, thin=False, flatness=0.0, difftrans=0.0),   # mix.rs:52-56; the two materials are given as material ids
    # translucent.rs:82-92 (reflect -> kr, transmit -> kt)
             # subsurface.rs:108-139 / kdsubsurface.rs:106-126
             subsurface=dict(Kr=1.0, Kt=1.0, eta=1.33, uroughness=0.0, vroughness=0.0, scale=1.0, g=0.0, name="",
@@ -203,7 +206,7 @@ class SceneBuilder:
         d.update(kw)
         # a parameter given as a string names a texture ("texture Kd" "name"); the constant field then keeps the default
         m.tex = (C.c_int32 * 16)(*([-1] * 16))
-        slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), reflect=(A.PT_MP_KR, 0), transmit=(A.PT_MP_KT, 0), amount=(A.PT_MP_KD, 0), opacity=(A.PT_MP_OPACITY, 0),
+        slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), reflect=(A.PT_MP_KR, 0), transmit=(A.PT_MP_KT, 0), amount=(A.PT_MP_KD, 0), color=(A.PT_MP_KD, 0), opacity=(A.PT_MP_OPACITY, 0),
                      eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0),
                      sigma=(A.PT_MP_SIGMA, 1), roughness=(A.PT_MP_ROUGHNESS, 1), uroughness=(A.PT_MP_U_ROUGHNESS, 1),
                      vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1), bumpmap=(A.PT_MP_BUMP, 1))
@@ -219,7 +222,7 @@ class SceneBuilder:
             for sl in (A.PT_MP_U_ROUGHNESS, A.PT_MP_V_ROUGHNESS):
                 if m.tex[sl] < 0 and "uroughness" not in kw and "vroughness" not in kw: pass
         three = lambda v: (C.c_float * 3)(*([float(v)] * 3 if np.isscalar(v) else [float(x) for x in v]))
-        m.kd = three(d.get("Kd", d.get("amount", 0))); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", d.get("reflect", 0))); m.kt = three(d.get("Kt", d.get("transmit", 0)))
+        m.kd = three(d.get("Kd", d.get("amount", d.get("color", 0)))); m.ks = three(d.get("Ks", 0)); m.kr = three(d.get("Kr", d.get("reflect", 0))); m.kt = three(d.get("Kt", d.get("transmit", 0)))
         m.opacity = three(d.get("opacity", 1)); m.eta_rgb = three(d.get("eta_rgb", (0.2, 0.92, 1.1))); m.k_rgb = three(d.get("k", (3.9, 2.45, 2.14)))
         m.sigma = d.get("sigma", 0.0); m.eta = d.get("eta", 1.5); m.roughness = d.get("roughness", 0.1)
         m.u_roughness = d.get("uroughness", -1.0); m.v_roughness = d.get("vroughness", -1.0)
@@ -248,6 +251,11 @@ class SceneBuilder:
                 if t is table: m.bssrdf_table = i; break
             else:
                 self.bssrdf_tables.append(table); m.bssrdf_table = len(self.bssrdf_tables) - 1
+        if kind == "disney":
+            if np.any(np.asarray(d["scatterdistance"], dtype=F) != 0): raise NotImplementedError("disney scatterdistance (DisneyBSSRDF)")
+            names = ("metallic", "speculartint", "anisotropic", "sheen", "sheentint", "clearcoat", "clearcoatgloss", "spectrans", "flatness", "difftrans")
+            if any(isinstance(d[n], str) for n in names): raise NotImplementedError("textured disney parameters other than color / eta / roughness")
+            m.disney = (C.c_float * 10)(*[float(d[n]) for n in names]); m.disney_thin = 1 if d["thin"] else 0
         if kind == "mix":
             ids = (d["namedmaterial1"], d["namedmaterial2"])
             for i in ids:

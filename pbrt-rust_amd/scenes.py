@@ -426,3 +426,37 @@ def mix_materials(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
     b.material("mix", amount=amount, namedmaterial1=m_trans, namedmaterial2=m_matte)   # textured second material: no differentials
     P, I = quad((-2.6, -0.5, -2.0), (2.6, -0.5, -2.0), (2.6, 1.6, -2.0), (-2.6, 1.6, -2.0)); b.trianglemesh(P, I, UV=uv * 2)
     return b
+
+
+def disney_spheres(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
+    """materials/disney.rs without the BSSRDF branch: plastic-like (diffuse + retro + sheen + specular + clearcoat), anisotropic
+    metal, specular transmission ("glass"), a thin sheet (diffuse + fake subsurface + retro + specular + diffuse transmission),
+    and a tinted dielectric; the textured variant drives color and roughness."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.2, 6.5), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=36.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.35, 0.4, 0.5))
+    b.attribute_begin(); b.area_light_source(L=(20.0, 18.0, 16.0))
+    P, I = quad((-1.2, 4.5, -1.0), (1.2, 4.5, -1.0), (1.2, 4.5, 1.0), (-1.2, 4.5, 1.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("distant", from_=(3.0, 4.0, 5.0), to=(0.0, 0.0, 0.0), L=(1.5, 1.5, 1.5))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=F)
+    color, rough = (0.8, 0.25, 0.15), 0.4
+    if textured:
+        b.texture("col", "spectrum", "checkerboard", uscale=6.0, vscale=6.0, tex1=(0.8, 0.25, 0.15), tex2=(0.15, 0.3, 0.8))
+        b.texture("rgh", "float", "checkerboard", uscale=3.0, vscale=3.0, tex1=0.15, tex2=0.6)
+        color, rough = "col", "rgh"
+    b.material("disney", color=(0.4, 0.4, 0.4), roughness=0.7, sheen=0.3)
+    P, I = quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I, UV=uv * 4)
+    b.material("disney", color=color, roughness=rough, sheen=0.8, sheentint=0.3, clearcoat=0.7, clearcoatgloss=0.6, speculartint=0.4)
+    b.attribute_begin(); b.translate(-2.4, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("disney", color=(0.9, 0.7, 0.3), metallic=1.0, roughness=0.3, anisotropic=0.8)
+    b.attribute_begin(); b.translate(-0.8, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("disney", color=(0.7, 0.9, 0.8), spectrans=1.0, roughness=0.15, eta=1.45, clearcoat=0.2)
+    b.attribute_begin(); b.translate(0.8, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("disney", color=color, metallic=0.3, spectrans=0.4, roughness=rough, eta=1.3)
+    b.attribute_begin(); b.translate(2.4, 0.2, 0.0); b.sphere(radius=0.7); b.attribute_end()
+    b.material("disney", color=(0.3, 0.7, 0.3), thin=True, flatness=0.6, difftrans=1.2, roughness=0.5)
+    P, I = quad((-1.5, -0.5, -2.0), (1.5, -0.5, -2.0), (1.5, 1.8, -2.0), (-1.5, 1.8, -2.0)); b.trianglemesh(P, I, UV=uv)
+    return b

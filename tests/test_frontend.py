@@ -463,3 +463,21 @@ WorldEnd
     assert list(t.kr) == pytest.approx([.2, .2, .2]) and list(t.kt) == pytest.approx([.7, .6, .5]) and t.roughness == pytest.approx(.3) and list(t.kd) == pytest.approx([.25] * 3)
     fb = mats[mixes[1].mix[0]]
     assert fb.type == A.PT_MAT_MATTE and list(fb.kd) == pytest.approx([.9, .8, .7]) and list(mixes[1].kd) == pytest.approx([.5] * 3)
+
+
+def test_disney_material_from_a_scene_file(pkg):
+    """disney.rs:842-887 parameter names and defaults; the BSSRDF branch (scatterdistance) and textured scalar parameters other
+    than eta / roughness are refused by name."""
+    A = pkg._abi
+    head = 'WorldBegin\nTexture "c" "color" "checkerboard"\n'
+    fs = pkg.frontend.FrontScene(text=head + 'Material "disney" "texture color" "c" "float metallic" .25 "float sheen" .5 "bool thin" "true" "float difftrans" .8\nShape "sphere"\nWorldEnd\n')
+    d = fs.desc()
+    m = [d.materials[i] for i in range(d.n_materials) if d.materials[i].type == A.PT_MAT_DISNEY][0]
+    assert m.tex[A.PT_MP_KD] >= 0 and m.disney_thin == 1 and m.eta == pytest.approx(1.5) and m.roughness == pytest.approx(0.5)
+    want = {A.PT_DS_METALLIC: .25, A.PT_DS_SPECULARTINT: 0, A.PT_DS_ANISOTROPIC: 0, A.PT_DS_SHEEN: .5, A.PT_DS_SHEENTINT: .5, A.PT_DS_CLEARCOAT: 0,
+            A.PT_DS_CLEARCOATGLOSS: 1, A.PT_DS_SPECTRANS: 0, A.PT_DS_FLATNESS: 0, A.PT_DS_DIFFTRANS: .8}
+    for k, v in want.items(): assert m.disney[k] == pytest.approx(v), k
+    with pytest.raises(Exception, match="scatterdistance"):
+        pkg.frontend.FrontScene(text=head + 'Material "disney" "rgb scatterdistance" [.1 .1 .1]\nShape "sphere"\nWorldEnd\n')
+    with pytest.raises(Exception, match="textured \"sheen\""):
+        pkg.frontend.FrontScene(text=head + 'Texture "f" "float" "checkerboard"\nMaterial "disney" "texture sheen" "f"\nShape "sphere"\nWorldEnd\n')

@@ -349,3 +349,21 @@ def test_mix_material_limits_are_reported(pkg, gpu):
     P, I = pkg.scenes.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)); b.trianglemesh(P, I)
     sd, rp = b.world_end()
     with pytest.raises(Exception, match="more than 5 BxDFs"): pkg.Scene(gpu, sd)
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_disney_material_matches_oracle(pkg, gpu, oracle, textured):
+    """materials/disney.rs (no BSSRDF): DisneyDiffuse / FakeSS / Retro / Sheen / Clearcoat (GTR1, its own sampling and the
+    `wi + wi` pdf), the separable-G microfacet distribution with DisneyFresnel, specular transmission, the thin-surface set."""
+    sd, rp = pkg.scenes.disney_spheres(textured=textured).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5 if textured else 2e-6, atol=1e-6 if textured else 1e-7)
+    assert film[..., :3].sum() > 0
+
+
+def test_disney_limits_are_reported(pkg, gpu):
+    b = pkg.scenes.disney_spheres()
+    b.material("disney", sheen=0.5, clearcoat=0.5, spectrans=0.5, thin=True)   # 8 BxDFs
+    P, I = pkg.scenes.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)); b.trianglemesh(P, I)
+    sd, rp = b.world_end()
+    with pytest.raises(Exception, match="more than 5 BxDFs"): pkg.Scene(gpu, sd)
+    with pytest.raises(NotImplementedError): b.material("disney", scatterdistance=(0.1, 0.1, 0.1))
