@@ -210,6 +210,9 @@ typedef struct PtLight {
 
 /* accelerators/bvh.rs:89-95 LinearBVHNode: left child at index+1, right child at `offset`
  * for interior nodes (n_prims == 0); leaves index `ordered_prims[offset .. offset+n_prims]`. */
+/* HomogeneousMedium (media/homogeneous.rs:13-29): sigma_a, sigma_s after "scale" (api.rs:706-722), Henyey-Greenstein g. */
+typedef struct PtMedium { float sigma_a[3]; float sigma_s[3]; float g; } PtMedium;
+
 typedef enum PtSplitMethod { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1 } PtSplitMethod;
 typedef struct PtBVHNode {
     float bmin[3];
@@ -300,6 +303,13 @@ typedef struct PtSceneDesc {
     const int32_t *tri_alpha; const int32_t *tri_shadow_alpha;
     uint32_t n_images; const PtImage *images;
     const float *ewa_weight_lut;   /* [128] = exp(-2 r2) - exp(-2), r2 = i/127 (mipmap.rs:40-50); required with EWA image maps */
+    /* Participating media for the volumetric path integrator (media/homogeneous.rs, core/medium.rs). Ignored by
+     * PT_INTEGRATOR_PATH exactly as the reference's PathIntegrator ignores Ray::medium. prim_medium_inside / _outside are the
+     * GeometricPrimitive's MediumInterface per primitive (PT_NONE = no medium; api.rs:1540-1560); NULL = no interfaces. Every
+     * primitive needs a material: the reference's own volpath mishandles material-less interface shapes (bounces underflow,
+     * volpath.rs:127-131), they are refused with PT_ERR_UNSUPPORTED. */
+    uint32_t n_media; const PtMedium *media;
+    const uint32_t *prim_medium_inside; const uint32_t *prim_medium_outside;
     /* bvh "splitmethod" (api.rs make_accelerator -> bvh.rs:918-940) for every accelerator the library builds (ignored for
      * an adopted one). PT_SPLIT_SAH: host SAH builder = the reference's tree. PT_SPLIT_HLBVH: built on the GPU
      * (Morton sort + LBVH treelets + SAH upper levels, bvh.rs:377-660; see csrc/gpu_bvh.hip for the exact tree). */
@@ -308,6 +318,7 @@ typedef struct PtSceneDesc {
 
 /* ---- render parameters ---------------------------------------------------------------- */
 
+typedef enum PtIntegratorType { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_VOLPATH = 1 } PtIntegratorType;
 typedef enum PtSamplerType { PT_SAMPLER_SOBOL = 0, PT_SAMPLER_HALTON = 1 } PtSamplerType;
 typedef enum PtLightStrategy { PT_LS_UNIFORM = 0, PT_LS_POWER = 1, PT_LS_SPATIAL = 2 } PtLightStrategy;
 
@@ -345,6 +356,11 @@ typedef struct PtRenderParams {
      * reference's default when a scene names no sampler, api.rs:215-241); "samplepixelcenter" (halton.rs:226). */
     uint32_t sampler_type;
     uint32_t sample_at_pixel_center;
+    /* Integrator "path" (integrators/path.rs) or "volpath" (integrators/volpath.rs: medium sampling per segment, transmittance
+     * on shadow / MIS rays, Henyey-Greenstein scattering). camera_medium: index into PtSceneDesc.media of the medium the camera
+     * sits in (CameraSample rays start in it, perspective.rs:114), PT_NONE for none; read only by PT_INTEGRATOR_VOLPATH. */
+    uint32_t integrator;
+    uint32_t camera_medium;
 } PtRenderParams;
 
 /* Device-side work counters: mirrors of the reference's stat counters

@@ -386,6 +386,7 @@ struct Ray {
     V3 o, d;
     Float t_max;
     Float time;
+    uint32_t medium = 0xFFFFFFFFu;   // Ray::medium (index into Scene::media, PT_NONE = vacuum); read by volpath only
     Ray() : t_max(INF), time(0) {}
     Ray(V3 o_, V3 d_, Float t = INF, Float tm = 0.0f) : o(o_), d(d_), t_max(t), time(tm) {}
 };

@@ -481,6 +481,205 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
     return L;
 }
 
+
+// ---- VolPathIntegrator (integrators/volpath.rs:76-186) with HomogeneousMedium (media/homogeneous.rs) and the Henyey-Greenstein
+//      phase function (core/medium.rs:149-194). Every primitive has a material (scene creation refuses the others), so the
+//      transmittance loops of VisibilityTester::tr (light.rs:125-150) and Scene::intersect_tr (scene.rs:68-87) end at their
+//      first hit.
+static inline Float dm_expf_(Float x) { return (Float)dm_expd((double)x); }   // f32::exp through the shared f64 exp
+static RGB medium_tr(const PtMedium &m, Float t_max, V3 d) {   // homogeneous.rs:32-35
+    Float l = fmin_(t_max * length(d), std::numeric_limits<Float>::max());
+    RGB r;
+    for (int i = 0; i < 3; ++i) r.c[i] = dm_expf_(-(m.sigma_a[i] + m.sigma_s[i]) * l);
+    return r;
+}
+struct MediumVertex { bool valid = false; V3 p, wo; uint32_t medium = PT_NONE; Float g = 0; };
+static RGB medium_sample(const PtMedium &m, uint32_t mid, const Ray &ray, SobolSampler &sampler, MediumVertex &mi) {   // homogeneous.rs:37-68
+    Float sigma_t[3] = {m.sigma_a[0] + m.sigma_s[0], m.sigma_a[1] + m.sigma_s[1], m.sigma_a[2] + m.sigma_s[2]};
+    Float uc = sampler.get_1d() * 3.0f;
+    size_t channel = std::min<size_t>(uc > 0.0f ? (size_t)uc : 0, 2);
+    Float dist = -dm_logf(1.0f - sampler.get_1d()) / sigma_t[channel];
+    Float dl = length(ray.d);
+    Float t = fmin_(dist / dl, ray.t_max);
+    bool sampled = t < ray.t_max;
+    if (sampled) { mi.valid = true; mi.p = ray.o + ray.d * t; mi.wo = -ray.d; mi.medium = mid; mi.g = m.g; }
+    RGB Tr, density;
+    Float pdf = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        Tr.c[i] = dm_expf_(-sigma_t[i] * fmin_(t, std::numeric_limits<Float>::max()) * dl);
+        density.c[i] = sampled ? sigma_t[i] * Tr.c[i] : Tr.c[i];
+        pdf += density.c[i];
+    }
+    pdf *= 1.0f / 3.0f;
+    if (pdf == 0.0f) pdf = 1.0f;
+    RGB ss(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]);
+    return sampled ? Tr * ss / pdf : Tr / pdf;
+}
+static inline Float phase_hg(Float cos_theta, Float g) {   // medium.rs:149-154
+    Float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return INV4_PI * (1.0f - g * g) / (denom * std::sqrt(denom));
+}
+static Float hg_sample_p(Float g, V3 wo, V3 &wi, P2 u) {   // medium.rs:173-193
+    Float cos_theta;
+    if (std::fabs(g) < 1.0e-3f) cos_theta = 1.0f - 2.0f * u.x;
+    else {
+        Float sqr_term = (1.0f - g * g) / (1.0f + g - 2.0f * g * u.x);
+        cos_theta = -(1.0f + g * g - sqr_term * sqr_term) / (2.0f * g);
+    }
+    Float sin_theta = std::sqrt(fmax_(1.0f - cos_theta * cos_theta, 0.0f));
+    Float phi = 2.0f * PI * u.y;
+    V3 v1, v2; coordinate_system(wo, v1, v2);
+    wi = v1 * sin_theta * dm_cosf(phi) + v2 * sin_theta * dm_sinf(phi) + wo * cos_theta;   // spherical_direction_basis (geometry.rs:36-38)
+    return phase_hg(cos_theta, g);
+}
+// the interaction's MediumInterface: the primitive's own when it is a transition, else the ray's medium on both sides
+// (primitive.rs:139-145); get_medium_vec (interaction.rs:54-66)
+struct MedIface { uint32_t inside = PT_NONE, outside = PT_NONE; };
+static MedIface surface_iface(const Scene &s, uint32_t prim, uint32_t ray_medium) {
+    MedIface m; m.inside = m.outside = ray_medium;
+    if (!s.prim_med_in.empty() && s.prim_med_in[prim] != s.prim_med_out[prim]) { m.inside = s.prim_med_in[prim]; m.outside = s.prim_med_out[prim]; }
+    return m;
+}
+static inline uint32_t medium_toward(const MedIface &m, V3 n, V3 w) { return dot(w, n) > 0.0f ? m.outside : m.inside; }
+
+// estimate_direct with handle_media = true (integrator.rs:109-237) for a surface (bsdf != nullptr) or a medium vertex
+static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedIface &mif, const SurfaceInteraction *si, const BSDF *bsdf, Float g,
+                               P2 uscatt, uint32_t li, P2 ulight) {
+    const Scene &S = *ctx.scene;
+    const int flags = BSDF_ALL & ~BSDF_SPECULAR;
+    RGB Ld(0.0f);
+    V3 wi; Float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+    RGB Li = ctx.lights->sample_li(li, it, ulight, wi, lightpdf, p1);
+    bool delta = ctx.lights->is_delta(li);
+    if (lightpdf > 0.0f && !Li.is_black()) {
+        RGB f;
+        if (bsdf) { f = bsdf->f(si->wo, wi, flags) * abs_dot(wi, si->sh_n); scattpdf = bsdf->pdf(si->wo, wi, flags); }
+        else { Float p = phase_hg(dot(it.wo, wi), g); f = RGB(p); scattpdf = p; }
+        if (!f.is_black()) {
+            // VisibilityTester::tr (light.rs:125-150): the first hit is opaque, else the segment's transmittance
+            Ray sr = spawn_ray_to(it, p1);
+            sr.medium = medium_toward(mif, it.n, sr.d);
+            SurfaceInteraction tmp;
+            RGB Tr(1.0f);
+            if (S.intersect(sr, tmp, *ctx.c)) Tr = RGB(0.0f);
+            else if (sr.medium != PT_NONE) Tr = Tr * medium_tr(S.media[sr.medium], sr.t_max, sr.d);
+            Li = Li * Tr;
+            if (!Li.is_black()) {
+                if (delta) Ld += f * Li / lightpdf;
+                else { Float weight = power_heuristic(1, lightpdf, 1, scattpdf); Ld += f * Li * weight / lightpdf; }
+            }
+        }
+    }
+    if (!delta) {
+        RGB f; bool sampled_specular = false;
+        if (bsdf) {
+            int sampled_type = 0;
+            f = bsdf->sample_f(si->wo, wi, uscatt, scattpdf, flags, sampled_type);
+            f = f * abs_dot(wi, si->sh_n);
+            sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
+        } else { Float p = hg_sample_p(g, it.wo, wi, uscatt); f = RGB(p); scattpdf = p; }
+        if (!f.is_black() && scattpdf > 0.0f) {
+            Float weight = 1.0f;
+            if (!sampled_specular) {
+                lightpdf = ctx.lights->pdf_li(li, it, wi);
+                if (lightpdf == 0.0f) return Ld;
+                weight = power_heuristic(1, scattpdf, 1, lightpdf);
+            }
+            SurfaceInteraction lisect;
+            Ray ray = spawn_ray(it, wi);
+            ray.medium = medium_toward(mif, it.n, wi);
+            // Scene::intersect_tr (scene.rs:68-87)
+            bool found = S.intersect(ray, lisect, *ctx.c);
+            RGB Tr(1.0f);
+            if (ray.medium != PT_NONE) Tr = Tr * medium_tr(S.media[ray.medium], ray.t_max, ray.d);
+            RGB li_(0.0f);
+            if (found) { if (S.prim_light[lisect.prim] == li) li_ = isect_le(ctx, lisect, -wi); }
+            else li_ = ctx.lights->light_le(li, ray);
+            if (!li_.is_black()) Ld += f * li_ * Tr * weight / scattpdf;
+        }
+    }
+    return Ld;
+}
+static RGB vol_uniform_sample_onelight(const RenderCtx &ctx, const IData &it, const MedIface &mif, const SurfaceInteraction *si, const BSDF *bsdf, Float g,
+                                       SobolSampler &sampler, const Distribution1D *distrib) {
+    if (ctx.scene->lights.empty()) return RGB(0.0f);
+    Float lightpdf = 0.0f;
+    size_t lightnum = distrib->sample_discrete(sampler.get_1d(), &lightpdf);
+    if (lightpdf == 0.0f) return RGB(0.0f);
+    P2 ulight = sampler.get_2d();
+    P2 uscatt = sampler.get_2d();
+    return vol_estimate_direct(ctx, it, mif, si, bsdf, g, uscatt, (uint32_t)lightnum, ulight) / lightpdf;
+}
+static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSampler &sampler, RayDiff rdiff = RayDiff()) {
+    const Scene &S = *ctx.scene;
+    RGB L(0.0f), beta(1.0f);
+    bool specular_bounce = false;
+    uint32_t bounces = 0;
+    Float etascale = 1.0f;
+    for (;;) {
+        SurfaceInteraction isect;
+        bool found = S.intersect(ray, isect, *ctx.c);
+        MediumVertex mi;
+        if (ray.medium != PT_NONE) beta *= medium_sample(S.media[ray.medium], ray.medium, ray, sampler, mi);
+        if (beta.is_black()) break;
+        if (mi.valid) {
+            if (bounces >= pp.max_depth) break;
+            const Distribution1D *distrib = ctx.lights->lookup(mi.p);
+            IData it; it.p = mi.p; it.p_error = V3(0, 0, 0); it.n = V3(0, 0, 0); it.wo = mi.wo;
+            MedIface mif; mif.inside = mif.outside = mi.medium;
+            L += beta * vol_uniform_sample_onelight(ctx, it, mif, nullptr, nullptr, mi.g, sampler, distrib);
+            V3 wi;
+            hg_sample_p(mi.g, mi.wo, wi, sampler.get_2d());
+            ray = spawn_ray(it, wi); ray.medium = mi.medium;
+            specular_bounce = false;
+        } else {
+            if (bounces == 0 || specular_bounce) {
+                if (found) L += isect_le(ctx, isect, -ray.d) * beta;
+                else for (uint32_t li : S.infinite_lights) L += ctx.lights->light_le(li, ray) * beta;
+            }
+            if (!found || bounces >= pp.max_depth) break;
+            const MedIface mif = surface_iface(S, isect.prim, ray.medium);
+            BSDF bsdf;
+            TexCtx tctx;
+            const bool textured = (bool)S.textures;
+            if (textured) tctx = compute_differentials(isect, rdiff);
+            rdiff.has = false;
+            if (!compute_scattering_functions(S, isect, bsdf, nullptr, nullptr, textured ? &tctx : nullptr)) {
+                // a material that leaves no BSDF (App. A #14): volpath.rs:127-131 then does `bounces -= 1; continue`, which skips the
+                // increment at the end of the loop -- the count drops by one (and wraps below zero, ending the path at its next vertex)
+                IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
+                uint32_t med = medium_toward(mif, isect.n, ray.d);
+                ray = spawn_ray(it, ray.d); ray.medium = med;
+                bounces -= 1;
+                continue;
+            }
+            const Distribution1D *distrib = ctx.lights->lookup(isect.p);
+            IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n; it.wo = isect.wo;
+            L += beta * vol_uniform_sample_onelight(ctx, it, mif, &isect, &bsdf, 0.0f, sampler, distrib);
+            V3 wo = -ray.d, wi;
+            Float pdf = 0.0f; int flags = 0;
+            RGB f = bsdf.sample_f(wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
+            if (f.is_black() || pdf == 0.0f) break;
+            beta *= f * abs_dot(wi, isect.sh_n) / pdf;
+            specular_bounce = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                Float eta = bsdf.eta;
+                etascale *= (dot(wo, isect.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
+            }
+            ray = spawn_ray(it, wi); ray.medium = medium_toward(mif, isect.n, wi);
+        }
+        RGB rrbeta = beta * etascale;
+        if (rrbeta.max_component_value() < pp.rr_threshold && bounces > 3) {
+            Float q = fmax_(1.0f - rrbeta.max_component_value(), 0.05f);
+            if (sampler.get_1d() < q) break;
+            beta = beta / (1.0f - q);
+        }
+        bounces += 1;
+    }
+    ctx.c->path_len[std::min<uint32_t>(bounces, 15)]++;
+    return L;
+}
+
 // ---- camera (cameras/perspective.rs:120-179, main ray only) ----------------------------------------
 struct Camera { M4 raster_to_camera, camera_to_world; Float lens_radius, focal_distance, shutter_open, shutter_close; };
 static Ray generate_ray(const Camera &cam, const CameraSample &cs) {
@@ -605,7 +804,8 @@ static void render_tiles(const RenderJob &job, float *film_xyzw, int nthreads, C
                         c.camera_rays++;
                         RayDiff rdiff;
                         if (job.scene->textures) rdiff = generate_ray_differentials(job.cam, cs, ray, rp.spp);
-                        RGB L = path_li(ctx, pp, ray, sampler, rdiff);
+                        if (rp.integrator == PT_INTEGRATOR_VOLPATH) ray.medium = rp.camera_medium;   // perspective.rs:114
+                        RGB L = rp.integrator == PT_INTEGRATOR_VOLPATH ? volpath_li(ctx, pp, ray, sampler, rdiff) : path_li(ctx, pp, ray, sampler, rdiff);
                         if (L.has_nans()) { L = RGB(0.0f); c.san_nan++; }
                         else if (L.y() < -1.0e-5f) { L = RGB(0.0f); c.san_neg++; }
                         else if (std::isinf(L.y())) { L = RGB(0.0f); c.san_inf++; }
@@ -708,6 +908,8 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
     }
     s.max_node_prims = d->max_node_prims ? d->max_node_prims : 4;
     s.split_method = d->split_method;
+    if (d->n_media && d->media) s.media.assign(d->media, d->media + d->n_media);
+    if (d->prim_medium_inside && d->prim_medium_outside) { s.prim_med_in.assign(d->prim_medium_inside, d->prim_medium_inside + d->n_prims); s.prim_med_out.assign(d->prim_medium_outside, d->prim_medium_outside + d->n_prims); }
     if (d->n_instances && d->top_refs) {
         s.objects.assign(d->objects, d->objects + d->n_objects);
         s.instances.assign(d->instances, d->instances + d->n_instances);

@@ -103,6 +103,8 @@ struct Scene {
     std::vector<Float> env_importance;
     RGB env_power_lookup;
     uint32_t max_node_prims = 4, split_method = PT_SPLIT_SAH;
+    // participating media (volpath only): HomogeneousMedium table + per-primitive MediumInterface (PT_NONE = none)
+    std::vector<PtMedium> media; std::vector<uint32_t> prim_med_in, prim_med_out;
     std::vector<PtBVHNode> nodes;       // top-level accelerator
     std::vector<uint32_t> ordered;      // positions in the top-level list (see top_ref)
     struct Accel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };

@@ -25,6 +25,7 @@ PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_L
 PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
 PT_SAMPLER_SOBOL, PT_SAMPLER_HALTON = range(2)
+PT_INTEGRATOR_PATH, PT_INTEGRATOR_VOLPATH = range(2)
 
 
 def shape_ref(kind, index):
@@ -46,6 +47,10 @@ class PtMaterial(C.Structure):
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
                 ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
                 ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32)]
+
+
+class PtMedium(C.Structure):
+    _fields_ = [("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("g", f32)]
 
 
 class PtLight(C.Structure):
@@ -104,7 +109,7 @@ class PtSceneDesc(C.Structure):
                 ("max_node_prims", u32), ("n_nodes", u32), ("nodes", C.POINTER(PtBVHNode)), ("ordered_prims", u32p),
                 ("n_objects", u32), ("objects", C.POINTER(PtObject)), ("n_instances", u32), ("instances", C.POINTER(PtInstance)),
                 ("n_top", u32), ("top_refs", u32p), ("n_bssrdf_tables", u32), ("bssrdf_tables", C.POINTER(PtBSSRDFTable)),
-                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("tri_alpha", i32p), ("tri_shadow_alpha", i32p), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp), ("split_method", u32)]
+                ("n_textures", u32), ("textures", C.POINTER(PtTexture)), ("tri_alpha", i32p), ("tri_shadow_alpha", i32p), ("n_images", u32), ("images", C.POINTER(PtImage)), ("ewa_weight_lut", fp), ("n_media", u32), ("media", C.POINTER(PtMedium)), ("prim_medium_inside", u32p), ("prim_medium_outside", u32p), ("split_method", u32)]
 
 
 class PtRenderParams(C.Structure):
@@ -114,7 +119,7 @@ class PtRenderParams(C.Structure):
                 ("raster_to_camera", f32 * 16), ("camera_to_world", f32 * 16), ("lens_radius", f32),
                 ("focal_distance", f32), ("shutter_open", f32), ("shutter_close", f32),
                 ("max_depth", u32), ("rr_threshold", f32), ("pixel_bounds", i32 * 4), ("light_strategy", u32),
-                ("tile_rank", u32), ("tile_world", u32), ("spp_per_pass", u32), ("profile", u32), ("sampler_type", u32), ("sample_at_pixel_center", u32)]
+                ("tile_rank", u32), ("tile_world", u32), ("spp_per_pass", u32), ("profile", u32), ("sampler_type", u32), ("sample_at_pixel_center", u32), ("integrator", u32), ("camera_medium", u32)]
 
 
 class PtCounters(C.Structure):

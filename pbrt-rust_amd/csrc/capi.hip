@@ -93,7 +93,8 @@ struct pt_scene {
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
-    bool class_used[kNumClasses] = {true, false, false, false, true};   // matte (default material) and the miss class always exist
+    bool class_used[kNumClasses] = {true, false, false, false, true, false};
+    bool has_null_material = false;   // a primitive without a material (refused by the volumetric integrator)   // matte (default material) and the miss class always exist
     bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
     void *bss_slab = nullptr; BssSoA bs{};
     uint32_t n_lights = 0;
@@ -211,9 +212,9 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
                         &ps.beta_r, &ps.beta_g, &ps.beta_b, &ps.L_r, &ps.L_g, &ps.L_b, &ps.etascale,
                         &ps.sh_ox, &ps.sh_oy, &ps.sh_oz, &ps.sh_dx, &ps.sh_dy, &ps.sh_dz, &ps.A_r, &ps.A_g, &ps.A_b,
                         &ps.mis_ox, &ps.mis_oy, &ps.mis_oz, &ps.mis_dx, &ps.mis_dy, &ps.mis_dz, &ps.mis_f_r, &ps.mis_f_g, &ps.mis_f_b,
-                        &ps.mis_w, &ps.mis_spdf, &ps.nee_choice_pdf, &ps.nb_r, &ps.nb_g, &ps.nb_b, &ps.mis_b0, &ps.mis_b1, &ps.mis_b2};
+                        &ps.mis_w, &ps.mis_spdf, &ps.nee_choice_pdf, &ps.nb_r, &ps.nb_g, &ps.nb_b, &ps.mis_b0, &ps.mis_b1, &ps.mis_b2, &ps.hit_t, &ps.mis_t};
         for (float **f : fa) { *f = (float *)p; p += capacity * 4; }
-        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim, &ps.hit_inst};
+        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim, &ps.hit_inst, &ps.medium, &ps.mis_medium, &ps.sh_prim};
         for (uint32_t **u : ua) { *u = (uint32_t *)p; p += capacity * 4; }
         ps.occluded = (uint8_t *)p;
         static_assert(sizeof(fa) / sizeof(fa[0]) + sizeof(ua) / sizeof(ua[0]) <= kPathSoAFloatArrays, "slab too small");
@@ -352,6 +353,7 @@ void fill_render_const(const PtRenderParams *rp, RenderConst &rc) {
     }
     rc.shutter_open = rp->shutter_open; rc.shutter_close = rp->shutter_close;
     rc.max_depth = rp->max_depth; rc.rr_threshold = rp->rr_threshold;
+    rc.volpath = rp->integrator == PT_INTEGRATOR_VOLPATH ? 1u : 0u; rc.camera_medium = rc.volpath ? rp->camera_medium : PT_NONE;
     rc.filter_radius[0] = rp->filter_radius[0]; rc.filter_radius[1] = rp->filter_radius[1];
     rc.max_sample_luminance = rp->max_sample_luminance;
     rc.film_w = (uint32_t)(rp->cropped_pixel_bounds[2] - rp->cropped_pixel_bounds[0]);
@@ -372,7 +374,8 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL, bool DIFF = false> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
-    if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
@@ -385,7 +388,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * 16u)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
-    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss"};
+    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
     for (int iter = 0; iter < 4096; ++iter) {
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
@@ -400,7 +403,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // continuation rays -> hit record + material-class routing
         tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
         tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
-        tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
+        tj.out_prim = ps.hit_prim; tj.out_t = rc.volpath ? ps.hit_t : nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
         tj.class_count = &qc->shade[cur][0];
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
         tj.kind = (iter == 0) ? 3 : 0;
@@ -409,7 +412,13 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         int st = launch_trace(sc, false, tj, n_ext);
         sc->end();
         if (st) return st;
-        if (n_ext) {  // material-sorted shade queues
+        if (n_ext && rc.volpath) {  // medium sampling (volpath.rs:98-105) + material-sorted shade queues + the medium-vertex queue
+            sc->begin("route", n_ext);
+            hipLaunchKernelGGL(k_medium_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, sc->ps,
+                               (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], &qc->shade[cur][0],
+                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4], sc->q.shade[cur][5], &qc->error);
+            sc->end();
+        } else if (n_ext) {  // material-sorted shade queues
             sc->begin("route", n_ext);
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], (const uint32_t *)ps.hit_prim, &qc->shade[cur][0],
@@ -419,7 +428,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // MIS rays of the previous vertex (closest hit, integrator.rs:215)
         tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
         tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;
-        tj.out_prim = ps.mis_prim; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2; tj.out_inst = nullptr;
+        tj.out_prim = ps.mis_prim; tj.out_t = rc.volpath ? ps.mis_t : nullptr; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2; tj.out_inst = nullptr;
         tj.class_count = nullptr;
         tj.kind = 1;
         sc->begin("extend_mis", n_mis);
@@ -432,6 +441,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         tj.out_occluded = ps.occluded;
         tj.kind = 2;
         sc->begin("shadow", n_shadow);
+        if (rc.volpath) {   // VisibilityTester::tr (light.rs:125-150) calls Scene::intersect: a closest-hit query, counted as one
+            tj.out_prim = ps.sh_prim; tj.out_t = nullptr; tj.out_b0 = tj.out_b1 = tj.out_b2 = nullptr; tj.out_inst = nullptr;
+            st = launch_trace(sc, false, tj, n_shadow);
+        } else
         st = launch_trace(sc, true, tj, n_shadow);
         sc->end();
         if (st) return st;
@@ -476,10 +489,15 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
             if (c == 3 && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
-            if (c == kMissClass) {
+            if (c == kMediumClass) {
+                const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 8u);
+                hipLaunchKernelGGL(k_shade_medium, dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, sj);
+            }
+            else if (c == kMissClass) {
                 const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 16u);
-                if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade_miss<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
-                else hipLaunchKernelGGL((k_shade_miss<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
+                if (rc.volpath) hipLaunchKernelGGL((k_shade_miss<true, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
+                else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade_miss<true, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
+                else hipLaunchKernelGGL((k_shade_miss<false, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
             }
             else if (c == 0) launch_shade<1, true>(sc, rc, grid, sj, class_n[c]);
             else if (c == 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
@@ -509,7 +527,7 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
-    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss"};
+    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
     for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
@@ -775,6 +793,17 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     UP(prim_shape, d->prim_shape, d->n_prims); UP(prim_material, d->prim_material, d->n_prims); UP(prim_light, d->prim_light, d->n_prims);
     ds.n_prims = d->n_prims;
     UP(materials, d->materials, d->n_materials); ds.n_materials = d->n_materials;
+    if (d->n_media && d->media) {   // participating media (volpath only)
+        UP(media, d->media, d->n_media); ds.n_media = d->n_media;
+        if (d->prim_medium_inside && d->prim_medium_outside) {
+            for (uint32_t i = 0; i < d->n_prims; ++i)
+                if ((d->prim_medium_inside[i] != PT_NONE && d->prim_medium_inside[i] >= d->n_media) || (d->prim_medium_outside[i] != PT_NONE && d->prim_medium_outside[i] >= d->n_media))
+                    return bail(fail(PT_ERR_INVALID_ARG, "primitive medium index out of range"));
+            UP(prim_med_in, d->prim_medium_inside, d->n_prims); UP(prim_med_out, d->prim_medium_outside, d->n_prims);
+        }
+        sc->class_used[kMediumClass] = true;
+    }
+    for (uint32_t i = 0; i < d->n_prims; ++i) if (d->prim_material[i] == PT_NONE) sc->has_null_material = true;
     UP(spheres, d->spheres, d->n_spheres); ds.n_spheres = d->n_spheres;
     UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
     if (d->n_lights) sc->host_lights.assign(d->lights, d->lights + d->n_lights);
@@ -919,6 +948,12 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     fill_render_const(rp, rc);
     if (rc.film_w == 0 || rc.film_h == 0 || rc.ntx == 0 || rc.nty == 0) return fail(PT_ERR_INVALID_ARG, "empty film or sample bounds");
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
+    if (rc.volpath) {   // VolPathIntegrator (volpath.rs): what this back end takes
+        if (sc->has_null_material) return fail(PT_ERR_UNSUPPORTED, "volpath: primitives without a material (medium-interface shells) are not supported; the reference's volpath mishandles them too (volpath.rs:127-131)");
+        if (sc->has_bssrdf) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials are not supported by the volumetric integrator here");
+        if (rp->max_depth >= 255) return fail(PT_ERR_INVALID_ARG, "volpath: maxdepth must be below 255");
+        if (rp->camera_medium != PT_NONE && rp->camera_medium >= sc->ds.n_media) return fail(PT_ERR_INVALID_ARG, "camera_medium out of range");
+    }
     const uint32_t ntiles = rc.ntx * rc.nty;
     rc.n_tile_slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world : 0;
     rc.n_pix_slots = rc.n_tile_slots * 256u;
@@ -939,7 +974,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
         // Halton scenes shade with the general kernels, which read the instance of a hit; the triangle-only traversal never writes it
-        if (rc.halton.enabled && sc->ds.n_spheres == 0 && sc->ds.n_instances == 0) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
+        if ((rc.halton.enabled || rc.volpath) && sc->ds.n_spheres == 0 && sc->ds.n_instances == 0) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;

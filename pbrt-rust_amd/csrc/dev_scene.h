@@ -65,6 +65,8 @@ struct DeviceScene {
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class
     const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)
+    const PtMedium *media; uint32_t n_media;                 // homogeneous media + per-primitive MediumInterface (volpath, dev_medium.h)
+    const uint32_t *prim_med_in; const uint32_t *prim_med_out;
     // textures (8f-1): nodes, one postfix program per node (tex_prog[tex_prog_offset[i] .. tex_prog_offset[i+1])), images
     const PtTexture *textures; uint32_t n_textures; const uint32_t *tex_prog_offset; const uint32_t *tex_prog;
     const DevImage *images; const float *ewa_lut;

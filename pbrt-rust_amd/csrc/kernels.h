@@ -7,8 +7,9 @@
 
 namespace ptd {
 
-constexpr int kNumClasses = 5;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
-constexpr int kMissClass = 4;       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
+constexpr int kNumClasses = 6;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
+constexpr int kMissClass = 4, kMediumClass = 5;   // 5 = medium vertices of the volumetric integrator (k_shade_medium)
+//       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
 constexpr int kLdsStack = 12;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
@@ -35,6 +36,11 @@ struct PathSoA {
     float *nb_r, *nb_g, *nb_b;                           // beta at NEE time
     uint32_t *mis_prim; float *mis_b0, *mis_b1, *mis_b2; // closest hit of the MIS ray
     uint8_t *occluded;
+    // volumetric path integrator only (PtRenderParams.integrator == PT_INTEGRATOR_VOLPATH)
+    uint32_t *medium;        // Ray::medium of the continuation ray (PT_NONE = vacuum)
+    float *hit_t;            // its hit parameter (ray.t_max after Scene::intersect); then the medium vertex's parameter
+    uint32_t *mis_medium; float *mis_t;   // the MIS ray's medium and hit parameter (Scene::intersect_tr)
+    uint32_t *sh_prim;       // closest hit of the shadow ray (VisibilityTester::tr intersects, it does not intersect_p)
 };
 // Per-path subsurface probe state (allocated only for scenes with a subsurface material): the sampled probe segment of
 // TabulatedBSSRDF::sample_sp (bssrdf.rs:357-365), the outgoing point's frame, and the chain counters.
@@ -46,7 +52,7 @@ struct BssSoA {
     uint32_t *cnt;   // nfound (bits 0-15) | matches seen on the re-walk (16-30) | phase (31: 0 counting, 1 re-walk to `selected`)
 };
 constexpr int kBssSoAArrays = 18;
-constexpr int kPathSoAFloatArrays = 51;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
+constexpr int kPathSoAFloatArrays = 56;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)
@@ -89,6 +95,7 @@ struct RenderConst {
     float dx_camera[3], dy_camera[3];  // perspective.rs:64-70
     float inv_sqrt_spp;                // Ray::scale_differential factor (integrator.rs:340)
     uint32_t max_depth; float rr_threshold;
+    uint32_t volpath, camera_medium;   // VolPathIntegrator (volpath.rs) instead of PathIntegrator; the camera's medium
     float filter_radius[2]; float max_sample_luminance;
     uint32_t film_w, film_h;
 };

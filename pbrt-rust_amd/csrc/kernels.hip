@@ -12,6 +12,7 @@
 #include "dev_bsdf.h"
 #include "dev_sphere.h"
 #include "dev_texture.h"
+#include "dev_medium.h"
 
 using namespace ptd;
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                 else {
                     job.out_prim[pid] = hit_prim;
                     if (job.out_t) job.out_t[pid] = hit_t;
-                    job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2;
+                    if (job.out_b0) { job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2; }   // NULL: only the hit / miss matters (volpath shadow rays)
                     if (SPH && job.out_inst) job.out_inst[pid] = hit_inst;
                 }
             }
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 }
             }
         }
+        if (alive && rc.volpath) ps.medium[pid] = rc.camera_medium;   // the camera ray starts in the camera's medium (perspective.rs:114)
         lq_push(s_q, pid, alive);
         lq_sync_flush(s_q, q_ext_count, q_ext, 256u, false);
         n_alive += alive ? 1ull : 0ull;
@@ -618,14 +620,15 @@ struct Prof { long long *t; int *r; unsigned long long *acc; };
 
 // Resolve the pending next-event estimation of the previous vertex once its shadow / MIS rays are traced
 // (integrator.rs:150-171,199-233): L += beta_at_nee * Ld / choice_pdf.
-template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
+template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
                                                 unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
     PT_T(1);
     n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
     RGB Ld(0.0f);
     const uint32_t li = ps.nee_light[pid];
-    if ((flags & PF_PEND_SHADOW) && !ps.occluded[pid]) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
+    // volpath: VisibilityTester::tr intersects (closest hit) and every surface is opaque; the segment's transmittance is already in A
+    if ((flags & PF_PEND_SHADOW) && (VOL ? ps.sh_prim[pid] == PT_NONE : !ps.occluded[pid])) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
     if (flags & PF_PEND_MIS) {
         const PtLight &Lt = s.lights[li];
         V3 wi(ps.mis_dx[pid], ps.mis_dy[pid], ps.mis_dz[pid]);
@@ -640,12 +643,17 @@ template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const Path
         } else { PT_T(2); lrad = light_le(s, Lt, wi); PT_T(1); }
         if (!lrad.is_black()) {
             RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
-            Ld = Ld + f * lrad * RGB(1.0f) * ps.mis_w[pid] / ps.mis_spdf[pid];
+            RGB Tr(1.0f);
+            if (VOL) {   // Scene::intersect_tr (scene.rs:68-87): transmittance of the MIS ray's medium up to its hit (or to infinity)
+                const uint32_t mm = ps.mis_medium[pid];
+                if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? ps.mis_t[pid] : PT_INF, wi);
+            }
+            Ld = Ld + f * lrad * Tr * ps.mis_w[pid] / ps.mis_spdf[pid];
         }
     }
     RGB nb(ps.nb_r[pid], ps.nb_g[pid], ps.nb_b[pid]);
     RGB Ldb = nb * (Ld / ps.nee_choice_pdf[pid]);
-    if (Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
+    if (!VOL && Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
     L = L + Ldb;
     flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
 }
@@ -653,9 +661,12 @@ template <bool SPH> PT_DEV void resolve_pending(const DeviceScene &s, const Path
 // uniform_sample_onelight + estimate_direct (integrator.rs:81-237) at one vertex: samples the light and the BSDF,
 // records the shadow / MIS rays and their weights in the path state; the estimate is summed by resolve_pending once
 // both rays are traced. Returns whether anything is pending (false: Ld is black).
-template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
+// VOL: estimate_direct with handle_media (integrator.rs:150-156,207-216) -- `mif` is the vertex's MediumInterface; MEDIUM: the
+// vertex is a MediumInteraction (f = phase value, no cosine; si carries only p and wo).
+template <bool SPH, class B, bool VOL = false, bool MEDIUM = false>
+PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSoA &ps, uint32_t pid, Sampler &smp,
                                           const SurfaceInteraction &si, const IData &it, const B &bsdf, RGB beta, uint32_t &flags,
-                                          bool &push_shadow, bool &push_mis, unsigned long long &n_bytes PT_PROF_ARG) {
+                                          bool &push_shadow, bool &push_mis, unsigned long long &n_bytes PT_PROF_ARG, MedIface mif = MedIface{PT_NONE, PT_NONE}) {
     bool nee_pending = false;
     if (s.n_lights > 0) {
         PT_T(5);
@@ -673,10 +684,14 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
             PT_T(7);
             const bool delta = light_is_delta(s.lights[li]);
             if (lightpdf > 0.0f && !Li.is_black()) {
-                RGB f = bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
+                RGB f = MEDIUM ? bsdf.f(si.wo, wi, bf) : bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
                 scattpdf = bsdf.pdf(si.wo, wi, bf);
                 if (!f.is_black()) {
                     V3 so, sd; spawn_ray_to(it, p1, so, sd);
+                    if (VOL) {   // Li *= visibility.tr(): the unoccluded segment's transmittance (light.rs:125-150)
+                        const uint32_t sm = medium_toward(mif, it.n, sd);
+                        if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
+                    }
                     RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
                     ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
                     ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
@@ -688,7 +703,7 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
                 PT_T(8);
                 int sampled_type = 0;
                 RGB f = bsdf.sample_f(si.wo, wi, uscatt, scattpdf, bf, sampled_type);
-                f = f * abs_dot(wi, si.sh_n);
+                if (!MEDIUM) f = f * abs_dot(wi, si.sh_n);
                 const bool sampled_specular = (sampled_type & BSDF_SPECULAR) != 0;
                 if (!f.is_black() && scattpdf > 0.0f) {
                     float weight = 1.0f;
@@ -706,6 +721,7 @@ template <bool SPH, class B> PT_DEV bool nee_vertex(const DeviceScene &s, const 
                         ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
                         ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
                         ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
+                        if (VOL) ps.mis_medium[pid] = medium_toward(mif, it.n, wi);
                         flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
                     }
                 }
@@ -771,7 +787,7 @@ PT_DEV RayDiff camera_ray_differentials(const RenderConst &rc, float pfx, float 
 // DIFF: the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only)
 template <int MAXL, int MODE, bool DIFF>
 __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
-    constexpr bool SPH = MODE >= 1, TEX = MODE == 2;
+    constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
@@ -809,7 +825,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
-        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
 
         PT_T(3);
         if (flags & PF_DEAD) {
@@ -872,14 +888,21 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
+                MedIface mif{PT_NONE, PT_NONE};
+                if (VOL) mif = surface_iface(s, hp, ps.medium[pid]);   // primitive.rs:139-145
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
                     V3 o; spawn_ray(it, rd, o);
                     ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    if (VOL) {   // volpath.rs:127-131 `bounces -= 1; continue`: the count drops by one and wraps below zero
+                        ps.medium[pid] = medium_toward(mif, si.n, rd);
+                        bounces = (bounces - 1u) & 0xffu;
+                    }
                     push_ext = true;
                 } else {
                     const V3 wo = -rd;  // path.rs:148; estimate_direct uses isect.wo (== -rd for triangles, triangle.rs:296)
                     // uniform_sample_onelight (integrator.rs:81-106)
-                    if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                    if (VOL) nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif);   // volpath.rs:136-138: unconditional
+                    else if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
                         const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
                         if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
@@ -940,6 +963,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                             bounces += 1;
                             ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
                             ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                            if (VOL) ps.medium[pid] = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
                             push_ext = true; n_bytes += 24 + 4 + 4;  // new ray, etascale, ext queue entry
                         }
                     }
@@ -994,12 +1018,157 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
 PT_INST_SHADE(1, 0, true) PT_INST_SHADE(1, 0, false) PT_INST_SHADE(2, 0, false) PT_INST_SHADE(5, 0, false)
 PT_INST_SHADE(1, 1, true) PT_INST_SHADE(1, 1, false) PT_INST_SHADE(2, 1, false) PT_INST_SHADE(5, 1, false)
 PT_INST_SHADE(1, 2, true) PT_INST_SHADE(1, 2, false) PT_INST_SHADE(2, 2, false) PT_INST_SHADE(5, 2, false)
+PT_INST_SHADE(1, 3, true) PT_INST_SHADE(1, 3, false) PT_INST_SHADE(2, 3, false) PT_INST_SHADE(5, 3, false)   // volpath
+
+
+// ---- volumetric path integrator: medium sampling between traversal and shading ---------------------------------------
+// volpath.rs:98-104: after Scene::intersect, a ray that travels in a medium samples it (two sampler dimensions) and scales beta;
+// a sampled medium vertex goes to the medium class, a black beta ends the path, everything else is routed as k_route does.
+__global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
+                                                     uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c5, uint32_t *error) {
+    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4, q5;
+    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q5);
+    __syncthreads();
+    const uint32_t count = *count_ptr;
+    const uint32_t rounded = (count + 255u) & ~255u;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+        const bool valid = qi < count;
+        uint32_t pid = 0, cls = (uint32_t)kMissClass;
+        if (valid) {
+            pid = queue[qi];
+            const uint32_t hp = ps.hit_prim[pid];
+            if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+            const uint32_t med = ps.medium[pid];
+            if (med != PT_NONE) {
+                uint32_t meta = ps.meta[pid];
+                Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = tabs.m32; smp.overflow = false;
+                smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
+                const float u_channel = smp.get_1d(), u_dist = smp.get_1d();
+                const V3 rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+                bool sampled; float t;
+                const RGB w = medium_sample(s.media[med], hp != PT_NONE ? ps.hit_t[pid] : PT_INF, rd, u_channel, u_dist, sampled, t);
+                const RGB beta = RGB(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]) * w;
+                ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+                uint32_t flags = meta >> 24;
+                if (beta.is_black()) { flags |= PF_DEAD; cls = (uint32_t)kMissClass; }          // volpath.rs:105 `break`
+                else if (sampled) { ps.hit_t[pid] = t; cls = (uint32_t)kMediumClass; }
+                if (smp.overflow) atomicMax(error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
+                ps.meta[pid] = (smp.dim & 0xffffu) | (meta & 0x00ff0000u) | (flags << 24);
+            }
+        }
+        lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u); lq_push(q2, pid, valid && cls == 2u);
+        lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u); lq_push(q5, pid, valid && cls == 5u);
+        __syncthreads();
+        lq_flush_nosync(q0, class_count + 0, c0, 256u, false); lq_flush_nosync(q1, class_count + 1, c1, 256u, false);
+        lq_flush_nosync(q2, class_count + 2, c2, 256u, false); lq_flush_nosync(q3, class_count + 3, c3, 256u, false);
+        lq_flush_nosync(q4, class_count + 4, c4, 256u, false); lq_flush_nosync(q5, class_count + 5, c5, 256u, false);
+        __syncthreads();
+    }
+    lq_flush_nosync(q0, class_count + 0, c0, 0u, true); lq_flush_nosync(q1, class_count + 1, c1, 0u, true);
+    lq_flush_nosync(q2, class_count + 2, c2, 0u, true); lq_flush_nosync(q3, class_count + 3, c3, 0u, true);
+    lq_flush_nosync(q4, class_count + 4, c4, 0u, true); lq_flush_nosync(q5, class_count + 5, c5, 0u, true);
+}
+
+// ---- medium vertices (class kMediumClass): volpath.rs:107-123 ---------------------------------------------------------------
+// uniform_sample_onelight with the phase function in the BSDF's place (integrator.rs:142-147,186-190), then a new direction from
+// the phase function; beta is unchanged (phase value / its pdf = 1) and the ray stays in the same medium.
+__global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ uint32_t s_hist[16];
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};
+#endif
+    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint32_t count = *job.count;
+    const uint32_t rounded = (count + 255u) & ~255u;
+    unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+        const bool valid = qi < count;
+        bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
+        int finished_bounces = -1;
+        uint32_t pid = 0;
+        if (valid) {
+            n_valid++;
+            pid = job.queue[qi];
+            const uint32_t meta = ps.meta[pid];
+            uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
+            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+            smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
+            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+            RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+            flags &= ~PF_CAMERA_RAY;
+            bool terminated = bounces >= rc.max_depth;   // volpath.rs:108
+            if (!terminated) {
+                smp.load_window();
+                const V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+                const uint32_t med = ps.medium[pid];
+                SurfaceInteraction si;   // only p and wo are read through the MediumInteraction
+                si.p = ro + rd * ps.hit_t[pid]; si.wo = -rd; si.n = V3(0.0f, 0.0f, 0.0f); si.sh_n = V3(0.0f, 0.0f, 0.0f); si.p_error = V3(0.0f, 0.0f, 0.0f);
+                IData it; it.p = si.p; it.p_error = V3(0.0f, 0.0f, 0.0f); it.n = V3(0.0f, 0.0f, 0.0f);
+                const PhaseBsdf phase{s.media[med].g, si.wo};
+                nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med});
+                V3 wi;
+                hg_sample_p(phase.g, si.wo, wi, smp.get_2d());
+                flags &= ~PF_SPECULAR;   // specular_bounce = false
+                // Russian roulette (volpath.rs:171-176)
+                const RGB rrbeta = beta * ps.etascale[pid];
+                bool rr_kill = false;
+                if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
+                    const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
+                    if (smp.get_1d() < q) rr_kill = true;
+                    else beta = beta / (1.0f - q);
+                }
+                if (rr_kill) terminated = true;
+                else {
+                    bounces += 1;
+                    ps.ox[pid] = si.p.x; ps.oy[pid] = si.p.y; ps.oz[pid] = si.p.z;   // mi.spawn_ray(wi): no offset (n = 0, p_error = 0)
+                    ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                    push_ext = true;
+                }
+            }
+            if (terminated) {
+                if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
+                else finished_bounces = (int)bounces;
+            }
+            if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
+            ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
+            ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+            ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+        }
+        lq_push(s_qext, pid, push_ext); lq_push(s_qres, pid, push_resolve); lq_push(s_qsh, pid, push_shadow); lq_push(s_qmis, pid, push_mis);
+        if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
+        __syncthreads();
+        lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+        lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+        lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
+        lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+        __syncthreads();
+    }
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    __syncthreads();
+    __syncthreads();
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    counter_add(&job.counters->stages, n_valid);
+    counter_add(&job.counters->shade_items[kMediumClass], n_valid);
+    counter_add(&job.counters->shade_bytes[kMediumClass], n_bytes);
+    (void)zero_num;
+}
 
 // ---- escaped rays and dead paths (class kMissClass) -------------------------------------------------------------------
 // More than half of the vertices of an open scene are rays that left it (S2: 54 %). They only need the previous vertex's
 // NEE resolved, the environment's Le where path.rs:106-117 adds it, and the path-length histogram entry -- none of the
 // BSDF / light-sampling code. Keeping them out of k_shade leaves its waves full of real surface hits.
-template <bool SPH>
+template <bool SPH, bool VOL>
 __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_hist[16];
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
@@ -1018,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
         const uint32_t meta = ps.meta[pid];
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
         RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
-        resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
         if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
             n_bytes += 12 + 12;
             const RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
@@ -1037,8 +1206,9 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
     counter_add(&job.counters->shade_bytes[kMissClass], n_bytes);
     (void)rc;
 }
-template __global__ void k_shade_miss<false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
-template __global__ void k_shade_miss<true>(DeviceScene, RenderConst, PathSoA, ShadeJob);
+template __global__ void k_shade_miss<false, false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
+template __global__ void k_shade_miss<true, false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
+template __global__ void k_shade_miss<true, true>(DeviceScene, RenderConst, PathSoA, ShadeJob);
 
 // ---- subsurface scattering: probe chains + exit-point vertex (path.rs:177-204, bssrdf.rs:334-410,559-574) --------------
 // One launch per wavefront iteration while any path walks a probe chain. Each queue entry is a path whose probe ray

@@ -33,6 +33,7 @@ struct GState {
     int material = -1;
     bool has_area = false; float area_L[3] = {1, 1, 1}; bool area_two_sided = false;
     std::map<std::string, int> float_tex, spec_tex, named_materials;
+    int medium_inside = -1, medium_outside = -1;   // MediumInterface (api.rs:1243-1253); -1 = none
 };
 
 struct Scene {
@@ -40,7 +41,8 @@ struct Scene {
     std::vector<float> P, N, S, UV; std::vector<uint8_t> vert_has_n, vert_has_s, vert_has_uv;
     std::vector<uint32_t> indices; std::vector<uint8_t> tri_flags; std::vector<int32_t> tri_alpha, tri_shadow_alpha;
     std::vector<PtSphere> spheres;
-    std::vector<uint32_t> prim_shape, prim_material, prim_light;
+    std::vector<uint32_t> prim_shape, prim_material, prim_light, prim_med_in, prim_med_out;
+    std::vector<PtMedium> media; std::map<std::string, int> named_media; int camera_medium = -1; bool volpath = false;
     std::vector<PtMaterial> materials; std::vector<PtLight> lights;
     std::vector<PtTexture> textures; std::vector<Pyramid> pyramids; std::vector<PtImage> images; std::vector<float> ewa_lut;
     std::vector<std::unique_ptr<BssTable>> bss_tables; std::vector<std::pair<float, float>> bss_keys; std::vector<PtBSSRDFTable> bss_desc;
@@ -110,7 +112,7 @@ private:
         else if (w == "AttributeBegin") { stack.push_back(gs); tstack.push_back(gs.ctm); }
         else if (w == "AttributeEnd") { if (stack.empty()) fail(d, "unmatched AttributeEnd"); gs = stack.back(); stack.pop_back(); if (!tstack.empty()) tstack.pop_back(); }
         else if (w == "ReverseOrientation") gs.reverse = !gs.reverse;
-        else if (w == "Camera") { sc.camera_name = str_arg(lx, d); sc.camera_params = read_params(lx); sc.camera_to_world = gs.ctm.inverse(); named_cs["camera"] = sc.camera_to_world; }
+        else if (w == "Camera") { sc.camera_name = str_arg(lx, d); sc.camera_params = read_params(lx); sc.camera_to_world = gs.ctm.inverse(); named_cs["camera"] = sc.camera_to_world; sc.camera_medium = gs.medium_outside; }
         else if (w == "Film") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); film(d, n, p); }
         else if (w == "Sampler") { sc.sampler = str_arg(lx, d); ParamSet p = read_params(lx); sc.spp = p.one_int("pixelsamples", 16); sc.sample_at_center = p.one_bool("samplepixelcenter", false); }
         else if (w == "PixelFilter") { sc.filter = str_arg(lx, d); sc.filter_params = read_params(lx); }
@@ -119,7 +121,25 @@ private:
                                        { const std::string sm = p.one_string("splitmethod", "sah"); if (sm == "hlbvh") sc.split_method = PT_SPLIT_HLBVH; else if (sm != "sah") fail(d, "splitmethod \"" + sm + "\" is not supported (sah, hlbvh)"); } sc.max_node_prims = (uint32_t)p.one_int("maxnodeprims", 4); }
         else if (w == "WorldBegin") { in_world = true; gs.ctm = Transform(); named_cs["world"] = gs.ctm; }
         else if (w == "WorldEnd") in_world = false;
-        else if (w == "Material") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.material = new_material(n, p); }
+        else if (w == "MakeNamedMedium") {   // api.rs:706-722,1219-1241
+            std::string n = str_arg(lx, d); ParamSet p = read_params(lx);
+            const std::string ty = p.one_string("type", "");
+            if (ty != "homogeneous") fail(d, "medium type \"" + ty + "\": only \"homogeneous\" media are supported");
+            float siga[3] = {0.0011f, 0.0024f, 0.014f}, sigs[3] = {2.55f, 3.21f, 3.77f};
+            const std::string preset = p.one_string("preset", "");
+            if (!preset.empty()) { auto it = named_media().find(preset); if (it != named_media().end()) { copy3(siga, it->second.sigma_a); copy3(sigs, it->second.sigma_prime_s); } }
+            const float scale = p.one_float("scale", 1.0f);
+            p.rgb("sigma_a", siga); p.rgb("sigma_s", sigs);
+            PtMedium m{}; for (int k = 0; k < 3; ++k) { m.sigma_a[k] = siga[k] * scale; m.sigma_s[k] = sigs[k] * scale; } m.g = p.one_float("g", 0.0f);
+            sc.media.push_back(m); sc.named_media[n] = (int)sc.media.size() - 1;
+        }
+        else if (w == "MediumInterface") {
+            const std::string in = str_arg(lx, d); std::string out = in;
+            { Token t = lx.peek(); if (t.kind == Token::Str) out = str_arg(lx, d); }   // one name = both sides (pbrtparser)
+            auto find = [&](const std::string &nm) { if (nm.empty()) return -1; auto it = sc.named_media.find(nm); if (it == sc.named_media.end()) fail(d, "named medium \"" + nm + "\" not defined"); return it->second; };
+            gs.medium_inside = find(in); gs.medium_outside = find(out);
+        }
+        else if (w == "Material") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.material = (n.empty() || n == "none") ? -1 : new_material(n, p); }
         else if (w == "MakeNamedMaterial") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.named_materials[n] = new_material(p.one_string("type", "matte"), p); }
         else if (w == "NamedMaterial") { std::string n = str_arg(lx, d); auto it = gs.named_materials.find(n); if (it == gs.named_materials.end()) fail(d, "named material \"" + n + "\" not defined"); gs.material = it->second; }
         else if (w == "Texture") { std::string name = str_arg(lx, d), ty = str_arg(lx, d), cls = str_arg(lx, d); ParamSet p = read_params(lx); texture(d, name, ty, cls, p); }
@@ -160,8 +180,9 @@ private:
         sc.film_scale = p.one_float("scale", 1.0f); sc.max_lum = p.one_float("maxsampleluminance", INFINITY);
         sc.filename = p.one_string("filename", "pbrt.exr");
     }
-    void integrator(const Token &d, const std::string &name, const ParamSet &p) {   // path.rs:225-253
-        if (name != "path") fail(d, "integrator \"" + name + "\": only \"path\" runs on this back end");
+    void integrator(const Token &d, const std::string &name, const ParamSet &p) {   // path.rs:225-253, volpath.rs:188-227 (same parameters)
+        if (name != "path" && name != "volpath") fail(d, "integrator \"" + name + "\": only \"path\" and \"volpath\" run on this back end");
+        sc.volpath = name == "volpath";
         sc.maxdepth = p.one_int("maxdepth", 5); sc.rr_threshold = p.one_float("rrthreshold", 1.0f);
         sc.strategy = p.one_string("lightsamplestrategy", "spatial");
         if (const std::vector<float> *pb = p.floats("int", "pixelbounds")) if (pb->size() == 4) { sc.has_pixel_bounds = true; for (int i = 0; i < 4; ++i) sc.pixel_bounds[i] = (int)(*pb)[i]; }
@@ -399,6 +420,7 @@ private:
     void add_prim(uint32_t shape_ref) {
         const uint32_t prim = (uint32_t)sc.prim_shape.size();
         sc.prim_shape.push_back(shape_ref); sc.prim_material.push_back(gs.material < 0 ? PT_NONE : (uint32_t)gs.material);
+        sc.prim_med_in.push_back(gs.medium_inside < 0 ? PT_NONE : (uint32_t)gs.medium_inside); sc.prim_med_out.push_back(gs.medium_outside < 0 ? PT_NONE : (uint32_t)gs.medium_outside);
         sc.prim_light.push_back((gs.has_area && !sc.in_object) ? new_area_light(prim) : PT_NONE);   // api.rs:1605-1608: area lights inside instances are dropped
         if (sc.in_object) sc.object_ranges[sc.current_object].second += 1; else sc.top_refs.push_back(prim);
     }
@@ -499,6 +521,7 @@ static void finish(Scene &sc, const Api &api) {
     d.n_lights = (uint32_t)sc.lights.size(); d.lights = sc.lights.data();
     if (sc.env_w) { d.env_width = sc.env_w; d.env_height = sc.env_h; d.env_texels = sc.env_texels.data(); d.env_importance = sc.env_importance.data(); for (int k = 0; k < 3; ++k) d.env_power_lookup[k] = sc.env_power_lookup[k]; }
     d.max_node_prims = sc.max_node_prims; d.split_method = sc.split_method;
+    if (!sc.media.empty()) { d.n_media = (uint32_t)sc.media.size(); d.media = sc.media.data(); d.prim_medium_inside = sc.prim_med_in.data(); d.prim_medium_outside = sc.prim_med_out.data(); }
     if (!sc.instances.empty()) { d.n_objects = (uint32_t)sc.objects.size(); d.objects = sc.objects.data(); d.n_instances = (uint32_t)sc.instances.size(); d.instances = sc.instances.data(); d.n_top = (uint32_t)sc.top_refs.size(); d.top_refs = sc.top_refs.data(); }
     for (auto &t : sc.bss_tables) { PtBSSRDFTable e{}; e.n_rho = (uint32_t)t->n_rho; e.n_radius = (uint32_t)t->n_radius; e.rho_samples = t->rho_samples.data(); e.radius_samples = t->radius_samples.data(); e.profile = t->profile.data(); e.rhoeff = t->rhoeff.data(); e.profile_cdf = t->profile_cdf.data(); sc.bss_desc.push_back(e); }
     d.n_bssrdf_tables = (uint32_t)sc.bss_desc.size(); d.bssrdf_tables = sc.bss_desc.data();
@@ -534,6 +557,7 @@ static void finish(Scene &sc, const Api &api) {
     r2c.flat(rp.raster_to_camera); sc.camera_to_world.flat(rp.camera_to_world);
     rp.lens_radius = cp.one_float("lensradius", 0.0f); rp.focal_distance = cp.one_float("focaldistance", 1.0e30f); rp.shutter_open = so; rp.shutter_close = scl;
     rp.max_depth = (uint32_t)sc.maxdepth; rp.rr_threshold = sc.rr_threshold;
+    rp.integrator = sc.volpath ? PT_INTEGRATOR_VOLPATH : PT_INTEGRATOR_PATH; rp.camera_medium = sc.camera_medium < 0 ? PT_NONE : (uint32_t)sc.camera_medium;
     if (!sc.has_pixel_bounds) for (int i = 0; i < 4; ++i) rp.pixel_bounds[i] = sb[i];
     else { const int *pb = sc.pixel_bounds; rp.pixel_bounds[0] = std::max(pb[0], sb[0]); rp.pixel_bounds[1] = std::max(pb[2], sb[1]); rp.pixel_bounds[2] = std::min(pb[1], sb[2]); rp.pixel_bounds[3] = std::min(pb[3], sb[3]); }   // path.rs:233-246
     rp.light_strategy = sc.strategy == "uniform" ? PT_LS_UNIFORM : sc.strategy == "power" ? PT_LS_POWER : PT_LS_SPATIAL;

@@ -161,7 +161,10 @@ class SceneBuilder:
         self.spp = 16
         self.sampler = "sobol"          # "sobol" | "halton" (Sampler directive; the reference's default is halton, api.rs:215-241)
         self.sample_at_pixel_center = False
-        self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None)
+        self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None, kind="path")   # kind: "path" | "volpath"
+        # participating media (api.rs:706-722,1219-1253): named homogeneous media, the current MediumInterface, the camera's medium
+        self.media = []; self.named_media = {}; self.medium_inside = None; self.medium_outside = None; self.camera_medium = None
+        self.prim_med_in = []; self.prim_med_out = []
         self.max_node_prims = 4
         self.split_method = "sah"   # accelerator "bvh" "string splitmethod": "sah" | "hlbvh" (bvh.rs:918-940)
         self.material("matte")  # api.rs:345-361 default material matte Kd .5
@@ -172,12 +175,32 @@ class SceneBuilder:
     def scale(self, x, y, z): self.ctm = self.ctm * Transform.scale(x, y, z)
     def rotate(self, deg, x, y, z): self.ctm = self.ctm * Transform.rotate(deg, (x, y, z))
     def look_at(self, e, l, u): self.ctm = self.ctm * Transform.look_at(e, l, u)
-    def attribute_begin(self): self._stack.append((self.ctm, self.reverse_orientation, self.material_id, self.area_light))
-    def attribute_end(self): self.ctm, self.reverse_orientation, self.material_id, self.area_light = self._stack.pop()
+    def attribute_begin(self): self._stack.append((self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside))
+    def attribute_end(self): self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside = self._stack.pop()
+
+    def make_named_medium(self, name, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0, preset=""):
+        """MakeNamedMedium "name" "string type" "homogeneous" (api.rs:706-722): preset from the subsurface table, then * scale."""
+        if preset:
+            from . import bssrdf as B
+            if preset in B.NAMED_MEDIA and sigma_a == (0.0011, 0.0024, 0.014) and sigma_s == (2.55, 3.21, 3.77): sigma_s, sigma_a = B.NAMED_MEDIA[preset]
+        m = A.PtMedium()
+        m.sigma_a = (C.c_float * 3)(*[float(F(x) * F(scale)) for x in sigma_a]); m.sigma_s = (C.c_float * 3)(*[float(F(x) * F(scale)) for x in sigma_s]); m.g = float(g)
+        self.media.append(m); self.named_media[name] = len(self.media) - 1
+
+    def medium_interface(self, inside="", outside=""):
+        """MediumInterface "inside" "outside" (api.rs:1243-1253); "" = no medium."""
+        self.medium_inside = self.named_media[inside] if inside else None
+        self.medium_outside = self.named_media[outside] if outside else None
+
+    def _prim_media(self, n):
+        none = A.PT_NONE
+        self.prim_med_in.append(np.full(n, none if self.medium_inside is None else self.medium_inside, dtype=np.uint32))
+        self.prim_med_out.append(np.full(n, none if self.medium_outside is None else self.medium_outside, dtype=np.uint32))
 
     # -- options
     def camera(self, fov=90.0, lensradius=0.0, focaldistance=1e6):
         self.cam.update(fov=fov, lensradius=lensradius, focaldistance=focaldistance, c2w=self.ctm.inverse())  # api.rs:1208
+        self.camera_medium = self.medium_outside   # the camera sits in the current outside medium (api.rs camera())
 
     def world_begin(self): self.ctm = Transform()
 
@@ -416,6 +439,7 @@ class SceneBuilder:
         self.prim_shape.append((np.uint32(A.PT_SHAPE_TRIANGLE << 30) | (np.arange(nt, dtype=np.uint32) + np.uint32(self.ntris))).astype(np.uint32))
         mid = A.PT_NONE if self.material_id is None else self.material_id
         self.prim_material.append(np.full(nt, mid, dtype=np.uint32))
+        self._prim_media(nt)
         if self.area_light is None or self.current_object is not None:  # api.rs:1605-1608: area lights inside instances are dropped
             self.prim_light.append(np.full(nt, A.PT_NONE, dtype=np.uint32))
         else:
@@ -442,6 +466,7 @@ class SceneBuilder:
         first_prim = self.nprims
         self.prim_shape.append(np.array([(A.PT_SHAPE_SPHERE << 30) | (len(self.spheres) - 1)], dtype=np.uint32))
         self.prim_material.append(np.array([A.PT_NONE if self.material_id is None else self.material_id], dtype=np.uint32))
+        self._prim_media(1)
         self.prim_light.append(np.array([A.PT_NONE if (self.area_light is None or self.current_object is not None) else self._new_area_light(first_prim)], dtype=np.uint32))
         if self.current_object is None: self.top_refs.append(np.array([first_prim], dtype=np.uint32))
         else: self.objects[self.current_object][1] += 1
@@ -505,6 +530,8 @@ class SceneBuilder:
         rp.lens_radius = self.cam["lensradius"]; rp.focal_distance = self.cam["focaldistance"]
         rp.shutter_open = self.cam["shutteropen"]; rp.shutter_close = self.cam["shutterclose"]
         rp.max_depth = self.integ["maxdepth"]; rp.rr_threshold = self.integ["rrthreshold"]
+        rp.integrator = {"path": A.PT_INTEGRATOR_PATH, "volpath": A.PT_INTEGRATOR_VOLPATH}[self.integ.get("kind", "path")]
+        rp.camera_medium = A.PT_NONE if self.camera_medium is None else self.camera_medium
         pb = self.integ["pixelbounds"]
         if pb is None: pb = sb
         else: pb = [max(pb[0], sb[0]), max(pb[2], sb[1]), min(pb[1], sb[2]), min(pb[3], sb[3])]  # path.rs:233-246
@@ -584,6 +611,8 @@ class SceneData:
         self.spheres = (A.PtSphere * max(1, len(b.spheres)))(*b.spheres)
         self.n_materials, self.n_lights, self.n_spheres = len(b.materials), len(b.lights), len(b.spheres)
         self.env = b.env
+        self.media = (A.PtMedium * max(1, len(b.media)))(*b.media); self.n_media = len(b.media)
+        self.prim_med_in = c1(b.prim_med_in) if b.media else None; self.prim_med_out = c1(b.prim_med_out) if b.media else None
         self.max_node_prims = b.max_node_prims
         self.split_method = {"sah": A.PT_SPLIT_SAH, "hlbvh": A.PT_SPLIT_HLBVH}[b.split_method]
         self.nodes = None; self.ordered = None
@@ -638,6 +667,9 @@ class SceneData:
             d.env_power_lookup = (C.c_float * 3)(*[float(x) for x in self.env["power_lookup"]])
         d.max_node_prims = self.max_node_prims
         d.split_method = self.split_method
+        if self.n_media:
+            d.n_media = self.n_media; d.media = self.media
+            d.prim_medium_inside = ptr(self.prim_med_in, A.u32p); d.prim_medium_outside = ptr(self.prim_med_out, A.u32p)
         if self.nodes is not None:
             d.n_nodes = len(self.nodes); d.nodes = self.nodes; d.ordered_prims = ptr(self.ordered, A.u32p)
         if self.top_refs is not None:

@@ -460,3 +460,31 @@ def disney_spheres(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
     b.material("disney", color=(0.3, 0.7, 0.3), thin=True, flatness=0.6, difftrans=1.2, roughness=0.5)
     P, I = quad((-1.5, -0.5, -2.0), (1.5, -0.5, -2.0), (1.5, 1.8, -2.0), (-1.5, 1.8, -2.0)); b.trianglemesh(P, I, UV=uv)
     return b
+
+
+def foggy_room(xres=96, yres=64, spp=16, maxdepth=5, g=0.3, camera_in_fog=True, strategy="spatial"):
+    """integrators/volpath.rs + media/homogeneous.rs: the camera sits in a thin homogeneous fog that fills the world (surfaces
+    without a MediumInterface keep the ray's medium, primitive.rs:139-145); a glass sphere holds a dense coloured medium (its
+    MediumInterface switches media at the dielectric boundary); lights: area light (MIS through the fog), point light, env."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth, kind="volpath", strategy=strategy)
+    b.make_named_medium("fog", sigma_a=(0.02, 0.02, 0.02), sigma_s=(0.12, 0.12, 0.14), g=g)
+    b.make_named_medium("juice", sigma_a=(0.3, 1.2, 2.0), sigma_s=(1.5, 1.0, 0.6), g=-0.2, scale=1.5)
+    if camera_in_fog: b.medium_interface("", "fog")
+    b.look_at((0.0, 1.6, 5.5), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.05, 0.06, 0.08))
+    b.attribute_begin(); b.area_light_source(L=(25.0, 22.0, 18.0))
+    P, I = quad((-0.7, 3.2, -0.7), (0.7, 3.2, -0.7), (0.7, 3.2, 0.7), (-0.7, 3.2, 0.7)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("point", from_=(-2.0, 2.0, 1.0), I=(12.0, 10.0, 8.0))
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I)
+    b.material("plastic", Kd=(0.6, 0.2, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2)
+    b.attribute_begin(); b.translate(-1.5, 0.1, 0.0); b.sphere(radius=0.6); b.attribute_end()
+    b.attribute_begin()
+    b.medium_interface("juice", "fog" if camera_in_fog else "")
+    b.material("glass", Kr=(1.0, 1.0, 1.0), Kt=(1.0, 1.0, 1.0), eta=1.33)
+    b.translate(0.9, 0.3, 0.3); b.sphere(radius=0.8)
+    b.attribute_end()
+    return b

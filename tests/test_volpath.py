@@ -1,0 +1,135 @@
+"""VolPathIntegrator (integrators/volpath.rs) with homogeneous media (media/homogeneous.rs) and the
+Henyey-Greenstein phase function (core/medium.rs). The reference's tests pin none of it; the oracle is checked against closed
+forms and against the path integrator, the GPU against the oracle (bit-exact counters, radiance within the stated tolerance).
+Material-less interface shells are refused: the reference's own volpath mishandles them (volpath.rs:127-131)."""
+import numpy as np
+import pytest
+
+
+def _absorbing_wall(pkg, sigma_a, dist, kind="volpath"):
+    """Camera inside a purely absorbing medium looking at an emissive wall `dist` away: L = Le * exp(-sigma_a * dist)."""
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=8, yres=8); b.spp = 1024
+    b.integ.update(maxdepth=2, kind=kind)
+    b.make_named_medium("smoke", sigma_a=sigma_a, sigma_s=(0.0, 0.0, 0.0))
+    b.medium_interface("", "smoke")
+    b.look_at((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0)); b.camera(fov=2.0)
+    b.world_begin()
+    b.material("matte", Kd=(0.0, 0.0, 0.0))
+    b.area_light_source(L=(3.0, 2.0, 1.0))
+    P, I = pkg.scenes.quad((-5.0, -5.0, -dist), (5.0, -5.0, -dist), (5.0, 5.0, -dist), (-5.0, 5.0, -dist))   # normal +z: faces the camera
+    b.trianglemesh(P, I)
+    return b.world_end()
+
+
+def test_absorbing_medium_closed_form(pkg, oracle):
+    sigma_a, dist = (0.1, 0.5, 1.5), 2.5
+    sd, rp = _absorbing_wall(pkg, sigma_a, dist)
+    s = oracle.scene(sd)
+    rgb = s.resolve(s.render(rp, nthreads=4)).reshape(-1, 3).mean(axis=0)
+    want = np.array([3.0, 2.0, 1.0]) * np.exp(-np.array(sigma_a) * dist)
+    # the estimator is binary per sample (survives with probability mean(Tr), then weighs Tr / mean(Tr)): 65 k samples -> about 1 %
+    assert np.all(np.abs(rgb - want) < 0.03 * want), (rgb, want)
+    sd, rp = _absorbing_wall(pkg, sigma_a, dist, kind="path")      # PathIntegrator ignores Ray::medium
+    s = oracle.scene(sd)
+    assert np.allclose(s.resolve(s.render(rp, nthreads=4)).reshape(-1, 3).mean(axis=0), [3.0, 2.0, 1.0], rtol=1e-6)
+
+
+def test_volpath_without_media_equals_path(pkg, oracle):
+    """With no medium anywhere volpath.rs reduces to path.rs on diffuse scenes (same sampler dimensions, same arithmetic)."""
+    b = pkg.scenes.ganesha_scale(n=12, xres=32, yres=24, spp=8)
+    sd, rp = b.world_end()
+    a = oracle.scene(sd).render(rp, nthreads=4)
+    b.integ["kind"] = "volpath"
+    sd2, rp2 = b.world_end()
+    assert rp2.integrator == pkg._abi.PT_INTEGRATOR_VOLPATH and rp2.camera_medium == pkg._abi.PT_NONE
+    c = oracle.scene(sd2).render(rp2, nthreads=4)
+    assert np.array_equal(a, c)
+
+
+def test_single_scattering_matches_a_quadrature(pkg, oracle):
+    """Isotropic fog lit by a point light, black surfaces, maxdepth 1 (single scattering only):
+    L = integral over the camera ray of sigma_s * exp(-sigma_t (t + d(t))) * I / (4 pi d(t)^2) dt, evaluated by quadrature."""
+    st_a, st_s = 0.05, 0.2
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=4, yres=4); b.spp = 4096
+    b.integ.update(maxdepth=1, kind="volpath")
+    b.make_named_medium("fog", sigma_a=(st_a,) * 3, sigma_s=(st_s,) * 3, g=0.0)
+    b.medium_interface("", "fog")
+    b.look_at((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0)); b.camera(fov=1.0)
+    b.world_begin()
+    b.light_source("point", from_=(-3.0, 1.0, -3.0), I=(10.0, 10.0, 10.0))   # x == z: create_pointlight translates by (P.x, P.y, P.x) (App. A #15)
+    b.material("matte", Kd=(0.0, 0.0, 0.0))
+    P, I = pkg.scenes.quad((-50.0, -50.0, -8.0), (50.0, -50.0, -8.0), (50.0, 50.0, -8.0), (-50.0, 50.0, -8.0)); b.trianglemesh(P, I)
+    sd, rp = b.world_end()
+    s = oracle.scene(sd)
+    got = s.resolve(s.render(rp, nthreads=8)).mean()
+    t = np.linspace(0.0, 8.0, 400001)
+    d = np.sqrt(9.0 + 1.0 + (t - 3.0) ** 2)
+    f = st_s * np.exp(-(st_a + st_s) * (t + d)) * 10.0 / (4.0 * np.pi * d * d)
+    want = np.trapezoid(f, t)
+    assert abs(got - want) < 0.03 * want, (got, want)
+
+
+def test_front_end_media_directives(pkg):
+    A = pkg._abi
+    fs = pkg.frontend.FrontScene(text='''MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.1 .2 .3] "rgb sigma_s" [1 2 3] "float scale" 2 "float g" .4
+MediumInterface "" "fog"
+Camera "perspective"
+Integrator "volpath" "integer maxdepth" 7
+WorldBegin
+Shape "sphere"
+AttributeBegin
+MediumInterface "fog" ""
+Shape "sphere" "float radius" 2
+AttributeEnd
+Shape "sphere" "float radius" 3
+WorldEnd
+''')
+    d, rp = fs.desc(), fs.render_params()
+    assert rp.integrator == A.PT_INTEGRATOR_VOLPATH and rp.camera_medium == 0 and rp.max_depth == 7
+    assert d.n_media == 1 and list(d.media[0].sigma_a) == pytest.approx([.2, .4, .6]) and list(d.media[0].sigma_s) == pytest.approx([2, 4, 6]) and d.media[0].g == pytest.approx(.4)
+    ins = [d.prim_medium_inside[i] for i in range(d.n_prims)]; outs = [d.prim_medium_outside[i] for i in range(d.n_prims)]
+    assert ins == [A.PT_NONE, 0, A.PT_NONE] and outs == [0, A.PT_NONE, 0]
+    with pytest.raises(Exception, match="homogeneous"):
+        pkg.frontend.FrontScene(text='MakeNamedMedium "m" "string type" "heterogeneous"\nWorldBegin\nWorldEnd\n')
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(g=0.0), dict(g=-0.6, strategy="uniform"), dict(camera_in_fog=False), dict(maxdepth=1)])
+def test_gpu_volpath_matches_oracle(pkg, gpu, oracle, kw):
+    from test_gpu_parity import _compare_render
+    sd, rp = pkg.scenes.foggy_room(**kw).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp)
+    assert film[..., :3].sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_volpath_halton_thin_lens_and_no_media(pkg, gpu, oracle):
+    from test_gpu_parity import _compare_render
+    b = pkg.scenes.foggy_room(xres=64, yres=48, spp=8); b.sampler = "halton"; b.cam.update(lensradius=0.05, focaldistance=5.0)
+    _compare_render(pkg, gpu, oracle, *b.world_end())
+    b = pkg.scenes.material_zoo(xres=64, yres=48, spp=8); b.integ["kind"] = "volpath"     # volpath over a scene without media
+    _compare_render(pkg, gpu, oracle, *b.world_end())
+    b = pkg.scenes.textured(xres=64, yres=48, spp=4); b.integ["kind"] = "volpath"
+    _compare_render(pkg, gpu, oracle, *b.world_end(), rtol=2e-5, atol=1e-6)
+    sd, rp = _absorbing_wall(pkg, (0.1, 0.5, 1.5), 2.5)
+    g = pkg.Scene(gpu, sd)
+    rgb = g.resolve(g.render(rp)).reshape(-1, 3).mean(axis=0)
+    want = np.array([3.0, 2.0, 1.0]) * np.exp(-np.array([0.1, 0.5, 1.5]) * 2.5)
+    assert np.all(np.abs(rgb - want) < 0.03 * want)
+
+
+@pytest.mark.gpu
+def test_gpu_volpath_refuses_what_it_cannot_render(pkg, gpu):
+    b = pkg.scenes.foggy_room()
+    b.material_id = None   # a shape without a material: a medium-interface shell
+    b.sphere(radius=0.2)
+    sd, rp = b.world_end()
+    g = pkg.Scene(gpu, sd)
+    with pytest.raises(Exception, match="without a material"): g.render(rp)
+    b = pkg.scenes.subsurface_c5(xres=32, yres=24, spp=2); b.integ["kind"] = "volpath"
+    sd, rp = b.world_end()
+    with pytest.raises(Exception, match="subsurface"): pkg.Scene(gpu, sd).render(rp)
