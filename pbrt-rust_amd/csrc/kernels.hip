@@ -1027,7 +1027,9 @@ PT_INST_SHADE(1, 3, true) PT_INST_SHADE(1, 3, false) PT_INST_SHADE(2, 3, false) 
 __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
                                                      uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c5, uint32_t *error) {
     __shared__ LdsQueue<1024> q0, q1, q2, q3, q4, q5;
+    __shared__ uint32_t s_sobol[kSobolLdsWords];
     lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q5);
+    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t count = *count_ptr;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -1041,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
             const uint32_t med = ps.medium[pid];
             if (med != PT_NONE) {
                 uint32_t meta = ps.meta[pid];
-                Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = tabs.m32; smp.overflow = false;
+                Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
                 smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
                 const float u_channel = smp.get_1d(), u_dist = smp.get_1d();
                 const V3 rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);

@@ -488,3 +488,10 @@ def foggy_room(xres=96, yres=64, spp=16, maxdepth=5, g=0.3, camera_in_fog=True, 
     b.translate(0.9, 0.3, 0.3); b.sphere(radius=0.8)
     b.attribute_end()
     return b
+
+
+def ganesha_halton_hlbvh(**kw):
+    """The S2 analogue with the reference's default sampler (halton) and the GPU-built accelerator (splitmethod "hlbvh")."""
+    b = ganesha_scale(**kw)
+    b.sampler = "halton"; b.split_method = "hlbvh"
+    return b

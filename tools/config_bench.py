@@ -12,7 +12,7 @@ from _pkg import import_pkg
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--configs", default="C1,C3,C4,C5,TEX")
+    ap.add_argument("--configs", default="C1,C3,C4,C5,TEX,VOL,DISNEY")
     args = ap.parse_args()
     pkg = import_pkg()
     lib = pkg.load_library(); lib.init(0)
@@ -23,6 +23,8 @@ def main():
         "C4": lambda: S.instanced_garden(n_inst=4000, plant_n=60, xres=1920, yres=1080, spp=args.spp),
         "C5": lambda: S.subsurface_c5(n=500, xres=1920, yres=1080, spp=args.spp),
         "TEX": lambda: S.textured(xres=1920, yres=1080, spp=args.spp),
+        "VOL": lambda: S.foggy_room(xres=1920, yres=1080, spp=args.spp),        # volpath: world-filling fog + a medium inside glass
+        "DISNEY": lambda: S.disney_spheres(xres=1920, yres=1080, spp=args.spp),
     }
     for name in args.configs.split(","):
         t0 = time.time()

@@ -24,6 +24,11 @@ CASES = {   # name -> (scene function, kwargs); kept tiny: each film is 40x24x4 
     "sphere_lights": ("sphere_lights", dict(xres=40, yres=24, spp=4)),
     "textured_bump_noise": ("textured", dict(xres=40, yres=24, spp=4, bump=True, noise=True)),
     "alpha_foliage": ("alpha_foliage", dict(xres=40, yres=24, spp=4)),
+    "translucent_panels": ("translucent_panels", dict(xres=40, yres=24, spp=4)),
+    "mix_materials_textured": ("mix_materials", dict(xres=40, yres=24, spp=4, textured=True)),
+    "disney_spheres": ("disney_spheres", dict(xres=40, yres=24, spp=4)),
+    "foggy_room_volpath": ("foggy_room", dict(xres=40, yres=24, spp=4)),
+    "ganesha_halton_hlbvh": ("ganesha_halton_hlbvh", dict(n=16, xres=40, yres=24, spp=4)),
 }
 COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests",
             "zero_radiance_paths_num", "zero_radiance_paths_den", "path_length_hist", "film_splats")
