@@ -32,6 +32,13 @@ int fail(int code, const std::string &msg) { g_error = msg; return code; }
         if (_e != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));     \
     } while (0)
 
+// Scratch device allocations of one C-ABI call: freed on every exit path (HIP_TRY returns early on errors).
+struct DevTmp {
+    std::vector<void *> p;
+    template <class T> hipError_t alloc(T **out, size_t bytes) { void *q = nullptr; hipError_t e = hipMalloc(&q, bytes ? bytes : 1); if (e == hipSuccess) { p.push_back(q); *out = (T *)q; } return e; }
+    ~DevTmp() { for (void *q : p) hipFree(q); }
+};
+
 int ensure_device() {
     if (g_device >= 0) return PT_OK;
     int n = 0;
@@ -979,10 +986,10 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
         }
-        float *dst = film_xyzw, *tmp = nullptr;
+        float *dst = film_xyzw, *tmp = nullptr; DevTmp film_tmp;
         std::vector<float> host;
         if (!film_is_device) {
-            HIP_TRY(hipMalloc((void **)&tmp, film_px * 16));
+            HIP_TRY(film_tmp.alloc(&tmp, film_px * 16));
             HIP_TRY(hipMemsetAsync(tmp, 0, film_px * 16, sc->stream));
             dst = tmp;
         }
@@ -993,7 +1000,6 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         if (!film_is_device) {
             host.resize(film_px * 4);
             HIP_TRY(hipMemcpy(host.data(), tmp, film_px * 16, hipMemcpyDeviceToHost));
-            hipFree(tmp);
             for (size_t i = 0; i < film_px * 4; ++i) film_xyzw[i] += host[i];
         }
         sc->resolve_timings();
@@ -1032,6 +1038,7 @@ int pt_get_kernel_stats(const pt_scene *sc, PtKernelStat *out, uint32_t max_entr
 }
 
 static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const float *d, const float *tmax, uint32_t *prim, float *t, float *b, uint8_t *hit) {
+    DevTmp scratch;
     if (!sc || !o || !d || !tmax) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (n == 0) return PT_OK;
     int st = ensure_workspace(sc, 0, 0);
@@ -1042,11 +1049,11 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
         soa[(size_t)6 * n + i] = tmax[i];
     }
     float *din = nullptr, *dout = nullptr; uint32_t *dprim = nullptr; uint8_t *docc = nullptr; uint32_t *dcount = nullptr;
-    HIP_TRY(hipMalloc((void **)&din, soa.size() * 4));
-    HIP_TRY(hipMalloc((void **)&dout, 4 * (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&dprim, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&docc, n));
-    HIP_TRY(hipMalloc((void **)&dcount, 4));
+    HIP_TRY(scratch.alloc(&din, soa.size() * 4));
+    HIP_TRY(scratch.alloc(&dout, 4 * (size_t)n * 4));
+    HIP_TRY(scratch.alloc(&dprim, (size_t)n * 4));
+    HIP_TRY(scratch.alloc(&docc, n));
+    HIP_TRY(scratch.alloc(&dcount, 4));
     HIP_TRY(hipMemcpy(din, soa.data(), soa.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dcount, &n, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
@@ -1074,7 +1081,6 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
         HIP_TRY(hipMemcpy(prim, dprim, (size_t)n * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; ++i) { t[i] = res[i]; for (int k = 0; k < 3; ++k) b[3 * (size_t)i + k] = res[(size_t)(1 + k) * n + i]; }
     }
-    hipFree(din); hipFree(dout); hipFree(dprim); hipFree(docc); hipFree(dcount);
     read_counters(sc);
     if (h.error) return fail((int)h.error, "traversal error raised on device");
     return PT_OK;
@@ -1090,6 +1096,7 @@ int pt_trace_any(pt_scene *sc, uint32_t n, const float *o, const float *d, const
 }
 
 int pt_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    DevTmp scratch;
     if (!sb || !pixel_xy || !sample_num || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (n_dims > 1024) return fail(PT_ERR_SOBOL_DIMENSIONS, "SobolSampler can only sample up to 1024 dimensions");
     int st = ensure_device();
@@ -1097,19 +1104,19 @@ int pt_sobol_samples(const int32_t sb[4], uint32_t n, const int32_t *pixel_xy, c
     PtRenderParams rp{}; std::memcpy(rp.sample_bounds, sb, 16);
     RenderConst rc; fill_render_const(&rp, rc);
     int32_t *dxy; uint32_t *dsn; float *dout; uint64_t *didx;
-    HIP_TRY(hipMalloc((void **)&dxy, (size_t)n * 8)); HIP_TRY(hipMalloc((void **)&dsn, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(hipMalloc((void **)&didx, (size_t)n * 8));
+    HIP_TRY(scratch.alloc(&dxy, (size_t)n * 8)); HIP_TRY(scratch.alloc(&dsn, (size_t)n * 4));
+    HIP_TRY(scratch.alloc(&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(scratch.alloc(&didx, (size_t)n * 8));
     HIP_TRY(hipMemcpy(dxy, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dsn, sample_num, (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_sobol_samples, dim3((n + 255) / 256), dim3(256), 0, 0, g_tabs, rc.sobol, n, dxy, dsn, n_dims, dout, didx);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, (size_t)n * n_dims * 4, hipMemcpyDeviceToHost));
     if (out_index) HIP_TRY(hipMemcpy(out_index, didx, (size_t)n * 8, hipMemcpyDeviceToHost));
-    hipFree(dxy); hipFree(dsn); hipFree(dout); hipFree(didx);
     return PT_OK;
 }
 
 int pt_halton_samples(const int32_t sb[4], uint32_t sample_at_pixel_center, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num, uint32_t n_dims, float *out, uint64_t *out_index) {
+    DevTmp scratch;
     if (!sb || !pixel_xy || !sample_num || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (n_dims > kHaltonMaxDims) return fail(PT_ERR_SOBOL_DIMENSIONS, "HaltonSampler can only sample 1000 dimensions");
     int st = ensure_device();
@@ -1117,31 +1124,30 @@ int pt_halton_samples(const int32_t sb[4], uint32_t sample_at_pixel_center, uint
     PtRenderParams rp{}; std::memcpy(rp.sample_bounds, sb, 16); rp.sampler_type = PT_SAMPLER_HALTON; rp.sample_at_pixel_center = sample_at_pixel_center;
     RenderConst rc; fill_render_const(&rp, rc);
     int32_t *dxy; uint32_t *dsn; float *dout; uint64_t *didx;
-    HIP_TRY(hipMalloc((void **)&dxy, (size_t)n * 8)); HIP_TRY(hipMalloc((void **)&dsn, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(hipMalloc((void **)&didx, (size_t)n * 8));
+    HIP_TRY(scratch.alloc(&dxy, (size_t)n * 8)); HIP_TRY(scratch.alloc(&dsn, (size_t)n * 4));
+    HIP_TRY(scratch.alloc(&dout, (size_t)n * n_dims * 4 + 4)); HIP_TRY(scratch.alloc(&didx, (size_t)n * 8));
     HIP_TRY(hipMemcpy(dxy, pixel_xy, (size_t)n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dsn, sample_num, (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_halton_samples, dim3((n + 255) / 256), dim3(256), 0, 0, g_tabs, rc.halton, n, dxy, dsn, n_dims, dout, didx);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, (size_t)n * n_dims * 4, hipMemcpyDeviceToHost));
     if (out_index) HIP_TRY(hipMemcpy(out_index, didx, (size_t)n * 8, hipMemcpyDeviceToHost));
-    hipFree(dxy); hipFree(dsn); hipFree(dout); hipFree(didx);
     return PT_OK;
 }
 
 int pt_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float *out_o, float *out_d) {
+    DevTmp scratch;
     if (!rp || !cs || !out_o || !out_d) return fail(PT_ERR_INVALID_ARG, "null argument");
     int st = ensure_device();
     if (st || n == 0) return st;
     RenderConst rc; fill_render_const(rp, rc);
     float *dcs, *dout;
-    HIP_TRY(hipMalloc((void **)&dcs, (size_t)n * 20)); HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 24));
+    HIP_TRY(scratch.alloc(&dcs, (size_t)n * 20)); HIP_TRY(scratch.alloc(&dout, (size_t)n * 24));
     HIP_TRY(hipMemcpy(dcs, cs, (size_t)n * 20, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_camera_rays, dim3((n + 255) / 256), dim3(256), 0, 0, rc, n, dcs, dout, dout + 3 * (size_t)n);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_o, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_d, dout + 3 * (size_t)n, (size_t)n * 12, hipMemcpyDeviceToHost));
-    hipFree(dcs); hipFree(dout);
     return PT_OK;
 }
 
