@@ -83,7 +83,7 @@ typedef enum PtMaterialType {
                               subsurface_from_diffuse, bssrdf.rs:190-202, and passes sigma_a/sigma_s) */
     PT_MAT_TRANSLUCENT = 8,/* materials/translucent.rs: Kd, Ks, roughness; kr = "reflect", kt = "transmit" */
     PT_MAT_MIX = 9,        /* materials/mix.rs: kd = "amount", mix[0] / mix[1] = the two named materials */
-    PT_MAT_DISNEY = 10     /* materials/disney.rs: kd = "color", eta, roughness + disney[] / disney_thin; scatterdistance must be 0 */
+    PT_MAT_DISNEY = 10     /* materials/disney.rs: kd = "color", eta, roughness + disney[] / disney_thin / disney_scatter */
 } PtMaterialType;
 
 /* ---- textures (core/texture.rs, textures/, core/mipmap.rs) --------------------------------------
@@ -185,6 +185,7 @@ typedef struct PtMaterial {
      * "color" = kd / tex[PT_MP_KD], "eta" = eta / tex[PT_MP_ETA], "roughness" = roughness / tex[PT_MP_ROUGHNESS] may be textured. */
     float disney[10];
     uint32_t disney_thin;
+    float disney_scatter[3];   /* "scatterdistance": non-black (and not thin) => DisneyBSSRDF (disney.rs:442-704) with a constant color */
 } PtMaterial;
 
 typedef enum PtLightType {

@@ -94,6 +94,14 @@ struct TabulatedBSSRDF {
     uint32_t material = PT_NONE;
     Float eta = 1;
     V3 po_p;
+    // DisneyBSSRDF (materials/disney.rs:442-704): the same separable machinery with an analytic profile; R = color * diffuse
+    // weight, d = scatter distance
+    bool disney = false; RGB dR, dD;
+    void init_disney(const SurfaceInteraction &s, uint32_t mat, Float eta_, RGB r, RGB d) {
+        disney = true; material = mat; eta = eta_; dR = r; dD = d;
+        ns = s.sh_n; ss = normalize(s.sh_dpdu); ts = cross(ns, ss); po_p = s.p;
+    }
+    static Float expf_(Float x) { return (Float)dm_expd((double)x); }
 
     void init(const SurfaceInteraction &s, uint32_t mat, Float eta_, RGB sigma_a, RGB sigma_s, const BssrdfTable *t) {
         table = t; material = mat; eta = eta_;
@@ -103,6 +111,12 @@ struct TabulatedBSSRDF {
         po_p = s.p;
     }
     RGB sr(Float r) const {
+        if (disney) {   // disney.rs:667-671
+            if (r < 1.0e-6f) r = 1.0e-6f;
+            RGB o;
+            for (int i = 0; i < 3; ++i) o.c[i] = dR.c[i] * (expf_(-r / dD.c[i]) + expf_(-r / (dD.c[i] * 3.0f))) / (dD.c[i] * 8.0f * PI * r);
+            return o;
+        }
         RGB Sr(0.0f);
         for (int ch = 0; ch < 3; ++ch) {
             Float roptical = r * sigma_t.c[ch];
@@ -122,11 +136,20 @@ struct TabulatedBSSRDF {
         return Sr.clamps(0.0f, INF);
     }
     Float sample_sr(int ch, Float u) const {
+        if (disney) {   // disney.rs:673-681
+            if (u < 0.25f) { u = fmin_(u * 4.0f, ONE_MINUS_EPSILON); return dD.c[ch] * dm_logf(1.0f / (1.0f - u)); }
+            u = fmin_((u - 0.25f) / 0.75f, ONE_MINUS_EPSILON);
+            return 3.0f * dD.c[ch] * dm_logf(1.0f / (1.0f - u));
+        }
         if (sigma_t.c[ch] == 0.0f) return -1.0f;
         return sample_catmull_rom_2d(table->n_rho, table->n_radius, table->rho_samples.data(), table->radius_samples.data(),
                                      table->profile.data(), table->profile_cdf.data(), rho.c[ch], u) / sigma_t.c[ch];
     }
     Float pdf_sr(int ch, Float r) const {
+        if (disney) {   // disney.rs:683-686
+            Float d = dD.c[ch];
+            return 0.25f * expf_(-r / d) / (2.0f * PI * d * r) + 0.75f * expf_(-r / (3.0f * d)) / (6.0f * PI * d * r);
+        }
         Float roptical = r * sigma_t.c[ch];
         int rho_off = 0, rad_off = 0; Float rw[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
         if (!catmull_rom_weights(table->n_rho, table->rho_samples.data(), rho.c[ch], rho_off, rw) ||

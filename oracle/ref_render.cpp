@@ -241,7 +241,15 @@ static bool material_scattering_functions(const Scene &scene, uint32_t mi, Surfa
                 Float flat = m.disney[PT_DS_FLATNESS];
                 { Bxdf b; b.kind = BX_DISNEY_DIFFUSE; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight * flat * (1.0f - dt); bsdf.add(b); }
                 { Bxdf b; b.kind = BX_DISNEY_FAKESS; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * (1.0f - dt) * flat * dweight; b.A = rough; bsdf.add(b); }
-            } else { Bxdf b; b.kind = BX_DISNEY_DIFFUSE; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight; bsdf.add(b); }
+            } else {
+                RGB sd(m.disney_scatter[0], m.disney_scatter[1], m.disney_scatter[2]);
+                if (sd.is_black()) { Bxdf b; b.kind = BX_DISNEY_DIFFUSE; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight; bsdf.add(b); }
+                else {   // a BSSRDF instead (disney.rs:768-776)
+                    Bxdf b; b.kind = BX_SPEC_T; b.type = BSDF_TRANSMISSION | BSDF_SPECULAR; b.t = RGB(1.0f); b.etaa = 1.0f; b.etab = e;
+                    b.fresnel.kind = FR_DIELECTRIC; b.fresnel.etai = 1.0f; b.fresnel.etat = e; bsdf.add(b);
+                    if (bssrdf) { bssrdf->init_disney(si, mi, e, c * dweight, sd); *has_bssrdf = true; }
+                }
+            }
             { Bxdf b; b.kind = BX_DISNEY_RETRO; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = c * dweight; b.A = rough; bsdf.add(b); }
             if (sheen_weight > 0.0f) { Bxdf b; b.kind = BX_DISNEY_SHEEN; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.r = csheen * sheen_weight * dweight; bsdf.add(b); }
         }

@@ -46,7 +46,7 @@ class PtMaterial(C.Structure):
     _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
                 ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
-                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32)]
+                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32), ("disney_scatter", f32 * 3)]
 
 
 class PtMedium(C.Structure):

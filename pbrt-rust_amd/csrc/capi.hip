@@ -624,6 +624,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             int n = 1 + (m.disney[PT_DS_CLEARCOAT] > 0.0f) + (m.disney[PT_DS_SPECTRANS] > 0.0f) + (thin ? 1 : 0);
             if (dw > 0.0f) n += (thin ? 2 : 1) + 1 + (m.disney[PT_DS_SHEEN] > 0.0f);
             if (n > 5) return fail(PT_ERR_UNSUPPORTED, "disney material with more than 5 BxDFs");
+            if (disney_has_bssrdf(m) && d->n_textures && m.tex[PT_MP_KD] >= 0) return fail(PT_ERR_UNSUPPORTED, "disney: a textured color together with scatterdistance");
+            if (disney_has_bssrdf(m) && (m.disney_scatter[0] <= 0.0f || m.disney_scatter[1] <= 0.0f || m.disney_scatter[2] <= 0.0f)) return fail(PT_ERR_INVALID_ARG, "disney: scatterdistance must be positive in every channel");
         }
         if (m.type == PT_MAT_MIX) {   // mix.rs:25-50: two plain materials whose lobes fit the five-lobe shade class together
             auto lobes = [](const PtMaterial &q) { switch (q.type) { case PT_MAT_GLASS: return 2; case PT_MAT_PLASTIC: return 2; case PT_MAT_UBER: return 5; case PT_MAT_TRANSLUCENT: return 4; case PT_MAT_DISNEY: return 5; default: return 1; } };
@@ -631,7 +633,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             for (int k = 0; k < 2; ++k) {
                 if (m.mix[k] >= d->n_materials) return fail(PT_ERR_INVALID_ARG, "mix material index out of range");
                 const PtMaterial &q = d->materials[m.mix[k]];
-                if (q.type == PT_MAT_MIX || q.type == PT_MAT_SUBSURFACE) return fail(PT_ERR_UNSUPPORTED, "mix of mix / subsurface materials");
+                if (q.type == PT_MAT_MIX || q.type == PT_MAT_SUBSURFACE || disney_has_bssrdf(q)) return fail(PT_ERR_UNSUPPORTED, "mix of mix / subsurface materials");
                 total += lobes(q);
             }
             if (total > 5) return fail(PT_ERR_UNSUPPORTED, "mix material with more than 5 BxDFs");
@@ -869,7 +871,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if (any_mask(d->tri_alpha)) UP(tri_alpha, d->tri_alpha, d->n_triangles);
             if (any_mask(d->tri_shadow_alpha)) UP(tri_shadow_alpha, d->tri_shadow_alpha, d->n_triangles);
         }
-        for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].type == PT_MAT_SUBSURFACE) sc->has_bssrdf = true;
+        for (uint32_t i = 0; i < d->n_materials; ++i) if (d->materials[i].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(d->materials[i])) sc->has_bssrdf = true;
         std::vector<uint32_t> inf;
         for (uint32_t i = 0; i < d->n_lights; ++i) if (d->lights[i].type == PT_LIGHT_INFINITE) inf.push_back(i);
         UP(infinite_lights, inf.data(), inf.size()); ds.n_infinite = (uint32_t)inf.size();

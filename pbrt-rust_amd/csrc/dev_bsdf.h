@@ -486,6 +486,11 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
 };
 
 PT_DEV RGB rgb3(const float *p) { return RGB(p[0], p[1], p[2]); }
+// DisneyMaterial attaches a BSSRDF when it is not thin, has diffuse weight and a non-black scatter distance (disney.rs:755-776)
+PT_HD bool disney_has_bssrdf(const PtMaterial &m) {
+    return m.type == PT_MAT_DISNEY && !m.disney_thin && (1.0f - m.disney[PT_DS_METALLIC]) * (1.0f - m.disney[PT_DS_SPECTRANS]) > 0.0f &&
+           (m.disney_scatter[0] != 0.0f || m.disney_scatter[1] != 0.0f || m.disney_scatter[2] != 0.0f);
+}
 PT_DEV Lobe mk_lobe(uint8_t kind, uint8_t type) { Lobe b; b.kind = kind; b.type = type; b.fresnel = FR_NOOP; b.sepg = 0; b.ax = b.ay = 0.001f; b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; return b; }
 PT_DEV void set_dist(Lobe &b, float ax, float ay) { b.ax = maxf(ax, 0.001f); b.ay = maxf(ay, 0.001f); }  // microfacet.rs:325-331
 
@@ -640,7 +645,8 @@ template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf_leaf(const PtMat
                 const float flat = m.disney[PT_DS_FLATNESS];
                 { Lobe b = mk_lobe(LB_DISNEY_DIFFUSE, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight * flat * (1.0f - dt); bsdf.add(b); }   // `flat`, not 1 - flat (disney.rs:759)
                 { Lobe b = mk_lobe(LB_DISNEY_FAKESS, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * (1.0f - dt) * flat * dweight; b.A = rough; bsdf.add(b); }
-            } else { Lobe b = mk_lobe(LB_DISNEY_DIFFUSE, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight; bsdf.add(b); }
+            } else if (m.disney_scatter[0] == 0.0f && m.disney_scatter[1] == 0.0f && m.disney_scatter[2] == 0.0f) { Lobe b = mk_lobe(LB_DISNEY_DIFFUSE, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight; bsdf.add(b); }
+            else { Lobe b = mk_lobe(LB_SPEC_T, BSDF_TRANSMISSION | BSDF_SPECULAR); b.t = RGB(1.0f); b.etaa = 1.0f; b.etab = e; bsdf.add(b); }   // + DisneyBSSRDF (disney.rs:768-776), sampled by the subsurface branch of k_shade
             { Lobe b = mk_lobe(LB_DISNEY_RETRO, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = c * dweight; b.A = rough; bsdf.add(b); }
             if (sheen_weight > 0.0f) { Lobe b = mk_lobe(LB_DISNEY_SHEEN, BSDF_REFLECTION | BSDF_DIFFUSE); b.r = csheen * sheen_weight * dweight; bsdf.add(b); }
         }

@@ -82,6 +82,7 @@ PT_DEV float sample_catmull_rom_2d(int size1, int size2, const float *nodes1, co
     return x0 + width * t;
 }
 
+PT_DEV float dm_expf_b(float x) { return (float)dm_expd((double)x); }   // f32::exp through the shared f64 exp
 PT_DEV float fresnel_moment1(float eta) {
     float eta2 = eta * eta, eta3 = eta2 * eta, eta4 = eta3 * eta, eta5 = eta4 * eta;
     if (eta < 1.0f) return 0.45966f - 1.73965f * eta + 3.37668f * eta2 - 3.904945f * eta3 + 2.49277f * eta4 - 0.68441f * eta5;
@@ -95,6 +96,7 @@ PT_DEV float bssrdf_sw(float eta, V3 w) {
 struct DevBssrdf {
     DevBssTable tb;
     float sigma_t[3], rho[3];
+    bool disney = false; float dR[3], dD[3];   // DisneyBSSRDF (disney.rs:442-704): R = color * diffuse weight, d = scatter distance
     V3 ns, ss, ts, po_p;
     float eta;
 
@@ -109,9 +111,24 @@ struct DevBssrdf {
             rho[i] = (sigma_t[i] != 0.0f) ? ss_ / sigma_t[i] : 0.0f;
         }
     }
+    // DisneyMaterial's BSSRDF (disney.rs:768-776): constant color; the weights are the material's constants
+    PT_DEV void init_disney(const PtMaterial &m) {
+        disney = true; eta = m.eta;
+        const float dw = (1.0f - m.disney[PT_DS_METALLIC]) * (1.0f - m.disney[PT_DS_SPECTRANS]);
+        for (int i = 0; i < 3; ++i) { dR[i] = clampf(m.kd[i], 0.0f, PT_INF) * dw; dD[i] = m.disney_scatter[i]; }
+    }
+    PT_DEV void init_material(const PtMaterial &m, const DevBssTable *tables) {
+        if (m.type == PT_MAT_DISNEY) init_disney(m); else init_medium(m, tables, rgb3(m.sigma_a), rgb3(m.sigma_s));
+    }
     PT_DEV void init_frame(const SurfaceInteraction &s) { ns = s.sh_n; ss = normalize(s.sh_dpdu); ts = cross(ns, ss); po_p = s.p; }
 
     PT_DEV RGB sr(float r) const {
+        if (disney) {   // disney.rs:667-671
+            if (r < 1.0e-6f) r = 1.0e-6f;
+            float o[3];
+            for (int i = 0; i < 3; ++i) o[i] = dR[i] * (dm_expf_b(-r / dD[i]) + dm_expf_b(-r / (dD[i] * 3.0f))) / (dD[i] * 8.0f * kPi * r);
+            return RGB(o[0], o[1], o[2]);
+        }
         float out[3] = {0.0f, 0.0f, 0.0f};
         for (int ch = 0; ch < 3; ++ch) {
             float roptical = r * sigma_t[ch];
@@ -131,10 +148,20 @@ struct DevBssrdf {
         return Sr.clamps(0.0f, PT_INF);
     }
     PT_DEV float sample_sr(int ch, float u) const {
+        if (disney) {   // disney.rs:673-681
+            const float d = ch == 0 ? dD[0] : ch == 1 ? dD[1] : dD[2];
+            if (u < 0.25f) { u = minf(u * 4.0f, kOneMinusEps); return d * dm_logf(1.0f / (1.0f - u)); }
+            u = minf((u - 0.25f) / 0.75f, kOneMinusEps);
+            return 3.0f * d * dm_logf(1.0f / (1.0f - u));
+        }
         if (sigma_t[ch] == 0.0f) return -1.0f;
         return sample_catmull_rom_2d(tb.n_rho, tb.n_radius, tb.rho_samples, tb.radius_samples, tb.profile, tb.profile_cdf, rho[ch], u) / sigma_t[ch];
     }
     PT_DEV float pdf_sr(int ch, float r) const {
+        if (disney) {   // disney.rs:683-686
+            const float d = ch == 0 ? dD[0] : ch == 1 ? dD[1] : dD[2];
+            return 0.25f * dm_expf_b(-r / d) / (2.0f * kPi * d * r) + 0.75f * dm_expf_b(-r / (3.0f * d)) / (6.0f * kPi * d * r);
+        }
         float roptical = r * sigma_t[ch];
         int rho_off = 0, rad_off = 0; float rw[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
         if (!catmull_rom_weights(tb.n_rho, tb.rho_samples, rho[ch], rho_off, rw) ||

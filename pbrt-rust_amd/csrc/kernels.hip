@@ -926,10 +926,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         if constexpr (MAXL == 5) {
                             // path.rs:177-183: importance sample the BSSRDF; the probe chain of sample_sp (bssrdf.rs:367-395)
                             // is walked by k_bssrdf over the following wavefront iterations
-                            if (s.materials[mi].type == PT_MAT_SUBSURFACE && (sflags & BSDF_TRANSMISSION)) {
+                            if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
                                 const P2 s2 = smp.get_2d();
                                 const float s1 = smp.get_1d();
-                                DevBssrdf bss; bss.init_medium(s.materials[mi], s.bss_tables, rgb3(s.materials[mi].sigma_a), rgb3(s.materials[mi].sigma_s)); bss.init_frame(si);
+                                DevBssrdf bss; bss.init_material(s.materials[mi], s.bss_tables); bss.init_frame(si);
                                 V3 start, target; float u1n = 0.0f;
                                 const BssSoA &bs = job.bs;
                                 if (!bss.probe_segment(s1, s2, start, target, u1n)) rr_kill = true;   // S is black: `break`
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
-                DevBssrdf bss; bss.init_medium(m, s.bss_tables, rgb3(m.sigma_a), rgb3(m.sigma_s));   // textured sigma_a / sigma_s are rejected at scene creation
+                DevBssrdf bss; bss.init_material(m, s.bss_tables);   // tabulated (textured sigma_a / sigma_s are rejected at scene creation) or DisneyBSSRDF
                 bss.ns = V3(bs.ns_x[pid], bs.ns_y[pid], bs.ns_z[pid]); bss.ss = V3(bs.ss_x[pid], bs.ss_y[pid], bs.ss_z[pid]);
                 bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
                 n_bytes += 36;

@@ -325,7 +325,9 @@ private:
                 m.disney[k] = p.one_float(ds[k].name, ds[k].dflt);
             }
             float sd[3] = {0.0f, 0.0f, 0.0f}; p.rgb("scatterdistance", sd);
-            if (!p.texture("scatterdistance").empty() || sd[0] != 0.0f || sd[1] != 0.0f || sd[2] != 0.0f) throw std::runtime_error("disney: scatterdistance (DisneyBSSRDF) is not supported");
+            if (!p.texture("scatterdistance").empty()) throw std::runtime_error("disney: a textured scatterdistance is not supported");
+            if ((sd[0] != 0.0f || sd[1] != 0.0f || sd[2] != 0.0f) && m.tex[PT_MP_KD] >= 0) throw std::runtime_error("disney: a textured color together with scatterdistance is not supported");
+            copy3(m.disney_scatter, sd);
             m.disney_thin = p.one_bool("thin", false) ? 1u : 0u;
         }
         else if (kind == "mix") {   // api.rs:615-640 + mix.rs:52-56: an undefined named material falls back to a matte made from these parameters

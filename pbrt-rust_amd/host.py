@@ -275,7 +275,9 @@ class SceneBuilder:
             else:
                 self.bssrdf_tables.append(table); m.bssrdf_table = len(self.bssrdf_tables) - 1
         if kind == "disney":
-            if np.any(np.asarray(d["scatterdistance"], dtype=F) != 0): raise NotImplementedError("disney scatterdistance (DisneyBSSRDF)")
+            sdv = np.asarray([d["scatterdistance"]] * 3 if np.isscalar(d["scatterdistance"]) else d["scatterdistance"], dtype=F)
+            m.disney_scatter = (C.c_float * 3)(*[float(x) for x in sdv])
+            if np.any(sdv != 0) and isinstance(kw.get("color"), str): raise NotImplementedError("disney: textured color together with scatterdistance")
             names = ("metallic", "speculartint", "anisotropic", "sheen", "sheentint", "clearcoat", "clearcoatgloss", "spectrans", "flatness", "difftrans")
             if any(isinstance(d[n], str) for n in names): raise NotImplementedError("textured disney parameters other than color / eta / roughness")
             m.disney = (C.c_float * 10)(*[float(d[n]) for n in names]); m.disney_thin = 1 if d["thin"] else 0

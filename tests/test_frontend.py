@@ -477,7 +477,9 @@ def test_disney_material_from_a_scene_file(pkg):
     want = {A.PT_DS_METALLIC: .25, A.PT_DS_SPECULARTINT: 0, A.PT_DS_ANISOTROPIC: 0, A.PT_DS_SHEEN: .5, A.PT_DS_SHEENTINT: .5, A.PT_DS_CLEARCOAT: 0,
             A.PT_DS_CLEARCOATGLOSS: 1, A.PT_DS_SPECTRANS: 0, A.PT_DS_FLATNESS: 0, A.PT_DS_DIFFTRANS: .8}
     for k, v in want.items(): assert m.disney[k] == pytest.approx(v), k
+    sd = pkg.frontend.FrontScene(text=head + 'Material "disney" "rgb scatterdistance" [.1 .2 .3]\nShape "sphere"\nWorldEnd\n').desc()
+    assert [list(sd.materials[i].disney_scatter) for i in range(sd.n_materials) if sd.materials[i].type == A.PT_MAT_DISNEY][0] == pytest.approx([.1, .2, .3])
     with pytest.raises(Exception, match="scatterdistance"):
-        pkg.frontend.FrontScene(text=head + 'Material "disney" "rgb scatterdistance" [.1 .1 .1]\nShape "sphere"\nWorldEnd\n')
+        pkg.frontend.FrontScene(text=head + 'Material "disney" "texture color" "c" "rgb scatterdistance" [.1 .1 .1]\nShape "sphere"\nWorldEnd\n')
     with pytest.raises(Exception, match="textured \"sheen\""):
         pkg.frontend.FrontScene(text=head + 'Texture "f" "float" "checkerboard"\nMaterial "disney" "texture sheen" "f"\nShape "sphere"\nWorldEnd\n')
