@@ -197,6 +197,28 @@ def test_full_size_properties(pkg, gpu):
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-6, atol=1e-7)
 
 
+def test_full_size_parity_gate_on_a_crop(pkg, gpu, oracle):
+    """SURVEY 8d parity gate at BASELINE size: S2 (4.3 M triangles, 1920x1080 film), 16 spp, the centre 256x256 crop rendered by the
+    HIP path and by the oracle (which adopts the library's tree -- identical to its own, see test_bvh_identical_to_oracle -- to skip a
+    second 4.3 M-triangle build): per-pixel L-infinity of the normalised film < 1e-3, and the exact counter equalities."""
+    b = pkg.scenes.ganesha_scale(n=1466, xres=1920, yres=1080, spp=16)
+    b.film.update(crop=(832 / 1920, 1088 / 1920, 412 / 1080, 668 / 1080))
+    sd, rp = b.world_end()
+    g = pkg.Scene(gpu, sd)
+    film = g.render(rp)
+    assert film.shape[:2] == (256, 256)
+    nodes, ordered = g.bvh()
+    sd.set_bvh(nodes, ordered)
+    orc = oracle.scene(sd)
+    ref = orc.render(rp, nthreads=32)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-3   # the gate; in practice the films agree to 2e-6 relative
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+
+
 def test_spheres_c1_matches_oracle(pkg, gpu, oracle):
     """Config C1: analytic spheres (mirror, glass, partial plastic sphere) + distant + area light."""
     sd, rp = pkg.scenes.spheres_c1(xres=96, yres=96, spp=8).world_end()
