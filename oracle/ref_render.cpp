@@ -639,6 +639,7 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
             V3 wi;
             hg_sample_p(mi.g, mi.wo, wi, sampler.get_2d());
             ray = spawn_ray(it, wi); ray.medium = mi.medium;
+            rdiff.has = false;   // mi.spawn_ray creates a ray without differentials (interaction.rs:32-36)
             specular_bounce = false;
         } else {
             if (bounces == 0 || specular_bounce) {

@@ -982,8 +982,9 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->film_rgbw, 0, film_px * 16, sc->stream));
         HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
-        // Halton scenes shade with the general kernels, which read the instance of a hit; the triangle-only traversal never writes it
-        if ((rc.halton.enabled || rc.volpath) && sc->ds.n_spheres == 0 && sc->ds.n_instances == 0) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
+        // The general shade kernels (textures, Halton, volpath) read the instance of a hit; the triangle-only traversal (k_trace<*, 0>)
+        // never writes it
+        if (sc->ds.n_spheres == 0 && sc->ds.n_instances == 0 && !sc->ds.tri_alpha && !sc->ds.tri_shadow_alpha) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;

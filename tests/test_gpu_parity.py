@@ -409,3 +409,16 @@ def test_disney_bssrdf_matches_oracle(pkg, gpu, oracle, g):
     assert gc["intersect_tests"] >= oc["intersect_tests"]   # re-walked probe segments (as for the tabulated BSSRDF)
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+
+
+def test_textured_triangle_only_scene(pkg, gpu, oracle):
+    """Regression (found by tests/test_fuzz_parity.py, seed 25): textures select the general shade kernels, which read the instance
+    of a hit, while a scene of triangles only is traversed by k_trace<*, 0>, which never writes it."""
+    b = pkg.scenes.ganesha_scale(n=12, xres=64, yres=48, spp=4)
+    b.texture("chk", "spectrum", "checkerboard", uscale=4.0, vscale=4.0, tex1=(0.8, 0.2, 0.2), tex2=(0.2, 0.2, 0.8))
+    b.material("matte", Kd="chk")
+    P, I = pkg.scenes.quad((-1.5, -1.2, 1.0), (1.5, -1.2, 1.0), (1.5, 0.5, 0.2), (-1.5, 0.5, 0.2))
+    b.trianglemesh(P, I, UV=np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32))
+    sd, rp = b.world_end()
+    assert len(b.spheres) == 0 and not b.instances
+    _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5, atol=1e-6)
