@@ -18,6 +18,8 @@ def random_scene(pkg, seed):
     b.split_method = pick("sah", "sah", "hlbvh")
     b.max_node_prims = int(pick(1, 2, 4, 6))
     b.filter.update(kind=pick("box", "gaussian", "triangle", "mitchell", "sinc"), radius=(u(0.5, 2.0), u(0.5, 2.0)))
+    if rng.random() < 0.25: x0, y0 = u(0.0, 0.4), u(0.0, 0.4); b.film.update(crop=(x0, x0 + u(0.3, 0.6), y0, y0 + u(0.3, 0.6)))
+    if rng.random() < 0.15: b.sample_at_pixel_center = True
     volpath = rng.random() < 0.4
     b.integ.update(maxdepth=int(pick(1, 3, 5, 8)), rrthreshold=pick(1.0, 0.3, 0.0), strategy=pick("spatial", "power", "uniform"), kind="volpath" if volpath else "path")
     if volpath:
@@ -47,13 +49,31 @@ def random_scene(pkg, seed):
     b.texture("img", "spectrum", "imagemap", pixels=S.test_image(12, 10, seed=int(rng.integers(1, 99))), uscale=u(1, 4), vscale=u(1, 4), trilinear=bool(rng.random() < 0.5))
     b.texture("fchk", "float", "checkerboard", uscale=u(2, 6), vscale=u(2, 6), tex1=u(0.02, 0.2), tex2=u(0.2, 0.8))
     b.texture("bump", "float", "checkerboard", uscale=u(4, 9), vscale=u(4, 9), tex1=u(0.0, 0.03), tex2=0.0)
-    col = lambda: pick(rgb(), rgb(), "chk", "img")
+    # the rest of the texture zoo (texture space shifted into the positive octant: the noise lattice index of a negative
+    # coordinate saturates in the reference, see tests/test_gpu_parity.py::test_textures_match_oracle)
+    b.attribute_begin(); b.translate(-20.0, -20.0, -20.0); b.scale(u(0.5, 2.0), u(0.5, 2.0), u(0.5, 2.0))
+    b.texture("fbm", "float", "fbm", octaves=int(pick(2, 4, 6)), roughness=u(0.3, 0.7))
+    b.texture("wrk", "spectrum", "wrinkled", octaves=int(pick(2, 5)), roughness=u(0.3, 0.7))
+    b.texture("mrb", "spectrum", "marble", octaves=int(pick(3, 6)), roughness=u(0.3, 0.7), scale=u(0.5, 2.0), variation=u(0.1, 0.4))
+    b.texture("wnd", "float", "windy")
+    b.texture("chk3", "spectrum", "checkerboard", dimension=3, tex1=rgb(), tex2=rgb())
+    b.attribute_end()
+    mapping = lambda: pick(dict(), dict(mapping="planar", v1=(u(0.2, 1), 0, u(0, 0.5)), v2=(0, u(0.2, 1), u(0, 0.5)), udelta=u(), vdelta=u()), dict(mapping="spherical"), dict(mapping="cylindrical"))
+    b.texture("dots", "spectrum", "dots", uscale=u(2, 6), vscale=u(2, 6), inside=rgb(), outside=pick(rgb(), "chk"), **mapping())
+    b.texture("uvt", "spectrum", "uv", uscale=u(1, 3), vscale=u(1, 3))
+    b.texture("bil", "spectrum", "bilerp", v00=rgb(), v01=rgb(), v10=rgb(), v11=rgb(), **mapping())
+    b.texture("mixt", "spectrum", "mix", tex1=pick(rgb(), "img"), tex2=pick(rgb(), "wrk"), amount=pick(u(), "fbm"))
+    b.texture("sclt", "spectrum", "scale", tex1=pick("chk", "mrb", "bil"), tex2=rgb(0.3, 1.0))
+    b.texture("img2", "spectrum", "imagemap", pixels=S.test_image(9, 7, seed=int(rng.integers(1, 99))), wrap=pick("repeat", "black"), gamma=bool(rng.random() < 0.3), scale=u(0.5, 1.5), maxanisotropy=pick(2.0, 8.0, 16.0), **mapping())
+    b.texture("holes", "float", "checkerboard", uscale=u(2, 5), vscale=u(2, 5), tex1=1.0, tex2=0.0)
+    col = lambda: pick(rgb(), rgb(), "chk", "img", "dots", "uvt", "bil", "mixt", "sclt", "img2", "wrk", "mrb", "chk3")
     def random_material(allow_mix=True, allow_sss=not volpath):
         kinds = ["matte", "mirror", "glass", "glass_rough", "plastic", "metal", "uber", "substrate", "translucent", "disney", "disney_thin"]
         if allow_mix: kinds.append("mix")
         if allow_sss: kinds += ["subsurface", "kdsubsurface", "disney_sss"]
         k = pick(*kinds)
         bump = {"bumpmap": "bump"} if rng.random() < 0.25 else {}
+        if rng.random() < 0.1: bump = {"bumpmap": pick("fbm", "wnd")}
         if k == "matte": b.material("matte", Kd=col(), sigma=pick(0.0, u(5, 40)), **bump)
         elif k == "mirror": b.material("mirror", Kr=rgb(0.5, 1.0))
         elif k == "glass": b.material("glass", Kr=rgb(0.5, 1.0), Kt=rgb(0.5, 1.0), eta=u(1.2, 1.8))
@@ -101,7 +121,9 @@ def random_scene(pkg, seed):
         elif shape == "mesh":
             Pm, Im, Nm = S.displaced_sphere(int(pick(4, 8)), with_normals=bool(rng.random() < 0.5)); b.trianglemesh(Pm * np.float32(u(0.3, 0.6)), Im, N=Nm)
         else:
-            b.rotate(u(-60, 60), 1.0, u(-1, 1), 0.0); h = u(0.4, 0.9); P, I = S.quad((-h, 0, 0), (h, 0, 0), (h, 2 * h, 0), (-h, 2 * h, 0)); b.trianglemesh(P, I, UV=uv)
+            b.rotate(u(-60, 60), 1.0, u(-1, 1), 0.0); h = u(0.4, 0.9); P, I = S.quad((-h, 0, 0), (h, 0, 0), (h, 2 * h, 0), (-h, 2 * h, 0))
+            masks = pick(dict(), dict(), dict(alpha="holes"), dict(alpha="holes", shadowalpha="holes"), dict(shadowalpha=0.0))
+            b.trianglemesh(P, I, UV=uv, **masks)
         b.attribute_end()
     return b
 
