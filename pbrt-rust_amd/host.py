@@ -126,6 +126,41 @@ def gaussian_filter_table(radius=(2.0, 2.0), alpha=2.0):  # filters/gaussian.rs:
     return t
 
 
+def filter_table(kind, radius, alpha=2.0, B=1.0 / 3.0, Cc=1.0 / 3.0, tau=3.0):
+    """Film::new's 16x16 table (film.rs:76-89) of filters/{boxfilter,gaussian,triangle,mitchell,sinc}.rs, each `evaluate` as written
+    there (the Mitchell polynomial's `6B*30C` term and the sinc window that is zero INSIDE the radius included)."""
+    if kind == "box": return box_filter_table()
+    if kind == "gaussian": return gaussian_filter_table(radius, alpha)
+    rx, ry = F(radius[0]), F(radius[1])
+    if kind == "triangle":
+        ev = lambda x, y: max(F(0), rx - abs(x)) * max(F(0), ry - abs(y))
+    elif kind == "mitchell":
+        B, Cc = F(B), F(Cc)
+        def m1(x):
+            a = abs(F(2) * x)
+            if a > 1: return ((-B - F(6) * Cc) * a * a * a + (F(6) * B * F(30) * Cc) * a * a + (F(-12) * B - F(48) * Cc) * a + (F(8) * B + F(24) * Cc)) * F(1.0 / 6.0)
+            return ((F(12) - F(9) * B - F(6) * Cc) * a * a * a + (F(-18) + F(12) * B + F(6) * Cc) * x * x + (F(6) - F(2) * B)) * F(1.0 / 6.0)
+        irx, iry = F(1) / rx, F(1) / ry
+        ev = lambda x, y: m1(x * irx) * m1(y * iry)
+    elif kind == "sinc":
+        tau = F(tau)
+        def sinc(x):
+            y = abs(x)
+            return F(1) if y < 1e-5 else F(math.sin(F(math.pi) * y)) / (F(math.pi) * y)
+        def ws(x, r):
+            y = abs(x)
+            if y < r: return F(0)
+            return sinc(y) * sinc(y / tau)
+        ev = lambda x, y: ws(x, rx) * ws(y, ry)
+    else:
+        raise ValueError(f"filter {kind!r}")
+    t = np.zeros(256, dtype=F)
+    for y in range(16):
+        for x in range(16):
+            t[y * 16 + x] = F(ev((F(x) + F(0.5)) * rx / F(16), (F(y) + F(0.5)) * ry / F(16)))
+    return t
+
+
 class SceneBuilder:
     """Directive-level mirror of core/api.rs for the rows in scope (no parser: SURVEY 8f-2)."""
 
@@ -154,6 +189,7 @@ class SceneBuilder:
         self.object_list = []
         self.instances = []
         self.current_object = None
+        self._tstack = []
         # options block defaults (api.rs:215-241, film.rs:364-398, sobol.rs:120, path.rs:228-249)
         self.film = dict(xres=1280, yres=720, crop=(0.0, 1.0, 0.0, 1.0), scale=1.0, max_lum=float("inf"))
         self.filter = dict(kind="box", radius=(0.5, 0.5), alpha=2.0)
@@ -175,8 +211,14 @@ class SceneBuilder:
     def scale(self, x, y, z): self.ctm = self.ctm * Transform.scale(x, y, z)
     def rotate(self, deg, x, y, z): self.ctm = self.ctm * Transform.rotate(deg, (x, y, z))
     def look_at(self, e, l, u): self.ctm = self.ctm * Transform.look_at(e, l, u)
-    def attribute_begin(self): self._stack.append((self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside))
-    def attribute_end(self): self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside = self._stack.pop()
+    # AttributeBegin / End push and pop the whole graphics state, named textures included (api.rs:1268-1327: GraphicsState owns
+    # float_textures / spectrum_textures); TransformBegin / End only the CTM
+    def attribute_begin(self): self._stack.append((self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside, dict(self.float_textures), dict(self.spectrum_textures)))
+    def attribute_end(self): self.ctm, self.reverse_orientation, self.material_id, self.area_light, self.medium_inside, self.medium_outside, self.float_textures, self.spectrum_textures = self._stack.pop()
+    def transform_begin(self): self._tstack.append(self.ctm)
+    def transform_end(self): self.ctm = self._tstack.pop()
+
+    def toggle_reverse_orientation(self): self.reverse_orientation = not self.reverse_orientation   # ReverseOrientation (api.rs)
 
     def make_named_medium(self, name, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0, preset=""):
         """MakeNamedMedium "name" "string type" "homogeneous" (api.rs:706-722): preset from the subsurface table, then * scale."""
@@ -510,12 +552,12 @@ class SceneBuilder:
         rp.cropped_pixel_bounds = (C.c_int32 * 4)(*crop)
         rx, ry = self.filter["radius"]
         rp.filter_radius = (C.c_float * 2)(rx, ry)
-        table = box_filter_table() if self.filter["kind"] == "box" else gaussian_filter_table((rx, ry), self.filter["alpha"])
+        table = filter_table(self.filter["kind"], (rx, ry), alpha=self.filter.get("alpha", 2.0), B=self.filter.get("B", 1.0 / 3.0), Cc=self.filter.get("C", 1.0 / 3.0), tau=self.filter.get("tau", 3.0))
         rp.filter_table = (C.c_float * 256)(*table)
         rp.max_sample_luminance = self.film["max_lum"]; rp.scale = self.film["scale"]
         rp.spp = self.spp
         rp.sampler_type = {"sobol": A.PT_SAMPLER_SOBOL, "halton": A.PT_SAMPLER_HALTON}[self.sampler]
-        rp.sample_at_pixel_center = 1 if self.sample_at_pixel_center else 0
+        rp.sample_at_pixel_center = 1 if (self.sample_at_pixel_center and self.sampler == "halton") else 0   # a HaltonSampler parameter (halton.rs:226-236)
         sb = [math.floor(F(crop[0]) + F(0.5) - F(rx)), math.floor(F(crop[1]) + F(0.5) - F(ry)),
               math.ceil(F(crop[2]) - F(0.5) + F(rx)), math.ceil(F(crop[3]) - F(0.5) + F(ry))]  # film.rs:104-112
         rp.sample_bounds = (C.c_int32 * 4)(*sb)

@@ -301,12 +301,12 @@ def textured(xres=96, yres=64, spp=8, maxdepth=4, trilinear=False, bump=False, n
     if noise:   # Perlin-noise textures (fbm, wrinkled, windy, marble, dots), as colours, a float roughness and a bump map
         # texture space is shifted so that coordinates stay positive: the reference's noise() saturates negative lattice
         # cells to 0 (`x.floor() as usize`), which makes the interpolation weights explode for negative inputs
-        b.attribute_begin(); b.translate(-20.0, -20.0, -20.0); b.scale(0.5, 0.5, 0.5)
+        b.transform_begin(); b.translate(-20.0, -20.0, -20.0); b.scale(0.5, 0.5, 0.5)   # TransformBegin: AttributeBegin would pop the textures
         b.texture("marb", "color", "marble", scale=2.0, variation=0.4, octaves=6)
         b.texture("fbmf", "float", "fbm", octaves=5, roughness=0.6)
         b.texture("wrk", "color", "wrinkled", octaves=4)
         b.texture("wind", "float", "windy")
-        b.attribute_end()
+        b.transform_end()
         b.texture("dots", "color", "dots", uscale=8.0, vscale=6.0, inside=(0.9, 0.1, 0.1), outside="marb")
         b.texture("windbump", "float", "scale", tex1="wind", tex2=0.2)
         b.texture("wrkscaled", "color", "scale", tex1="wrk", tex2=(0.35, 0.3, 0.25))
