@@ -211,3 +211,67 @@ def test_front_end_twin_of_random_scenes(pkg, oracle, tmp_path, seed):
     ok = np.isfinite(ia).all(axis=2) & np.isfinite(ib).all(axis=2)
     diff = np.abs(ia - ib)[ok]; ref = np.maximum(np.abs(ia)[ok], 1e-2)
     assert (np.max(diff / ref, axis=1) > 0.05).mean() < 0.06   # a few pixels flip at silhouettes / checker edges; the rest agree
+
+
+def _edge_case_geometry(pkg, seed):
+    """Axis-aligned boxes on an integer lattice, degenerate and sliver triangles, coincident faces, far-away and tiny geometry."""
+    rng = np.random.default_rng(seed)
+    b = pkg.host.SceneBuilder()
+    b.max_node_prims = int(rng.choice([1, 2, 4]))
+    P, I = [], []
+    def add(p, i): base = sum(len(q) for q in P); P.append(np.asarray(p, np.float32)); I.append(np.asarray(i, np.uint32) + np.uint32(base))
+    for _ in range(int(rng.integers(3, 9))):   # lattice boxes: faces, edges and corners shared exactly
+        lo = rng.integers(-3, 3, 3).astype(np.float32); hi = lo + rng.integers(1, 3, 3).astype(np.float32)
+        c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
+        add(c, [[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]])
+    add([[0, 0, 0], [1, 0, 0], [1, 0, 0]], [[0, 1, 2]])                                  # two equal vertices
+    add([[0, 0, 0], [1, 1, 1], [2, 2, 2]], [[0, 1, 2]])                                  # collinear
+    add([[0, 5, 0], [1, 5, 0], [0.5, 5 + 1e-7, 0]], [[0, 1, 2]])                         # sliver
+    add([[-1, 4, -1], [1, 4, -1], [0, 4, 1]], [[0, 1, 2], [0, 1, 2], [2, 1, 0]])         # coincident, both windings
+    add(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]]) * 1e-4 + [0.5, 0.5, 0.5], [[0, 1, 2]])   # tiny
+    add(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]]) * 1e4 + [0, 0, -2e4], [[0, 1, 2]])       # huge and far
+    b.trianglemesh(np.concatenate(P), np.concatenate(I))
+    return b.world_end()[0]
+
+
+def _edge_case_rays(seed, n):
+    rng = np.random.default_rng(seed + 1000)
+    o = rng.integers(-4, 5, (n, 3)).astype(np.float32) * np.float32(0.5)                 # lattice and half-lattice origins: on faces / edges
+    d = np.zeros((n, 3), np.float32)
+    kind = rng.integers(0, 4, n)
+    ax = rng.integers(0, 3, n); sg = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    d[np.arange(n), ax] = sg                                                               # axis aligned (two zero components -> infinite reciprocals)
+    diag = kind == 1; d[diag] = rng.choice([-1.0, 0.0, 1.0], (int(diag.sum()), 3)).astype(np.float32)
+    rnd = kind >= 2; d[rnd] = rng.normal(size=(int(rnd.sum()), 3)).astype(np.float32)
+    zero = (d == 0).all(axis=1); d[zero, 0] = 1.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = np.where(rng.random(n) < 0.5, np.inf, rng.integers(1, 12, n) * 0.5).astype(np.float32)   # finite t_max exactly at lattice distances
+    return o, d.astype(np.float32), t
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_oracle_traces_edge_case_rays(pkg, oracle, seed):
+    s = oracle.scene(_edge_case_geometry(pkg, seed))
+    o, d, t = _edge_case_rays(seed, 5000)
+    prim, th, bb = s.trace_closest(o, d, t)
+    assert (prim != 0xFFFFFFFF).mean() > 0.1 and np.isfinite(th[prim != 0xFFFFFFFF]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_gpu_traversal_of_edge_case_rays(pkg, gpu, oracle, seed):
+    """Traversal corners: axis-aligned rays (zero direction components), origins on faces / edges / corners, t_max exactly at a hit,
+    degenerate, sliver, coincident, tiny and huge triangles. Hits (primitive, t, barycentrics), occlusion and the node / triangle
+    counters must be bit-identical."""
+    sd = _edge_case_geometry(pkg, seed)
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    o, d, t = _edge_case_rays(seed, 20000)
+    gp, gt, gb = g.trace_closest(o, d, t); gc = g.counters()
+    op, ot, ob = orc.trace_closest(o, d, t); oc = orc.counters()
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    for k in ("bvh_nodes_visited", "triangle_tests", "intersect_tests"): assert gc[k] == oc[k], k
+    tf = np.where(np.isinf(t), np.float32(50.0), t)
+    gh = g.trace_any(o, d, tf); gc = g.counters()
+    oh = orc.trace_any(o, d, tf); oc = orc.counters()
+    assert np.array_equal(gh, oh)
+    for k in ("bvh_nodes_visited", "triangle_tests", "shadow_tests"): assert gc[k] == oc[k], k
