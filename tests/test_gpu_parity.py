@@ -178,6 +178,24 @@ def test_tile_sharding_sums_to_full_render(pkg, gpu):
     assert np.array_equal(acc, full)  # box filter: disjoint pixels, bit-identical sum
 
 
+def test_tile_sharding_with_halton_and_volpath(pkg, gpu):
+    """The multi-GPU partition (16x16 sample tiles, tile_index % world == rank) under the Halton sampler and the volumetric
+    integrator: a sample's radiance depends only on (pixel, sample number), so the shards sum to the single render."""
+    b = pkg.scenes.foggy_room(xres=80, yres=48, spp=4); b.sampler = "halton"
+    sd, rp = b.world_end()
+    g = pkg.Scene(gpu, sd)
+    full = g.render(rp)
+    acc = np.zeros_like(full)
+    for r in range(4):
+        rp.tile_rank, rp.tile_world = r, 4
+        g.render(rp, film=acc)
+    # Halton's first dimension is not clamped below 1 (pbrt_macros:101): a sample can land in the neighbouring pixel, possibly of
+    # another shard, so those pixels are float sums in a different order
+    assert np.array_equal(acc[..., 3], full[..., 3])
+    np.testing.assert_allclose(acc[..., :3], full[..., :3], rtol=2e-6, atol=1e-7)
+    assert (acc[..., :3] == full[..., :3]).mean() > 0.99
+
+
 def test_full_size_properties(pkg, gpu):
     """BASELINE size (1920x1080, 4.3 M triangles) at 2 spp: size-independent properties instead of an oracle run:
     weight sum == spp in every pixel (box filter), film is finite and non-negative in Y, rendering twice is bit-identical
