@@ -69,7 +69,11 @@ typedef struct PtSphere {
     float radius, z_min, z_max, theta_min, theta_max, phi_max;
     uint32_t reverse_orientation;
     uint32_t transform_swaps_handedness;
+    /* kind = PT_QUADRIC_DISK: shapes/disk.rs:17-43 -- `z_min` = `z_max` = height, `radius`, `inner_radius`, `phi_max` (theta_* unused) */
+    uint32_t kind;
+    float inner_radius;
 } PtSphere;
+typedef enum PtQuadricKind { PT_QUADRIC_SPHERE = 0, PT_QUADRIC_DISK = 1 } PtQuadricKind;
 
 typedef enum PtMaterialType {
     PT_MAT_MATTE = 0,      /* materials/matte.rs      */

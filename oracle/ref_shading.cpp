@@ -364,7 +364,11 @@ RGB LightSampler::power(uint32_t li) const {
 
 // Shape::area: triangle.rs:550-554, sphere.rs:291-293
 static Float shape_area(const Scene &s, uint32_t sh) {
-    if ((sh >> 30) == PT_SHAPE_SPHERE) { const PtSphere &S = s.spheres[sh & 0x3fffffffu]; return S.phi_max * S.radius * (S.z_max - S.z_min); }
+    if ((sh >> 30) == PT_SHAPE_SPHERE) {
+        const PtSphere &S = s.spheres[sh & 0x3fffffffu];
+        if (S.kind == PT_QUADRIC_DISK) return S.phi_max * 0.5f * (S.radius * S.radius - S.inner_radius * S.inner_radius);   // disk.rs:120-122
+        return S.phi_max * S.radius * (S.z_max - S.z_min);
+    }
     return s.tri_area(sh & 0x3fffffffu);
 }
 
@@ -419,6 +423,28 @@ RGB LightSampler::sample_li(uint32_t li, const IData &ref, P2 u, V3 &wi, Float &
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
         uint32_t sh = s.prim_shape[L.prim];
+        if ((sh >> 30) == PT_SHAPE_SPHERE && s.spheres[sh & 0x3fffffffu].kind == PT_QUADRIC_DISK) {
+            // Disk::sample (disk.rs:124-139) + the default Shape::sample_interaction (shape.rs:40-52)
+            const PtSphere &S = s.spheres[sh & 0x3fffffffu];
+            P2 pd = concentric_sample_disk(u);
+            M4 o2w = m4_from(S.object_to_world), w2o = m4_from(S.world_to_object);
+            IData it;
+            it.n = normalize(xf_normal_inv(w2o, V3(0.0f, 0.0f, 0.1f)));
+            if (S.reverse_orientation) it.n = it.n * -1.0f;
+            it.p = xf_point_abs_err(o2w, V3(pd.x * S.radius, pd.y * S.radius, S.z_min), V3(0.0f, 0.0f, 0.0f), it.p_error);
+            pdf = 1.0f / shape_area(s, sh);
+            V3 w = it.p - ref.p;
+            if (length_squared(w) == 0.0f) pdf = 0.0f;
+            else {
+                w = normalize(w);
+                pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -w);
+                if (std::isinf(pdf)) pdf = 0.0f;
+            }
+            if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+            wi = normalize(it.p - ref.p);
+            p1 = it;
+            return area_l(li, it.n, -wi);
+        }
         if ((sh >> 30) == PT_SHAPE_SPHERE) {
             IData it = sphere_sample_interaction(s.spheres[sh & 0x3fffffffu], ref, u, pdf);
             if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
@@ -503,6 +529,14 @@ Float LightSampler::pdf_li(uint32_t li, const IData &ref, V3 wi) const {
     const PtLight &L = s.lights[li];
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // shape.rs:63-82 (intersect with s = None)
+        if ((s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE && s.spheres[s.prim_shape[L.prim] & 0x3fffffffu].kind == PT_QUADRIC_DISK) {   // Shape::pdf_wi default
+            Ray ray = spawn_ray(ref, wi);
+            Float thit; SurfaceInteraction il;
+            if (!s.sphere_intersect(s.prim_shape[L.prim] & 0x3fffffffu, ray, thit, il, false)) return 0.0f;
+            Float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * shape_area(s, s.prim_shape[L.prim]));
+            if (std::isinf(pdf)) pdf = 0.0f;
+            return pdf;
+        }
         if ((s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {  // Sphere::pdf_wi (sphere.rs:380-395)
             uint32_t si_ = s.prim_shape[L.prim] & 0x3fffffffu;
             const PtSphere &S = s.spheres[si_];

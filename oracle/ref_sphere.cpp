@@ -111,14 +111,65 @@ Bounds3 Scene::sphere_world_bound(uint32_t si) const {  // shape.rs:23-25 + sphe
     return ret;
 }
 
+// ---- Disk (shapes/disk.rs:55-118): the same PtSphere record with kind == PT_QUADRIC_DISK (z_min = height)
+static bool disk_hit(const PtSphere &S, const Ray &r, bool is_intersect_p, Float &t_out, V3 &p_hit_out, Float &phi_out, Ray &ray_obj) {
+    M4 w2o = m4_from(S.world_to_object);
+    V3 oerr, derr;
+    V3 o = xf_point_err(w2o, r.o, oerr);
+    V3 d = xf_vector_err(w2o, r.d, derr);
+    Float l2 = length_squared(d);
+    if (l2 > 0.0f) { Float dt = dot(vabs(d), oerr) / l2; o = o + d * dt; }   // transform_ray_error
+    ray_obj = Ray(o, d, r.t_max, r.time);
+    if (d.z == 0.0f) return false;
+    Float t = (S.z_min - o.z) / (is_intersect_p ? d.z : r.d.z);   // `r.d.z`: the world ray, as written at disk.rs:66
+    if (t <= 0.0f || t >= r.t_max) return false;
+    V3 ph = o + d * t;
+    Float dist2 = ph.x * ph.x + ph.y * ph.y;
+    if (dist2 > S.radius * S.radius || dist2 < S.inner_radius * S.inner_radius) return false;
+    Float phi = dm_atan2f(ph.y, ph.x);
+    if (phi < 0.0f) phi += 2.0f * PI;
+    if (phi > S.phi_max) return false;
+    t_out = t; p_hit_out = ph; phi_out = phi;
+    return true;
+}
+
 bool Scene::sphere_intersect_p(uint32_t si, const Ray &r) const {
     Float t, phi; V3 ph; Ray ro;
+    if (spheres[si].kind == PT_QUADRIC_DISK) return disk_hit(spheres[si], r, true, t, ph, phi, ro);
     return sphere_hit(spheres[si], r, true, t, ph, phi, ro);
 }
 
-bool Scene::sphere_intersect(uint32_t si, const Ray &r, Float &thit, SurfaceInteraction &out, bool) const {
+bool Scene::sphere_intersect(uint32_t si, const Ray &r, Float &thit, SurfaceInteraction &out, bool with_shape) const {
     const PtSphere &S = spheres[si];
     Float t, phi; V3 p_hit; Ray ray;
+    if (S.kind == PT_QUADRIC_DISK) {   // disk.rs:55-99
+        if (!disk_hit(S, r, false, t, p_hit, phi, ray)) return false;
+        Float dist2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+        Float r_hit = std::sqrt(dist2);
+        Float u = phi / S.phi_max, v = (S.radius - r_hit) / (S.radius - S.inner_radius);
+        V3 dpdu(-S.phi_max * p_hit.y, S.phi_max * p_hit.x, 0.0f);
+        V3 dpdv = V3(p_hit.x, p_hit.y, 0.0f) * (S.inner_radius - S.radius) / r_hit;
+        p_hit.z = S.z_min;
+        // SurfaceInteraction::new (interaction.rs:186-216): the normal flips only when the interaction knows its shape
+        bool flip = with_shape && ((S.reverse_orientation != 0) != (S.transform_swaps_handedness != 0));
+        V3 n = normalize(cross(dpdu, dpdv));
+        if (flip) n = -n;
+        V3 wo = normalize(-ray.d);
+        M4 o2w = m4_from(S.object_to_world), w2o = m4_from(S.world_to_object);
+        SurfaceInteraction ret;
+        ret.p = xf_point_abs_err(o2w, p_hit, V3(0.0f, 0.0f, 0.0f), ret.p_error);
+        ret.n = normalize(xf_normal_inv(w2o, n));
+        ret.wo = normalize(xf_vector(o2w, wo));
+        ret.uv = P2(u, v);
+        ret.dpdu = xf_vector(o2w, dpdu); ret.dpdv = xf_vector(o2w, dpdv);
+        ret.sh_n = face_forward(normalize(xf_normal_inv(w2o, n)), ret.n);
+        ret.sh_dpdu = ret.dpdu; ret.sh_dpdv = ret.dpdv;
+        ret.sh_dndu = V3(0.0f, 0.0f, 0.0f); ret.sh_dndv = V3(0.0f, 0.0f, 0.0f);
+        ret.has_shape = with_shape; ret.shape_flip = flip;
+        out = ret;
+        thit = t;
+        return true;
+    }
     if (!sphere_hit(S, r, false, t, p_hit, phi, ray)) return false;
     // sphere.rs:148-192
     Float u = phi / S.phi_max;

@@ -26,6 +26,7 @@ PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
 PT_SAMPLER_SOBOL, PT_SAMPLER_HALTON = range(2)
 PT_INTEGRATOR_PATH, PT_INTEGRATOR_VOLPATH = range(2)
+PT_QUADRIC_SPHERE, PT_QUADRIC_DISK = range(2)
 
 
 def shape_ref(kind, index):
@@ -39,7 +40,7 @@ fp, u32p, u8p, i32p, u64p = C.POINTER(f32), C.POINTER(u32), C.POINTER(u8), C.POI
 class PtSphere(C.Structure):
     _fields_ = [("object_to_world", f32 * 16), ("world_to_object", f32 * 16),
                 ("radius", f32), ("z_min", f32), ("z_max", f32), ("theta_min", f32), ("theta_max", f32),
-                ("phi_max", f32), ("reverse_orientation", u32), ("transform_swaps_handedness", u32)]
+                ("phi_max", f32), ("reverse_orientation", u32), ("transform_swaps_handedness", u32), ("kind", u32), ("inner_radius", f32)]
 
 
 class PtMaterial(C.Structure):

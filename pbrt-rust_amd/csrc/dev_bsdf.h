@@ -12,16 +12,6 @@ enum LobeKind : uint8_t { LB_LAMBERT_R, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, 
                           LB_DISNEY_DIFFUSE, LB_DISNEY_FAKESS, LB_DISNEY_RETRO, LB_DISNEY_SHEEN, LB_DISNEY_CLEARCOAT };   // materials/disney.rs
 enum FresnelKind : uint8_t { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR, FR_DISNEY };
 
-// sampling.rs:153-176
-PT_DEV P2 concentric_sample_disk(P2 u) {
-    float ox = u.x * 2.0f - 1.0f, oy = u.y * 2.0f - 1.0f;
-    if (ox == 0.0f && oy == 0.0f) return P2(0.0f, 0.0f);
-    float theta, r;
-    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
-    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
-    float s, c; dm_sincosf(theta, s, c);
-    return P2(c * r, s * r);
-}
 PT_DEV V3 cosine_sample_hemisphere(P2 u) {  // sampling.rs:188-193
     P2 d = concentric_sample_disk(u);
     float z = sqrtf(maxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));

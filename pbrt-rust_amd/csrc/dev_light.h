@@ -158,6 +158,28 @@ template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li
     p1.p = V3(); p1.p_error = V3(); p1.n = V3();
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
+        if (SPH && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE && s.spheres[s.prim_shape[L.prim] & 0x3fffffffu].kind == PT_QUADRIC_DISK) {
+            // Disk::sample (disk.rs:124-139: the whole disk of `radius`, normal from (0, 0, 0.1)) + Shape::sample_interaction (shape.rs:40-52)
+            const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];
+            const P2 pd = concentric_sample_disk(u);
+            const M4 o2w = ldm4g(S.object_to_world), w2o = ldm4g(S.world_to_object);
+            IData it;
+            it.n = normalize(xf_normal_inv(w2o, V3(0.0f, 0.0f, 0.1f)));
+            if (S.reverse_orientation) it.n = it.n * -1.0f;
+            it.p = xf_point_abs_err(o2w, V3(pd.x * S.radius, pd.y * S.radius, S.z_min), V3(0.0f, 0.0f, 0.0f), it.p_error);
+            pdf = 1.0f / s.light_area[li];
+            V3 w = it.p - ref.p;
+            if (length_squared(w) == 0.0f) pdf = 0.0f;
+            else {
+                w = normalize(w);
+                pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -w);
+                if (__builtin_isinf(pdf)) pdf = 0.0f;
+            }
+            if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+            wi = normalize(it.p - ref.p);
+            p1 = it;
+            return area_l(L, it.n, -wi);
+        }
         if (SPH && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {   // SPH == false: the scene holds no sphere
             IData it = sphere_sample_interaction(s.spheres[s.prim_shape[L.prim] & 0x3fffffffu], ref, u, pdf);
             if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
@@ -244,6 +266,16 @@ template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li,
 #ifdef PT_ABL_LIGHTPDF   // timing ablation only
     return 0.5f + 0.0f * L.L[0];
 #endif
+    if (SPH && L.type == PT_LIGHT_DIFFUSE_AREA && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE && s.spheres[s.prim_shape[L.prim] & 0x3fffffffu].kind == PT_QUADRIC_DISK) {
+        // Shape::pdf_wi (shape.rs:59-73): intersect without a shape (no orientation flip), signed cosine
+        const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];
+        V3 o; spawn_ray(ref, wi, o);
+        SurfaceInteraction il;
+        if (!sphere_fill_interaction(S, o, wi, il, false)) return 0.0f;
+        float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * s.light_area[li]);
+        if (__builtin_isinf(pdf)) pdf = 0.0f;
+        return pdf;
+    }
     if (SPH && L.type == PT_LIGHT_DIFFUSE_AREA && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE) {  // Sphere::pdf_wi (sphere.rs:380-395)
         const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];
         const V3 pcenter = xf_point(ldm4g(S.object_to_world), V3(0.0f, 0.0f, 0.0f));

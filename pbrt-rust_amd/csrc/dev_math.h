@@ -341,4 +341,15 @@ PT_HDX V3 offset_ray_origin(V3 p, V3 perr, V3 n, V3 w) {
 PT_HD float spherical_theta(V3 v) { return dm_acosf(clampf(v.z, -1.0f, 1.0f)); }  // geometry.rs:39-42
 PT_HD float spherical_phi(V3 v) { float p = dm_atan2f(v.y, v.x); return (p < 0.0f) ? p + 2.0f * kPi : p; }
 
+// sampling.rs:153-176
+PT_HD P2 concentric_sample_disk(P2 u) {
+    float ox = u.x * 2.0f - 1.0f, oy = u.y * 2.0f - 1.0f;
+    if (ox == 0.0f && oy == 0.0f) return P2(0.0f, 0.0f);
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
+    else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
+    float s, c; dm_sincosf(theta, s, c);
+    return P2(c * r, s * r);
+}
+
 }  // namespace ptd

@@ -81,6 +81,19 @@ PT_DEV bool sphere_hit(const PtSphere &S, V3 r_o, V3 r_d, float r_tmax, bool is_
     const float l2 = length_squared(d);
     if (l2 > 0.0f) { const float dt = dot(vabs(d), oerr) / l2; o = o + d * dt; }
     d_obj = d;
+    if (S.kind == PT_QUADRIC_DISK) {   // Disk::intersect / intersect_p (disk.rs:55-118)
+        if (d.z == 0.0f) return false;
+        const float t = (S.z_min - o.z) / (is_intersect_p ? d.z : r_d.z);   // intersect divides by the WORLD ray's d.z, as written there (disk.rs:66)
+        if (t <= 0.0f || t >= r_tmax) return false;
+        V3 ph = o + d * t;
+        const float dist2 = ph.x * ph.x + ph.y * ph.y;
+        if (dist2 > S.radius * S.radius || dist2 < S.inner_radius * S.inner_radius) return false;
+        float phi = dm_atan2f(ph.y, ph.x);
+        if (phi < 0.0f) phi += 2.0f * kPi;
+        if (phi > S.phi_max) return false;
+        t_out = t; p_hit_out = ph; phi_out = phi;
+        return true;
+    }
     const EFloat ox(o.x, oerr.x), oy(o.y, oerr.y), oz(o.z, oerr.z), dx(d.x, derr.x), dy(d.y, derr.y), dz(d.z, derr.z);
     const EFloat a = dx * dx + dy * dy + dz * dz;
     const EFloat b = EFloat(2.0f) * (dx * ox + dy * oy + dz * oz);
@@ -112,9 +125,33 @@ PT_DEV bool sphere_hit(const PtSphere &S, V3 r_o, V3 r_d, float r_tmax, bool is_
 
 // Sphere::intersect's SurfaceInteraction (sphere.rs:148-192) for a ray known to hit (re-evaluated at shade time with
 // t_max = inf: the accepted root does not depend on t_max once the hit was accepted).
-PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceInteraction &si) {
+// `with_shape`: the interaction knows its shape (GeometricPrimitive::intersect passes it, Shape::pdf_wi does not): only then
+// SurfaceInteraction::new flips the normal for reverse_orientation ^ transform_swaps_handedness (interaction.rs:194-199).
+PT_DEV bool sphere_fill_interaction(const PtSphere &S, V3 r_o, V3 r_d, SurfaceInteraction &si, bool with_shape = true) {
     float t, phi; V3 p_hit, d_obj;
     if (!sphere_hit(S, r_o, r_d, PT_INF, false, t, p_hit, phi, d_obj)) return false;
+    if (S.kind == PT_QUADRIC_DISK) {   // disk.rs:78-96
+        const float dist2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+        const float r_hit = sqrtf(dist2);
+        si.uv = P2(phi / S.phi_max, (S.radius - r_hit) / (S.radius - S.inner_radius));
+        const V3 dpdu(-S.phi_max * p_hit.y, S.phi_max * p_hit.x, 0.0f);
+        const V3 dpdv = V3(p_hit.x, p_hit.y, 0.0f) * (S.inner_radius - S.radius) / r_hit;
+        p_hit.z = S.z_min;
+        const bool flip = with_shape && ((S.reverse_orientation != 0) != (S.transform_swaps_handedness != 0));
+        V3 n = normalize(cross(dpdu, dpdv));
+        if (flip) n = -n;
+        const V3 wo = normalize(-d_obj);
+        const M4 o2w = ldm4g(S.object_to_world), w2o = ldm4g(S.world_to_object);
+        si.p = xf_point_abs_err(o2w, p_hit, V3(0.0f, 0.0f, 0.0f), si.p_error);
+        si.n = normalize(xf_normal_inv(w2o, n));
+        si.wo = normalize(xf_vector(o2w, wo));
+        si.dpdu = xf_vector(o2w, dpdu); si.dpdv = xf_vector(o2w, dpdv);
+        si.sh_n = face_forward(normalize(xf_normal_inv(w2o, n)), si.n);
+        si.sh_dpdu = si.dpdu; si.sh_dpdv = si.dpdv;
+        si.sh_dndu = V3(0.0f, 0.0f, 0.0f); si.sh_dndv = V3(0.0f, 0.0f, 0.0f);
+        si.has_shape = with_shape; si.shape_flip = flip;
+        return true;
+    }
     const float theta = dm_acosf(clampf(p_hit.z / S.radius, -1.0f, 1.0f));
     si.uv = P2(phi / S.phi_max, (theta - S.theta_min) / (S.theta_max - S.theta_min));   // sphere.rs:148-152
     const float zradius = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);

@@ -141,7 +141,8 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
             a = tri_area(ld3(s.P, s.indices[3 * tri]), ld3(s.P, s.indices[3 * tri + 1]), ld3(s.P, s.indices[3 * tri + 2]));
         } else {  // Sphere::area (sphere.rs:291-293)
             const PtSphere &S = s.spheres[shape & 0x3fffffffu];
-            a = S.phi_max * S.radius * (S.z_max - S.z_min);
+            a = S.kind == PT_QUADRIC_DISK ? S.phi_max * 0.5f * (S.radius * S.radius - S.inner_radius * S.inner_radius)   // Disk::area (disk.rs:120-122)
+                                          : S.phi_max * S.radius * (S.z_max - S.z_min);
         }
     }
     area[i] = a;

@@ -465,6 +465,15 @@ private:
             s.reverse_orientation = gs.reverse ? 1u : 0u; s.transform_swaps_handedness = gs.ctm.swaps_handedness() ? 1u : 0u;
             sc.spheres.push_back(s);
             add_prim(((uint32_t)PT_SHAPE_SPHERE << 30) | ((uint32_t)sc.spheres.size() - 1));
+        } else if (kind == "disk") {   // disk.rs:17-43,175-189: a PtSphere record of kind PT_QUADRIC_DISK
+            auto cl = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+            PtSphere s{}; gs.ctm.flat(s.object_to_world); gs.ctm.flat(s.world_to_object, true);
+            s.kind = PT_QUADRIC_DISK; s.radius = p.one_float("radius", 1.0f); s.inner_radius = p.one_float("innerradius", 0.0f);
+            s.z_min = s.z_max = p.one_float("height", 0.0f);
+            s.phi_max = (3.14159265358979323846f / 180.0f) * cl(p.one_float("phimax", 360.0f), 0.0f, 360.0f);
+            s.reverse_orientation = gs.reverse ? 1u : 0u; s.transform_swaps_handedness = gs.ctm.swaps_handedness() ? 1u : 0u;
+            sc.spheres.push_back(s);
+            add_prim(((uint32_t)PT_SHAPE_SPHERE << 30) | ((uint32_t)sc.spheres.size() - 1));
         } else fail(d, "shape \"" + kind + "\" is not implemented on this back end");
     }
     void object_instance(const Token &d, const std::string &name) {   // api.rs:1669-1713

@@ -518,6 +518,25 @@ class SceneBuilder:
         return first_prim
 
     # -- instancing (api.rs:1630-1713)
+    def disk(self, height=0.0, radius=1.0, innerradius=0.0, phimax=360.0):
+        """shapes/disk.rs:17-43,175-189: stored in the sphere table with kind = PT_QUADRIC_DISK (z_min = z_max = height)."""
+        s = A.PtSphere()
+        s.object_to_world = (C.c_float * 16)(*self.ctm.m.flatten()); s.world_to_object = (C.c_float * 16)(*self.ctm.m_inv.flatten())
+        s.kind = A.PT_QUADRIC_DISK; s.radius = F(radius); s.inner_radius = F(innerradius); s.z_min = s.z_max = F(height)
+        s.phi_max = F(math.pi / 180.0) * F(min(max(F(phimax), F(0)), F(360)))
+        s.reverse_orientation = 1 if self.reverse_orientation else 0
+        s.transform_swaps_handedness = 1 if self.ctm.swaps_handedness() else 0
+        self.spheres.append(s)
+        first_prim = self.nprims
+        self.prim_shape.append(np.array([(A.PT_SHAPE_SPHERE << 30) | (len(self.spheres) - 1)], dtype=np.uint32))
+        self.prim_material.append(np.array([A.PT_NONE if self.material_id is None else self.material_id], dtype=np.uint32))
+        self._prim_media(1)
+        self.prim_light.append(np.array([A.PT_NONE if (self.area_light is None or self.current_object is not None) else self._new_area_light(first_prim)], dtype=np.uint32))
+        if self.current_object is None: self.top_refs.append(np.array([first_prim], dtype=np.uint32))
+        else: self.objects[self.current_object][1] += 1
+        self.nprims += 1
+        return first_prim
+
     def object_begin(self, name):
         self.attribute_begin()
         self.objects[name] = [self.nprims, 0]

@@ -462,6 +462,40 @@ def disney_spheres(xres=96, yres=64, spp=16, maxdepth=5, textured=False):
     return b
 
 
+def disk_scene(xres=96, yres=64, spp=16, maxdepth=5):
+    """shapes/disk.rs as surfaces and as area lights: full, annular and partial-sweep disks, a non-uniformly scaled and a mirrored
+    (handedness-swapping) one, ReverseOrientation, a two-sided-looking pair of emitters (disk lights emit towards their normal
+    only, diffuse.rs:73-82) and a disk inside an object instance."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 2.6, 6.5), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.15, 0.17, 0.2))
+    b.attribute_begin(); b.area_light_source(L=(14.0, 13.0, 12.0))   # facing down: rotate the +z normal to -y
+    b.translate(-1.0, 4.0, 0.0); b.rotate(90.0, 1.0, 0.0, 0.0); b.disk(radius=1.1, innerradius=0.3); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(4.0, 9.0, 14.0))     # partial sweep, reversed so that it emits upwards-sideways
+    b.translate(2.4, 0.4, 0.5); b.rotate(-60.0, 0.0, 1.0, 0.0); b.toggle_reverse_orientation()
+    b.disk(radius=0.6, phimax=250.0); b.attribute_end()
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    b.attribute_begin(); b.translate(0.0, -0.5, 0.0); b.rotate(-90.0, 1.0, 0.0, 0.0); b.disk(radius=9.0); b.attribute_end()   # floor
+    b.material("plastic", Kd=(0.7, 0.3, 0.2), Ks=(0.4, 0.4, 0.4), roughness=0.08)
+    b.attribute_begin(); b.translate(-2.2, 0.6, 0.0); b.rotate(-35.0, 1.0, 0.2, 0.0); b.disk(radius=0.9, innerradius=0.35, phimax=300.0); b.attribute_end()
+    b.material("metal", roughness=0.05)
+    b.attribute_begin(); b.translate(0.0, 0.8, -1.5); b.scale(1.6, 0.8, 1.0); b.disk(height=0.2, radius=1.0); b.attribute_end()
+    b.material("glass", index=1.5)
+    b.attribute_begin(); b.translate(1.2, 0.5, 1.2); b.scale(-1.0, 1.0, 1.0); b.rotate(25.0, 0.0, 1.0, 0.0); b.disk(radius=0.7, phimax=200.0); b.attribute_end()
+    # z-preserving transforms: the only ones for which Disk::intersect's world-space r.d.z (disk.rs:65) is the right divisor
+    b.material("uber", Kd=(0.3, 0.4, 0.7), Ks=(0.3, 0.3, 0.3), roughness=0.2)
+    b.attribute_begin(); b.translate(0.0, 1.2, -3.0); b.rotate(30.0, 0.0, 0.0, 1.0); b.scale(1.5, 1.0, 1.0); b.disk(radius=1.6, innerradius=0.5, phimax=300.0); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(6.0, 6.0, 6.0)); b.translate(0.0, 2.0, 5.0); b.toggle_reverse_orientation(); b.disk(radius=0.8); b.attribute_end()
+    b.material("matte", Kd=(0.2, 0.6, 0.3))
+    b.object_begin("d"); b.disk(radius=0.4, innerradius=0.1); b.sphere(radius=0.15); b.object_end()
+    for k in range(3):
+        b.attribute_begin(); b.translate(-1.5 + 1.5 * k, 0.1, 2.6); b.rotate(-60.0 + 20.0 * k, 1.0, 0.0, 0.0); b.object_instance("d"); b.attribute_end()
+    return b
+
+
 def foggy_room(xres=96, yres=64, spp=16, maxdepth=5, g=0.3, camera_in_fog=True, strategy="spatial"):
     """integrators/volpath.rs + media/homogeneous.rs: the camera sits in a thin homogeneous fog that fills the world (surfaces
     without a MediumInterface keep the ray's medium, primitive.rs:139-145); a glass sphere holds a dense coloured medium (its

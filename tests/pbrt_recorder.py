@@ -117,6 +117,7 @@ def make_recorder(pkg, out_dir):
             self._emit('Shape "trianglemesh" ' + " ".join(parts)); super().trianglemesh(P, indices, N=N, UV=UV, S=S, alpha=alpha, shadowalpha=shadowalpha)
 
         def sphere(self, **kw): self._emit('Shape "sphere" ' + self._params(kw)); super().sphere(**kw)
+        def disk(self, **kw): self._emit('Shape "disk" ' + self._params(kw)); super().disk(**kw)
         def object_begin(self, name): self._emit('ObjectBegin "%s"' % name); super().object_begin(name); self.lines.pop()   # the base class' AttributeBegin is implied
         def object_end(self): super().object_end(); self.lines.pop(); self._emit("ObjectEnd")
         def object_instance(self, name): self._emit('ObjectInstance "%s"' % name); super().object_instance(name)

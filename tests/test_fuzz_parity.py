@@ -38,11 +38,19 @@ def random_scene(pkg, seed, builder=None):
         if k == "point": x = u(-3, 3); b.light_source("point", from_=(x, u(1.5, 4), x), I=rgb(2, 15))
         elif k == "spot": b.light_source("spot", from_=(u(-3, 3), u(2, 4), u(-1, 3)), to=(u(-1, 1), 0.0, u(-1, 1)), I=rgb(5, 40), coneangle=u(15, 50), conedeltaangle=u(2, 10))
         else: b.light_source("distant", from_=(u(-3, 3), u(2, 5), u(-3, 3)), to=(0.0, 0.0, 0.0), L=rgb(0.3, 2.0))
+    # Disk::intersect divides by the WORLD ray's d.z (disk.rs:65): under a transform that does not keep z the reported hit is off
+    # the ray, and a BSSRDF probe chain (bssrdf.rs:376-394) through such a disk need not make progress -- chains of > 10^5
+    # segments were seen, beyond the device's 15-bit chain counter. Scenes with subsurface materials keep their disks z-aligned.
+    sss_ok = (not volpath) and rng.random() < 0.6
     b.attribute_begin(); b.area_light_source(L=rgb(5, 25), twosided=bool(rng.random() < 0.4))
     if rng.random() < 0.5:
         P, I = S.quad((-0.8, 3.5, -0.8), (0.8, 3.5, -0.8), (0.8, 3.5, 0.8), (-0.8, 3.5, 0.8)); b.trianglemesh(P, I)
-    else:
+    elif rng.random() < 0.5:
         b.translate(u(-1, 1), 3.2, u(-1, 1)); b.sphere(radius=u(0.15, 0.4))
+    elif sss_ok:   # a disk light whose transform keeps z (see sss_ok above): in front of the scene, reversed so that it emits to -z
+        b.translate(u(-1, 1), u(1.5, 2.5), 4.0); b.rotate(u(0, 360), 0.0, 0.0, 1.0); b.toggle_reverse_orientation(); b.disk(radius=u(0.4, 0.9), innerradius=pick(0.0, u(0.0, 0.3)), phimax=pick(360.0, u(200, 360)))
+    else:   # a disk light facing down (disk.rs): rotate its +z normal towards -y
+        b.translate(u(-1, 1), 3.4, u(-1, 1)); b.rotate(90.0 + u(-20, 20), 1.0, 0.0, 0.0); b.disk(radius=u(0.4, 0.9), innerradius=pick(0.0, u(0.0, 0.3)), phimax=pick(360.0, u(200, 360)))
     b.attribute_end()
     # textures
     b.texture("chk", "spectrum", "checkerboard", uscale=u(2, 8), vscale=u(2, 8), tex1=rgb(), tex2=rgb(), aamode=pick("none", "closedform"))
@@ -67,7 +75,7 @@ def random_scene(pkg, seed, builder=None):
     b.texture("img2", "spectrum", "imagemap", pixels=S.test_image(9, 7, seed=int(rng.integers(1, 99))), wrap=pick("repeat", "black"), gamma=bool(rng.random() < 0.3), scale=u(0.5, 1.5), maxanisotropy=pick(2.0, 8.0, 16.0), **mapping())
     b.texture("holes", "float", "checkerboard", uscale=u(2, 5), vscale=u(2, 5), tex1=1.0, tex2=0.0)
     col = lambda: pick(rgb(), rgb(), "chk", "img", "dots", "uvt", "bil", "mixt", "sclt", "img2", "wrk", "mrb", "chk3")
-    def random_material(allow_mix=True, allow_sss=not volpath):
+    def random_material(allow_mix=True, allow_sss=sss_ok):
         kinds = ["matte", "mirror", "glass", "glass_rough", "plastic", "metal", "uber", "substrate", "translucent", "disney", "disney_thin"]
         if allow_mix: kinds.append("mix")
         if allow_sss: kinds += ["subsurface", "kdsubsurface", "disney_sss"]
@@ -115,9 +123,13 @@ def random_scene(pkg, seed, builder=None):
         random_material()
         b.translate(u(-2.5, 2.5), u(-0.1, 0.8), u(-2.0, 1.5))
         if rng.random() < 0.3: b.toggle_reverse_orientation()
-        shape = pick("sphere", "partial", "mesh", "quad")
+        shape = pick("sphere", "partial", "mesh", "quad", "disk")
         if shape == "sphere": b.sphere(radius=u(0.3, 0.7))
         elif shape == "partial": b.rotate(u(0, 360), u(-1, 1), 1.0, u(-1, 1)); b.scale(u(0.7, 1.3), u(0.7, 1.3), u(0.7, 1.3)); r = u(0.3, 0.7); b.sphere(radius=r, zmin=-r * u(0.2, 1.0), zmax=r * u(0.2, 1.0), phimax=u(120, 360))
+        elif shape == "disk":
+            if sss_ok: b.rotate(u(0, 360), 0.0, 0.0, 1.0)
+            else: b.rotate(u(0, 360), u(-1, 1), 1.0, u(-1, 1))
+            b.scale(u(0.7, 1.3), u(0.7, 1.3), 1.0); b.disk(height=u(-0.2, 0.2), radius=u(0.4, 0.9), innerradius=pick(0.0, u(0.05, 0.3)), phimax=pick(360.0, u(90, 360)))
         elif shape == "mesh":
             Pm, Im, Nm = S.displaced_sphere(int(pick(4, 8)), with_normals=bool(rng.random() < 0.5)); b.trianglemesh(Pm * np.float32(u(0.3, 0.6)), Im, N=Nm)
         else:

@@ -400,6 +400,20 @@ def test_disney_material_matches_oracle(pkg, gpu, oracle, textured):
     assert film[..., :3].sum() > 0
 
 
+def test_disk_shapes_and_lights_match_oracle(pkg, gpu, oracle):
+    """shapes/disk.rs: intersect (incl. its world-space r.d.z parallel test), sample / pdf as diffuse area lights, annulus and
+    partial sweeps, scaled / mirrored / reversed / instanced disks."""
+    sd, rp = pkg.scenes.disk_scene().world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp)
+    assert film[..., :3].sum() > 0
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    o, d = _random_rays(100000, 11); tmax = np.full(len(o), np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(o, d, tmax); op, ot, ob = orc.trace_closest(o, d, tmax)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(g.trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
+    for k in ("bvh_nodes_visited", "intersect_tests", "shadow_tests"): assert g.counters()[k] == orc.counters()[k], k
+
+
 def test_disney_limits_are_reported(pkg, gpu):
     b = pkg.scenes.disney_spheres()
     b.material("disney", sheen=0.5, clearcoat=0.5, spectrans=0.5, thin=True)   # 8 BxDFs
