@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 disables)")
     ap.add_argument("--dump-image", default="")
+    ap.add_argument("--sim-world", type=int, default=0, help="single-GPU study: render rank 0's shard of an N-rank job (value is then this rank's share only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,6 +68,7 @@ def main():
     scene = pkg.Scene(lib, sd)        # host SAH build + upload + packet build
     t_up = time.time() - t_up
     rp.tile_rank, rp.tile_world = rank, world
+    if args.sim_world > 1 and world == 1: rp.tile_rank, rp.tile_world = 0, args.sim_world
     rp.spp_per_pass = args.spp_per_pass
     rp.profile = 1                    # HIP events around every launch, on the render stream
     cb = rp.cropped_pixel_bounds

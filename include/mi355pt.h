@@ -40,7 +40,10 @@ typedef enum PtStatus {
                                      (the reference panics: samplers/sobol.rs:69-73)         */
     PT_ERR_STACK_OVERFLOW = 6,    /* BVH traversal stack deeper than 64 entries
                                      (the reference has no check: accelerators/bvh.rs:722)   */
-    PT_ERR_OUT_OF_MEMORY = 7
+    PT_ERR_OUT_OF_MEMORY = 7,
+    PT_ERR_PROBE_CHAIN = 8        /* a BSSRDF probe chain (core/bssrdf.rs:376-394) found more than 32767 intersections or a
+                                     pass needed more than 65536 wavefront iterations: the reference would still be walking its
+                                     linked list; the render is abandoned instead of returning a truncated chain          */
 } PtStatus;
 
 /* ---- scene description -------------------------------------------------------------- */

@@ -7,7 +7,7 @@ import ctypes as C
 
 PT_OK = 0
 PT_ERR_INVALID_ARG, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_UNSUPPORTED = 1, 2, 3, 4
-PT_ERR_SOBOL_DIMENSIONS, PT_ERR_STACK_OVERFLOW, PT_ERR_OUT_OF_MEMORY = 5, 6, 7
+PT_ERR_SOBOL_DIMENSIONS, PT_ERR_STACK_OVERFLOW, PT_ERR_OUT_OF_MEMORY, PT_ERR_PROBE_CHAIN = 5, 6, 7, 8
 
 PT_TRI_REVERSE_ORIENTATION = 1
 PT_TRI_SWAPS_HANDEDNESS = 2

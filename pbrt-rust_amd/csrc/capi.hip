@@ -396,11 +396,13 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     sc->end();
     int cur = 0;
     static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
-    for (int iter = 0; iter < 4096; ++iter) {
+    const int kMaxIterations = 65536;   // a path needs <= max_depth + null-surface skips + probe segments iterations
+    for (int iter = 0; iter <= kMaxIterations; ++iter) {
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
-        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : "Sobol dimension overflow (>= 1024)");
+        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 32767 intersections" : "Sobol dimension overflow (>= 1024)");
+        if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 65536 wavefront iterations");
         const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
         if (n_ext == 0 && n_resolve == 0 && n_probe == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);

@@ -10,7 +10,10 @@ namespace ptd {
 constexpr int kNumClasses = 6;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
 constexpr int kMissClass = 4, kMediumClass = 5;   // 5 = medium vertices of the volumetric integrator (k_shade_medium)
 //       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
-constexpr int kLdsStack = 12;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
+constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
 

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
     uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
-    uint32_t *spill = job.spill + ((size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 + lane) * (2 * (kMaxStack - kLdsStack));
+    // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
+    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLdsStack)) + lane;
     const uint32_t count = *job.count;
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
             sp--;
             uint32_t w0, w1;
             if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
-            else { w0 = spill[2 * (sp - kLdsStack)]; w1 = spill[2 * (sp - kLdsStack) + 1]; }
+            else { w0 = spill[(2 * (sp - kLdsStack)) * 64]; w1 = spill[(2 * (sp - kLdsStack) + 1) * 64]; }
             if (SPH && w1 == kMarker) {                // the object's BVH is exhausted: back to world space (primitive.rs:70-77)
                 pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
                 ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]); rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                     else {
                         const uint32_t w0 = far_ref | (pending << 25), w1 = __float_as_uint(tmin_far);
                         if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
-                        else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = w1; }
+                        else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = w1; }
                         sp++; pending = 0;
                     }
                 } else pending++;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                             if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
                             else {
                                 if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
-                                else { spill[2 * (sp - kLdsStack)] = w0; spill[2 * (sp - kLdsStack) + 1] = kMarker; }
+                                else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = kMarker; }
                                 sp++; pending = 0;
                                 t_max_world = t_max; in_inst = q2.z; inst_hit = false;
                                 ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
@@ -1258,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
         if (hp != PT_NONE) {
             fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
             const bool match = s.prim_material[hp] == mat;   // bssrdf.rs:385-391
-            if (!rewalk) { if (match && nfound < 0xffffu) nfound++; }
+            if (!rewalk) { if (match) { if (nfound < 0x7fffu) nfound++; else atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); } }   // `seen` has 15 bits
             else if (match) {
                 // bssrdf.rs:398: selected = clamp((u1n * nfound) as usize, 0, nfound - 1)
                 const uint32_t selected = min(f2u32_sat(u1n * (float)nfound), nfound - 1u);

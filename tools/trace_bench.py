@@ -49,3 +49,21 @@ run("bounce_closest", p2, v, np.full(len(p2), np.inf, np.float32))
 run("bounce_any", p2, v, np.full(len(p2), 3.0, np.float32), any_hit=True)
 perm = rng.permutation(len(p2))
 run("bounce_closest_shuffled", p2[perm], v[perm], np.full(len(p2), np.inf, np.float32))
+# Bound study: (1) every ray identical -> all 64 lanes of a step fetch ONE record: the issue/ALU ceiling of the loop;
+# (2) groups of 64 identical rays -> each wave step touches one record but waves differ: adds the cache-capacity effect
+# without per-lane address divergence; (3) groups of 8.
+m = int(os.environ.get('STUDY_RAYS', '16000000'))   # large enough that ramp-up and drain of the persistent waves do not matter
+sel = rng.integers(0, len(p2), size=m)
+inf = np.full(m, np.inf, np.float32)
+one = np.repeat(sel[:1], m)
+run("identical_rays", p2[one], v[one], inf)
+g64 = np.repeat(sel[: m // 64], 64)[:m]
+run("groups_of_64", p2[g64], v[g64], inf[: len(g64)])
+g8 = np.repeat(sel[: m // 8], 8)[:m]
+run("groups_of_8", p2[g8], v[g8], inf[: len(g8)])
+run("independent_same_count", p2[sel], v[sel], inf)
+# (4) K distinct rays tiled over the launch: every wave step has 64 different addresses (full per-lane divergence) but the
+# footprint of the whole launch is K rays' worth of records -- separates the address-processing cost from cache misses.
+for K in (64, 4096, 262144):
+    t = np.tile(sel[:K], m // K)
+    run(f"tiled_{K}_distinct", p2[t], v[t], inf[: len(t)])
