@@ -86,16 +86,25 @@ struct Hit { uint32_t prim; float t, b0, b1, b2; };
 PT_DEV V3 ld3(const float *p, uint32_t i) { return V3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 
 // Watertight ray-triangle test shared by intersect / intersect_p (triangle.rs:136-233 == :400-495).
-PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float t_max, float &t, float &b0, float &b1, float &b2) {
-    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    V3 ad = vabs(rd);
-    int kz = max_dimension(ad);
+// The part of the test that depends on the ray only (triangle.rs:147-160): permutation axis and shear constants. The traversal
+// kernel evaluates it once per ray instead of once per triangle.
+struct TriRay { int kz; float Sx, Sy, Sz; };
+PT_DEV TriRay tri_ray_setup(V3 rd) {
+    TriRay r;
+    r.kz = max_dimension(vabs(rd));
     // permute(kx, ky, kz) with kx = kz+1 mod 3, ky = kx+1 mod 3
     float dx, dy, dz;
-    if (kz == 0) { dx = rd.y; dy = rd.z; dz = rd.x; p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x); }
-    else if (kz == 1) { dx = rd.z; dy = rd.x; dz = rd.y; p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y); }
+    if (r.kz == 0) { dx = rd.y; dy = rd.z; dz = rd.x; }
+    else if (r.kz == 1) { dx = rd.z; dy = rd.x; dz = rd.y; }
     else { dx = rd.x; dy = rd.y; dz = rd.z; }
-    float Sx = -dx / dz, Sy = -dy / dz, Sz = 1.0f / dz;
+    r.Sx = -dx / dz; r.Sy = -dy / dz; r.Sz = 1.0f / dz;
+    return r;
+}
+PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t_max, float &t, float &b0, float &b1, float &b2) {
+    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    if (tr.kz == 0) { p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x); }
+    else if (tr.kz == 1) { p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y); }
+    const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -131,6 +140,10 @@ PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float t_max, float
     float deltat = 3.0f * (gammaf(3) * maxe * maxzt + deltae * maxzt + deltaz * maxe) * fabsf(invdet);
     if (t <= deltat) return false;
     return true;
+}
+
+PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float t_max, float &t, float &b0, float &b1, float &b2) {
+    return tri_hit_params(p0, p1, p2, ro, tri_ray_setup(rd), t_max, t, b0, b1, b2);
 }
 
 PT_DEV void tri_uvs(const DeviceScene &s, uint32_t tri, uint32_t i0, uint32_t i1, uint32_t i2, P2 uv[3]) {  // triangle.rs:109-115
