@@ -22,7 +22,7 @@ int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
-uint32_t g_trace_waves_per_cu = 20;               // persistent trace waves per CU = 5 per SIMD, the occupancy of k_trace<*, 0> (env PT_TRACE_WAVES_PER_CU)
+uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
 SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }

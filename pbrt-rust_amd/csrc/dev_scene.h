@@ -119,13 +119,16 @@ PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t
         double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
         e2 = (float)(p1typ0tx - p1txp0ty);
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    // the three rejections of triangle.rs:191-208 folded into one predicate and one exit (same comparisons): with tens of lanes
+    // testing different triangles an early return rarely skips anything for the wave
+    const bool mixed = ((e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f)) & ((e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f));
     float det = e0 + e1 + e2;
-    if (det == 0.0f) return false;
     p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
     float tscaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-    if (det < 0.0f && (tscaled >= 0.0f || tscaled < t_max * det)) return false;
-    else if (det > 0.0f && (tscaled <= 0.0f || tscaled >= t_max * det)) return false;
+    const float tmd = t_max * det;
+    const bool out_neg = (det < 0.0f) & ((tscaled >= 0.0f) | (tscaled < tmd));
+    const bool out_pos = (det > 0.0f) & ((tscaled <= 0.0f) | (tscaled >= tmd));
+    if (mixed | (det == 0.0f) | out_neg | out_pos) return false;
     float invdet = 1.0f / det;
     b0 = e0 * invdet; b1 = e1 * invdet; b2 = e2 * invdet;
     t = tscaled * invdet;
@@ -265,24 +268,25 @@ PT_DEV bool slab_test(const float bmin[3], const float bmax[3], V3 ro, V3 inv_di
 // The same arithmetic split in two: the part that does not depend on ray.t_max (returned bool: slabs overlap and
 // tmax > 0) and the entry distance tmin_out; intersect_p2 == slab_geo(..) && tmin_out < ray.t_max.
 PT_DEV bool slab_geo(const float bmin[3], const float bmax[3], V3 ro, V3 inv_dir, bool nx, bool ny, bool nz, float &tmin_out) {
+    // Straight-line form of bounds.rs:559-580 (same operations and comparisons, the early returns folded into one predicate): two
+    // boxes are tested per traversal step by 64 lanes, an early return never skips work for the wave, it only costs branches.
+    // tmin_out is meaningful only when the result is true.
     float tmin = ((nx ? bmax[0] : bmin[0]) - ro.x) * inv_dir.x;
     float tmax = ((nx ? bmin[0] : bmax[0]) - ro.x) * inv_dir.x;
-    float tymin = ((ny ? bmax[1] : bmin[1]) - ro.y) * inv_dir.y;
+    const float tymin = ((ny ? bmax[1] : bmin[1]) - ro.y) * inv_dir.y;
     float tymax = ((ny ? bmin[1] : bmax[1]) - ro.y) * inv_dir.y;
-    const float k = 1.0f + 2.0f * gammaf(3);
-    tmax *= k; tymax *= k;
-    tmin_out = PT_INF;
-    if (tmin > tymax || tymin > tmax) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
-    float tzmin = ((nz ? bmax[2] : bmin[2]) - ro.z) * inv_dir.z;
+    const float tzmin = ((nz ? bmax[2] : bmin[2]) - ro.z) * inv_dir.z;
     float tzmax = ((nz ? bmin[2] : bmax[2]) - ro.z) * inv_dir.z;
-    tzmax *= k;
-    if (tmin > tzmax || tzmin > tmax) return false;
-    if (tzmin > tmin) tmin = tzmin;
-    if (tzmax < tmax) tmax = tzmax;
+    const float k = 1.0f + 2.0f * gammaf(3);
+    tmax *= k; tymax *= k; tzmax *= k;
+    const bool miss_xy = (tmin > tymax) | (tymin > tmax);
+    tmin = (tymin > tmin) ? tymin : tmin;
+    tmax = (tymax < tmax) ? tymax : tmax;
+    const bool miss_z = (tmin > tzmax) | (tzmin > tmax);
+    tmin = (tzmin > tmin) ? tzmin : tmin;
+    tmax = (tzmax < tmax) ? tzmax : tmax;
     tmin_out = tmin;
-    return tmax > 0.0f;
+    return !(miss_xy | miss_z) & (tmax > 0.0f);
 }
 
 }  // namespace ptd
