@@ -55,7 +55,9 @@ class FrontScene:
             raise ValueError(L.ptf_last_error().decode(errors="replace"))
 
     def desc(self):
-        return lib().ptf_scene_desc(self.h).contents
+        d = lib().ptf_scene_desc(self.h).contents
+        d._owner = self   # the struct points into the C++ scene: keep it alive as long as the view is
+        return d
 
     def render_params(self):
         rp = A.PtRenderParams()
