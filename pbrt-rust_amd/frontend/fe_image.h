@@ -133,7 +133,7 @@ inline std::vector<float> ewa_weight_lut() { std::vector<float> l(128); for (int
 // lights/infinite.rs:62-81 for power-of-two maps with aspect <= 2:1 (level-0 bilinear lookup; see host.py _env_importance)
 inline std::vector<float> env_importance(const std::vector<float> &tex, int w, int h) {
     auto pow2 = [](int n) { return n > 0 && (n & (n - 1)) == 0; };
-    if (!(pow2(w) && pow2(h) && std::max(w, h) <= 2 * std::min(w, h))) throw std::runtime_error("environment maps must be power-of-two sized with aspect <= 2:1");
+    if (!(pow2(w) && pow2(h) && std::max(w, h) <= 2 * std::min(w, h))) throw std::runtime_error("environment maps must have an aspect <= 2:1 after power-of-two resampling");
     const int W = 2 * w, H = 2 * h;
     std::vector<float> img((size_t)W * H);
     auto tx = [&](long s, long t, int k) { s %= w; if (s < 0) s += w; t %= h; if (t < 0) t += h; return tex[((size_t)t * w + s) * 3 + k]; };

@@ -388,6 +388,11 @@ private:
                 Image im = read_image(sc.base_dir + map);
                 sc.env_w = (uint32_t)im.w; sc.env_h = (uint32_t)im.h; sc.env_texels.resize(im.rgb.size());
                 for (size_t i = 0; i < im.rgb.size(); ++i) sc.env_texels[i] = im.rgb[i] * L[i % 3];   // infinite.rs:46-50
+                if ((sc.env_w & (sc.env_w - 1)) || (sc.env_h & (sc.env_h - 1))) {   // MIPMap::new resamples to powers of two (mipmap.rs:81-140); le / importance / power read that pyramid
+                    Pyramid py = build_mipmap(sc.env_texels, (int)sc.env_w, (int)sc.env_h, 3, 0);
+                    sc.env_w = (uint32_t)py.width; sc.env_h = (uint32_t)py.height;
+                    sc.env_texels.assign(py.texels.begin(), py.texels.begin() + (size_t)py.width * py.height * 3);
+                }
             }
             sc.env_importance = env_importance(sc.env_texels, (int)sc.env_w, (int)sc.env_h);
             {   // InfiniteAreaLight::power reads map.lookup((.5,.5), .5) = triangle(levels - 2, st) (infinite.rs:103-109, mipmap.rs:202-223)

@@ -448,6 +448,10 @@ class SceneBuilder:
             else:
                 tex = (np.asarray(tex, dtype=F) * L.reshape(1, 1, 3)).astype(F)   # infinite.rs:46-50: texels *= L * scale
             tex = np.ascontiguousarray(tex, dtype=F)
+            eh, ew, _ = tex.shape
+            if (ew & (ew - 1)) or (eh & (eh - 1)):   # MIPMap::new resamples to the next powers of two (mipmap.rs:81-140);
+                from .textures import build_mipmap   # `le`, the importance image and `power` all read that pyramid (infinite.rs:60-66)
+                tex = np.ascontiguousarray(build_mipmap(tex, "repeat")[0][0], dtype=F)
             self.env = dict(texels=tex, importance=_env_importance(tex), power_lookup=_env_power_lookup(tex))
         else:
             raise ValueError(kind)
@@ -624,12 +628,13 @@ def _env_importance(tex):
     """lights/infinite.rs:62-81 importance image (2w x 2h): `map.lookup(st, fwidth).y() * sin(theta)` with
     fwidth = 0.5 / min(2w, 2h).  MIPMap::lookup (mipmap.rs:202-223) picks level = levels - 1 + log2(fwidth)
     = log2(max(w,h)/min(w,h)) - 2, which is < 0 for power-of-two maps with aspect <= 2:1 -> `triangle(0, st)`, the
-    level-0 bilinear lookup with Repeat wrap (mipmap.rs:295-327).  Other sizes need the resampled pyramid
-    (mipmap.rs:60-190) and are rejected here: resample on the host first."""
+    level-0 bilinear lookup with Repeat wrap (mipmap.rs:295-327).  Non-power-of-two maps arrive here already resampled
+    (`add_light`), so `tex` is level 0 of the reference's pyramid; aspects above 2:1 would need pyramid levels > 0 and
+    are rejected."""
     h, w, _ = tex.shape
     pow2 = lambda n: n > 0 and (n & (n - 1)) == 0
     if not (pow2(w) and pow2(h) and max(w, h) <= 2 * min(w, h)):
-        raise NotImplementedError("environment maps must be power-of-two sized with aspect <= 2:1 (MIPMap resampling / pyramid levels > 0 are not restated)")
+        raise NotImplementedError("environment maps must have an aspect <= 2:1 after power-of-two resampling (pyramid levels > 0 of the importance lookup are not restated)")
     W, H = 2 * w, 2 * h
     y_w = np.array([0.212671, 0.715160, 0.072169], dtype=F)
     lum = (y_w[0] * tex[..., 0] + y_w[1] * tex[..., 1] + y_w[2] * tex[..., 2]).astype(F)

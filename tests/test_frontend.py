@@ -394,6 +394,33 @@ def test_hdr_environment_map(pkg, tmp_path):
     assert np.array_equal(np.ctypeslib.as_array(a.env_texels, shape=(n,)), np.ctypeslib.as_array(b.env_texels, shape=(n,)))
 
 
+def test_non_power_of_two_environment_map_is_resampled(pkg, tmp_path):
+    """MIPMap::new resamples a 12x7 map to 16x8 (mipmap.rs:81-140) and InfiniteAreaLight reads everything from that pyramid
+    (infinite.rs:60-80): C++ front end == Python mirror for texels, importance image and the power lookup; a constant map stays
+    constant (the Lanczos weights are normalised), so its importance image is Y * sin(theta)."""
+    rng = np.random.default_rng(21)
+    rgbe = np.concatenate([rng.integers(1, 256, (7, 12, 3)), rng.integers(126, 132, (7, 12, 1))], axis=2).astype(np.uint8)
+    (tmp_path / "sky.hdr").write_bytes(_hdr_bytes(rgbe))
+    tex = rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:4].astype(np.float32) - 136.0).astype(np.float32)
+    scene = 'WorldBegin\nLightSource "infinite" "rgb L" [0.5 1 2] "string mapname" "sky.hdr"\nShape "sphere"\nWorldEnd\n'
+    fs = pkg.frontend.FrontScene(text=scene, base_dir=str(tmp_path)); d = fs.desc()
+    b = pkg.host.SceneBuilder(); b.light_source("infinite", L=(0.5, 1, 2), texels=tex)
+    assert (d.env_width, d.env_height) == (16, 8) and b.env["texels"].shape == (8, 16, 3)
+    got = np.ctypeslib.as_array(d.env_texels, shape=(8, 16, 3))
+    assert np.allclose(got, b.env["texels"], rtol=1e-5, atol=1e-7) and got.min() >= 0.0
+    imp = np.ctypeslib.as_array(d.env_importance, shape=(16, 32))
+    assert np.allclose(imp, b.env["importance"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(list(d.env_power_lookup), b.env["power_lookup"], rtol=1e-5)
+    # the resampled rows interpolate the original ones: the mean radiance is kept to a few per cent
+    assert abs(got.mean() / (tex * np.float32([0.5, 1, 2])).mean() - 1) < 0.1
+    c = pkg.host.SceneBuilder(); c.light_source("infinite", texels=np.full((5, 10, 3), 0.75, np.float32))
+    assert c.env["texels"].shape == (8, 16, 3) and np.allclose(c.env["texels"], 0.75, rtol=1e-6)
+    sin_t = np.sin(np.pi * (np.arange(16) + 0.5) / 16)
+    assert np.allclose(c.env["importance"], (0.75 * sin_t)[:, None] * np.ones((1, 32)), rtol=1e-5)
+    with pytest.raises(Exception, match="aspect"):
+        pkg.host.SceneBuilder().light_source("infinite", texels=np.ones((2, 9, 3), np.float32))
+
+
 def _exr_zip_half(img):   # (h, w, 3) float -> scan-line EXR, ZIP (16 lines per block), HALF channels B, G, R
     import struct, zlib
     h, w, _ = img.shape
