@@ -395,6 +395,7 @@ typedef struct PtKernelStat {
     uint64_t bvh_nodes;              /* trace kernels: Bounds3f::intersect_p2 executed (32 B each);
                                         shade kernels: path-state + queue bytes moved                 */
     uint64_t triangle_tests;         /* trace kernels: triangle packets tested (48 B each)          */
+    char kernel[48];                 /* the kernel symbol behind this launch kind, as `rocprofv3 --stats` prints it */
 } PtKernelStat;
 
 typedef struct pt_scene pt_scene;

@@ -139,7 +139,7 @@ class PtCounters(C.Structure):
 
 
 class PtKernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", u64), ("total_ms", C.c_double), ("items", u64), ("bvh_nodes", u64), ("triangle_tests", u64)]
+    _fields_ = [("name", C.c_char * 32), ("launches", u64), ("total_ms", C.c_double), ("items", u64), ("bvh_nodes", u64), ("triangle_tests", u64), ("kernel", C.c_char * 48)]
 
 
 # Every symbol include/mi355pt.h declares, with its signature (restype, argtypes).

@@ -8,7 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "kernels.hip"  // single translation unit: kernels + host driver
+#include "kern_decl.h"   // kernel declarations; the definitions are instantiated by the tu_*.hip translation units
 #include "host_bvh.h"
 
 extern "C" const unsigned char pt_sobol_blob[];   // tables_blob.cpp (.incbin of data/sobol_tables.bin)
@@ -90,8 +90,8 @@ int upload_tables() {
     return PT_OK;
 }
 
-struct Stat { std::string name; uint64_t launches = 0; double ms = 0; uint64_t items = 0, nodes = 0, tris = 0; };
-struct TimedLaunch { int stat; hipEvent_t a, b; };
+struct Stat { std::string name, kernel; uint64_t launches = 0; double ms = 0; uint64_t items = 0, nodes = 0, tris = 0; };
+struct TimedLaunch { int stat; hipEvent_t a, b; bool closed; };
 
 }  // namespace
 
@@ -121,6 +121,7 @@ struct pt_scene {
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
     bool profile = false;
+    int last_stat = -1;
 
     template <class T> int dalloc(T **out, size_t count) {
         void *p = nullptr;
@@ -150,13 +151,26 @@ struct pt_scene {
     // bracket a launch with HIP events on the render stream when profiling
     void begin(const char *name, uint64_t items) {
         int id = stat_id(name);
+        last_stat = id;
         stats[id].launches++; stats[id].items += items;
-        if (profile) { TimedLaunch t{id, get_event(), get_event()}; hipEventRecord(t.a, stream); timed.push_back(t); }
+        if (profile) { TimedLaunch t{id, get_event(), get_event(), false}; hipEventRecord(t.a, stream); timed.push_back(t); }
     }
-    void end() { if (profile) hipEventRecord(timed.back().b, stream); }
+    void end() { if (profile && !timed.empty()) { hipEventRecord(timed.back().b, stream); timed.back().closed = true; } }
+    // the kernel symbol behind the launch kind opened by the last begin(), as rocprofv3 prints it
+    void set_kernel(const std::string &symbol) { if (last_stat >= 0 && last_stat < (int)stats.size()) stats[last_stat].kernel = symbol; }
     void resolve_timings() {
-        for (auto &t : timed) { float ms = 0; hipEventElapsedTime(&ms, t.a, t.b); stats[t.stat].ms += ms; event_pool.push_back(t.a); event_pool.push_back(t.b); }
+        for (auto &t : timed) {
+            float ms = 0;
+            if (t.closed && t.stat >= 0 && t.stat < (int)stats.size() && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) stats[t.stat].ms += ms;
+            event_pool.push_back(t.a); event_pool.push_back(t.b);
+        }
         timed.clear();
+    }
+    // A call that failed half way leaves event pairs behind whose stat ids belong to the statistics of THAT call: hand the
+    // events back without touching `stats` (entry of every C-ABI call that clears `stats`, and pt_scene_destroy).
+    void drop_timings() {
+        for (auto &t : timed) { event_pool.push_back(t.a); event_pool.push_back(t.b); }
+        timed.clear(); last_stat = -1;
     }
 };
 
@@ -192,6 +206,7 @@ int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
     if (any) { if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
     else { if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
     #undef PT_LAUNCH_TRACE
+    sc->set_kernel(std::string("k_trace<") + (any ? "true" : "false") + ", " + std::to_string(mode) + ">");
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -309,6 +324,7 @@ int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
         if ((st = sc->dalloc(&fint, ncell))) return st;
         size_t total = ncell * nl;
         sc->begin("light_grid", total);
+        sc->set_kernel("k_light_grid_contrib");
         hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, g.nvox[0], g.nvox[1], g.nvox[2], func);
         hipLaunchKernelGGL(k_light_grid_finish, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, sc->stream, nl, ncell, func, cdf, fint);
         sc->end();
@@ -381,6 +397,8 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL, bool DIFF = false> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
+    const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
+    sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + (DIFF ? "true" : "false") + ">");
     if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
@@ -392,6 +410,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     QCounters *qc = sc->qc;
     HIP_TRY(hipMemsetAsync(qc, 0, offsetof(QCounters, error), sc->stream));
     sc->begin("generate", total);
+        sc->set_kernel("k_generate");
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * 16u)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
@@ -417,18 +436,21 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
         tj.kind = (iter == 0) ? 3 : 0;
         tj.class_count = nullptr;
-        sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
-        int st = launch_trace(sc, false, tj, n_ext);
-        sc->end();
-        if (st) return st;
+        int st = PT_OK;
+        if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
+            sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
+            st = launch_trace(sc, false, tj, n_ext);
+            sc->end();
+            if (st) return st;
+        }
         if (n_ext && rc.volpath) {  // medium sampling (volpath.rs:98-105) + material-sorted shade queues + the medium-vertex queue
-            sc->begin("route", n_ext);
+            sc->begin("route", n_ext); sc->set_kernel("k_medium_route");
             hipLaunchKernelGGL(k_medium_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, sc->ps,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], &qc->shade[cur][0],
                                sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4], sc->q.shade[cur][5], &qc->error);
             sc->end();
         } else if (n_ext) {  // material-sorted shade queues
-            sc->begin("route", n_ext);
+            sc->begin("route", n_ext); sc->set_kernel("k_route");
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], (const uint32_t *)ps.hit_prim, &qc->shade[cur][0],
                                sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4]);
@@ -440,23 +462,27 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         tj.out_prim = ps.mis_prim; tj.out_t = rc.volpath ? ps.mis_t : nullptr; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2; tj.out_inst = nullptr;
         tj.class_count = nullptr;
         tj.kind = 1;
-        sc->begin("extend_mis", n_mis);
-        st = launch_trace(sc, false, tj, n_mis);
-        sc->end();
-        if (st) return st;
+        if (n_mis) {
+            sc->begin("extend_mis", n_mis);
+            st = launch_trace(sc, false, tj, n_mis);
+            sc->end();
+            if (st) return st;
+        }
         // shadow rays (any hit, light.rs:120-123)
         tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
         tj.ox = ps.sh_ox; tj.oy = ps.sh_oy; tj.oz = ps.sh_oz; tj.dx = ps.sh_dx; tj.dy = ps.sh_dy; tj.dz = ps.sh_dz;
         tj.out_occluded = ps.occluded;
         tj.kind = 2;
-        sc->begin("shadow", n_shadow);
-        if (rc.volpath) {   // VisibilityTester::tr (light.rs:125-150) calls Scene::intersect: a closest-hit query, counted as one
-            tj.out_prim = ps.sh_prim; tj.out_t = nullptr; tj.out_b0 = tj.out_b1 = tj.out_b2 = nullptr; tj.out_inst = nullptr;
-            st = launch_trace(sc, false, tj, n_shadow);
-        } else
-        st = launch_trace(sc, true, tj, n_shadow);
-        sc->end();
-        if (st) return st;
+        if (n_shadow) {
+            sc->begin("shadow", n_shadow);
+            if (rc.volpath) {   // VisibilityTester::tr (light.rs:125-150) calls Scene::intersect: a closest-hit query, counted as one
+                tj.out_prim = ps.sh_prim; tj.out_t = nullptr; tj.out_b0 = tj.out_b1 = tj.out_b2 = nullptr; tj.out_inst = nullptr;
+                st = launch_trace(sc, false, tj, n_shadow);
+            } else
+            st = launch_trace(sc, true, tj, n_shadow);
+            sc->end();
+            if (st) return st;
+        }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
         if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-395): one segment per iteration, then k_bssrdf
             tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
@@ -476,6 +502,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
             const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * 8u);
             sc->begin("bssrdf", n_probe);
+            sc->set_kernel((sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? "k_bssrdf<true>" : "k_bssrdf<false>");
             if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_bssrdf<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
             else hipLaunchKernelGGL((k_bssrdf<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
             sc->end();
@@ -500,10 +527,12 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c == kMediumClass) {
                 const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 8u);
+                sc->set_kernel("k_shade_medium");
                 hipLaunchKernelGGL(k_shade_medium, dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, sj);
             }
             else if (c == kMissClass) {
                 const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 16u);
+                sc->set_kernel(rc.volpath ? "k_shade_miss<true, true>" : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? "k_shade_miss<true, false>" : "k_shade_miss<false, false>");
                 if (rc.volpath) hipLaunchKernelGGL((k_shade_miss<true, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
                 else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade_miss<true, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
                 else hipLaunchKernelGGL((k_shade_miss<false, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
@@ -519,6 +548,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         cur = 1 - cur;
     }
     sc->begin("film", total);
+        sc->set_kernel("k_film");
     hipLaunchKernelGGL(k_film, dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
     sc->end();
     HIP_TRY(hipGetLastError());
@@ -933,6 +963,7 @@ void pt_scene_destroy(pt_scene *sc) {
     if (sc->qbuf) hipFree(sc->qbuf);
     if (sc->bss_slab) hipFree(sc->bss_slab);
     if (sc->film_rgbw) hipFree(sc->film_rgbw);
+    sc->drop_timings();
     for (auto e : sc->event_pool) hipEventDestroy(e);
     if (sc->stream) hipStreamDestroy(sc->stream);
     delete sc;
@@ -959,10 +990,10 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     fill_render_const(rp, rc);
     if (rc.film_w == 0 || rc.film_h == 0 || rc.ntx == 0 || rc.nty == 0) return fail(PT_ERR_INVALID_ARG, "empty film or sample bounds");
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
+    if (rp->max_depth > 254) return fail(PT_ERR_INVALID_ARG, "maxdepth must be <= 254 (the bounce count of a path is kept in 8 bits)");
     if (rc.volpath) {   // VolPathIntegrator (volpath.rs): what this back end takes
         if (sc->has_null_material) return fail(PT_ERR_UNSUPPORTED, "volpath: primitives without a material (medium-interface shells) are not supported; the reference's volpath mishandles them too (volpath.rs:127-131)");
         if (sc->has_bssrdf) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials are not supported by the volumetric integrator here");
-        if (rp->max_depth >= 255) return fail(PT_ERR_INVALID_ARG, "volpath: maxdepth must be below 255");
         if (rp->camera_medium != PT_NONE && rp->camera_medium >= sc->ds.n_media) return fail(PT_ERR_INVALID_ARG, "camera_medium out of range");
     }
     const uint32_t ntiles = rc.ntx * rc.nty;
@@ -970,6 +1001,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     rc.n_pix_slots = rc.n_tile_slots * 256u;
     const size_t film_px = (size_t)rc.film_w * rc.film_h;
     sc->profile = rp->profile != 0;
+    sc->drop_timings();
     sc->stats.clear();
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
@@ -999,6 +1031,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
             dst = tmp;
         }
         sc->begin("film_finish", film_px);
+        sc->set_kernel("k_film_finish");
         hipLaunchKernelGGL(k_film_finish, dim3((unsigned)((film_px + 255) / 256)), dim3(256), 0, sc->stream, sc->film_rgbw, dst, (uint32_t)film_px);
         sc->end();
         HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -1035,6 +1068,7 @@ int pt_get_kernel_stats(const pt_scene *sc, PtKernelStat *out, uint32_t max_entr
     for (uint32_t i = 0; i < n; ++i) {
         std::memset(&out[i], 0, sizeof out[i]);
         std::snprintf(out[i].name, sizeof out[i].name, "%s", sc->stats[i].name.c_str());
+        std::snprintf(out[i].kernel, sizeof out[i].kernel, "%s", sc->stats[i].kernel.c_str());
         out[i].launches = sc->stats[i].launches; out[i].total_ms = sc->stats[i].ms; out[i].items = sc->stats[i].items;
         out[i].bvh_nodes = sc->stats[i].nodes; out[i].triangle_tests = sc->stats[i].tris;
     }
@@ -1069,7 +1103,7 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     tj.tmax = din + 6 * (size_t)n;
     tj.out_prim = dprim; tj.out_t = dout; tj.out_b0 = dout + n; tj.out_b1 = dout + 2 * (size_t)n; tj.out_b2 = dout + 3 * (size_t)n;
     tj.out_occluded = docc; tj.class_count = nullptr; tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
-    sc->profile = true; sc->stats.clear();
+    sc->profile = true; sc->drop_timings(); sc->stats.clear();
     tj.kind = any ? 2 : 0;
     sc->begin(any ? "trace_any_api" : "trace_closest_api", n);
     st = launch_trace(sc, any, tj, n);

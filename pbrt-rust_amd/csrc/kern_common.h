@@ -1,0 +1,92 @@
+// kern_common.h -- includes and wave / LDS-queue helpers shared by every kernel translation unit.
+//
+//
+// Pipeline per pass (one pass = s_count samples of every pixel owned by this rank):
+//   k_generate   integrator.rs:331-346  sampler.rs:170-180  perspective.rs:120-179
+//   repeat until no path is alive:
+//     k_trace<closest>  bvh.rs:705-760 + triangle.rs:136-233   (continuation rays, then MIS rays)
+//     k_trace<any>      bvh.rs:762-814 + triangle.rs:400-495   (shadow rays)
+//     k_shade<class>    path.rs:97-217 + integrator.rs:81-237  (one launch per material class queue)
+//   k_film       integrator.rs:350-374 + film.rs:292-331
+// Queues hold path ids; path state is SoA in HBM (kernels.h). Compaction is wave64 ballot + popcount.
+#pragma once
+#include "kernels.h"
+#include "dev_bsdf.h"
+#include "dev_sphere.h"
+#include "dev_texture.h"
+#include "dev_medium.h"
+
+using namespace ptd;
+
+// ---- wave-level helpers ------------------------------------------------------------------------
+PT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Stream compaction: append `value` for every lane with pred set; one atomic per wave.
+PT_DEV void queue_push(uint32_t *count, uint32_t *buf, uint32_t value, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) buf[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+PT_DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+PT_DEV void counter_add(unsigned long long *dst, unsigned long long v) {  // call wave-convergent
+    v = wave_sum(v);
+    if (lane_id() == 0 && v) atomicAdd(dst, v);
+}
+
+// Staging of queue appends in LDS. A single global counter sustains only ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md, row "dequeue"); one atomic per wave per append made every queue-producing kernel atomic bound.
+//
+// LdsQueue (block level, streaming kernels): appends go to a block-wide LDS buffer with LDS atomics (one per wave) and
+// the whole block flushes ~1000 entries with ONE global atomic. All threads of the block call lq_sync_flush together.
+template <int CAP> struct LdsQueue { uint32_t count; uint32_t base; uint32_t buf[CAP]; };
+template <int CAP> PT_DEV void lq_init(LdsQueue<CAP> &q) { if (threadIdx.x == 0) { q.count = 0; q.base = 0; } }
+template <int CAP> PT_DEV void lq_push(LdsQueue<CAP> &q, uint32_t value, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&q.count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (pred) q.buf[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+// Flush when fewer than `reserve` free slots remain (or force). Block-uniform; contains __syncthreads().
+template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount, uint32_t *gbuf, uint32_t reserve, bool force) {
+    __syncthreads();
+    const uint32_t n = q.count;
+    if (n != 0 && (force || n + reserve > (uint32_t)CAP)) {
+        if (threadIdx.x == 0) q.base = atomicAdd(gcount, n);
+        __syncthreads();
+        const uint32_t b = q.base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gbuf[b + i] = q.buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) q.count = 0;
+    }
+    __syncthreads();
+}
+
+// (Measured alternative, not kept: barrier-free per-wave buffers. With 256-entry buffers the 4x more frequent returning
+// atomics made every producer slower; with 768-entry buffers k_shade still lost 10 % -- the barriers keep the four waves of
+// a block in lockstep through a 150 KB kernel, which evidently helps instruction fetch.)
+
+// Several queues per kernel: one barrier makes the pushes visible, each queue that is nearly full flushes (block-uniform
+// decision, rare), one barrier closes the round -- instead of two barriers per queue per iteration.
+template <int CAP> PT_DEV void lq_flush_nosync(LdsQueue<CAP> &q, uint32_t *gcount, uint32_t *gbuf, uint32_t reserve, bool force) {
+    const uint32_t n = q.count;   // the caller's barrier precedes this read
+    if (n != 0 && (force || n + reserve > (uint32_t)CAP)) {
+        if (threadIdx.x == 0) q.base = atomicAdd(gcount, n);
+        __syncthreads();
+        const uint32_t b = q.base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gbuf[b + i] = q.buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) q.count = 0;
+    }
+}

@@ -1,0 +1,342 @@
+// kern_misc.h -- split out of the former single-file kernels.hip so that the translation units compile in parallel.
+#pragma once
+#include "kern_common.h"
+// ---- scene preparation ---------------------------------------------------------------------------
+// Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
+// (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_refs) return;
+    uint32_t prim = ordered[i];      // primitive index, or PT_TOP_INSTANCE | instance index
+    TriPacket p;
+    if (prim & PT_TOP_INSTANCE) {
+        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
+        out[i] = p;
+        return;
+    }
+    uint32_t shape = s.prim_shape[prim];
+    p.prim = prim; p.shape = shape; p.flags = 0;
+    if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
+        uint32_t tri = shape & 0x3fffffffu;
+        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+        V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
+        P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
+        V3 dpdu, dpdv;
+        bool ok = tri_partials(p0, p1, p2, uv, dpdu, dpdv);
+        p.p0[0] = p0.x; p.p0[1] = p0.y; p.p0[2] = p0.z; p.p1x = p1.x;
+        p.p1yz[0] = p1.y; p.p1yz[1] = p1.z; p.p2xy[0] = p2.x; p.p2xy[1] = p2.y; p.p2z = p2.z;
+        p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS);
+        if ((s.tri_alpha && s.tri_alpha[tri] >= 0) || (s.tri_shadow_alpha && s.tri_shadow_alpha[tri] >= 0)) p.flags |= TP_ALPHA;
+    } else {
+        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.flags = TP_SPHERE;
+    }
+    out[i] = p;
+}
+
+// Mark the last packet of every leaf (offsets of the last primitive of each leaf, computed on the host).
+__global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) leaf[last_index[i]].flags |= TP_LAST;
+}
+
+__global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight::new -> shape.area()
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n_lights) return;
+    float a = 0.0f;
+    const PtLight &L = s.lights[i];
+    if (L.type == PT_LIGHT_DIFFUSE_AREA) {
+        uint32_t shape = s.prim_shape[L.prim];
+        if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
+            uint32_t tri = shape & 0x3fffffffu;
+            a = tri_area(ld3(s.P, s.indices[3 * tri]), ld3(s.P, s.indices[3 * tri + 1]), ld3(s.P, s.indices[3 * tri + 2]));
+        } else {  // Sphere::area (sphere.rs:291-293)
+            const PtSphere &S = s.spheres[shape & 0x3fffffffu];
+            a = S.kind == PT_QUADRIC_DISK ? S.phi_max * 0.5f * (S.radius * S.radius - S.inner_radius * S.inner_radius)   // Disk::area (disk.rs:120-122)
+                                          : S.phi_max * S.radius * (S.z_max - S.z_min);
+        }
+    }
+    area[i] = a;
+}
+// ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
+// Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
+// material's class (escaped rays -> the miss class). Block-level staged appends: one global atomic per ~1000 entries per class.
+__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *hit_prim,
+                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4) {
+    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4;
+    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4);
+    __syncthreads();
+    const uint32_t count = *count_ptr;
+    const uint32_t rounded = (count + 255u) & ~255u;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+        const bool valid = qi < count;
+        uint32_t pid = 0, cls = (uint32_t)kMissClass;   // escaped rays: their own light kernel (k_shade_miss)
+        if (valid) {
+            pid = queue[qi];
+            const uint32_t hp = hit_prim[pid];
+            if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+        }
+        lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
+        lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
+        __syncthreads();
+        lq_flush_nosync(q0, class_count + 0, c0, 256u, false); lq_flush_nosync(q1, class_count + 1, c1, 256u, false);
+        lq_flush_nosync(q2, class_count + 2, c2, 256u, false); lq_flush_nosync(q3, class_count + 3, c3, 256u, false);
+        lq_flush_nosync(q4, class_count + 4, c4, 256u, false);
+        __syncthreads();
+    }
+    lq_flush_nosync(q0, class_count + 0, c0, 0u, true); lq_flush_nosync(q1, class_count + 1, c1, 0u, true);
+    lq_flush_nosync(q2, class_count + 2, c2, 0u, true); lq_flush_nosync(q3, class_count + 3, c3, 0u, true);
+    lq_flush_nosync(q4, class_count + 4, c4, 0u, true);
+}
+// ---- camera rays -------------------------------------------------------------------------------------
+// pixel slot -> pixel: slot = tile_slot*256 + ty*16 + tx, tile index = tile_rank + tile_slot*tile_world
+PT_DEV bool slot_to_pixel(const RenderConst &rc, uint32_t slot, int32_t &px, int32_t &py) {
+    uint32_t tile_slot = slot >> 8, in_tile = slot & 255u;
+    uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
+    uint32_t tx = tile % rc.ntx, ty = tile / rc.ntx;
+    px = rc.sample_bounds[0] + (int32_t)(tx * 16u + (in_tile & 15u));
+    py = rc.sample_bounds[1] + (int32_t)(ty * 16u + (in_tile >> 4));
+    if (ty >= rc.nty || px >= rc.sample_bounds[2] || py >= rc.sample_bounds[3]) return false;
+    // integrator.rs:328: pixels outside the integrator's pixel_bounds are skipped
+    return px >= rc.pixel_bounds[0] && px < rc.pixel_bounds[2] && py >= rc.pixel_bounds[1] && py < rc.pixel_bounds[3];
+}
+
+PT_DEV void camera_ray(const RenderConst &rc, float pfx, float pfy, float time_u, P2 plens_u, V3 &o, V3 &d) {  // perspective.rs:120-179
+    V3 pcamera = xf_point(rc.raster_to_camera, V3(pfx, pfy, 0.0f));
+    V3 ro(0.0f, 0.0f, 0.0f), rd = normalize(pcamera);
+    if (rc.lens_radius > 0.0f) {
+        P2 dsk = concentric_sample_disk(plens_u);
+        float lx = dsk.x * rc.lens_radius, ly = dsk.y * rc.lens_radius;
+        float ft = rc.focal_distance / rd.z;
+        V3 pfocus = ro + rd * ft;
+        ro = V3(lx, ly, 0.0f);
+        rd = normalize(pfocus - ro);
+    }
+    (void)time_u;  // ray.time = lerp(time, open, close) has no effect without animated transforms
+    // Transform::transform_ray (transform.rs:543-577)
+    V3 oerr;
+    V3 ow = xf_point_err(rc.camera_to_world, ro, oerr);
+    V3 dw = xf_vector(rc.camera_to_world, rd);
+    float l2 = length_squared(dw);
+    if (l2 > 0.0f) { float dt = dot(vabs(dw), oerr) / l2; ow = ow + dw * dt; }
+    o = ow; d = dw;
+}
+
+__global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
+    // LDS copies of what every lane needs: Sobol' rows of dimensions 0..4 and the two van-der-Corput matrices of m
+    __shared__ uint32_t s_rows[5 * 52];
+    __shared__ uint64_t s_vdc[2 * 52];
+    __shared__ LdsQueue<1024> s_q;
+    lq_init(s_q);
+    const uint32_t m = (uint32_t)rc.sobol.log2_resolution;
+    for (uint32_t i = threadIdx.x; i < 5 * 52; i += blockDim.x) s_rows[i] = tabs.m32[i];
+    if (m > 0) for (uint32_t i = threadIdx.x; i < 2 * 52; i += blockDim.x) s_vdc[i] = (i < 52) ? tabs.vdc[(m - 1) * 52 + i] : tabs.vdc_inv[(m - 1) * 52 + (i - 52)];
+    __syncthreads();
+    const uint32_t total = rc.n_pix_slots * rc.s_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounded = (total + 255u) & ~255u;   // whole blocks iterate together (block-level queue flushes)
+    unsigned long long n_alive = 0;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < rounded; pid += stride) {
+        bool alive = false;
+        if (pid < total) {
+            const uint32_t slot = pid % rc.n_pix_slots, sl = pid / rc.n_pix_slots;
+            int32_t px, py;
+            if (slot_to_pixel(rc, slot, px, py)) {
+                const uint64_t sample = rc.s_begin + sl;
+                if (rc.halton.enabled) {   // HaltonSampler: same GlobalSampler bookkeeping, its own index and dimensions (halton.rs:122-165)
+                    const uint64_t index = halton_index_for_sample(rc.halton, px, py, sample);
+                    const float fx = halton_sample_dimension(tabs, rc.halton, index, 0u), fy = halton_sample_dimension(tabs, rc.halton, index, 1u);
+                    const float pfx = (float)px + fx, pfy = (float)py + fy;   // get_camera_sample: p_film = pixel + get_2d() (sampler.rs:170-180)
+                    const float tm = halton_sample_dimension(tabs, rc.halton, index, 2u);
+                    const P2 pl(halton_sample_dimension(tabs, rc.halton, index, 3u), halton_sample_dimension(tabs, rc.halton, index, 4u));
+                    V3 o, d;
+                    camera_ray(rc, pfx, pfy, tm, pl, o, d);
+                    ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
+                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                    ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
+                    ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
+                    ps.etascale[pid] = 1.0f;
+                    ps.sobol_index[pid] = index;
+                    ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);
+                    alive = true;
+                } else {
+                const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
+                // get_camera_sample (sampler.rs:170-180): pfilm = get_2d, time = get_1d, plens = get_2d; one pass over the index bits
+                uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                for (uint64_t a = index; a != 0; a &= a - 1) {
+                    const int i = __builtin_ctzll(a);
+                    v0 ^= s_rows[i]; v1 ^= s_rows[52 + i]; v2 ^= s_rows[104 + i]; v3 ^= s_rows[156 + i]; v4 ^= s_rows[208 + i];
+                }
+                // sobol.rs:77-81: film dimensions are remapped to the pixel
+                float fx = sobol_to_float(v0) * (float)rc.sobol.resolution + (float)rc.sobol.sb_min[0];
+                fx = clampf(fx - (float)px, 0.0f, kOneMinusEps);
+                float fy = sobol_to_float(v1) * (float)rc.sobol.resolution + (float)rc.sobol.sb_min[1];
+                fy = clampf(fy - (float)py, 0.0f, kOneMinusEps);
+                const float pfx = (float)px + fx, pfy = (float)py + fy;
+                V3 o, d;
+                camera_ray(rc, pfx, pfy, sobol_to_float(v2), P2(sobol_to_float(v3), sobol_to_float(v4)), o, d);
+                ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
+                ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
+                ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
+                ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
+                ps.etascale[pid] = 1.0f;
+                ps.sobol_index[pid] = index;
+                ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
+                alive = true;
+                }
+            }
+        }
+        if (alive && rc.volpath) ps.medium[pid] = rc.camera_medium;   // the camera ray starts in the camera's medium (perspective.rs:114)
+        lq_push(s_q, pid, alive);
+        lq_sync_flush(s_q, q_ext_count, q_ext, 256u, false);
+        n_alive += alive ? 1ull : 0ull;
+    }
+    lq_sync_flush(s_q, q_ext_count, q_ext, 0u, true);
+    counter_add(&counters->camera_rays, n_alive);
+}
+// ---- film ----------------------------------------------------------------------------------------------------
+// One thread per pixel slot; its s_count samples are added in sample order (integrator.rs:331-376),
+// FilmTile::add_sample (film.rs:292-331) with the tile's pixel bounds == footprint clipped to the crop window.
+__global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long nan_c = 0, neg_c = 0, inf_c = 0, splats = 0;
+    int32_t px, py;
+    if (slot < rc.n_pix_slots && slot_to_pixel(rc, slot, px, py)) {
+        // tile pixel bounds (Film::get_film_tile, film.rs:125-140)
+        uint32_t tile_slot = slot >> 8;
+        uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
+        int32_t tx0 = rc.sample_bounds[0] + (int32_t)((tile % rc.ntx) * 16u), ty0 = rc.sample_bounds[1] + (int32_t)((tile / rc.ntx) * 16u);
+        int32_t tx1 = min(tx0 + 16, rc.sample_bounds[2]), ty1 = min(ty0 + 16, rc.sample_bounds[3]);
+        int64_t tb0 = max(f2i_sat(ceilf((float)tx0 - 0.5f - rc.filter_radius[0])), (int64_t)rc.crop[0]);
+        int64_t tb1 = max(f2i_sat(ceilf((float)ty0 - 0.5f - rc.filter_radius[1])), (int64_t)rc.crop[1]);
+        int64_t tb2 = min(f2i_sat(floorf((float)tx1 - 0.5f + rc.filter_radius[0])) + 1, (int64_t)rc.crop[2]);
+        int64_t tb3 = min(f2i_sat(floorf((float)ty1 - 0.5f + rc.filter_radius[1])) + 1, (int64_t)rc.crop[3]);
+        const float invrx = 1.0f / rc.filter_radius[0], invry = 1.0f / rc.filter_radius[1];
+        // Splats onto this thread's own pixel are accumulated in registers, seeded with the pixel's current value, and written
+        // back once: the additions happen in sample order exactly as before (and as FilmTile::add_sample does), without one
+        // L2 atomic per channel per sample. Splats onto other pixels (wide filters; for the box filter only the pfilm == px
+        // edge case) still use atomics; should one of them land on this pixel meanwhile, the final compare-and-swap fails
+        // and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
+        const bool own_ok = px >= tb0 && px < tb2 && py >= tb1 && py < tb3;
+        float *own = film_rgbw + 4 * ((size_t)(py - rc.crop[1]) * rc.film_w + (size_t)(px - rc.crop[0]));
+        float seed[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
+        for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
+            const uint32_t pid = sl * rc.n_pix_slots + slot;
+            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+            // integrator.rs:350-368
+            if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
+            else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
+            else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
+            if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
+            const float dx = ps.pfilm_x[pid] - 0.5f, dy = ps.pfilm_y[pid] - 0.5f;
+            int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
+            int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
+            for (int64_t y = p0y; y < p1y; ++y) {
+                const float fy = fabsf(((float)y - dy) * invry * 16.0f);
+                const uint32_t iy = min(f2u32_sat(floorf(fy)), 15u);
+                for (int64_t x = p0x; x < p1x; ++x) {
+                    const float fx = fabsf(((float)x - dx) * invrx * 16.0f);
+                    const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
+                    const float fw = filter_table[iy * 16 + ix];
+                    const RGB c = L * RGB(1.0f) * RGB(fw);
+                    if (own_ok && x == (int64_t)px && y == (int64_t)py) { acc[0] += c.r; acc[1] += c.g; acc[2] += c.b; acc[3] += fw; }
+                    else {
+                        float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
+                        atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                    }
+                    splats++;
+                }
+            }
+        }
+        if (own_ok) for (int k = 0; k < 4; ++k) {
+            if (__float_as_uint(acc[k]) == __float_as_uint(seed[k])) continue;
+            const uint32_t old = atomicCAS((uint32_t *)(own + k), __float_as_uint(seed[k]), __float_as_uint(acc[k]));
+            if (old != __float_as_uint(seed[k])) atomicAdd(own + k, acc[k] - seed[k]);
+        }
+    }
+    counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
+    counter_add(&counters->san_inf, inf_c); counter_add(&counters->splats, splats);
+}
+
+// Film::merge_film_tile (film.rs:142-161): RGB sums -> XYZ, added to the caller's film.
+__global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float rgb[3] = {film_rgbw[4 * i], film_rgbw[4 * i + 1], film_rgbw[4 * i + 2]}, xyz[3];
+    rgb_to_xyz(rgb, xyz);
+    film_xyzw[4 * i] += xyz[0]; film_xyzw[4 * i + 1] += xyz[1]; film_xyzw[4 * i + 2] += xyz[2]; film_xyzw[4 * i + 3] += film_rgbw[4 * i + 3];
+}
+// ---- spatial light distribution (lightdistrib.rs:151-228), all voxels precomputed ---------------------------
+__global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t ncell = (size_t)nvx * nvy * nvz;
+    if (gid >= ncell * s.n_lights) return;
+    const uint32_t j = (uint32_t)(gid % s.n_lights);
+    const size_t cell = gid / s.n_lights;
+    const uint32_t pi0 = (uint32_t)(cell % nvx), pi1 = (uint32_t)((cell / nvx) % nvy), pi2 = (uint32_t)(cell / ((size_t)nvx * nvy));
+    V3 p0((float)pi0 / (float)nvx, (float)pi1 / (float)nvy, (float)pi2 / (float)nvz);
+    V3 p1((float)(pi0 + 1) / (float)nvx, (float)(pi1 + 1) / (float)nvy, (float)(pi2 + 1) / (float)nvz);
+    V3 a(lerpf(p0.x, s.wb_min[0], s.wb_max[0]), lerpf(p0.y, s.wb_min[1], s.wb_max[1]), lerpf(p0.z, s.wb_min[2], s.wb_max[2]));
+    V3 b(lerpf(p1.x, s.wb_min[0], s.wb_max[0]), lerpf(p1.y, s.wb_min[1], s.wb_max[1]), lerpf(p1.z, s.wb_min[2], s.wb_max[2]));
+    V3 vmin(minf(a.x, b.x), minf(a.y, b.y), minf(a.z, b.z)), vmax(maxf(a.x, b.x), maxf(a.y, b.y), maxf(a.z, b.z));
+    float contrib = 0.0f;
+    for (uint32_t i = 0; i < 128; ++i) {
+        V3 u3(radical_inverse(0, i), radical_inverse(1, i), radical_inverse(2, i));
+        IData intr;
+        intr.p = V3(lerpf(u3.x, vmin.x, vmax.x), lerpf(u3.y, vmin.y, vmax.y), lerpf(u3.z, vmin.z, vmax.z));
+        P2 u(radical_inverse(3, i), radical_inverse(4, i));
+        float pdf = 0.0f; V3 wi; IData vis;
+        RGB Li = light_sample_li<true>(s, j, intr, u, wi, pdf, vis);
+        if (pdf > 0.0f) contrib += Li.y() / pdf;
+    }
+    func[gid] = contrib;
+}
+// Per voxel: floor at 0.001*avg, then Distribution1D::new (sampling.rs:12-34)
+__global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int) {
+    const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    float *f = func + cell * n_lights, *c = cdf + cell * (n_lights + 1);
+    float sum = 0.0f;
+    for (uint32_t j = 0; j < n_lights; ++j) sum += f[j];
+    const float avg = sum / (128.0f * (float)n_lights);
+    const float min_contrib = (avg > 0.0f) ? 0.001f * avg : 1.0f;
+    for (uint32_t j = 0; j < n_lights; ++j) f[j] = maxf(f[j], min_contrib);
+    c[0] = 0.0f;
+    for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] = c[i - 1] + f[i - 1] / (float)n_lights;
+    const float fi = c[n_lights];
+    if (fi == 0.0f) { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] = (float)i / (float)n_lights; }
+    else { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] /= fi; }
+    func_int[cell] = fi;
+}
+// ---- parity helpers -------------------------------------------------------------------------------------------
+__global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
+                                 uint32_t n_dims, float *out, uint64_t *out_index) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t index = halton_index_for_sample(hp, pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_num[i]);
+    if (out_index) out_index[i] = index;
+    for (uint32_t d = 0; d < n_dims; ++d) out[(size_t)i * n_dims + d] = halton_sample_dimension(tabs, hp, index, d);
+}
+
+__global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
+                                uint32_t n_dims, float *out, uint64_t *out_index) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
+    uint64_t index = sobol_interval_to_index(tabs, (uint32_t)sp.log2_resolution, sample_num[i], (uint32_t)(px - sp.sb_min[0]), (uint32_t)(py - sp.sb_min[1]));
+    if (out_index) out_index[i] = index;
+    for (uint32_t d = 0; d < n_dims; ++d)
+        out[(size_t)i * n_dims + d] = (d < 2) ? sobol_pixel_dim(tabs.m32, sp, index, (int)d, d == 0 ? px : py) : sobol_sample_float(tabs.m32, index, d);
+}
+__global__ void k_camera_rays(RenderConst rc, uint32_t n, const float *cs, float *out_o, float *out_d) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d;
+    camera_ray(rc, cs[5 * i], cs[5 * i + 1], cs[5 * i + 2], P2(cs[5 * i + 3], cs[5 * i + 4]), o, d);
+    out_o[3 * i] = o.x; out_o[3 * i + 1] = o.y; out_o[3 * i + 2] = o.z;
+    out_d[3 * i] = d.x; out_d[3 * i + 1] = d.y; out_d[3 * i + 2] = d.z;
+}

@@ -1,0 +1,237 @@
+// kern_shade.h -- split out of the former single-file kernels.hip so that the translation units compile in parallel.
+#pragma once
+#include "kern_shade_common.h"
+#ifndef PT_SHADE_ATTR
+#define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
+#endif
+// MODE: 0 = triangle-only scenes, 1 = general geometry (spheres and/or instances), 2 = general geometry + textures
+// DIFF: the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only)
+template <int MAXL, int MODE, bool DIFF>
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+    constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
+    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
+    // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
+    __shared__ uint32_t s_hist[16];
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 64) s_pacc[threadIdx.x] = 0;
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};
+#endif
+    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint32_t count = *job.count;
+    const uint32_t rounded = (count + 255u) & ~255u;   // whole blocks iterate together
+    unsigned long long zero_num = 0, zero_den = 0, n_valid = 0, n_bytes = 0;  // n_bytes: path-state + queue bytes
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
+    const bool valid = qi < count;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
+    int finished_bounces = -1;
+    uint32_t pid = 0;
+    PT_T(0);
+    if (valid) {
+        n_valid++;
+        n_bytes += 4 + 4 + 8 + 12 + 12 + /* write back */ 12 + 12 + 4;   // queue, meta, sobol index, L, beta
+        pid = job.queue[qi];
+        uint32_t meta = ps.meta[pid];
+        uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
+        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+        smp.base = 0xffffffffu;
+        RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+        RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+
+        // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+
+        PT_T(3);
+        if (flags & PF_DEAD) {
+            finished_bounces = (int)bounces;
+        } else {
+            n_bytes += 24 + 16;  // ray + hit record
+            V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+            const uint32_t hp = ps.hit_prim[pid];
+            const bool found = hp != PT_NONE;
+            SurfaceInteraction si;
+            if (found) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+            // path.rs:106-117
+            if (bounces == 0 || (flags & PF_SPECULAR)) {
+                if (found) {
+                    const uint32_t al = s.prim_light[hp];
+                    if (al != PT_NONE) L = L + area_l(s.lights[al], si.n, -rd) * beta;
+                } else {
+                    for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
+                }
+            }
+            bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
+            if (!terminated) {
+                PT_T(4);
+                smp.load_window();
+                PT_T(10);
+                Bsdf<MAXL, DIFF> bsdf;
+                const uint32_t mi = s.prim_material[hp];
+                bool has_bsdf = false;
+                if (TEX) {
+                    // compute_scattering_functions -> compute_differentials(ray) (interaction.rs:262-342): only the camera ray
+                    // carries differentials; every spawned ray has none
+                    RayDiff rdiff; rdiff.has = false;
+                    if (flags & PF_CAMERA_RAY) {
+                        P2 plens_u(0.0f, 0.0f);
+                        if (rc.lens_radius > 0.0f) plens_u = rc.halton.enabled ? P2(halton_sample_dimension(tabs, rc.halton, smp.index, 3u), halton_sample_dimension(tabs, rc.halton, smp.index, 4u))
+                                                                              : P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
+                        rdiff = camera_ray_differentials(rc, ps.pfilm_x[pid], ps.pfilm_y[pid], plens_u, ro, rd);
+                    }
+                    const TexCtx tctx = compute_differentials(si, rdiff);
+                    if (mi != PT_NONE && s.materials[mi].tex[PT_MP_BUMP] >= 0) {   // bump() (core/material.rs:46-87)
+                        const int dtex = s.materials[mi].tex[PT_MP_BUMP];
+                        TexCtx e = tctx;
+                        float du = 0.5f * (fabsf(tctx.dudx) + fabsf(tctx.dudy));
+                        if (du == 0.0f) du = 0.0005f;
+                        e.p = si.p + si.sh_dpdu * du; e.uv = P2(si.uv.x + du, si.uv.y + 0.0f);
+                        const float udisplace = tex_eval(s, dtex, e).r;
+                        float dv = 0.5f * (fabsf(tctx.dvdx) + fabsf(tctx.dvdy));
+                        if (dv == 0.0f) dv = 0.0005f;
+                        e.p = si.p + si.sh_dpdv * dv; e.uv = P2(si.uv.x + 0.0f, si.uv.y + dv);
+                        const float vdisplace = tex_eval(s, dtex, e).r;
+                        const float displace = tex_eval(s, dtex, tctx).r;
+                        const V3 bdpdu = si.sh_dpdu + si.sh_n * ((udisplace - displace) / du) + si.sh_dndu * displace;
+                        const V3 bdpdv = si.sh_dpdv + si.sh_n * ((vdisplace - displace) / dv) + si.sh_dndv * displace;
+                        si.sh_n = normalize(cross(bdpdu, bdpdv));   // set_shading_geometry(.., false), interaction.rs:228-249
+                        if (si.has_shape) { if (si.shape_flip) si.sh_n = -si.sh_n; si.sh_n = face_forward(si.sh_n, si.n); }
+                        si.sh_dpdu = bdpdu; si.sh_dpdv = bdpdv;
+                    }
+                    const TexMatEval E{s, tctx};
+                    has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E, s.materials);
+                } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
+                flags &= ~PF_CAMERA_RAY;
+                IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
+                MedIface mif{PT_NONE, PT_NONE};
+                if (VOL) mif = surface_iface(s, hp, ps.medium[pid]);   // primitive.rs:139-145
+                if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
+                    V3 o; spawn_ray(it, rd, o);
+                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    if (VOL) {   // volpath.rs:127-131 `bounces -= 1; continue`: the count drops by one and wraps below zero
+                        ps.medium[pid] = medium_toward(mif, si.n, rd);
+                        bounces = (bounces - 1u) & 0xffu;
+                    }
+                    push_ext = true;
+                } else {
+                    const V3 wo = -rd;  // path.rs:148; estimate_direct uses isect.wo (== -rd for triangles, triangle.rs:296)
+                    // uniform_sample_onelight (integrator.rs:81-106)
+                    if (VOL) nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif);   // volpath.rs:136-138: unconditional
+                    else if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                        zero_den++;
+                        const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
+                        if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
+                    }
+                    // path.rs:148-174: sample the BSDF for the next direction
+                    PT_T(11);
+                    V3 wi; float pdf = 0.0f; int sflags = 0;
+                    RGB f = bsdf.sample_f(wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
+                    if (f.is_black() || pdf == 0.0f) terminated = true;
+                    else {
+                        beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
+                        if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
+                        float etascale = ps.etascale[pid];
+                        if ((sflags & BSDF_SPECULAR) && (sflags & BSDF_TRANSMISSION)) {
+                            const float eta = bsdf.eta;
+                            etascale *= (dot(wo, si.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
+                            ps.etascale[pid] = etascale;
+                        }
+                        V3 o; spawn_ray(it, wi, o);
+                        bool rr_kill = false, to_probe = false;
+                        if constexpr (MAXL == 5) {
+                            // path.rs:177-183: importance sample the BSSRDF; the probe chain of sample_sp (bssrdf.rs:367-395)
+                            // is walked by k_bssrdf over the following wavefront iterations
+                            if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
+                                const P2 s2 = smp.get_2d();
+                                const float s1 = smp.get_1d();
+                                DevBssrdf bss; bss.init_material(s.materials[mi], s.bss_tables); bss.init_frame(si);
+                                V3 start, target; float u1n = 0.0f;
+                                const BssSoA &bs = job.bs;
+                                if (!bss.probe_segment(s1, s2, start, target, u1n)) rr_kill = true;   // S is black: `break`
+                                else {
+                                    const V3 pd = target - start;
+                                    if (pd.x == 0.0f && pd.y == 0.0f && pd.z == 0.0f) rr_kill = true;  // empty chain: nfound == 0
+                                    else {
+                                        bs.start_x[pid] = start.x; bs.start_y[pid] = start.y; bs.start_z[pid] = start.z;
+                                        bs.target_x[pid] = target.x; bs.target_y[pid] = target.y; bs.target_z[pid] = target.z;
+                                        bs.po_x[pid] = si.p.x; bs.po_y[pid] = si.p.y; bs.po_z[pid] = si.p.z;
+                                        bs.ns_x[pid] = bss.ns.x; bs.ns_y[pid] = bss.ns.y; bs.ns_z[pid] = bss.ns.z;
+                                        bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
+                                        bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
+                                        // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
+                                        ps.ox[pid] = start.x; ps.oy[pid] = start.y; ps.oz[pid] = start.z;
+                                        ps.dx[pid] = pd.x; ps.dy[pid] = pd.y; ps.dz[pid] = pd.z;
+                                        to_probe = true; push_probe = true; n_bytes += 18 * 4 + 24 + 4;
+                                    }
+                                }
+                            }
+                        }
+                        // path.rs:206-214 Russian roulette
+                        RGB rrbeta = beta * etascale;
+                        if (!to_probe && !rr_kill && rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
+                            const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
+                            if (smp.get_1d() < q) rr_kill = true;
+                            else beta = beta / (1.0f - q);
+                        }
+                        if (rr_kill) terminated = true;
+                        else if (!to_probe) {
+                            bounces += 1;
+                            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                            ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                            if (VOL) ps.medium[pid] = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
+                            push_ext = true; n_bytes += 24 + 4 + 4;  // new ray, etascale, ext queue entry
+                        }
+                    }
+                }
+            }
+            if (terminated) {
+                if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
+                else finished_bounces = (int)bounces;
+            }
+        }
+        PT_T(12);
+        if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
+        ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
+        ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+        ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+    }
+    PT_T(13);
+    lq_push(s_qext, pid, push_ext);
+    lq_push(s_qres, pid, push_resolve);
+    lq_push(s_qsh, pid, push_shadow);
+    lq_push(s_qmis, pid, push_mis);
+    if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)
+    if constexpr (MAXL == 5) if (job.probe_next) lq_push(s_qprobe, pid, push_probe);
+    __syncthreads();
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    __syncthreads();
+    }  // persistent loop over the queue
+    lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
+    lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
+    lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
+    lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    __syncthreads();
+    __syncthreads();   // s_hist complete
+#ifdef PT_REGION_PROFILE
+    PT_T(14);
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(&job.counters->regions[threadIdx.x], s_pacc[threadIdx.x] + s_pacc[16 + threadIdx.x] + s_pacc[32 + threadIdx.x] + s_pacc[48 + threadIdx.x]);
+#endif
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->zero_den, zero_den);
+    counter_add(&job.counters->stages, n_valid);
+    counter_add(&job.counters->shade_items[job.cls], n_valid);
+    counter_add(&job.counters->shade_bytes[job.cls], n_bytes);
+}

@@ -1,0 +1,293 @@
+// kern_trace.h -- split out of the former single-file kernels.hip so that the translation units compile in parallel.
+#pragma once
+#include "kern_common.h"
+// ---- BVH traversal ---------------------------------------------------------------------------------
+
+// Persistent waves ("persistent threads"): every lane owns one ray at a time; lanes whose ray has finished are
+// refilled from the queue with one atomicAdd per wave, so a wave stays populated until the queue drains.
+//
+// The reference visits nodes one at a time (test node, then push far child / descend near child, bvh.rs:728-751).
+// Here one 64-byte record per interior node carries BOTH children's bounds, so a ray performs one dependent fetch
+// per interior node it enters instead of one per node it tests. Results and counters stay those of the reference:
+//  * the near child is tested immediately with the current t_max -- exactly when the reference tests it;
+//  * the far child's slab arithmetic is evaluated now but its `tmin < ray.t_max` comparison is deferred to pop time
+//    (tmin is kept on the stack), which is when the reference performs the whole test with the then-current t_max;
+//  * a far child whose t_max-independent part already fails is not pushed; the reference would pop, test and
+//    discard it later, so the number of such skipped entries lying directly below each pushed entry is carried along
+//    (6 bits in the stack word) and added to the node-visit counter at the moment the reference would pop them.
+// Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
+
+// GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
+#ifndef PT_TRACE_ATTR
+#define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
+                        // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
+#endif
+// MODE: 0 = triangle-only scenes, 1 = general geometry (spheres, instances), 2 = general geometry + alpha-masked triangles
+template <bool ANY, int MODE>
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+    constexpr bool SPH = MODE >= 1, ALPHA = MODE == 2;
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
+    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLdsStack)) + lane;
+    const uint32_t count = *job.count;
+    const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
+    const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
+    uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
+#ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
+    uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0;
+#define PT_UTIL(it, act, pred) do { const unsigned long long m_ = __ballot(pred); if (pred) { act++; it += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } } while (0)
+#else
+#define PT_UTIL(it, act, pred) do { } while (0)
+#endif
+
+    // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
+    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
+    uint32_t state = ST_IDLE;
+    bool exhausted = false;
+    constexpr int kChunk = 256;
+    uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
+    uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
+    V3 ro, rd, inv_dir;
+    TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
+    bool nx = false, ny = false, nz = false, found = false;
+    float t_max = 0.0f;
+    uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
+    uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
+    constexpr uint32_t kMarker = 0xFFC0DEADu;   // stack word 1 of an "end of instance" entry (never a real tmin)
+
+    // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
+    auto pop_next = [&]() {
+        for (;;) {
+            n_nodes += pending; pending = 0;          // skipped far children above the top entry: popped + failed
+            if (sp == 0) { state = ST_DONE; return; }
+            sp--;
+            uint32_t w0, w1;
+            if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
+            else { w0 = spill[(2 * (sp - kLdsStack)) * 64]; w1 = spill[(2 * (sp - kLdsStack) + 1) * 64]; }
+            if (SPH && w1 == kMarker) {                // the object's BVH is exhausted: back to world space (primitive.rs:70-77)
+                pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
+                ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]); rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
+                inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                tray = tri_ray_setup(rd);
+                t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
+                in_inst = PT_NONE; inst_hit = false;
+                if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; return; }  // remaining packets of the outer leaf
+                continue;
+            }
+            n_nodes++;                                 // the reference tests the popped node now
+            pending = (w0 >> 25) & 63u;
+            if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
+                cur = w0 & kRefMask;
+                state = (w0 & kLeafBit) ? ST_LEAF : ST_ENTER;
+                return;
+            }
+        }
+    };
+
+    for (;;) {
+        // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
+        //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
+        //      paid once per batch instead of once per ray.
+        const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
+        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF);
+        if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
+            const bool retire = state == ST_DONE;
+            if (retire) {
+                if (ANY) job.out_occluded[pid] = found ? 1 : 0;
+                else {
+                    job.out_prim[pid] = hit_prim;
+                    if (job.out_t) job.out_t[pid] = hit_t;
+                    if (job.out_b0) { job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2; }   // NULL: only the hit / miss matters (volpath shadow rays)
+                    if (SPH && job.out_inst) job.out_inst[pid] = hit_inst;
+                }
+            }
+            if (retire) state = ST_IDLE;
+            if (!exhausted) {
+                // work fetch: the wave reserves kChunk consecutive queue entries with one atomic and hands them
+                // out over several refills (consecutive entries are spatially coherent rays)
+                if (chunk_left == 0) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(job.head, (uint32_t)kChunk);
+                    chunk_next = __shfl(base, 0);
+                    chunk_left = (chunk_next < count) ? min((uint32_t)kChunk, count - chunk_next) : 0u;
+                    if (chunk_left == 0) exhausted = true;
+                }
+                const uint32_t rank = (uint32_t)__popcll(donem & ((1ull << lane) - 1ull));
+                const uint32_t take = min(chunk_left, (uint32_t)__popcll(donem));
+                const uint32_t qi = chunk_next + rank;
+                const bool get = state == ST_IDLE && rank < take;
+                chunk_next += take; chunk_left -= take;
+                if (get) {
+                    pid = job.queue ? job.queue[qi] : qi;
+                    ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]);
+                    rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
+                    t_max = job.tmax ? job.tmax[pid] : job.scalar_tmax;
+                    inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                    tray = tri_ray_setup(rd);
+                    sp = 0; pending = 0; found = false;
+                    hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                    in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
+                    n_rays++;
+                    state = ST_DONE;
+                    if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
+                        n_nodes++;
+                        if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
+                            cur = s.root_ref & kRefMask;
+                            state = (s.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(state != ST_IDLE) == 0ull) break;   // queue drained and every lane retired
+
+        // ---- one record per lane and iteration: a lane at an interior node fetches its 64-byte two-wide record, a lane at a leaf
+        //      its next 48-byte packet; both kinds of fetch are in flight together and nobody waits for a phase change
+        // lanes at a leaf join in once `leaf_quorum` of them wait (or no lane is at a node), so the triangle test is not
+        // executed for a handful of lanes in every iteration
+        const bool at_node = state == ST_ENTER;
+        const unsigned long long leaf_m = __ballot(state == ST_LEAF);
+        const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || __ballot(at_node) == 0ull);
+        PT_UTIL(u_it1, u_act1, at_node || at_leaf);
+        PT_UTIL(u_it2, u_act2, at_leaf);
+        if (at_node || at_leaf) {
+            const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
+            // Pin the whole record in front of the node / leaf branch: left alone, the compiler sinks the fields only the node path
+            // reads (q2.z, q3.z) below the branch as two more dword loads, i.e. a second dependent L1 round trip in every node step
+            // (measured: extend 143 -> 126 ms per step).
+            asm volatile("" :: "v"(q2.z), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+            bool need_pop = false;
+            if (at_node) {
+                const float lmin[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+                const float lmax[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                const float rmin[3] = {__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+                const float rmax[3] = {__uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w)};
+                const uint32_t axis = q3.z & 0xffu;
+                const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);   // near child = right when the ray is negative along the split axis
+                float tmin_l, tmin_r;
+                const bool geo_l = slab_geo(lmin, lmax, ro, inv_dir, nx, ny, nz, tmin_l);
+                const bool geo_r = slab_geo(rmin, rmax, ro, inv_dir, nx, ny, nz, tmin_r);
+                const bool geo_near = neg ? geo_r : geo_l, geo_far = neg ? geo_l : geo_r;
+                const float tmin_near = neg ? tmin_r : tmin_l, tmin_far = neg ? tmin_l : tmin_r;
+                const uint32_t near_ref = neg ? q3.y : q3.x, far_ref = neg ? q3.x : q3.y;
+                // reference: push far, cur = near, test near
+                if (geo_far) {
+                    if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    else {
+                        const uint32_t w0 = far_ref | (pending << 25), w1 = __float_as_uint(tmin_far);
+                        if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
+                        else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = w1; }
+                        sp++; pending = 0;
+                    }
+                } else pending++;
+                n_nodes++;  // the near child's test
+                if (geo_near && tmin_near < t_max) {
+                    cur = near_ref & kRefMask;
+                    state = (near_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                } else need_pop = true;
+            } else {
+                // leaf packets in ordered_prims order
+                const uint32_t fl = q2.w, li = cur;
+                bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
+                if (fl & TP_INSTANCE) {
+                    if constexpr (SPH) {  // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
+                        const DevInstance &I = s.instances[q2.z];
+                        // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
+                        const M4 w2i = ldm4g(I.world_to_instance);
+                        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+                        const float l2 = length_squared(d2);
+                        float tm2 = t_max;
+                        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
+                        const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
+                        const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
+                        bool enter = true;
+                        if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+                        if (enter) {
+                            // remember where to resume: the rest of this leaf (if any) and the outer skip count
+                            const bool more = !(fl & TP_LAST);
+                            const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
+                            if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                            else {
+                                if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
+                                else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = kMarker; }
+                                sp++; pending = 0;
+                                t_max_world = t_max; in_inst = q2.z; inst_hit = false;
+                                ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
+                                tray = tri_ray_setup(rd);
+                                cur = I.root_ref & kRefMask;
+                                state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                                advance = false;
+                            }
+                        }
+                    }
+                } else if (fl & TP_SPHERE) {
+                    if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
+                        n_sph++;
+                        float t, phi; V3 ph, dobj;
+                        if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, ANY, t, ph, phi, dobj)) {
+                            found = true;
+                            if (ANY) { state = ST_DONE; advance = false; }
+                            else {
+                                t_max = t;
+                                hit_prim = q2.y; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
+                                hit_inst = in_inst; inst_hit = in_inst != PT_NONE;
+                            }
+                        }
+                    }
+                } else {
+                    n_tris++;
+                    V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                    V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+                    V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+                    float t, b0, b1, b2;
+                    bool hit = tri_hit_params(p0, p1, p2, ro, tray, t_max, t, b0, b1, b2);
+                    if constexpr (ALPHA) {
+                        // Triangle::intersect (triangle.rs:275-285) / intersect_p (:497-545) with an alpha mask: the hit is
+                        // discarded where the mask evaluates to 0; intersect_p then also rejects degenerate triangles
+                        if (hit && (fl & TP_ALPHA) && !(fl & TP_BOGUS)) {
+                            const uint32_t tri = q2.z & 0x3fffffffu;
+                            P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
+                            TexCtx c; c.dpdx = V3(0.0f, 0.0f, 0.0f); c.dpdy = V3(0.0f, 0.0f, 0.0f); c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
+                            c.p = p0 * b0 + p1 * b1 + p2 * b2;
+                            c.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
+                            const int32_t a = s.tri_alpha ? s.tri_alpha[tri] : -1;
+                            if (a >= 0 && tex_eval(s, a, c).r == 0.0f) hit = false;
+                            if (ANY && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
+                        } else if (ANY && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
+                    }
+                    if (hit) {
+                        if (ANY) { found = true; state = ST_DONE; advance = false; }
+                        else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
+                            found = true; t_max = t;  // primitive.rs:137
+                            hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                            if (SPH) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
+                        }
+                    }
+                }
+                if (advance) { if (fl & TP_LAST) need_pop = true; else cur = li + 1u; }
+            }
+            if (need_pop) pop_next();
+        }
+    }
+    counter_add(&job.counters->nodes, n_nodes);
+    counter_add(&job.counters->tri_tests, n_tris);
+    if (SPH) counter_add(&job.counters->sphere_tests, n_sph);
+    counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
+    counter_add(&job.counters->k_nodes[job.kind], n_nodes);
+    counter_add(&job.counters->k_tris[job.kind], n_tris);
+    counter_add(&job.counters->k_rays[job.kind], n_rays);
+#ifdef PT_TRACE_UTIL
+    for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
+    if (lane == 0) {
+        atomicAdd(&job.counters->regions[4 * job.kind + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * job.kind + 1], (unsigned long long)u_act1);
+        atomicAdd(&job.counters->regions[4 * job.kind + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * job.kind + 3], (unsigned long long)u_act2);
+    }
+#endif
+}

@@ -1,0 +1,12 @@
+// tu_shade.hip -- the surface shade kernels of one MODE (0 triangle-only, 1 general geometry, 2 + textures, 3 volpath) and one
+// lobe budget; compiled once per (PT_TU_MODE, PT_TU_MAXL) pair so the sixteen instantiations build in parallel.
+#include "kern_shade.h"
+#if !defined(PT_TU_MODE) || !defined(PT_TU_MAXL)
+#error "compile with -DPT_TU_MODE=0..3 -DPT_TU_MAXL=1|2|5"
+#endif
+#define PT_INST_SHADE(L, S, D) template __global__ void k_shade<L, S, D>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
+#if PT_TU_MAXL == 1
+PT_INST_SHADE(1, PT_TU_MODE, true) PT_INST_SHADE(1, PT_TU_MODE, false)
+#else
+PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, false)
+#endif

@@ -105,7 +105,7 @@ class Scene:
     def kernel_stats(self):
         arr = (A.PtKernelStat * 32)(); n = C.c_uint32()
         self.L.check(self.L.lib.pt_get_kernel_stats(self.h, arr, 32, C.byref(n)))
-        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, items=arr[i].items, bvh_nodes=arr[i].bvh_nodes, triangle_tests=arr[i].triangle_tests) for i in range(n.value)]
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, items=arr[i].items, bvh_nodes=arr[i].bvh_nodes, triangle_tests=arr[i].triangle_tests, kernel=arr[i].kernel.decode()) for i in range(n.value)]
 
     def trace_closest(self, o, d, tmax):
         o, d, tmax = (np.ascontiguousarray(x, dtype=np.float32) for x in (o, d, tmax))

@@ -529,3 +529,239 @@ def ganesha_halton_hlbvh(**kw):
     b = ganesha_scale(**kw)
     b.sampler = "halton"; b.split_method = "hlbvh"
     return b
+
+
+# ---- the S3 / S4 / S5 workloads at their specified scale (configs C3 / C4 / C5) --------------------
+
+class PCG32:
+    """core/rng.rs:10-75 (PCG32, `RNG::new(sequence_index)`): the generator SURVEY 8(d) names for S4's random transforms."""
+    MULT, DEFAULT_STATE, M64 = 0x5851F42D4C957F2D, 0x853C49E6748FEA9B, (1 << 64) - 1
+
+    def __init__(self, seq):
+        self.state, self.inc = 0, ((seq << 1) | 1) & self.M64
+        self.u32(); self.state = (self.state + self.DEFAULT_STATE) & self.M64; self.u32()
+
+    def u32(self):
+        old = self.state
+        self.state = (old * self.MULT + self.inc) & self.M64
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF; rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def f(self):
+        return min(float(np.float32(0.99999994)), float(np.float32(self.u32()) * np.float32(2.0 ** -32)))
+
+    def uniform(self, lo, hi):
+        return lo + (hi - lo) * self.f()
+
+
+def grid_patch(p00, du, dv, nu, nv):
+    """Planar patch p00 + s*du + t*dv, s,t in [0,1], subdivided into nu x nv quads (2*nu*nv triangles, normal du x dv)."""
+    p00, du, dv = (np.asarray(x, dtype=np.float64) for x in (p00, du, dv))
+    s = np.linspace(0.0, 1.0, nu + 1); t = np.linspace(0.0, 1.0, nv + 1)
+    ss, tt = np.meshgrid(s, t, indexing="xy")
+    P = p00[None, :] + ss.ravel()[:, None] * du[None, :] + tt.ravel()[:, None] * dv[None, :]
+    i0 = (np.arange(nu)[None, :] + (nu + 1) * np.arange(nv)[:, None]).ravel().astype(np.uint32)
+    tris = np.stack([np.stack([i0, i0 + 1, i0 + nu + 2], axis=1), np.stack([i0, i0 + nu + 2, i0 + nu + 1], axis=1)], axis=1).reshape(-1, 3)
+    return P.astype(F), tris.astype(np.uint32)
+
+
+def merge_meshes(parts):
+    Ps, Is, base = [], [], 0
+    for P, I in parts:
+        Ps.append(P); Is.append(I + np.uint32(base)); base += len(P)
+    return np.concatenate(Ps).astype(F), np.concatenate(Is).astype(np.uint32)
+
+
+def subdivided_box(lo, hi, n):
+    """Axis-aligned box, every face an n x n grid (12*n*n triangles), outward normals."""
+    x0, y0, z0 = lo; x1, y1, z1 = hi
+    dx, dy, dz = (x1 - x0, 0, 0), (0, y1 - y0, 0), (0, 0, z1 - z0)
+    faces = [((x0, y0, z0), dz, dy), ((x1, y0, z0), dy, dz), ((x0, y0, z0), dx, dz), ((x0, y1, z0), dz, dx), ((x0, y0, z0), dy, dx), ((x0, y0, z1), dx, dy)]
+    return merge_meshes([grid_patch(p, a, b, n, n) for p, a, b in faces])
+
+
+def torus_mesh(nu, nv, R, r):
+    """Torus around the y axis: nu x nv quads, per-vertex normals."""
+    u = np.linspace(0.0, 2.0 * np.pi, nu + 1); v = np.linspace(0.0, 2.0 * np.pi, nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="xy"); uu, vv = uu.ravel(), vv.ravel()
+    P = np.stack([(R + r * np.cos(vv)) * np.cos(uu), r * np.sin(vv), (R + r * np.cos(vv)) * np.sin(uu)], axis=1)
+    N = np.stack([np.cos(vv) * np.cos(uu), np.sin(vv), np.cos(vv) * np.sin(uu)], axis=1)
+    i0 = (np.arange(nu)[None, :] + (nu + 1) * np.arange(nv)[:, None]).ravel().astype(np.uint32)
+    tris = np.stack([np.stack([i0, i0 + nu + 1, i0 + 1], axis=1), np.stack([i0 + 1, i0 + nu + 1, i0 + nu + 2], axis=1)], axis=1).reshape(-1, 3)
+    return P.astype(F), tris.astype(np.uint32), N.astype(F)
+
+
+def pot_mesh(nu, nv):
+    """A lathe "pot" (teapot-body stand-in): surface of revolution of a bulged profile around the y axis, nu x nv quads."""
+    u = np.linspace(0.0, 2.0 * np.pi, nu + 1); t = np.linspace(0.0, 1.0, nv + 1)
+    uu, tt = np.meshgrid(u, t, indexing="xy"); uu, tt = uu.ravel(), tt.ravel()
+    rad = 0.08 + 0.55 * np.sin(np.pi * np.clip(tt * 0.92 + 0.04, 0.0, 1.0)) ** 0.8 + 0.12 * np.exp(-((tt - 0.93) / 0.04) ** 2) + 0.03 * np.cos(12.0 * uu) * np.sin(np.pi * tt)
+    P = np.stack([rad * np.cos(uu), 1.1 * tt, rad * np.sin(uu)], axis=1)
+    i0 = (np.arange(nu)[None, :] + (nu + 1) * np.arange(nv)[:, None]).ravel().astype(np.uint32)
+    tris = np.stack([np.stack([i0, i0 + nu + 1, i0 + 1], axis=1), np.stack([i0 + 1, i0 + nu + 1, i0 + nu + 2], axis=1)], axis=1).reshape(-1, 3)
+    return P.astype(F), tris.astype(np.uint32)
+
+
+def country_kitchen_s3(xres=1920, yres=1080, spp=1024, maxdepth=5, wall_n=280, box_n=48, obj_n=112, n_objects=8):
+    """S3 / config C3: Cornell-style closed room, ~1 M triangles from subdivided walls and boxes (6 walls of wall_n^2
+    quads + two boxes of box_n^2 quads per face) + ~200 k triangles of tessellated tori / lathe pots (n_objects x 2*obj_n^2),
+    materials assigned round-robin from {matte, plastic roughness .1, uber, metal (copper defaults, metal.rs:13-53,116-117),
+    mirror, glass index 1.5} and 64 emissive triangles (a 8x4 grid of quads under the ceiling, one DiffuseAreaLight each)."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 3.0, 4.7), (0.0, 2.0, -2.0), (0.0, 1.0, 0.0)); b.camera(fov=62.0)
+    b.world_begin()
+    palette = [("matte", dict(Kd=(0.6, 0.6, 0.6))), ("plastic", dict(Kd=(0.25, 0.35, 0.6), Ks=(0.25, 0.25, 0.25), roughness=0.1)),
+               ("uber", dict(Kd=(0.5, 0.25, 0.2), Ks=(0.25, 0.25, 0.25), Kr=(0.1, 0.1, 0.1), roughness=0.1)), ("metal", dict()),
+               ("mirror", dict(Kr=(0.9, 0.9, 0.9))), ("glass", dict(eta=1.5))]
+    counter = [0]
+    def next_material():
+        kind, kw = palette[counter[0] % len(palette)]; counter[0] += 1
+        b.material(kind, **kw)
+    # 64 emissive triangles: 8 x 4 quads, 0.5 x 0.5 each, facing down
+    b.attribute_begin(); b.area_light_source(L=(22.0, 20.0, 16.0))
+    for j in range(4):
+        for i in range(8):
+            x0, z0 = -4.0 + i * 1.0 + 0.25, -3.0 + j * 1.5
+            P, I = quad((x0, 5.98, z0), (x0 + 0.5, 5.98, z0), (x0 + 0.5, 5.98, z0 + 0.5), (x0, 5.98, z0 + 0.5))
+            b.trianglemesh(P, I)
+    b.attribute_end()
+    # room [-5,5] x [0,6] x [-5,5], inward normals; order: floor, left, right, back, ceiling, front
+    walls = [((-5, 0, -5), (0, 0, 10), (10, 0, 0)), ((-5, 0, -5), (0, 6, 0), (0, 0, 10)), ((5, 0, -5), (0, 0, 10), (0, 6, 0)),
+             ((-5, 0, -5), (10, 0, 0), (0, 6, 0)), ((-5, 6, -5), (10, 0, 0), (0, 0, 10)), ((-5, 0, 5), (0, 6, 0), (10, 0, 0))]
+    for p, du, dv in walls:
+        next_material()
+        P, I = grid_patch(p, du, dv, wall_n, wall_n); b.trianglemesh(P, I)
+    for lo, hi, ang in (((-0.9, 0.0, -0.9), (0.9, 3.4, 0.9), 17.0), ((-0.8, 0.0, -0.8), (0.8, 1.6, 0.8), -20.0)):
+        b.attribute_begin(); next_material()
+        b.translate(-1.9 if ang > 0 else 1.8, 0.0, -2.2 if ang > 0 else -0.4); b.rotate(ang, 0.0, 1.0, 0.0)
+        P, I = subdivided_box(lo, hi, box_n); b.trianglemesh(P, I); b.attribute_end()
+    for k in range(n_objects):
+        b.attribute_begin(); next_material()
+        ang = 2.0 * np.pi * k / max(1, n_objects)
+        cx, cz = 3.3 * np.cos(ang), -0.6 + 2.9 * np.sin(ang)
+        if k % 2 == 0:
+            b.translate(float(cx), 0.32 + 0.9 * (k % 4 == 2), float(cz)); b.rotate(25.0 * k, 1.0, 0.3, 0.0)
+            P, I, N = torus_mesh(obj_n, obj_n, 0.62, 0.26); b.trianglemesh(P, I, N=N)
+        else:
+            b.translate(float(cx), 0.0, float(cz)); b.rotate(40.0 * k, 0.0, 1.0, 0.0); b.scale(0.9, 0.9, 0.9)
+            P, I = pot_mesh(obj_n, obj_n); b.trianglemesh(P, I)
+        b.attribute_end()
+    return b
+
+
+def terrain_height(x, z):
+    """S4 terrain: 3 * fbm over a 80 x 80 field (x, z arrays -> y)."""
+    p = np.stack([np.asarray(x, dtype=np.float64) * 0.05 + 31.0, np.full(np.shape(x), 7.0), np.asarray(z, dtype=np.float64) * 0.05 + 17.0], axis=-1).reshape(-1, 3)
+    return (3.0 * fbm(p, 5)).reshape(np.shape(x))
+
+
+def plant_meshes(scale=1.0):
+    """Three 50 k-triangle "plants": a bush (displaced sphere, 2*158^2 = 49,928 triangles), a tree (cone trunk 2,048 + 23,976 leaf
+    quads = 50,000) and a grass tuft (5,000 blades x 10 triangles = 50,000). `scale` < 1 thins them out for small tests."""
+    rng = np.random.default_rng(20260107)
+    n = max(4, int(round(158 * scale)))
+    bushP, bushI, bushN = displaced_sphere(n, with_normals=True)
+    bushP = (bushP * np.array([0.9, 0.8, 0.9], dtype=F) + np.array([0.0, 0.8, 0.0], dtype=F)).astype(F)
+    # tree: trunk + leaf quads in an ellipsoidal crown
+    nt_u, nt_v = max(4, int(64 * scale)), max(2, int(16 * scale))
+    u = np.linspace(0.0, 2.0 * np.pi, nt_u + 1); t = np.linspace(0.0, 1.0, nt_v + 1)
+    uu, tt = np.meshgrid(u, t, indexing="xy"); uu, tt = uu.ravel(), tt.ravel()
+    rad = 0.16 * (1.0 - 0.8 * tt)
+    trunkP = np.stack([rad * np.cos(uu), 2.0 * tt, rad * np.sin(uu)], axis=1)
+    i0 = (np.arange(nt_u)[None, :] + (nt_u + 1) * np.arange(nt_v)[:, None]).ravel().astype(np.uint32)
+    trunkI = np.stack([np.stack([i0, i0 + nt_u + 1, i0 + 1], axis=1), np.stack([i0 + 1, i0 + nt_u + 1, i0 + nt_u + 2], axis=1)], axis=1).reshape(-1, 3)
+    n_leaf = max(8, int(round(23976 * scale * scale)))
+    c = rng.normal(size=(n_leaf, 3)); c /= np.linalg.norm(c, axis=1, keepdims=True); c *= rng.random((n_leaf, 1)) ** (1.0 / 3.0)
+    c = c * np.array([1.1, 0.9, 1.1]) + np.array([0.0, 2.3, 0.0])
+    a = rng.normal(size=(n_leaf, 3)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    bb = np.cross(a, rng.normal(size=(n_leaf, 3))); bb /= np.linalg.norm(bb, axis=1, keepdims=True)
+    s = 0.07
+    leafP = np.stack([c - s * a - s * bb, c + s * a - s * bb, c + s * a + s * bb, c - s * a + s * bb], axis=1).reshape(-1, 3)
+    q = (4 * np.arange(n_leaf, dtype=np.uint32))[:, None]
+    leafI = np.concatenate([q + np.array([0, 1, 2], dtype=np.uint32), q + np.array([0, 2, 3], dtype=np.uint32)], axis=1).reshape(-1, 3)
+    treeP, treeI = merge_meshes([(trunkP.astype(F), trunkI.astype(np.uint32)), (leafP.astype(F), leafI.astype(np.uint32))])
+    # grass tuft: blades of 5 segments (10 triangles), bending outwards
+    n_blade = max(4, int(round(5000 * scale * scale)))
+    base = rng.normal(size=(n_blade, 2)) * 0.35; dirn = rng.normal(size=(n_blade, 2)); dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    height = rng.uniform(0.5, 1.3, n_blade); bend = rng.uniform(0.1, 0.6, n_blade)
+    seg = np.linspace(0.0, 1.0, 6)
+    side = np.stack([-dirn[:, 1], dirn[:, 0]], axis=1) * 0.012
+    cx = base[:, None, 0] + dirn[:, None, 0] * bend[:, None] * seg[None, :] ** 2; cz = base[:, None, 1] + dirn[:, None, 1] * bend[:, None] * seg[None, :] ** 2
+    cy = height[:, None] * seg[None, :]
+    wid = (1.0 - 0.85 * seg)[None, :]
+    left = np.stack([cx - side[:, None, 0] * wid, cy, cz - side[:, None, 1] * wid], axis=2); right = np.stack([cx + side[:, None, 0] * wid, cy, cz + side[:, None, 1] * wid], axis=2)
+    grassP = np.stack([left, right], axis=2).reshape(n_blade, 12, 3)    # vertex 2*j = left_j, 2*j+1 = right_j
+    j = np.arange(5, dtype=np.uint32)
+    one = np.stack([np.stack([2 * j, 2 * j + 1, 2 * j + 3], axis=1), np.stack([2 * j, 2 * j + 3, 2 * j + 2], axis=1)], axis=1).reshape(-1, 3)
+    grassI = ((12 * np.arange(n_blade, dtype=np.uint32))[:, None, None] + one[None, :, :]).reshape(-1, 3)
+    return (bushP, bushI, bushN), (treeP, treeI.astype(np.uint32), None), (grassP.reshape(-1, 3).astype(F), grassI.astype(np.uint32), None)
+
+
+def ecosystem_s4(xres=1920, yres=1080, spp=2048, maxdepth=5, n_inst=2000, terrain_n=500, plant_scale=1.0, env_size=(512, 256), seed=7, flatten=False):
+    """S4 / config C4: `n_inst` ObjectInstances of three 50 k-triangle plants (random translate / rotate / scale from
+    PCG32 sequence `seed`, rng.rs) over a 2*terrain_n^2-triangle fbm terrain, lit only by a 512x256 synthetic sky environment map
+    (importance-sampled InfiniteAreaLight). `flatten=True` emits the same geometry without instancing (small tests)."""
+    rng = PCG32(seed)
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 7.0, 44.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.attribute_begin(); b.rotate(-90.0, 1.0, 0.0, 0.0)   # lat-long map: +z pole -> +y
+    b.light_source("infinite", L=(1.0, 1.0, 1.0), texels=sky_env(*env_size)); b.attribute_end()
+    g = np.linspace(-40.0, 40.0, terrain_n + 1)
+    gx, gz = np.meshgrid(g, g, indexing="xy")
+    tP = np.stack([gx.ravel(), terrain_height(gx.ravel(), gz.ravel()), gz.ravel()], axis=1).astype(F)
+    i0 = (np.arange(terrain_n)[None, :] + (terrain_n + 1) * np.arange(terrain_n)[:, None]).ravel().astype(np.uint32)
+    tI = np.stack([np.stack([i0, i0 + terrain_n + 1, i0 + 1], axis=1), np.stack([i0 + 1, i0 + terrain_n + 1, i0 + terrain_n + 2], axis=1)], axis=1).reshape(-1, 3)
+    b.material("matte", Kd=(0.32, 0.28, 0.18)); b.trianglemesh(tP, tI.astype(np.uint32))
+    plants = plant_meshes(plant_scale)
+    mats = [("plastic", dict(Kd=(0.1, 0.45, 0.12), Ks=(0.15, 0.15, 0.15), roughness=0.25)), ("matte", dict(Kd=(0.18, 0.5, 0.15))), ("matte", dict(Kd=(0.35, 0.6, 0.2)))]
+    names = ("bush", "tree", "grass")
+    if not flatten:
+        for name, (P, I, N), (kind, kw) in zip(names, plants, mats):
+            b.object_begin(name); b.material(kind, **kw); b.trianglemesh(P, I, N=N); b.object_end()
+    for k in range(n_inst):
+        tx, tz = rng.uniform(-38.0, 38.0), rng.uniform(-38.0, 38.0)
+        ang, tilt, sc = rng.uniform(0.0, 360.0), rng.uniform(-8.0, 8.0), rng.uniform(0.6, 1.6)
+        ty = float(terrain_height(np.array([tx]), np.array([tz]))[0]) - 0.05
+        b.attribute_begin()
+        b.translate(tx, ty, tz); b.rotate(ang, 0.0, 1.0, 0.0); b.rotate(tilt, 1.0, 0.0, 0.0); b.scale(sc, sc, sc)
+        if not flatten: b.object_instance(names[k % 3])
+        else:
+            (P, I, N), (kind, kw) = plants[k % 3], mats[k % 3]
+            b.material(kind, **kw); b.trianglemesh(P, I, N=N)
+        b.attribute_end()
+    return b
+
+
+def dragon_s5(xres=1920, yres=1080, spp=4096, maxdepth=5, n=1466, env_size=(512, 256)):
+    """S5 / config C5: the S2 mesh (2*n^2-triangle displaced sphere) scaled x0.02 with
+    `Material "subsurface" "string name" "Skin1" "float scale" 20 "float eta" 1.5` (src/scenes/sss-dragon.pbrt) over a plain
+    matte plane, lit by an environment map."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 0.03, 0.1), (0.0, 0.006, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=35.0)
+    b.world_begin()
+    b.attribute_begin(); b.rotate(-90.0, 1.0, 0.0, 0.0)
+    b.light_source("infinite", L=(1.0, 1.0, 1.0), texels=sky_env(*env_size)); b.attribute_end()
+    b.material("matte", Kd=(0.4, 0.4, 0.4))
+    P, I = quad((-0.2, -0.024, -0.2), (-0.2, -0.024, 0.2), (0.2, -0.024, 0.2), (0.2, -0.024, -0.2)); b.trianglemesh(P, I)
+    b.attribute_begin()
+    b.scale(0.02, 0.02, 0.02)
+    b.material("subsurface", name="Skin1", scale=20.0, eta=1.5)
+    P, I, N = displaced_sphere(n, with_normals=False)
+    b.trianglemesh(P, I, N=N); b.attribute_end()
+    return b
+
+
+CONFIG_SCENES = {   # bench.py --config / tests: name -> (builder, spp named by BASELINE.json, description)
+    "C2": (ganesha_scale, 256, "S2 Ganesha-scale: 4,298,312-triangle displaced sphere (matte) + ground + quad area light + constant env"),
+    "C3": (country_kitchen_s3, 1024, "S3 Country-Kitchen-scale: closed room of subdivided walls/boxes (~1.0 M triangles) + 8 tessellated tori/pots (~0.2 M), "
+           "materials round-robin {matte, plastic, uber, metal, mirror, glass}, 64 emissive triangles"),
+    "C4": (ecosystem_s4, 2048, "S4 Ecosystem-scale: 2,000 object instances of three 50 k-triangle plants over a 500 k-triangle terrain, 512x256 environment map only"),
+    "C5": (dragon_s5, 4096, "S5 Dragon-subsurface-scale: the 4,298,312-triangle S2 mesh x0.02 with subsurface Skin1 (scale 20, eta 1.5) over a matte plane, environment map"),
+}

@@ -1,0 +1,100 @@
+"""BASELINE configs C3 / C4 / C5 at SURVEY 8(d)'s S3 / S4 / S5 specification (pbrt-rust_amd/scenes.py).
+
+GPU gates (the S2 gate of test_gpu_parity.py is the template): the full-size scene, 1920x1080 film, a 256x256 crop rendered
+by the HIP path through the C ABI and by the CPU oracle on the same tree -- exact work counters, identical weights,
+films equal to 2e-6 relative and normalised L-infinity < 1e-3 (the north-star gate).  CPU tests: the scene generators
+meet the specification (triangle / instance / light counts, PCG32 stream of rng.rs) and the oracle renders them."""
+import numpy as np
+import pytest
+
+COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats",
+            "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite")
+
+
+def test_pcg32_matches_the_oracle_rng(pkg, oracle):
+    """scenes.PCG32 == core/rng.rs (the oracle's restatement is pinned by tests/sampling.rs's shuffle KAT in test_oracle_kats)."""
+    import ctypes as C
+    for seq in (0, 7, 12345):
+        u = np.zeros(64, np.uint32); f = np.zeros(64, np.float32)
+        oracle.lib.orc_rng_u32_stream(seq, 0, 64, u.ctypes.data_as(pkg._abi.u32p), f.ctypes.data_as(pkg._abi.fp))
+        r = pkg.scenes.PCG32(seq)
+        assert [r.u32() for _ in range(64)] == u.tolist()
+
+
+def test_config_scenes_meet_the_specification(pkg):
+    S = pkg.scenes
+    d = S.country_kitchen_s3(xres=64, yres=36, spp=1).world_end()[0].desc()
+    room = 6 * 2 * 280 * 280 + 2 * 12 * 48 * 48
+    assert d.n_triangles == room + 8 * 2 * 112 * 112 + 64 and 0.95e6 < room < 1.05e6 and d.n_lights == 64
+    kinds = {d.materials[i].type for i in range(d.n_materials)}
+    A = pkg._abi
+    assert {A.PT_MAT_MATTE, A.PT_MAT_PLASTIC, A.PT_MAT_UBER, A.PT_MAT_METAL, A.PT_MAT_MIRROR, A.PT_MAT_GLASS} <= kinds
+    d = S.ecosystem_s4(xres=64, yres=36, spp=1).world_end()[0].desc()
+    assert d.n_instances == 2000 and d.n_objects == 3 and d.n_top == 500000 + 2000 and d.env_width == 512 and d.env_height == 256
+    assert [d.objects[i].n_prims for i in range(3)] == [49928, 50000, 50000] and d.n_lights == 1
+    d = S.dragon_s5(xres=64, yres=36, spp=1, n=64).world_end()[0].desc()     # full size: n = 1466 (bench.py / the GPU gate)
+    assert d.n_triangles == 2 * 64 * 64 + 2 and d.n_bssrdf_tables == 1
+    m = [d.materials[i] for i in range(d.n_materials) if d.materials[i].type == A.PT_MAT_SUBSURFACE][0]
+    assert m.scale == 20.0 and m.eta == 1.5
+
+
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+def test_oracle_renders_the_config_miniatures(pkg, oracle, name):
+    """The oracle walks every code path of the three configs at reduced size (finite film, all paths accounted for)."""
+    S = pkg.scenes
+    b = {"C3": lambda: S.country_kitchen_s3(xres=48, yres=27, spp=2, wall_n=12, box_n=4, obj_n=10),
+         "C4": lambda: S.ecosystem_s4(xres=48, yres=27, spp=2, n_inst=60, terrain_n=24, plant_scale=0.08, env_size=(32, 16)),
+         "C5": lambda: S.dragon_s5(xres=48, yres=27, spp=2, n=40, env_size=(32, 16))}[name]()
+    sd, rp = b.world_end()
+    o = oracle.scene(sd)
+    film = o.render(rp, nthreads=4)
+    c = o.counters()
+    assert np.isfinite(film).all() and c["camera_rays"] == 48 * 27 * 2 == sum(c["path_length_hist"])
+
+
+def _gate(pkg, gpu, oracle, b, crop_px, spp_threads=16, exact_intersections=True):
+    x0, y0 = crop_px
+    b.film.update(crop=(x0 / 1920, (x0 + 256) / 1920, y0 / 1080, (y0 + 256) / 1080))
+    sd, rp = b.world_end()
+    g = pkg.Scene(gpu, sd)
+    film = g.render(rp)
+    assert film.shape[:2] == (256, 256)
+    nodes, ordered = g.bvh()
+    if sd.desc().n_instances == 0:
+        sd.set_bvh(nodes, ordered)          # the oracle adopts the library's top-level tree (identical to its own: test_bvh_identical_to_oracle)
+    orc = oracle.scene(sd)
+    if sd.desc().n_instances:
+        on, oo = orc.bvh()
+        assert bytes(nodes) == bytes(on) and np.array_equal(ordered, oo)
+    ref = orc.render(rp, nthreads=spp_threads)
+    gc, oc = g.counters(), orc.counters()
+    for k in COUNTERS:
+        if k == "intersect_tests" and not exact_intersections:
+            assert gc[k] >= oc[k]
+            continue
+        if k in ("bvh_nodes_visited", "triangle_tests") and not exact_intersections:
+            continue
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-3     # the north-star gate
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+    return gc
+
+
+@pytest.mark.gpu
+def test_c3_country_kitchen_gate(pkg, gpu, oracle):
+    """S3: ~1.2 M triangles, six material kinds round-robin (all four surface shade classes), 64 emissive triangles."""
+    gc = _gate(pkg, gpu, oracle, pkg.scenes.country_kitchen_s3(spp=8), (832, 500))
+    assert gc["path_length_hist"][5] > 0
+
+
+@pytest.mark.gpu
+def test_c4_ecosystem_gate(pkg, gpu, oracle):
+    """S4: 2,000 instances of three 50 k-triangle objects over a 500 k-triangle terrain, 512x256 environment map only."""
+    _gate(pkg, gpu, oracle, pkg.scenes.ecosystem_s4(spp=8), (832, 540))
+
+
+@pytest.mark.gpu
+def test_c5_dragon_subsurface_gate(pkg, gpu, oracle):
+    """S5: the 4.3 M-triangle S2 mesh x0.02 with subsurface Skin1 (probe-ray chains of TabulatedBSSRDF::sample_sp)."""
+    _gate(pkg, gpu, oracle, pkg.scenes.dragon_s5(spp=8), (832, 412), exact_intersections=False)
