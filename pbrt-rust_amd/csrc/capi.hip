@@ -104,6 +104,7 @@ struct pt_scene {
     bool has_null_material = false;   // a primitive without a material (refused by the volumetric integrator)   // matte (default material) and the miss class always exist
     bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
     void *bss_slab = nullptr; BssSoA bs{};
+    uint4 *probe_ring = nullptr;       // k_trace<.., PROBE>: kProbeRing x 3 x uint4 per persistent lane
     uint32_t n_lights = 0;
     std::vector<PtLight> host_lights; uint32_t env_w = 0, env_h = 0; float env_texel0[3] = {0, 0, 0};
     // light grids (lazy, per effective strategy)
@@ -196,17 +197,22 @@ void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func
     else { for (size_t i = 1; i < n + 1; ++i) cdf[i] /= func_int; }
 }
 
-int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper) {
+int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper, bool probe = false) {
     if (n_upper == 0) return PT_OK;
-    job.refill_min = g_refill_min[job.kind & 3]; job.leaf_quorum = g_leaf_quorum[job.kind & 3];
+    job.refill_min = g_refill_min[job.kind == 4 ? 0 : (job.kind & 3)]; job.leaf_quorum = g_leaf_quorum[job.kind == 4 ? 0 : (job.kind & 3)];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
     const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? 1 : 0;  // kernels.hip: k_trace MODE
-    #define PT_LAUNCH_TRACE(A, M) hipLaunchKernelGGL((k_trace<A, M>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
+    #define PT_LAUNCH_TRACE(A, M) hipLaunchKernelGGL((k_trace<A, M, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
+    if (probe) {
+        if (mode == 2) hipLaunchKernelGGL((k_trace<false, 2, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+        else if (mode == 1) hipLaunchKernelGGL((k_trace<false, 1, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+        else hipLaunchKernelGGL((k_trace<false, 0, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+    } else
     if (any) { if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
     else { if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
     #undef PT_LAUNCH_TRACE
-    sc->set_kernel(std::string("k_trace<") + (any ? "true" : "false") + ", " + std::to_string(mode) + ">");
+    sc->set_kernel(std::string("k_trace<") + (any ? "true" : "false") + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ">");
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -220,6 +226,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 6 KB per wave)
         if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * (kMaxStack - kLdsStack)))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
+        if (sc->has_bssrdf && (st = sc->dalloc(&sc->probe_ring, (size_t)sc->spill_waves * 64 * kProbeRing * 3))) return st;
     }
     if (capacity > sc->capacity) {
         if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
@@ -420,7 +427,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
-        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 32767 intersections" : "Sobol dimension overflow (>= 1024)");
+        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 2^32 - 1 intersections" : "Sobol dimension overflow (>= 1024)");
         if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 65536 wavefront iterations");
         const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
         if (n_ext == 0 && n_resolve == 0 && n_probe == 0) break;
@@ -484,18 +491,17 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             if (st) return st;
         }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
-        if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-395): one segment per iteration, then k_bssrdf
+        if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-402): each lane of k_trace<.., PROBE> walks a whole chain, then k_bssrdf
             tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
             tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
-            tj.out_prim = ps.hit_prim; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
-            tj.out_occluded = nullptr; tj.kind = 0;
+            tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
+            tj.out_occluded = nullptr; tj.kind = 4; tj.bs = sc->bs; tj.ring = sc->probe_ring;
             sc->begin("extend_probe", n_probe);
-            st = launch_trace(sc, false, tj, n_probe);
+            st = launch_trace(sc, false, tj, n_probe, true);
             sc->end();
             if (st) return st;
             BssrdfJob bj{};
             bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
-            bj.probe_next = sc->q.probe[1 - cur]; bj.probe_next_count = &qc->probe[1 - cur];
             bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
             bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
@@ -568,8 +574,8 @@ void read_counters(pt_scene *sc) {
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
     static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
-    static const char *kn[4] = {"extend", "extend_mis", "shadow", "extend_camera"};
-    for (int k = 0; k < 4; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; }
+    static const char *kn[5] = {"extend", "extend_mis", "shadow", "extend_camera", "extend_probe"};
+    for (int k = 0; k < 5; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; if (k == 4) s.items = d.k_rays[k]; }   // probe chains: items = segments traced
     for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
 #ifdef PT_TRACE_UTIL
     for (int k = 0; k < 4; ++k)

@@ -2,18 +2,16 @@
 #pragma once
 #include "kern_shade_common.h"
 // ---- subsurface scattering: probe chains + exit-point vertex (path.rs:177-204, bssrdf.rs:334-410,559-574) --------------
-// One launch per wavefront iteration while any path walks a probe chain. Each queue entry is a path whose probe ray
-// (ps.ox.. / ps.dx.., t_max = 1 - eps) was just traced into ps.hit_*. The chain is walked twice: a counting walk
-// (nfound) and, once the miss ends it, a re-walk from the segment start up to match number `selected` -- the reference
-// keeps the chain in a Vec and indexes it; re-walking is deterministic and keeps the per-path state fixed-size.
+// One launch per wavefront iteration in which probe chains ran. Each queue entry is a path whose whole chain was walked by
+// k_trace<.., PROBE> in the launch before (kern_trace.h); this kernel finishes the vertex at the selected exit point.
 // When the exit point pi is reached the lane finishes the vertex: resolve po's next-event estimation, beta *= S / pdf,
 // NEE at pi through the adapter BSDF, sample the adapter BSDF, Russian roulette, bounces += 1.
 template <bool SPH>
 __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
-    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis, s_qprobe;
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ uint32_t s_hist[16];
-    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -28,54 +26,22 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
-    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
     int finished_bounces = -1;
     uint32_t pid = 0;
     if (valid) {
         n_valid++;
         pid = job.queue[qi];
+        // k_trace<.., PROBE> walked the whole chain: the hit record is the selected intersection (PT_NONE: no intersection with
+        // the BSSRDF's material, S = 0), ps.ox.. / ps.dx.. the segment that found it, bs.cnt the chain's nfound
         const V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
-        const V3 target(bs.target_x[pid], bs.target_y[pid], bs.target_z[pid]);
         const uint32_t hp = ps.hit_prim[pid];
         const uint32_t mat = bs.mat[pid];
-        uint32_t cnt = bs.cnt[pid];
-        uint32_t nfound = cnt & 0xffffu, seen = (cnt >> 16) & 0x7fffu; const bool rewalk = (cnt >> 31) != 0u;
-        const float u1n = bs.u1n[pid];
-        bool chain_end = false, at_exit = false, dead = false;
+        const uint32_t nfound = bs.cnt[pid];
+        const bool at_exit = hp != PT_NONE, dead = !at_exit;
         SurfaceInteraction si;
-        if (hp != PT_NONE) {
-            fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
-            const bool match = s.prim_material[hp] == mat;   // bssrdf.rs:385-391
-            if (!rewalk) { if (match) { if (nfound < 0x7fffu) nfound++; else atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); } }   // `seen` has 15 bits
-            else if (match) {
-                // bssrdf.rs:398: selected = clamp((u1n * nfound) as usize, 0, nfound - 1)
-                const uint32_t selected = min(f2u32_sat(u1n * (float)nfound), nfound - 1u);
-                if (seen == selected) at_exit = true;
-                seen++;
-            }
-            if (!at_exit) {  // base = si.get_data(); next segment base -> target (interaction.rs:38-43)
-                const V3 d = target - si.p;
-                if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) chain_end = true;
-                else {
-                    const V3 o = offset_ray_origin(si.p, si.p_error, si.n, d);
-                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-                    ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
-                    push_probe = true;
-                }
-            }
-        } else chain_end = true;
-        if (chain_end) {
-            if (!rewalk && nfound > 0u) {  // chain counted: walk it again up to the selected intersection
-                const V3 start(bs.start_x[pid], bs.start_y[pid], bs.start_z[pid]);
-                const V3 d = target - start;
-                ps.ox[pid] = start.x; ps.oy[pid] = start.y; ps.oz[pid] = start.z;
-                ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
-                cnt = nfound | (1u << 31); seen = 0u;
-                bs.cnt[pid] = cnt;
-                push_probe = true;
-            } else dead = true;   // nfound == 0: S = 0 (bssrdf.rs:397); a re-walk never ends before `selected`
-        } else if (push_probe) bs.cnt[pid] = nfound | (seen << 16) | (rewalk ? (1u << 31) : 0u);
-        n_bytes += 4 + 24 + 16 + 12 + 8 + 4 + (push_probe ? 24 + 4 + 4 : 0);
+        if (at_exit) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+        n_bytes += 4 + 24 + 16 + 8;
 
         if (at_exit || dead) {
             uint32_t meta = ps.meta[pid];
@@ -143,21 +109,18 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
         }
     }
-    lq_push(s_qprobe, pid, push_probe);
     lq_push(s_qext, pid, push_ext);
     lq_push(s_qres, pid, push_resolve);
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
     __syncthreads();
-    lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
     __syncthreads();
     }
-    lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);

@@ -3,33 +3,6 @@
 #include "kern_common.h"
 // ---- shading ---------------------------------------------------------------------------------------------
 
-// Rebuild the SurfaceInteraction of a recorded hit (triangle: from the barycentrics; sphere: re-evaluated from the ray).
-template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, uint32_t inst, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
-    const uint32_t sh = s.prim_shape[prim];
-    if (SPH && inst != PT_NONE) {  // TransformedPrimitive::intersect (primitive.rs:58-80): object-space interaction, then to world
-        const DevInstance &I = s.instances[inst];
-        const M4 w2i = ldm4g(I.world_to_instance), i2w = ldm4g(I.instance_to_world);
-        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
-        const float l2 = length_squared(d2);
-        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; }
-        if ((sh >> 30) == PT_SHAPE_SPHERE) sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], o2, d2, si);
-        else tri_fill_interaction(s, sh & 0x3fffffffu, d2, b0, b1, b2, true, si);
-        if (!I.identity) {  // transform_surface_interaction (transform.rs:607-636)
-            V3 perr;
-            si.p = xf_point_abs_err(i2w, si.p, si.p_error, perr); si.p_error = perr;
-            si.n = normalize(xf_normal_inv(w2i, si.n));
-            si.wo = normalize(xf_vector(i2w, si.wo));
-            si.dpdu = xf_vector(i2w, si.dpdu); si.dpdv = xf_vector(i2w, si.dpdv);
-            si.sh_n = face_forward(normalize(xf_normal_inv(w2i, si.sh_n)), si.n);
-            si.sh_dpdu = xf_vector(i2w, si.sh_dpdu); si.sh_dpdv = xf_vector(i2w, si.sh_dpdv);
-            si.sh_dndu = xf_normal_inv(w2i, si.sh_dndu); si.sh_dndv = xf_normal_inv(w2i, si.sh_dndv);
-        }
-        return;
-    }
-    if (SPH && (sh >> 30) == PT_SHAPE_SPHERE) { sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], ro, rd, si); return; }
-    tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
-}
-
 // ---- optional region timers (build with -DPT_REGION_PROFILE): wave time between markers is charged to the region of the
 // previous marker; one lane per wave updates three LDS words. Printed by the host when the scene is destroyed.
 #ifdef PT_REGION_PROFILE

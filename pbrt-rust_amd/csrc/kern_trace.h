@@ -23,8 +23,14 @@
                         // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
 #endif
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres, instances), 2 = general geometry + alpha-masked triangles
-template <bool ANY, int MODE>
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+// PROBE (closest hit only): every queue entry is a whole BSSRDF probe chain (TabulatedBSSRDF::sample_sp, bssrdf.rs:367-402). The lane
+// walks the chain of Scene::intersect calls itself -- hit, interaction, next segment towards the target -- keeps the last
+// kProbeRing matching intersections in a per-lane ring in HBM, and retires with the SELECTED intersection as its hit record
+// (`selected = clamp((u1 * nfound) as usize, 0, nfound - 1)`), so that one launch replaces what used to be one wavefront
+// iteration (a trace launch, a k_bssrdf launch and a host round trip) per segment, twice over.
+template <bool ANY, int MODE, bool PROBE>
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+    static_assert(!(ANY && PROBE), "probe chains are closest-hit queries");
     constexpr bool SPH = MODE >= 1, ALPHA = MODE == 2;
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
     const uint32_t lane = lane_id();
@@ -58,6 +64,11 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
     // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
     uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
     constexpr uint32_t kMarker = 0xFFC0DEADu;   // stack word 1 of an "end of instance" entry (never a real tmin)
+    // PROBE: chain state of the lane. A chain with more than kProbeRing matches after the selected one is walked a second time
+    // ("rewalk") up to match number `selected`; the rewalk's work is not counted (the reference indexes its Vec instead).
+    uint32_t nfound = 0, seen = 0; bool rewalk = false;
+    uint32_t sv_nodes = 0, sv_tris = 0, sv_rays = 0, sv_sph = 0;
+    uint4 *ring = PROBE ? job.ring + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * (kProbeRing * 3 * 64) + lane : nullptr;
 
     // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
     auto pop_next = [&]() {
@@ -96,7 +107,81 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
         const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
         const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF);
         if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
-            const bool retire = state == ST_DONE;
+            bool retire = state == ST_DONE;
+            if constexpr (PROBE) {
+                if (retire) {   // one step of the chain loop of bssrdf.rs:373-395, in world space (every instance marker is popped)
+                    const V3 target(job.bs.target_x[pid], job.bs.target_y[pid], job.bs.target_z[pid]);
+                    bool finish = false, next_seg = false, chain_end = false;
+                    if (hit_prim != PT_NONE) {
+                        SurfaceInteraction si;
+                        fill_hit<SPH>(s, hit_prim, SPH ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
+                        if (s.prim_material[hit_prim] == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
+                            if (!rewalk) {
+                                const uint32_t k = nfound % (uint32_t)kProbeRing;
+                                ring[(3 * k + 0) * 64] = make_uint4(hit_prim, hit_inst, __float_as_uint(hb0), __float_as_uint(hb1));
+                                ring[(3 * k + 1) * 64] = make_uint4(__float_as_uint(hb2), __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z));
+                                ring[(3 * k + 2) * 64] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), 0u);
+                                if (nfound == 0xffffffffu) atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); else nfound++;
+                            } else {
+                                const uint32_t selected = min(f2u32_sat(job.bs.u1n[pid] * (float)nfound), nfound - 1u);
+                                if (seen == selected) finish = true;
+                                seen++;
+                            }
+                        }
+                        if (!finish) {   // base = si.get_data(); the next segment runs base -> target (interaction.rs:38-43)
+                            const V3 d = target - si.p;
+                            if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) chain_end = true;
+                            else { ro = offset_ray_origin(si.p, si.p_error, si.n, d); rd = d; next_seg = true; }
+                        }
+                    } else chain_end = true;
+                    if (chain_end) {
+                        if (!rewalk && nfound > 0u) {
+                            // bssrdf.rs:398: selected = clamp((u1 * nfound) as usize, 0, nfound - 1)
+                            const uint32_t selected = min(f2u32_sat(job.bs.u1n[pid] * (float)nfound), nfound - 1u);
+                            if (nfound - selected <= (uint32_t)kProbeRing) {
+                                const uint32_t k = selected % (uint32_t)kProbeRing;
+                                const uint4 e0 = ring[(3 * k + 0) * 64], e1 = ring[(3 * k + 1) * 64], e2 = ring[(3 * k + 2) * 64];
+                                hit_prim = e0.x; hit_inst = e0.y; hb0 = __uint_as_float(e0.z); hb1 = __uint_as_float(e0.w); hb2 = __uint_as_float(e1.x);
+                                ro = V3(__uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w));
+                                rd = V3(__uint_as_float(e2.x), __uint_as_float(e2.y), __uint_as_float(e2.z));
+                                finish = true;
+                            } else {   // the selected intersection has left the ring: walk again from the start, uncounted
+                                rewalk = true; seen = 0u;
+                                sv_nodes = n_nodes; sv_tris = n_tris; sv_rays = n_rays; sv_sph = n_sph;
+                                ro = V3(job.bs.start_x[pid], job.bs.start_y[pid], job.bs.start_z[pid]); rd = target - ro;
+                                next_seg = true;
+                            }
+                        } else { hit_prim = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
+                    }
+                    if (next_seg || finish) {   // the segment's ray lives in the path state: the instance marker reloads it, k_bssrdf rebuilds the exit point from it
+                        float *wox = const_cast<float *>(job.ox), *woy = const_cast<float *>(job.oy), *woz = const_cast<float *>(job.oz);
+                        float *wdx = const_cast<float *>(job.dx), *wdy = const_cast<float *>(job.dy), *wdz = const_cast<float *>(job.dz);
+                        wox[pid] = ro.x; woy[pid] = ro.y; woz[pid] = ro.z; wdx[pid] = rd.x; wdy[pid] = rd.y; wdz[pid] = rd.z;
+                    }
+                    if (next_seg) {
+                        retire = false;
+                        t_max = job.scalar_tmax;
+                        inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                        tray = tri_ray_setup(rd);
+                        sp = 0; pending = 0; found = false;
+                        hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                        in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
+                        n_rays++;                                  // Scene::intersect of the next segment
+                        state = ST_DONE;                           // (a segment that misses the world bound is a miss: resolved at the next refill round)
+                        if (s.n_nodes > 0) {
+                            n_nodes++;
+                            if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
+                                cur = s.root_ref & kRefMask;
+                                state = (s.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                            }
+                        }
+                    } else {
+                        if (rewalk) { n_nodes = sv_nodes; n_tris = sv_tris; n_rays = sv_rays; n_sph = sv_sph; }
+                        job.bs.cnt[pid] = nfound;
+                    }
+                }
+            }
             if (retire) {
                 if (ANY) job.out_occluded[pid] = found ? 1 : 0;
                 else {
@@ -117,8 +202,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                     chunk_left = (chunk_next < count) ? min((uint32_t)kChunk, count - chunk_next) : 0u;
                     if (chunk_left == 0) exhausted = true;
                 }
-                const uint32_t rank = (uint32_t)__popcll(donem & ((1ull << lane) - 1ull));
-                const uint32_t take = min(chunk_left, (uint32_t)__popcll(donem));
+                // PROBE: lanes that went on to their chain's next segment are in `donem` but not idle any more
+                const unsigned long long idlem = PROBE ? __ballot(state == ST_IDLE) : donem;
+                const uint32_t rank = (uint32_t)__popcll(idlem & ((1ull << lane) - 1ull));
+                const uint32_t take = min(chunk_left, (uint32_t)__popcll(idlem));
                 const uint32_t qi = chunk_next + rank;
                 const bool get = state == ST_IDLE && rank < take;
                 chunk_next += take; chunk_left -= take;
@@ -133,6 +220,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
                     sp = 0; pending = 0; found = false;
                     hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                     in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
+                    if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; }
                     n_rays++;
                     state = ST_DONE;
                     if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
@@ -286,8 +374,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0) ? 5 : 1) PT_TRACE_ATTR voi
 #ifdef PT_TRACE_UTIL
     for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
     if (lane == 0) {
-        atomicAdd(&job.counters->regions[4 * job.kind + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * job.kind + 1], (unsigned long long)u_act1);
-        atomicAdd(&job.counters->regions[4 * job.kind + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * job.kind + 3], (unsigned long long)u_act2);
+        atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 1], (unsigned long long)u_act1);
+        atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 3], (unsigned long long)u_act2);
     }
 #endif
 }

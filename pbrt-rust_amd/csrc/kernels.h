@@ -16,6 +16,7 @@ constexpr int kMissClass = 4, kMediumClass = 5;   // 5 = medium vertices of the 
 constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
+constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
 
 // path flags (meta >> 24)
 enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
@@ -52,7 +53,7 @@ struct BssSoA {
     float *po_x, *po_y, *po_z, *ns_x, *ns_y, *ns_z, *ss_x, *ss_y, *ss_z;
     float *u1n;
     uint32_t *mat;   // material id of the BSSRDF (Arc::ptr_eq test of the chain, bssrdf.rs:385-391)
-    uint32_t *cnt;   // nfound (bits 0-15) | matches seen on the re-walk (16-30) | phase (31: 0 counting, 1 re-walk to `selected`)
+    uint32_t *cnt;   // nfound of the finished chain (written by k_trace<.., PROBE>, read by k_bssrdf)
 };
 constexpr int kBssSoAArrays = 18;
 constexpr int kPathSoAFloatArrays = 56;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
@@ -80,7 +81,7 @@ struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long regions[16];            // PT_REGION_PROFILE builds: wave cycles per k_shade region
     unsigned long long bss_items, bss_bytes;   // k_bssrdf: probe steps processed / state bytes moved
-    unsigned long long k_nodes[4], k_tris[4], k_rays[4];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera
+    unsigned long long k_nodes[5], k_tris[5], k_rays[5];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera, 4 extend_probe (segments)
 };
 
 struct RenderConst {
@@ -123,6 +124,9 @@ struct TraceJob {
     uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera (per-kind work counters)
     uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)
     uint32_t leaf_quorum;    // lanes waiting at a leaf join the record fetch once this many wait (or no lane is at a node)
+    // PROBE launches only: the chains' per-path inputs (start, target, material, u1) / output (cnt = nfound) and the per-lane ring
+    BssSoA bs;
+    uint4 *ring;             // [waves_in_grid][kProbeRing][3][64 lanes]
 };
 
 struct ShadeJob {
@@ -137,9 +141,8 @@ struct ShadeJob {
     BssSoA bs;
 };
 
-struct BssrdfJob {           // k_bssrdf: one step of every probe chain + the finish of chains that reached their exit point
+struct BssrdfJob {           // k_bssrdf: the vertex at the exit point of every finished probe chain
     const uint32_t *queue; const uint32_t *count;
-    uint32_t *probe_next, *probe_next_count;
     uint32_t *ext_next, *ext_next_count;
     uint32_t *shade_next0, *shade_next0_count;
     uint32_t *shadow, *shadow_count, *mis, *mis_count;

@@ -216,6 +216,27 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False):
     return b
 
 
+def subsurface_sheets(xres=64, yres=48, spp=8, maxdepth=5, n_sheets=40):
+    """A stack of thin parallel sheets (plus one sphere) sharing ONE subsurface material, spaced far below the mean free path:
+    probe chains (bssrdf.rs:373-395) along the sheets' normal collect tens of matching intersections."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth)
+    b.look_at((0.0, 1.2, 4.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.4, 0.45, 0.5))
+    b.attribute_begin(); b.area_light_source(L=(20.0, 18.0, 15.0))
+    P, I = quad((-1.0, 3.0, -1.0), (1.0, 3.0, -1.0), (1.0, 3.0, 1.0), (-1.0, 3.0, 1.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-6.0, -0.5, -6.0), (-6.0, -0.5, 6.0), (6.0, -0.5, 6.0), (6.0, -0.5, -6.0)); b.trianglemesh(P, I)
+    b.material("subsurface", sigma_a=(0.01, 0.02, 0.04), sigma_s=(1.0, 1.2, 1.5), scale=1.0, eta=1.3)
+    for k in range(n_sheets):
+        z = 0.6 - 0.03 * k
+        P, I = quad((-1.2, -0.3, z), (1.2, -0.3, z), (1.2, 1.3, z), (-1.2, 1.3, z)); b.trianglemesh(P, I)
+    b.attribute_begin(); b.translate(1.9, 0.2, 0.4); b.sphere(radius=0.5); b.attribute_end()
+    return b
+
+
 def sky_env(w=16, h=8):
     """A small procedural lat-long environment (rows = theta from +z pole, columns = phi): blue-to-white gradient with a
     bright 'sun' patch, so that the importance image is strongly non-uniform."""

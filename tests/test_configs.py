@@ -97,4 +97,4 @@ def test_c4_ecosystem_gate(pkg, gpu, oracle):
 @pytest.mark.gpu
 def test_c5_dragon_subsurface_gate(pkg, gpu, oracle):
     """S5: the 4.3 M-triangle S2 mesh x0.02 with subsurface Skin1 (probe-ray chains of TabulatedBSSRDF::sample_sp)."""
-    _gate(pkg, gpu, oracle, pkg.scenes.dragon_s5(spp=8), (832, 412), exact_intersections=False)
+    _gate(pkg, gpu, oracle, pkg.scenes.dragon_s5(spp=8), (832, 412))
