@@ -22,6 +22,7 @@ int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
+uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
 SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -202,15 +203,17 @@ int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper, bool pr
     job.refill_min = g_refill_min[job.kind == 4 ? 0 : (job.kind & 3)]; job.leaf_quorum = g_leaf_quorum[job.kind == 4 ? 0 : (job.kind & 3)];
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
-    const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? 1 : 0;  // kernels.hip: k_trace MODE
+    const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : sc->ds.n_spheres > 0 ? 1 : sc->ds.n_instances > 0 ? 3 : 0;  // kern_trace.h: k_trace MODE
+    job.inst_quorum = g_inst_quorum;
     #define PT_LAUNCH_TRACE(A, M) hipLaunchKernelGGL((k_trace<A, M, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
     if (probe) {
-        if (mode == 2) hipLaunchKernelGGL((k_trace<false, 2, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+        if (mode == 3) hipLaunchKernelGGL((k_trace<false, 3, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
+        else if (mode == 2) hipLaunchKernelGGL((k_trace<false, 2, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
         else if (mode == 1) hipLaunchKernelGGL((k_trace<false, 1, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
         else hipLaunchKernelGGL((k_trace<false, 0, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
     } else
-    if (any) { if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
-    else { if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
+    if (any) { if (mode == 3) PT_LAUNCH_TRACE(true, 3); else if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
+    else { if (mode == 3) PT_LAUNCH_TRACE(false, 3); else if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
     #undef PT_LAUNCH_TRACE
     sc->set_kernel(std::string("k_trace<") + (any ? "true" : "false") + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ">");
     HIP_TRY(hipGetLastError());
@@ -231,22 +234,16 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
     if (capacity > sc->capacity) {
         if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
         if (sc->bss_slab) { hipFree(sc->bss_slab); sc->bss_slab = nullptr; }
-        size_t bytes = capacity * (size_t)(kPathSoAFloatArrays * 4 + 8 + 1) + 4096;
+        size_t bytes = capacity * (size_t)kPathBytes + 4096;
         hipError_t e = hipMalloc(&sc->slab, bytes);
         if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "path-state slab: " + std::string(hipGetErrorString(e)));
-        char *p = (char *)sc->slab;
+        char *p = (char *)sc->slab;   // hipMalloc returns 256-byte aligned memory; every record array starts on a 64-byte line
         PathSoA &ps = sc->ps;
-        ps.sobol_index = (uint64_t *)p; p += capacity * 8;
-        float **fa[] = {&ps.pfilm_x, &ps.pfilm_y, &ps.ox, &ps.oy, &ps.oz, &ps.dx, &ps.dy, &ps.dz, &ps.hit_b0, &ps.hit_b1, &ps.hit_b2,
-                        &ps.beta_r, &ps.beta_g, &ps.beta_b, &ps.L_r, &ps.L_g, &ps.L_b, &ps.etascale,
-                        &ps.sh_ox, &ps.sh_oy, &ps.sh_oz, &ps.sh_dx, &ps.sh_dy, &ps.sh_dz, &ps.A_r, &ps.A_g, &ps.A_b,
-                        &ps.mis_ox, &ps.mis_oy, &ps.mis_oz, &ps.mis_dx, &ps.mis_dy, &ps.mis_dz, &ps.mis_f_r, &ps.mis_f_g, &ps.mis_f_b,
-                        &ps.mis_w, &ps.mis_spdf, &ps.nee_choice_pdf, &ps.nb_r, &ps.nb_g, &ps.nb_b, &ps.mis_b0, &ps.mis_b1, &ps.mis_b2, &ps.hit_t, &ps.mis_t};
-        for (float **f : fa) { *f = (float *)p; p += capacity * 4; }
-        uint32_t **ua[] = {&ps.hit_prim, &ps.meta, &ps.nee_light, &ps.mis_prim, &ps.hit_inst, &ps.medium, &ps.mis_medium, &ps.sh_prim};
-        for (uint32_t **u : ua) { *u = (uint32_t *)p; p += capacity * 4; }
-        ps.occluded = (uint8_t *)p;
-        static_assert(sizeof(fa) / sizeof(fa[0]) + sizeof(ua) / sizeof(ua[0]) <= kPathSoAFloatArrays, "slab too small");
+        ps.core = (float *)p; p += capacity * (size_t)PathSoA::kCoreWords * 4;
+        ps.nee = (float *)p; p += capacity * (size_t)PathSoA::kNeeWords * 4;
+        ps.mis = (float *)p; p += capacity * (size_t)PathSoA::kMisWords * 4;
+        ps.ray = (float *)p; p += capacity * (size_t)PathSoA::kRayWords * 4;
+        ps.hit = (float *)p; p += capacity * (size_t)PathSoA::kHitWords * 4;
         if (sc->has_bssrdf) {
             e = hipMalloc(&sc->bss_slab, capacity * (size_t)kBssSoAArrays * 4);
             if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "BSSRDF probe state: " + std::string(hipGetErrorString(e)));
@@ -437,12 +434,12 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         PathSoA &ps = sc->ps;
         // continuation rays -> hit record + material-class routing
         tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
-        tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
-        tj.out_prim = ps.hit_prim; tj.out_t = rc.volpath ? ps.hit_t : nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
-        tj.class_count = &qc->shade[cur][0];
-        for (int c = 0; c < kNumClasses; ++c) tj.class_buf[c] = sc->q.shade[cur][c];
+        const bool general = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || sc->ds.tri_alpha || sc->ds.tri_shadow_alpha;
+        tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4; tj.per_ray_tmax = 0;
+        tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_word = nullptr; tj.out_word_stride = 0;
+        tj.out_t = rc.volpath ? &ps.hit_t(0) : nullptr; tj.out_t_stride = PathSoA::kHitWords;
+        tj.out_inst = general ? &ps.hit_inst(0) : nullptr; tj.out_inst_stride = PathSoA::kHitWords;
         tj.kind = (iter == 0) ? 3 : 0;
-        tj.class_count = nullptr;
         int st = PT_OK;
         if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
             sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
@@ -459,15 +456,15 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         } else if (n_ext) {  // material-sorted shade queues
             sc->begin("route", n_ext); sc->set_kernel("k_route");
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
-                               (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], (const uint32_t *)ps.hit_prim, &qc->shade[cur][0],
+                               (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0],
                                sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4]);
             sc->end();
         }
         // MIS rays of the previous vertex (closest hit, integrator.rs:215)
         tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
-        tj.ox = ps.mis_ox; tj.oy = ps.mis_oy; tj.oz = ps.mis_oz; tj.dx = ps.mis_dx; tj.dy = ps.mis_dy; tj.dz = ps.mis_dz;
-        tj.out_prim = ps.mis_prim; tj.out_t = rc.volpath ? ps.mis_t : nullptr; tj.out_b0 = ps.mis_b0; tj.out_b1 = ps.mis_b1; tj.out_b2 = ps.mis_b2; tj.out_inst = nullptr;
-        tj.class_count = nullptr;
+        tj.ray = (const float4 *)ps.mis; tj.ray_stride = PathSoA::kMisWords / 4;
+        tj.out_hit = (float4 *)&ps.mis_prim(0); tj.out_hit_stride = PathSoA::kMisWords / 4;
+        tj.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; tj.out_t_stride = PathSoA::kMisWords; tj.out_inst = nullptr;
         tj.kind = 1;
         if (n_mis) {
             sc->begin("extend_mis", n_mis);
@@ -477,13 +474,13 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         }
         // shadow rays (any hit, light.rs:120-123)
         tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
-        tj.ox = ps.sh_ox; tj.oy = ps.sh_oy; tj.oz = ps.sh_oz; tj.dx = ps.sh_dx; tj.dy = ps.sh_dy; tj.dz = ps.sh_dz;
-        tj.out_occluded = ps.occluded;
+        tj.ray = (const float4 *)ps.nee; tj.ray_stride = PathSoA::kNeeWords / 4;
+        tj.out_hit = nullptr; tj.out_word = &ps.occluded(0); tj.out_word_stride = PathSoA::kNeeWords; tj.out_t = nullptr; tj.out_inst = nullptr;
         tj.kind = 2;
         if (n_shadow) {
             sc->begin("shadow", n_shadow);
             if (rc.volpath) {   // VisibilityTester::tr (light.rs:125-150) calls Scene::intersect: a closest-hit query, counted as one
-                tj.out_prim = ps.sh_prim; tj.out_t = nullptr; tj.out_b0 = tj.out_b1 = tj.out_b2 = nullptr; tj.out_inst = nullptr;
+                // (closest-hit kernel without out_hit: the primitive goes to out_word = nee.sh_prim, the slot `occluded` uses otherwise)
                 st = launch_trace(sc, false, tj, n_shadow);
             } else
             st = launch_trace(sc, true, tj, n_shadow);
@@ -493,9 +490,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
         if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-402): each lane of k_trace<.., PROBE> walks a whole chain, then k_bssrdf
             tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
-            tj.ox = ps.ox; tj.oy = ps.oy; tj.oz = ps.oz; tj.dx = ps.dx; tj.dy = ps.dy; tj.dz = ps.dz;
-            tj.out_prim = ps.hit_prim; tj.out_t = nullptr; tj.out_b0 = ps.hit_b0; tj.out_b1 = ps.hit_b1; tj.out_b2 = ps.hit_b2; tj.out_inst = ps.hit_inst;
-            tj.out_occluded = nullptr; tj.kind = 4; tj.bs = sc->bs; tj.ring = sc->probe_ring;
+            tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4;
+            tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_word = nullptr; tj.out_t = nullptr;
+            tj.out_inst = &ps.hit_inst(0); tj.out_inst_stride = PathSoA::kHitWords;
+            tj.kind = 4; tj.bs = sc->bs; tj.ring = sc->probe_ring;
             sc->begin("extend_probe", n_probe);
             st = launch_trace(sc, false, tj, n_probe, true);
             sc->end();
@@ -608,6 +606,7 @@ int pt_init(int device_ordinal) {
     if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
     g_device = device_ordinal;
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; } }
+    if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
     return upload_tables();
@@ -1024,7 +1023,8 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
         // The general shade kernels (textures, Halton, volpath) read the instance of a hit; the triangle-only traversal (k_trace<*, 0>)
         // never writes it
-        if (sc->ds.n_spheres == 0 && sc->ds.n_instances == 0 && !sc->ds.tri_alpha && !sc->ds.tri_shadow_alpha) HIP_TRY(hipMemsetAsync(sc->ps.hit_inst, 0xFF, (size_t)rc.n_pix_slots * S * 4, sc->stream));
+        if (sc->ds.n_spheres == 0 && sc->ds.n_instances == 0 && !sc->ds.tri_alpha && !sc->ds.tri_shadow_alpha && (sc->ds.n_textures > 0 || rc.halton.enabled || rc.volpath || sc->has_bssrdf))
+            HIP_TRY(hipMemsetAsync(sc->ps.hit, 0xFF, (size_t)rc.n_pix_slots * S * PathSoA::kHitWords * 4, sc->stream));   // hit_inst = PT_NONE everywhere
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
@@ -1088,27 +1088,28 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     if (n == 0) return PT_OK;
     int st = ensure_workspace(sc, 0, 0);
     if (st) return st;
-    std::vector<float> soa(7 * (size_t)n);
+    std::vector<float> recs(8 * (size_t)n, 0.0f);   // 32-byte ray records {o.xyz, d.x} {d.y, d.z, t_max, -}
     for (uint32_t i = 0; i < n; ++i) {
-        for (int k = 0; k < 3; ++k) { soa[(size_t)k * n + i] = o[3 * (size_t)i + k]; soa[(size_t)(3 + k) * n + i] = d[3 * (size_t)i + k]; }
-        soa[(size_t)6 * n + i] = tmax[i];
+        float *r = recs.data() + 8 * (size_t)i;
+        r[0] = o[3 * (size_t)i]; r[1] = o[3 * (size_t)i + 1]; r[2] = o[3 * (size_t)i + 2];
+        r[3] = d[3 * (size_t)i]; r[4] = d[3 * (size_t)i + 1]; r[5] = d[3 * (size_t)i + 2]; r[6] = tmax[i];
     }
-    float *din = nullptr, *dout = nullptr; uint32_t *dprim = nullptr; uint8_t *docc = nullptr; uint32_t *dcount = nullptr;
-    HIP_TRY(scratch.alloc(&din, soa.size() * 4));
+    float *din = nullptr, *dout = nullptr, *dt = nullptr; uint32_t *docc = nullptr; uint32_t *dcount = nullptr;
+    HIP_TRY(scratch.alloc(&din, recs.size() * 4));
     HIP_TRY(scratch.alloc(&dout, 4 * (size_t)n * 4));
-    HIP_TRY(scratch.alloc(&dprim, (size_t)n * 4));
-    HIP_TRY(scratch.alloc(&docc, n));
+    HIP_TRY(scratch.alloc(&dt, (size_t)n * 4));
+    HIP_TRY(scratch.alloc(&docc, (size_t)n * 4));
     HIP_TRY(scratch.alloc(&dcount, 4));
-    HIP_TRY(hipMemcpy(din, soa.data(), soa.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(din, recs.data(), recs.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dcount, &n, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
     HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
     TraceJob tj{};
     tj.queue = nullptr; tj.count = dcount; tj.head = &sc->qc->head[0];
-    tj.ox = din; tj.oy = din + n; tj.oz = din + 2 * (size_t)n; tj.dx = din + 3 * (size_t)n; tj.dy = din + 4 * (size_t)n; tj.dz = din + 5 * (size_t)n;
-    tj.tmax = din + 6 * (size_t)n;
-    tj.out_prim = dprim; tj.out_t = dout; tj.out_b0 = dout + n; tj.out_b1 = dout + 2 * (size_t)n; tj.out_b2 = dout + 3 * (size_t)n;
-    tj.out_occluded = docc; tj.class_count = nullptr; tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
+    tj.ray = (const float4 *)din; tj.ray_stride = 2; tj.per_ray_tmax = 1;
+    tj.out_hit = (float4 *)dout; tj.out_hit_stride = 1; tj.out_t = dt; tj.out_t_stride = 1;
+    tj.out_word = docc; tj.out_word_stride = 1; tj.out_inst = nullptr;
+    tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
     sc->profile = true; sc->drop_timings(); sc->stats.clear();
     tj.kind = any ? 2 : 0;
     sc->begin(any ? "trace_any_api" : "trace_closest_api", n);
@@ -1119,12 +1120,15 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     sc->resolve_timings();
     QCounters h;
     HIP_TRY(hipMemcpy(&h, sc->qc, sizeof h, hipMemcpyDeviceToHost));
-    if (any) HIP_TRY(hipMemcpy(hit, docc, n, hipMemcpyDeviceToHost));
-    else {
+    if (any) {
+        std::vector<uint32_t> occ(n);
+        HIP_TRY(hipMemcpy(occ.data(), docc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) hit[i] = occ[i] ? 1 : 0;
+    } else {
         std::vector<float> res(4 * (size_t)n);
         HIP_TRY(hipMemcpy(res.data(), dout, res.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(prim, dprim, (size_t)n * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < n; ++i) { t[i] = res[i]; for (int k = 0; k < 3; ++k) b[3 * (size_t)i + k] = res[(size_t)(1 + k) * n + i]; }
+        HIP_TRY(hipMemcpy(t, dt, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) { std::memcpy(&prim[i], &res[4 * (size_t)i], 4); for (int k = 0; k < 3; ++k) b[3 * (size_t)i + k] = res[4 * (size_t)i + 1 + k]; }
     }
     read_counters(sc);
     if (h.error) return fail((int)h.error, "traversal error raised on device");

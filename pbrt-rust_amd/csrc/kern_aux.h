@@ -18,24 +18,24 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
         uint32_t pid = 0, cls = (uint32_t)kMissClass;
         if (valid) {
             pid = queue[qi];
-            const uint32_t hp = ps.hit_prim[pid];
+            const uint32_t hp = ps.hit_prim(pid);
             if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
-            const uint32_t med = ps.medium[pid];
+            const uint32_t med = ps.medium(pid);
             if (med != PT_NONE) {
-                uint32_t meta = ps.meta[pid];
-                Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+                uint32_t meta = ps.meta(pid);
+                Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
                 smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
                 const float u_channel = smp.get_1d(), u_dist = smp.get_1d();
-                const V3 rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+                const V3 rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
                 bool sampled; float t;
-                const RGB w = medium_sample(s.media[med], hp != PT_NONE ? ps.hit_t[pid] : PT_INF, rd, u_channel, u_dist, sampled, t);
-                const RGB beta = RGB(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]) * w;
-                ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
+                const RGB w = medium_sample(s.media[med], hp != PT_NONE ? ps.hit_t(pid) : PT_INF, rd, u_channel, u_dist, sampled, t);
+                const RGB beta = RGB(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid)) * w;
+                ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
                 uint32_t flags = meta >> 24;
                 if (beta.is_black()) { flags |= PF_DEAD; cls = (uint32_t)kMissClass; }          // volpath.rs:105 `break`
-                else if (sampled) { ps.hit_t[pid] = t; cls = (uint32_t)kMediumClass; }
+                else if (sampled) { ps.hit_t(pid) = t; cls = (uint32_t)kMediumClass; }
                 if (smp.overflow) atomicMax(error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
-                ps.meta[pid] = (smp.dim & 0xffffu) | (meta & 0x00ff0000u) | (flags << 24);
+                ps.meta(pid) = (smp.dim & 0xffffu) | (meta & 0x00ff0000u) | (flags << 24);
             }
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u); lq_push(q2, pid, valid && cls == 2u);
@@ -78,21 +78,21 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
         if (valid) {
             n_valid++;
             pid = job.queue[qi];
-            const uint32_t meta = ps.meta[pid];
+            const uint32_t meta = ps.meta(pid);
             uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
             smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
-            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
-            RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+            RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
+            RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
             flags &= ~PF_CAMERA_RAY;
             bool terminated = bounces >= rc.max_depth;   // volpath.rs:108
             if (!terminated) {
                 smp.load_window();
-                const V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
-                const uint32_t med = ps.medium[pid];
+                const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
+                const uint32_t med = ps.medium(pid);
                 SurfaceInteraction si;   // only p and wo are read through the MediumInteraction
-                si.p = ro + rd * ps.hit_t[pid]; si.wo = -rd; si.n = V3(0.0f, 0.0f, 0.0f); si.sh_n = V3(0.0f, 0.0f, 0.0f); si.p_error = V3(0.0f, 0.0f, 0.0f);
+                si.p = ro + rd * ps.hit_t(pid); si.wo = -rd; si.n = V3(0.0f, 0.0f, 0.0f); si.sh_n = V3(0.0f, 0.0f, 0.0f); si.p_error = V3(0.0f, 0.0f, 0.0f);
                 IData it; it.p = si.p; it.p_error = V3(0.0f, 0.0f, 0.0f); it.n = V3(0.0f, 0.0f, 0.0f);
                 const PhaseBsdf phase{s.media[med].g, si.wo};
                 nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med});
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 hg_sample_p(phase.g, si.wo, wi, smp.get_2d());
                 flags &= ~PF_SPECULAR;   // specular_bounce = false
                 // Russian roulette (volpath.rs:171-176)
-                const RGB rrbeta = beta * ps.etascale[pid];
+                const RGB rrbeta = beta * ps.etascale(pid);
                 bool rr_kill = false;
                 if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                     const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 if (rr_kill) terminated = true;
                 else {
                     bounces += 1;
-                    ps.ox[pid] = si.p.x; ps.oy[pid] = si.p.y; ps.oz[pid] = si.p.z;   // mi.spawn_ray(wi): no offset (n = 0, p_error = 0)
-                    ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                    ps.ox(pid) = si.p.x; ps.oy(pid) = si.p.y; ps.oz(pid) = si.p.z;   // mi.spawn_ray(wi): no offset (n = 0, p_error = 0)
+                    ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
                     push_ext = true;
                 }
             }
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 else finished_bounces = (int)bounces;
             }
             if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
-            ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
-            ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
-            ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+            ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
+            ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
+            ps.meta(pid) = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
         }
         lq_push(s_qext, pid, push_ext); lq_push(s_qres, pid, push_resolve); lq_push(s_qsh, pid, push_shadow); lq_push(s_qmis, pid, push_mis);
         if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
@@ -166,18 +166,18 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
         n_valid++;
         n_bytes += 4 + 4 + 12 + 12 + /* write back */ 12 + 4;
         const uint32_t pid = job.queue[qi];
-        const uint32_t meta = ps.meta[pid];
+        const uint32_t meta = ps.meta(pid);
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
-        RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+        RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
         resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
         if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
             n_bytes += 12 + 12;
-            const RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
-            const V3 rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
+            const RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
+            const V3 rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
             for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
         }
-        ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
-        ps.meta[pid] = (meta & 0x00ffffffu) | ((flags & ~PF_CAMERA_RAY) << 24);
+        ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
+        ps.meta(pid) = (meta & 0x00ffffffu) | ((flags & ~PF_CAMERA_RAY) << 24);
         atomicAdd(&s_hist[bounces > 15u ? 15u : bounces], 1u);   // path.rs:219
     }
     __syncthreads();

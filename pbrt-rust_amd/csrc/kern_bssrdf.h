@@ -34,22 +34,22 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
         pid = job.queue[qi];
         // k_trace<.., PROBE> walked the whole chain: the hit record is the selected intersection (PT_NONE: no intersection with
         // the BSSRDF's material, S = 0), ps.ox.. / ps.dx.. the segment that found it, bs.cnt the chain's nfound
-        const V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
-        const uint32_t hp = ps.hit_prim[pid];
+        const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
+        const uint32_t hp = ps.hit_prim(pid);
         const uint32_t mat = bs.mat[pid];
         const uint32_t nfound = bs.cnt[pid];
         const bool at_exit = hp != PT_NONE, dead = !at_exit;
         SurfaceInteraction si;
-        if (at_exit) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+        if (at_exit) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
         n_bytes += 4 + 24 + 16 + 8;
 
         if (at_exit || dead) {
-            uint32_t meta = ps.meta[pid];
+            uint32_t meta = ps.meta(pid);
             uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-            Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
             smp.base = 0xffffffffu;
-            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
-            RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+            RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
+            RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
             // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
             resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
                         V3 o; spawn_ray(it, wi, o);
                         // path.rs:206-214 Russian roulette
-                        const RGB rrbeta = beta * ps.etascale[pid];
+                        const RGB rrbeta = beta * ps.etascale(pid);
                         bool rr_kill = false;
                         if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                             const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                         if (rr_kill) terminated = true;
                         else {
                             bounces += 1;
-                            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-                            ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
+                            ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
+                            ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
                             push_ext = true; n_bytes += 24 + 4 + 4;
                         }
                     }
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                 else finished_bounces = (int)bounces;
             }
             if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
-            ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
-            ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
-            ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+            ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
+            ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
+            ps.meta(pid) = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
         }
     }
     lq_push(s_qext, pid, push_ext);

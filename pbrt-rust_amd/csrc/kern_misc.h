@@ -62,7 +62,7 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
 // material's class (escaped rays -> the miss class). Block-level staged appends: one global atomic per ~1000 entries per class.
-__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *hit_prim,
+__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
                                               uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4) {
     __shared__ LdsQueue<1024> q0, q1, q2, q3, q4;
     lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
         uint32_t pid = 0, cls = (uint32_t)kMissClass;   // escaped rays: their own light kernel (k_shade_miss)
         if (valid) {
             pid = queue[qi];
-            const uint32_t hp = hit_prim[pid];
+            const uint32_t hp = ps.hit_prim(pid);
             if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
@@ -152,14 +152,14 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                     const P2 pl(halton_sample_dimension(tabs, rc.halton, index, 3u), halton_sample_dimension(tabs, rc.halton, index, 4u));
                     V3 o, d;
                     camera_ray(rc, pfx, pfy, tm, pl, o, d);
-                    ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
-                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-                    ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
-                    ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
-                    ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
-                    ps.etascale[pid] = 1.0f;
-                    ps.sobol_index[pid] = index;
-                    ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);
+                    ps.pfilm_x(pid) = pfx; ps.pfilm_y(pid) = pfy;
+                    ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
+                    ps.dx(pid) = d.x; ps.dy(pid) = d.y; ps.dz(pid) = d.z;
+                    ps.beta_r(pid) = 1.0f; ps.beta_g(pid) = 1.0f; ps.beta_b(pid) = 1.0f;
+                    ps.L_r(pid) = 0.0f; ps.L_g(pid) = 0.0f; ps.L_b(pid) = 0.0f;
+                    ps.etascale(pid) = 1.0f;
+                    ps.sobol_index(pid) = index;
+                    ps.meta(pid) = 5u | (PF_CAMERA_RAY << 24);
                     alive = true;
                 } else {
                 const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
@@ -177,19 +177,19 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 const float pfx = (float)px + fx, pfy = (float)py + fy;
                 V3 o, d;
                 camera_ray(rc, pfx, pfy, sobol_to_float(v2), P2(sobol_to_float(v3), sobol_to_float(v4)), o, d);
-                ps.pfilm_x[pid] = pfx; ps.pfilm_y[pid] = pfy;
-                ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-                ps.dx[pid] = d.x; ps.dy[pid] = d.y; ps.dz[pid] = d.z;
-                ps.beta_r[pid] = 1.0f; ps.beta_g[pid] = 1.0f; ps.beta_b[pid] = 1.0f;
-                ps.L_r[pid] = 0.0f; ps.L_g[pid] = 0.0f; ps.L_b[pid] = 0.0f;
-                ps.etascale[pid] = 1.0f;
-                ps.sobol_index[pid] = index;
-                ps.meta[pid] = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
+                ps.pfilm_x(pid) = pfx; ps.pfilm_y(pid) = pfy;
+                ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
+                ps.dx(pid) = d.x; ps.dy(pid) = d.y; ps.dz(pid) = d.z;
+                ps.beta_r(pid) = 1.0f; ps.beta_g(pid) = 1.0f; ps.beta_b(pid) = 1.0f;
+                ps.L_r(pid) = 0.0f; ps.L_g(pid) = 0.0f; ps.L_b(pid) = 0.0f;
+                ps.etascale(pid) = 1.0f;
+                ps.sobol_index(pid) = index;
+                ps.meta(pid) = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
                 alive = true;
                 }
             }
         }
-        if (alive && rc.volpath) ps.medium[pid] = rc.camera_medium;   // the camera ray starts in the camera's medium (perspective.rs:114)
+        if (alive && rc.volpath) ps.medium(pid) = rc.camera_medium;   // the camera ray starts in the camera's medium (perspective.rs:114)
         lq_push(s_q, pid, alive);
         lq_sync_flush(s_q, q_ext_count, q_ext, 256u, false);
         n_alive += alive ? 1ull : 0ull;
@@ -226,13 +226,13 @@ __global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const 
         if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
         for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
             const uint32_t pid = sl * rc.n_pix_slots + slot;
-            RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
+            RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
             // integrator.rs:350-368
             if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
             else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
             else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
             if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
-            const float dx = ps.pfilm_x[pid] - 0.5f, dy = ps.pfilm_y[pid] - 0.5f;
+            const float dx = ps.pfilm_x(pid) - 0.5f, dy = ps.pfilm_y(pid) - 0.5f;
             int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
             int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
             for (int64_t y = p0y; y < p1y; ++y) {

@@ -38,12 +38,12 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         n_valid++;
         n_bytes += 4 + 4 + 8 + 12 + 12 + /* write back */ 12 + 12 + 4;   // queue, meta, sobol index, L, beta
         pid = job.queue[qi];
-        uint32_t meta = ps.meta[pid];
+        uint32_t meta = ps.meta(pid);
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-        Sampler smp; smp.index = ps.sobol_index[pid]; smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+        Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
         smp.base = 0xffffffffu;
-        RGB L(ps.L_r[pid], ps.L_g[pid], ps.L_b[pid]);
-        RGB beta(ps.beta_r[pid], ps.beta_g[pid], ps.beta_b[pid]);
+        RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
+        RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
         resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
@@ -53,11 +53,11 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
             finished_bounces = (int)bounces;
         } else {
             n_bytes += 24 + 16;  // ray + hit record
-            V3 ro(ps.ox[pid], ps.oy[pid], ps.oz[pid]), rd(ps.dx[pid], ps.dy[pid], ps.dz[pid]);
-            const uint32_t hp = ps.hit_prim[pid];
+            V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
+            const uint32_t hp = ps.hit_prim(pid);
             const bool found = hp != PT_NONE;
             SurfaceInteraction si;
-            if (found) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst[pid] : PT_NONE, ro, rd, ps.hit_b0[pid], ps.hit_b1[pid], ps.hit_b2[pid], si);
+            if (found) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
             // path.rs:106-117
             if (bounces == 0 || (flags & PF_SPECULAR)) {
                 if (found) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         P2 plens_u(0.0f, 0.0f);
                         if (rc.lens_radius > 0.0f) plens_u = rc.halton.enabled ? P2(halton_sample_dimension(tabs, rc.halton, smp.index, 3u), halton_sample_dimension(tabs, rc.halton, smp.index, 4u))
                                                                               : P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
-                        rdiff = camera_ray_differentials(rc, ps.pfilm_x[pid], ps.pfilm_y[pid], plens_u, ro, rd);
+                        rdiff = camera_ray_differentials(rc, ps.pfilm_x(pid), ps.pfilm_y(pid), plens_u, ro, rd);
                     }
                     const TexCtx tctx = compute_differentials(si, rdiff);
                     if (mi != PT_NONE && s.materials[mi].tex[PT_MP_BUMP] >= 0) {   // bump() (core/material.rs:46-87)
@@ -110,12 +110,12 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                 MedIface mif{PT_NONE, PT_NONE};
-                if (VOL) mif = surface_iface(s, hp, ps.medium[pid]);   // primitive.rs:139-145
+                if (VOL) mif = surface_iface(s, hp, ps.medium(pid));   // primitive.rs:139-145
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
                     V3 o; spawn_ray(it, rd, o);
-                    ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
+                    ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
                     if (VOL) {   // volpath.rs:127-131 `bounces -= 1; continue`: the count drops by one and wraps below zero
-                        ps.medium[pid] = medium_toward(mif, si.n, rd);
+                        ps.medium(pid) = medium_toward(mif, si.n, rd);
                         bounces = (bounces - 1u) & 0xffu;
                     }
                     push_ext = true;
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                     else {
                         beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
-                        float etascale = ps.etascale[pid];
+                        float etascale = ps.etascale(pid);
                         if ((sflags & BSDF_SPECULAR) && (sflags & BSDF_TRANSMISSION)) {
                             const float eta = bsdf.eta;
                             etascale *= (dot(wo, si.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
-                            ps.etascale[pid] = etascale;
+                            ps.etascale(pid) = etascale;
                         }
                         V3 o; spawn_ray(it, wi, o);
                         bool rr_kill = false, to_probe = false;
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                                         bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
                                         bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
                                         // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
-                                        ps.ox[pid] = start.x; ps.oy[pid] = start.y; ps.oz[pid] = start.z;
-                                        ps.dx[pid] = pd.x; ps.dy[pid] = pd.y; ps.dz[pid] = pd.z;
+                                        ps.ox(pid) = start.x; ps.oy(pid) = start.y; ps.oz(pid) = start.z;
+                                        ps.dx(pid) = pd.x; ps.dy(pid) = pd.y; ps.dz(pid) = pd.z;
                                         to_probe = true; push_probe = true; n_bytes += 18 * 4 + 24 + 4;
                                     }
                                 }
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         if (rr_kill) terminated = true;
                         else if (!to_probe) {
                             bounces += 1;
-                            ps.ox[pid] = o.x; ps.oy[pid] = o.y; ps.oz[pid] = o.z;
-                            ps.dx[pid] = wi.x; ps.dy[pid] = wi.y; ps.dz[pid] = wi.z;
-                            if (VOL) ps.medium[pid] = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
+                            ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
+                            ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
+                            if (VOL) ps.medium(pid) = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
                             push_ext = true; n_bytes += 24 + 4 + 4;  // new ray, etascale, ext queue entry
                         }
                     }
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         }
         PT_T(12);
         if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
-        ps.L_r[pid] = L.r; ps.L_g[pid] = L.g; ps.L_b[pid] = L.b;
-        ps.beta_r[pid] = beta.r; ps.beta_g[pid] = beta.g; ps.beta_b[pid] = beta.b;
-        ps.meta[pid] = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+        ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
+        ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
+        ps.meta(pid) = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
     }
     PT_T(13);
     lq_push(s_qext, pid, push_ext);

@@ -25,33 +25,33 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
     PT_T(1);
     n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
     RGB Ld(0.0f);
-    const uint32_t li = ps.nee_light[pid];
+    const uint32_t li = ps.nee_light(pid);
     // volpath: VisibilityTester::tr intersects (closest hit) and every surface is opaque; the segment's transmittance is already in A
-    if ((flags & PF_PEND_SHADOW) && (VOL ? ps.sh_prim[pid] == PT_NONE : !ps.occluded[pid])) Ld = Ld + RGB(ps.A_r[pid], ps.A_g[pid], ps.A_b[pid]);
+    if ((flags & PF_PEND_SHADOW) && (VOL ? ps.sh_prim(pid) == PT_NONE : !ps.occluded(pid))) Ld = Ld + RGB(ps.A_r(pid), ps.A_g(pid), ps.A_b(pid));
     if (flags & PF_PEND_MIS) {
         const PtLight &Lt = s.lights[li];
-        V3 wi(ps.mis_dx[pid], ps.mis_dy[pid], ps.mis_dz[pid]);
+        V3 wi(ps.mis_dx(pid), ps.mis_dy(pid), ps.mis_dz(pid));
         RGB lrad(0.0f);
-        const uint32_t mp = ps.mis_prim[pid];
+        const uint32_t mp = ps.mis_prim(pid);
         if (mp != PT_NONE) {
             if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
                 SurfaceInteraction lsi;
-                fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox[pid], ps.mis_oy[pid], ps.mis_oz[pid]), wi, ps.mis_b0[pid], ps.mis_b1[pid], ps.mis_b2[pid], lsi);  // lights are never inside instances (api.rs:1605-1608)
+                fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox(pid), ps.mis_oy(pid), ps.mis_oz(pid)), wi, ps.mis_b0(pid), ps.mis_b1(pid), ps.mis_b2(pid), lsi);  // lights are never inside instances (api.rs:1605-1608)
                 lrad = area_l(Lt, lsi.n, -wi);
             }
         } else { PT_T(2); lrad = light_le(s, Lt, wi); PT_T(1); }
         if (!lrad.is_black()) {
-            RGB f(ps.mis_f_r[pid], ps.mis_f_g[pid], ps.mis_f_b[pid]);
+            RGB f(ps.mis_f_r(pid), ps.mis_f_g(pid), ps.mis_f_b(pid));
             RGB Tr(1.0f);
             if (VOL) {   // Scene::intersect_tr (scene.rs:68-87): transmittance of the MIS ray's medium up to its hit (or to infinity)
-                const uint32_t mm = ps.mis_medium[pid];
-                if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? ps.mis_t[pid] : PT_INF, wi);
+                const uint32_t mm = ps.mis_medium(pid);
+                if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? ps.mis_t(pid) : PT_INF, wi);
             }
-            Ld = Ld + f * lrad * Tr * ps.mis_w[pid] / ps.mis_spdf[pid];
+            Ld = Ld + f * lrad * Tr * ps.mis_w(pid) / ps.mis_spdf(pid);
         }
     }
-    RGB nb(ps.nb_r[pid], ps.nb_g[pid], ps.nb_b[pid]);
-    RGB Ldb = nb * (Ld / ps.nee_choice_pdf[pid]);
+    RGB nb(ps.nb_r(pid), ps.nb_g(pid), ps.nb_b(pid));
+    RGB Ldb = nb * (Ld / ps.nee_choice_pdf(pid));
     if (!VOL && Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
     L = L + Ldb;
     flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
@@ -92,9 +92,9 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                         if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
                     }
                     RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
-                    ps.sh_ox[pid] = so.x; ps.sh_oy[pid] = so.y; ps.sh_oz[pid] = so.z;
-                    ps.sh_dx[pid] = sd.x; ps.sh_dy[pid] = sd.y; ps.sh_dz[pid] = sd.z;
-                    ps.A_r[pid] = A.r; ps.A_g[pid] = A.g; ps.A_b[pid] = A.b;
+                    ps.sh_ox(pid) = so.x; ps.sh_oy(pid) = so.y; ps.sh_oz(pid) = so.z;
+                    ps.sh_dx(pid) = sd.x; ps.sh_dy(pid) = sd.y; ps.sh_dz(pid) = sd.z;
+                    ps.A_r(pid) = A.r; ps.A_g(pid) = A.g; ps.A_b(pid) = A.b;
                     flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 24 + 12 + 4;
                 }
             }
@@ -116,18 +116,18 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                     }
                     if (!skip) {
                         V3 mo; spawn_ray(it, wi, mo);
-                        ps.mis_ox[pid] = mo.x; ps.mis_oy[pid] = mo.y; ps.mis_oz[pid] = mo.z;
-                        ps.mis_dx[pid] = wi.x; ps.mis_dy[pid] = wi.y; ps.mis_dz[pid] = wi.z;
-                        ps.mis_f_r[pid] = f.r; ps.mis_f_g[pid] = f.g; ps.mis_f_b[pid] = f.b;
-                        ps.mis_w[pid] = weight; ps.mis_spdf[pid] = scattpdf;
-                        if (VOL) ps.mis_medium[pid] = medium_toward(mif, it.n, wi);
+                        ps.mis_ox(pid) = mo.x; ps.mis_oy(pid) = mo.y; ps.mis_oz(pid) = mo.z;
+                        ps.mis_dx(pid) = wi.x; ps.mis_dy(pid) = wi.y; ps.mis_dz(pid) = wi.z;
+                        ps.mis_f_r(pid) = f.r; ps.mis_f_g(pid) = f.g; ps.mis_f_b(pid) = f.b;
+                        ps.mis_w(pid) = weight; ps.mis_spdf(pid) = scattpdf;
+                        if (VOL) ps.mis_medium(pid) = medium_toward(mif, it.n, wi);
                         flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
                     }
                 }
             }
             if (nee_pending) {
-                ps.nee_light[pid] = li; ps.nee_choice_pdf[pid] = choice_pdf;
-                ps.nb_r[pid] = beta.r; ps.nb_g[pid] = beta.g; ps.nb_b[pid] = beta.b; n_bytes += 8 + 12;
+                ps.nee_light(pid) = li; ps.nee_choice_pdf(pid) = choice_pdf;
+                ps.nb_r(pid) = beta.r; ps.nb_g(pid) = beta.g; ps.nb_b(pid) = beta.b; n_bytes += 8 + 12;
             }
         }
     }

@@ -29,13 +29,17 @@
 // (`selected = clamp((u1 * nfound) as usize, 0, nfound - 1)`), so that one launch replaces what used to be one wavefront
 // iteration (a trace launch, a k_bssrdf launch and a host round trip) per segment, twice over.
 template <bool ANY, int MODE, bool PROBE>
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY && PROBE), "probe chains are closest-hit queries");
-    constexpr bool SPH = MODE >= 1, ALPHA = MODE == 2;
+    // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
+    //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
+    constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
+    __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
     uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
     uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLdsStack)) + lane;
     const uint32_t count = *job.count;
@@ -50,7 +54,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
 #endif
 
     // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
-    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3 };
+    // ST_INST (an instance packet at `cur` waits to be entered) and ST_RET (the instance's marker was popped, the world ray waits to
+    // be restored) are the two transform steps of TransformedPrimitive (primitive.rs:58-88): ~200 instructions that only a few lanes
+    // need in any one iteration, so they run in a step of their own once `inst_quorum` lanes wait for it (like leaves, below)
+    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5 };
     uint32_t state = ST_IDLE;
     bool exhausted = false;
     constexpr int kChunk = 256;
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
     uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
     uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
+    uint32_t xf_arg = 0;   // ST_INST: instance index | TP_LAST of its packet in bit 31; ST_RET: word 0 of the popped marker entry
     constexpr uint32_t kMarker = 0xFFC0DEADu;   // stack word 1 of an "end of instance" entry (never a real tmin)
     // PROBE: chain state of the lane. A chain with more than kProbeRing matches after the selected one is walked a second time
     // ("rewalk") up to match number `selected`; the rewalk's work is not counted (the reference indexes its Vec instead).
@@ -79,16 +87,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
             uint32_t w0, w1;
             if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
             else { w0 = spill[(2 * (sp - kLdsStack)) * 64]; w1 = spill[(2 * (sp - kLdsStack) + 1) * 64]; }
-            if (SPH && w1 == kMarker) {                // the object's BVH is exhausted: back to world space (primitive.rs:70-77)
-                pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
-                ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]); rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
-                inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
-                tray = tri_ray_setup(rd);
-                t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
-                in_inst = PT_NONE; inst_hit = false;
-                if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; return; }  // remaining packets of the outer leaf
-                continue;
+            if (INST && w1 == kMarker) {               // the object's BVH is exhausted: back to world space (primitive.rs:70-77), in the transform step
+                xf_arg = w0; state = ST_RET;
+                return;
             }
             n_nodes++;                                 // the reference tests the popped node now
             pending = (w0 >> 25) & 63u;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
         //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
         //      paid once per batch instead of once per ray.
         const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
-        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF);
+        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_INST || state == ST_RET);
         if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
             bool retire = state == ST_DONE;
             if constexpr (PROBE) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                     bool finish = false, next_seg = false, chain_end = false;
                     if (hit_prim != PT_NONE) {
                         SurfaceInteraction si;
-                        fill_hit<SPH>(s, hit_prim, SPH ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
+                        fill_hit<INST>(s, hit_prim, INST ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
                         if (s.prim_material[hit_prim] == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
                             if (!rewalk) {
                                 const uint32_t k = nfound % (uint32_t)kProbeRing;
@@ -153,10 +154,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                             }
                         } else { hit_prim = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
                     }
-                    if (next_seg || finish) {   // the segment's ray lives in the path state: the instance marker reloads it, k_bssrdf rebuilds the exit point from it
-                        float *wox = const_cast<float *>(job.ox), *woy = const_cast<float *>(job.oy), *woz = const_cast<float *>(job.oz);
-                        float *wdx = const_cast<float *>(job.dx), *wdy = const_cast<float *>(job.dy), *wdz = const_cast<float *>(job.dz);
-                        wox[pid] = ro.x; woy[pid] = ro.y; woz[pid] = ro.z; wdx[pid] = rd.x; wdy[pid] = rd.y; wdz[pid] = rd.z;
+                    if (next_seg || finish) {   // the segment's ray goes back to the path state: k_bssrdf rebuilds the exit point from it
+                        float4 *rw = const_cast<float4 *>(job.ray) + (size_t)pid * job.ray_stride;
+                        rw[0] = make_float4(ro.x, ro.y, ro.z, rd.x); rw[1] = make_float4(rd.y, rd.z, 0.0f, 0.0f);
                     }
                     if (next_seg) {
                         retire = false;
@@ -183,12 +183,12 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                 }
             }
             if (retire) {
-                if (ANY) job.out_occluded[pid] = found ? 1 : 0;
+                if (ANY) job.out_word[(size_t)pid * job.out_word_stride] = found ? 1u : 0u;
                 else {
-                    job.out_prim[pid] = hit_prim;
-                    if (job.out_t) job.out_t[pid] = hit_t;
-                    if (job.out_b0) { job.out_b0[pid] = hb0; job.out_b1[pid] = hb1; job.out_b2[pid] = hb2; }   // NULL: only the hit / miss matters (volpath shadow rays)
-                    if (SPH && job.out_inst) job.out_inst[pid] = hit_inst;
+                    if (job.out_hit) job.out_hit[(size_t)pid * job.out_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
+                    else job.out_word[(size_t)pid * job.out_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
+                    if (job.out_t) job.out_t[(size_t)pid * job.out_t_stride] = hit_t;
+                    if (INST && job.out_inst) job.out_inst[(size_t)pid * job.out_inst_stride] = hit_inst;
                 }
             }
             if (retire) state = ST_IDLE;
@@ -211,9 +211,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                 chunk_next += take; chunk_left -= take;
                 if (get) {
                     pid = job.queue ? job.queue[qi] : qi;
-                    ro = V3(job.ox[pid], job.oy[pid], job.oz[pid]);
-                    rd = V3(job.dx[pid], job.dy[pid], job.dz[pid]);
-                    t_max = job.tmax ? job.tmax[pid] : job.scalar_tmax;
+                    const float4 r0 = job.ray[(size_t)pid * job.ray_stride], r1 = job.ray[(size_t)pid * job.ray_stride + 1];   // one 32-byte record
+                    ro = V3(r0.x, r0.y, r0.z);
+                    rd = V3(r0.w, r1.x, r1.y);
+                    t_max = job.per_ray_tmax ? r1.z : job.scalar_tmax;
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                     tray = tri_ray_setup(rd);
@@ -242,6 +243,57 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
         const bool at_node = state == ST_ENTER;
         const unsigned long long leaf_m = __ballot(state == ST_LEAF);
         const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || __ballot(at_node) == 0ull);
+        if constexpr (INST) {
+            // ---- transform step: enter instances / return from them, once enough lanes wait (or nothing else can run)
+            const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);
+            if (xf_m != 0ull && ((uint32_t)__popcll(xf_m) >= job.inst_quorum || __ballot(at_node || at_leaf) == 0ull)) {
+                bool need_pop = false;
+                if (state == ST_RET) {
+                    const uint32_t w0 = xf_arg;
+                    pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
+                    ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
+                    inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                    tray = tri_ray_setup(rd);
+                    t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
+                    in_inst = PT_NONE; inst_hit = false;
+                    if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; }  // remaining packets of the outer leaf
+                    else need_pop = true;
+                } else if (state == ST_INST) {   // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
+                    const uint32_t li = cur;
+                    const bool more = !(xf_arg & 0x80000000u);
+                    const uint32_t ii = xf_arg & 0x7fffffffu;
+                    const DevInstance &I = s.instances[ii];
+                    // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
+                    const M4 w2i = ldm4g(I.world_to_instance);
+                    V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+                    const float l2 = length_squared(d2);
+                    float tm2 = t_max;
+                    if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
+                    const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
+                    const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
+                    bool enter = true;
+                    if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+                    if (enter && (pending > 63u || sp >= (uint32_t)kMaxStack)) { atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW); enter = false; }
+                    if (enter) {
+                        // remember where to resume: the rest of this leaf (if any) and the outer skip count
+                        const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
+                        if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
+                        else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = kMarker; }
+                        sp++; pending = 0;
+                        wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
+                        t_max_world = t_max; in_inst = ii; inst_hit = false;
+                        ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
+                        tray = tri_ray_setup(rd);
+                        cur = I.root_ref & kRefMask;
+                        state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                    } else if (more) { cur = li + 1u; state = ST_LEAF; }
+                    else need_pop = true;
+                }
+                if (need_pop) pop_next();
+                continue;   // states changed: re-evaluate which step runs next
+            }
+        }
         PT_UTIL(u_it1, u_act1, at_node || at_leaf);
         PT_UTIL(u_it2, u_act2, at_leaf);
         if (at_node || at_leaf) {
@@ -285,36 +337,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                 const uint32_t fl = q2.w, li = cur;
                 bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
                 if (fl & TP_INSTANCE) {
-                    if constexpr (SPH) {  // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
-                        const DevInstance &I = s.instances[q2.z];
-                        // ray = inverse(prim_to_world).transform_ray(r)  (transform.rs:543-577, t_max -= dt)
-                        const M4 w2i = ldm4g(I.world_to_instance);
-                        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
-                        const float l2 = length_squared(d2);
-                        float tm2 = t_max;
-                        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; tm2 -= dt; }
-                        const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
-                        const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
-                        bool enter = true;
-                        if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
-                        if (enter) {
-                            // remember where to resume: the rest of this leaf (if any) and the outer skip count
-                            const bool more = !(fl & TP_LAST);
-                            const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
-                            if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
-                            else {
-                                if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
-                                else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = kMarker; }
-                                sp++; pending = 0;
-                                t_max_world = t_max; in_inst = q2.z; inst_hit = false;
-                                ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
-                                tray = tri_ray_setup(rd);
-                                cur = I.root_ref & kRefMask;
-                                state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
-                                advance = false;
-                            }
-                        }
-                    }
+                    if constexpr (INST) { xf_arg = q2.z | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
                 } else if (fl & TP_SPHERE) {
                     if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
                         n_sph++;
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? 5 : 1) PT_TRAC
                         else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
                             found = true; t_max = t;  // primitive.rs:137
                             hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
-                            if (SPH) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
+                            if (INST) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
                         }
                     }
                 }

@@ -22,30 +22,49 @@ constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersection
 enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
                   PF_CAMERA_RAY = 32u };   // the ray still carries the camera's differentials (cleared at the first shaded vertex)
 
-// SoA path state in HBM; index = path id (pid). Every array has `capacity` entries.
+// Path state in HBM: five arrays of 16-byte-aligned RECORDS indexed by path id (pid). A record holds what one kernel reads or
+// writes together, so a lane moves whole 16-byte quads of one 32- or 64-byte line (dwordx4 accesses, every fetched sector fully
+// used) however sparse the path ids of a queue have become -- round 1 kept one 4-byte array per field, which cost one memory
+// instruction per field and fetched a 64-byte sector for every 4 bytes once the surviving paths were scattered.
+//   core  64 B  {L.rgb, etascale} {beta.rgb, meta} {sobol_index, pfilm.xy} {medium, mis_medium, -, -}      generate / shade / film
+//   ray   32 B  {o.xyz, d.x} {d.yz, (t_max), -}                                                            continuation ray: shade -> trace
+//   hit   32 B  {prim, b0, b1, b2} {inst, t, -, -}                                                         trace -> route / shade
+//   nee   64 B  {sh_o.xyz, sh_d.x} {sh_d.yz, occluded | sh_prim, nee_light} {A.rgb, choice_pdf} {nb.rgb, -}  pending shadow ray + its terms
+//   mis   64 B  {mis_o.xyz, mis_d.x} {mis_d.yz, w, spdf} {mis_prim, b0, b1, b2} {f.rgb, mis_t}              pending MIS ray + its hit
+// The accessors below name single words of those records; adjacent words accessed together merge into dwordx2/x4 instructions.
 struct PathSoA {
-    float *pfilm_x, *pfilm_y;
-    float *ox, *oy, *oz, *dx, *dy, *dz;                 // continuation ray (t_max = inf)
-    uint32_t *hit_prim; float *hit_b0, *hit_b1, *hit_b2; // closest hit of the continuation ray
-    uint32_t *hit_inst;                                  // instance the hit went through (PT_NONE: top level)
-    float *beta_r, *beta_g, *beta_b, *L_r, *L_g, *L_b, *etascale;
-    uint64_t *sobol_index;
-    uint32_t *meta;                                      // dim (bits 0-15) | bounces (16-23) | flags (24-31)
+    float *core, *ray, *hit, *nee, *mis;
+    static constexpr int kCoreWords = 16, kRayWords = 8, kHitWords = 8, kNeeWords = 16, kMisWords = 16;
+#define PT_REC_F(name, arr, words, off) PT_HD float &name(size_t p) const { return arr[p * words + off]; }
+#define PT_REC_U(name, arr, words, off) PT_HD uint32_t &name(size_t p) const { return reinterpret_cast<uint32_t *>(arr)[p * words + off]; }
+    PT_REC_F(L_r, core, 16, 0) PT_REC_F(L_g, core, 16, 1) PT_REC_F(L_b, core, 16, 2) PT_REC_F(etascale, core, 16, 3)
+    PT_REC_F(beta_r, core, 16, 4) PT_REC_F(beta_g, core, 16, 5) PT_REC_F(beta_b, core, 16, 6)
+    PT_REC_U(meta, core, 16, 7)                          // dim (bits 0-15) | bounces (16-23) | flags (24-31)
+    PT_HD uint64_t &sobol_index(size_t p) const { return reinterpret_cast<uint64_t *>(core)[p * 8 + 4]; }   // words 8-9
+    PT_REC_F(pfilm_x, core, 16, 10) PT_REC_F(pfilm_y, core, 16, 11)
+    PT_REC_U(medium, core, 16, 12)                       // volpath: Ray::medium of the continuation ray (PT_NONE = vacuum)
+    PT_REC_U(mis_medium, core, 16, 13)                   // volpath: the MIS ray's medium
+    PT_REC_F(ox, ray, 8, 0) PT_REC_F(oy, ray, 8, 1) PT_REC_F(oz, ray, 8, 2) PT_REC_F(dx, ray, 8, 3) PT_REC_F(dy, ray, 8, 4) PT_REC_F(dz, ray, 8, 5)   // continuation ray (t_max = inf)
+    PT_REC_U(hit_prim, hit, 8, 0) PT_REC_F(hit_b0, hit, 8, 1) PT_REC_F(hit_b1, hit, 8, 2) PT_REC_F(hit_b2, hit, 8, 3)   // closest hit of the continuation ray
+    PT_REC_U(hit_inst, hit, 8, 4)                        // instance the hit went through (PT_NONE: top level)
+    PT_REC_F(hit_t, hit, 8, 5)                           // volpath: ray.t_max after Scene::intersect; then the medium vertex's parameter
     // pending next-event estimation of the previous vertex
-    float *sh_ox, *sh_oy, *sh_oz, *sh_dx, *sh_dy, *sh_dz; // shadow ray (t_max = 1 - eps)
-    float *A_r, *A_g, *A_b;                              // f*Li*w/lightpdf if unoccluded
-    float *mis_ox, *mis_oy, *mis_oz, *mis_dx, *mis_dy, *mis_dz;
-    float *mis_f_r, *mis_f_g, *mis_f_b, *mis_w, *mis_spdf;
-    uint32_t *nee_light; float *nee_choice_pdf;
-    float *nb_r, *nb_g, *nb_b;                           // beta at NEE time
-    uint32_t *mis_prim; float *mis_b0, *mis_b1, *mis_b2; // closest hit of the MIS ray
-    uint8_t *occluded;
-    // volumetric path integrator only (PtRenderParams.integrator == PT_INTEGRATOR_VOLPATH)
-    uint32_t *medium;        // Ray::medium of the continuation ray (PT_NONE = vacuum)
-    float *hit_t;            // its hit parameter (ray.t_max after Scene::intersect); then the medium vertex's parameter
-    uint32_t *mis_medium; float *mis_t;   // the MIS ray's medium and hit parameter (Scene::intersect_tr)
-    uint32_t *sh_prim;       // closest hit of the shadow ray (VisibilityTester::tr intersects, it does not intersect_p)
+    PT_REC_F(sh_ox, nee, 16, 0) PT_REC_F(sh_oy, nee, 16, 1) PT_REC_F(sh_oz, nee, 16, 2) PT_REC_F(sh_dx, nee, 16, 3) PT_REC_F(sh_dy, nee, 16, 4) PT_REC_F(sh_dz, nee, 16, 5)   // shadow ray (t_max = 1 - eps)
+    PT_REC_U(occluded, nee, 16, 6)                       // any-hit result of the shadow ray ...
+    PT_REC_U(sh_prim, nee, 16, 6)                        // ... or (volpath) its closest hit: VisibilityTester::tr intersects, it does not intersect_p
+    PT_REC_U(nee_light, nee, 16, 7)
+    PT_REC_F(A_r, nee, 16, 8) PT_REC_F(A_g, nee, 16, 9) PT_REC_F(A_b, nee, 16, 10)   // f*Li*w/lightpdf if unoccluded
+    PT_REC_F(nee_choice_pdf, nee, 16, 11)
+    PT_REC_F(nb_r, nee, 16, 12) PT_REC_F(nb_g, nee, 16, 13) PT_REC_F(nb_b, nee, 16, 14)   // beta at NEE time
+    PT_REC_F(mis_ox, mis, 16, 0) PT_REC_F(mis_oy, mis, 16, 1) PT_REC_F(mis_oz, mis, 16, 2) PT_REC_F(mis_dx, mis, 16, 3) PT_REC_F(mis_dy, mis, 16, 4) PT_REC_F(mis_dz, mis, 16, 5)
+    PT_REC_F(mis_w, mis, 16, 6) PT_REC_F(mis_spdf, mis, 16, 7)
+    PT_REC_U(mis_prim, mis, 16, 8) PT_REC_F(mis_b0, mis, 16, 9) PT_REC_F(mis_b1, mis, 16, 10) PT_REC_F(mis_b2, mis, 16, 11)   // closest hit of the MIS ray
+    PT_REC_F(mis_f_r, mis, 16, 12) PT_REC_F(mis_f_g, mis, 16, 13) PT_REC_F(mis_f_b, mis, 16, 14)
+    PT_REC_F(mis_t, mis, 16, 15)                         // volpath: the MIS ray's hit parameter (Scene::intersect_tr)
+#undef PT_REC_F
+#undef PT_REC_U
 };
+constexpr int kPathBytes = 4 * (PathSoA::kCoreWords + PathSoA::kRayWords + PathSoA::kHitWords + PathSoA::kNeeWords + PathSoA::kMisWords);   // 256 B per path
 // Per-path subsurface probe state (allocated only for scenes with a subsurface material): the sampled probe segment of
 // TabulatedBSSRDF::sample_sp (bssrdf.rs:357-365), the outgoing point's frame, and the chain counters.
 struct BssSoA {
@@ -56,7 +75,6 @@ struct BssSoA {
     uint32_t *cnt;   // nfound of the finished chain (written by k_trace<.., PROBE>, read by k_bssrdf)
 };
 constexpr int kBssSoAArrays = 18;
-constexpr int kPathSoAFloatArrays = 56;  // 4-byte arrays in the slab (+ one u64 array + one u8 array)
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)
@@ -108,22 +126,22 @@ struct TraceJob {
     const uint32_t *queue;   // path ids (NULL => identity)
     const uint32_t *count;   // device count of queue entries
     uint32_t *head;          // persistent-wave work head (zeroed before launch)
-    const float *ox, *oy, *oz, *dx, *dy, *dz;
-    const float *tmax;       // per-ray t_max or NULL => scalar_tmax
+    // rays: 32-byte records {o.xyz, d.x} {d.y, d.z, t_max, -} at ray[pid * ray_stride] (stride in 16-byte quads: 2 = ray records, 4 = the
+    // leading quads of nee / mis records); t_max is read from the record only if per_ray_tmax, else scalar_tmax
+    const float4 *ray; uint32_t ray_stride; uint32_t per_ray_tmax;
     float scalar_tmax;
-    // outputs (indexed by path id)
-    uint32_t *out_prim; float *out_t, *out_b0, *out_b1, *out_b2;
-    uint32_t *out_inst;      // may be NULL
-    uint8_t *out_occluded;
-    // shade-queue routing (closest-hit of continuation rays only)
-    uint32_t *class_count;   // [kNumClasses] or NULL
-    uint32_t *class_buf[kNumClasses];
+    // outputs (indexed by path id; strides in their own units)
+    float4 *out_hit; uint32_t out_hit_stride;       // closest hit {prim, b0, b1, b2} as one quad (NULL: not wanted)
+    uint32_t *out_word; uint32_t out_word_stride;   // any-hit: occluded flag; closest hit without out_hit: the primitive (volpath shadow rays)
+    float *out_t; uint32_t out_t_stride;            // may be NULL
+    uint32_t *out_inst; uint32_t out_inst_stride;   // may be NULL
     uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - kLdsStack)]
     uint32_t *error;
     DevCounters *counters;
     uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera (per-kind work counters)
     uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)
     uint32_t leaf_quorum;    // lanes waiting at a leaf join the record fetch once this many wait (or no lane is at a node)
+    uint32_t inst_quorum;    // lanes waiting to enter / leave an object instance run the transform step once this many wait
     // PROBE launches only: the chains' per-path inputs (start, target, material, u1) / output (cnt = nfound) and the per-lane ring
     BssSoA bs;
     uint4 *ring;             // [waves_in_grid][kProbeRing][3][64 lanes]

@@ -7,8 +7,10 @@
 template __global__ void k_trace<false, 0, true>(DeviceScene, TraceJob);
 template __global__ void k_trace<false, 1, true>(DeviceScene, TraceJob);
 template __global__ void k_trace<false, 2, true>(DeviceScene, TraceJob);
+template __global__ void k_trace<false, 3, true>(DeviceScene, TraceJob);
 #else
 template __global__ void k_trace<PT_TU_ANY != 0, 0, false>(DeviceScene, TraceJob);
 template __global__ void k_trace<PT_TU_ANY != 0, 1, false>(DeviceScene, TraceJob);
 template __global__ void k_trace<PT_TU_ANY != 0, 2, false>(DeviceScene, TraceJob);
+template __global__ void k_trace<PT_TU_ANY != 0, 3, false>(DeviceScene, TraceJob);
 #endif
