@@ -22,6 +22,7 @@ int g_num_cus = 256;
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
+bool g_refill_from_env = false;
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
 SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -201,6 +202,7 @@ void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func
 int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper, bool probe = false) {
     if (n_upper == 0) return PT_OK;
     job.refill_min = g_refill_min[job.kind == 4 ? 0 : (job.kind & 3)]; job.leaf_quorum = g_leaf_quorum[job.kind == 4 ? 0 : (job.kind & 3)];
+    if (sc->ds.n_instances > 0 && !g_refill_from_env) job.refill_min = 8;   // rays through instanced scenes are long (S4: 200 node visits): idle lanes are refilled early (measured 24 -> 8: +9 %)
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
     const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : sc->ds.n_spheres > 0 ? 1 : sc->ds.n_instances > 0 ? 3 : 0;  // kern_trace.h: k_trace MODE
@@ -434,11 +436,9 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         PathSoA &ps = sc->ps;
         // continuation rays -> hit record + material-class routing
         tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
-        const bool general = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || sc->ds.tri_alpha || sc->ds.tri_shadow_alpha;
         tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4; tj.per_ray_tmax = 0;
         tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_word = nullptr; tj.out_word_stride = 0;
-        tj.out_t = rc.volpath ? &ps.hit_t(0) : nullptr; tj.out_t_stride = PathSoA::kHitWords;
-        tj.out_inst = general ? &ps.hit_inst(0) : nullptr; tj.out_inst_stride = PathSoA::kHitWords;
+        tj.out_hit2 = (float4 *)ps.hit + 1; tj.out_t = nullptr; tj.out_t_stride = 0;   // {inst, t, packet, packet flags}
         tj.kind = (iter == 0) ? 3 : 0;
         int st = PT_OK;
         if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
@@ -464,7 +464,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
         tj.ray = (const float4 *)ps.mis; tj.ray_stride = PathSoA::kMisWords / 4;
         tj.out_hit = (float4 *)&ps.mis_prim(0); tj.out_hit_stride = PathSoA::kMisWords / 4;
-        tj.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; tj.out_t_stride = PathSoA::kMisWords; tj.out_inst = nullptr;
+        tj.out_hit2 = nullptr; tj.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; tj.out_t_stride = PathSoA::kMisWords;
         tj.kind = 1;
         if (n_mis) {
             sc->begin("extend_mis", n_mis);
@@ -475,7 +475,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // shadow rays (any hit, light.rs:120-123)
         tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
         tj.ray = (const float4 *)ps.nee; tj.ray_stride = PathSoA::kNeeWords / 4;
-        tj.out_hit = nullptr; tj.out_word = &ps.occluded(0); tj.out_word_stride = PathSoA::kNeeWords; tj.out_t = nullptr; tj.out_inst = nullptr;
+        tj.out_hit = nullptr; tj.out_hit2 = nullptr; tj.out_word = &ps.occluded(0); tj.out_word_stride = PathSoA::kNeeWords; tj.out_t = nullptr;
         tj.kind = 2;
         if (n_shadow) {
             sc->begin("shadow", n_shadow);
@@ -491,8 +491,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-402): each lane of k_trace<.., PROBE> walks a whole chain, then k_bssrdf
             tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
             tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4;
-            tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_word = nullptr; tj.out_t = nullptr;
-            tj.out_inst = &ps.hit_inst(0); tj.out_inst_stride = PathSoA::kHitWords;
+            tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_hit2 = (float4 *)ps.hit + 1; tj.out_word = nullptr; tj.out_t = nullptr;
             tj.kind = 4; tj.bs = sc->bs; tj.ring = sc->probe_ring;
             sc->begin("extend_probe", n_probe);
             st = launch_trace(sc, false, tj, n_probe, true);
@@ -605,7 +604,7 @@ int pt_init(int device_ordinal) {
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
     g_device = device_ordinal;
-    if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; } }
+    if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; g_refill_from_env = true; } }
     if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
@@ -1021,10 +1020,6 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         HIP_TRY(hipMemsetAsync(sc->film_rgbw, 0, film_px * 16, sc->stream));
         HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
         HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
-        // The general shade kernels (textures, Halton, volpath) read the instance of a hit; the triangle-only traversal (k_trace<*, 0>)
-        // never writes it
-        if (sc->ds.n_spheres == 0 && sc->ds.n_instances == 0 && !sc->ds.tri_alpha && !sc->ds.tri_shadow_alpha && (sc->ds.n_textures > 0 || rc.halton.enabled || rc.volpath || sc->has_bssrdf))
-            HIP_TRY(hipMemsetAsync(sc->ps.hit, 0xFF, (size_t)rc.n_pix_slots * S * PathSoA::kHitWords * 4, sc->stream));   // hit_inst = PT_NONE everywhere
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
@@ -1108,7 +1103,7 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     tj.queue = nullptr; tj.count = dcount; tj.head = &sc->qc->head[0];
     tj.ray = (const float4 *)din; tj.ray_stride = 2; tj.per_ray_tmax = 1;
     tj.out_hit = (float4 *)dout; tj.out_hit_stride = 1; tj.out_t = dt; tj.out_t_stride = 1;
-    tj.out_word = docc; tj.out_word_stride = 1; tj.out_inst = nullptr;
+    tj.out_word = docc; tj.out_word_stride = 1; tj.out_hit2 = nullptr;
     tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
     sc->profile = true; sc->drop_timings(); sc->stats.clear();
     tj.kind = any ? 2 : 0;

@@ -19,6 +19,9 @@ struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads p
     float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
 };
 enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11, TP_ALPHA = 1u << 12 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
+// flags bits 13-15: shade-queue class of the primitive's material (what k_route needs), bits 16-31: its material index, 0xffff =
+// "none or too large: read prim_material" -- so that neither routing nor shading has to chase prim -> material -> class through HBM
+constexpr uint32_t kTpClassShift = 13, kTpMatShift = 16, kTpMatNone = 0xffffu;
 
 // Two-wide traversal record (64 B, four dwordx4 loads): one per INTERIOR node of the reference tree, holding the
 // bounds of both children, so that a ray fetches once per interior node it enters instead of once per node it tests.
@@ -186,10 +189,14 @@ struct SurfaceInteraction {
     uint32_t prim;
 };
 // `with_shape` = the `s: Option<Arc<Shapes>>` argument (None inside Shape::pdf_wi, shape.rs:72).
-PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
-    uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
-    V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
-    P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
+// tri_fill_from: the triangle's vertices and flag byte are already at hand (the 48-byte TriPacket the traversal hit); the index
+// triple is fetched only for meshes with per-vertex N / S / UV.
+PT_DEVX void tri_fill_from(const DeviceScene &s, uint32_t tri, uint32_t fl, V3 p0, V3 p1, V3 p2, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
+    uint32_t i0 = 0, i1 = 0, i2 = 0;
+    if (fl & (PT_TRI_HAS_N | PT_TRI_HAS_S | PT_TRI_HAS_UV)) { i0 = s.indices[3 * tri]; i1 = s.indices[3 * tri + 1]; i2 = s.indices[3 * tri + 2]; }
+    P2 uv[3];   // triangle.rs:109-115
+    if (fl & PT_TRI_HAS_UV) { uv[0] = P2(s.UV[2 * i0], s.UV[2 * i0 + 1]); uv[1] = P2(s.UV[2 * i1], s.UV[2 * i1 + 1]); uv[2] = P2(s.UV[2 * i2], s.UV[2 * i2 + 1]); }
+    else { uv[0] = P2(0.0f, 0.0f); uv[1] = P2(1.0f, 0.0f); uv[2] = P2(1.0f, 1.0f); }
     V3 dpdu, dpdv; tri_partials(p0, p1, p2, uv, dpdu, dpdv);
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float xabs = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
@@ -200,7 +207,6 @@ PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, 
     si.dpdu = dpdu; si.sh_dpdu = dpdu; si.dpdv = dpdv; si.sh_dpdv = dpdv;
     si.sh_dndu = V3(0.0f, 0.0f, 0.0f); si.sh_dndv = V3(0.0f, 0.0f, 0.0f);
     si.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);   // triangle.rs:266-268
-    uint32_t fl = s.tri_flags[tri];
     bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
     si.has_shape = with_shape; si.shape_flip = flip;
     V3 nn = normalize(cross(dp02, dp12));
@@ -243,6 +249,10 @@ PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, 
         }
         si.sh_dpdu = ss; si.sh_dpdv = ts;
     }
+}
+PT_DEVX void tri_fill_interaction(const DeviceScene &s, uint32_t tri, V3 ray_d, float b0, float b1, float b2, bool with_shape, SurfaceInteraction &si) {
+    const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+    tri_fill_from(s, tri, s.tri_flags[tri], ld3(s.P, i0), ld3(s.P, i1), ld3(s.P, i2), ray_d, b0, b1, b2, with_shape, si);
 }
 PT_DEV float tri_area(V3 p0, V3 p1, V3 p2) { return 0.5f * length(cross(p1 - p0, p2 - p0)); }  // triangle.rs:550-554
 

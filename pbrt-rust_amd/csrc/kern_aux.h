@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
         if (valid) {
             pid = queue[qi];
             const uint32_t hp = ps.hit_prim(pid);
-            if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+            cls = (ps.hit_pflags(pid) >> kTpClassShift) & 7u;   // the hit packet's class bits, kMissClass for a miss (written by k_trace)
             const uint32_t med = ps.medium(pid);
             if (med != PT_NONE) {
                 uint32_t meta = ps.meta(pid);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
         const uint32_t nfound = bs.cnt[pid];
         const bool at_exit = hp != PT_NONE, dead = !at_exit;
         SurfaceInteraction si;
-        if (at_exit) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
+        if (at_exit) fill_hit_pkt<SPH>(s, ps.hit_pkt(pid), SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
         n_bytes += 4 + 24 + 16 + 8;
 
         if (at_exit || dead) {

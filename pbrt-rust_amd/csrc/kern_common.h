@@ -118,3 +118,41 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
     tri_fill_interaction(s, sh & 0x3fffffffu, rd, b0, b1, b2, true, si);
 }
 
+// The same interaction rebuilt from the hit's TriPacket (hit record word `hit_pkt`): vertices, shape reference and flag byte come
+// from ONE 48-byte line (three dwordx4 loads) instead of the prim_shape -> indices -> P chain of dependent gathers. Returns the
+// packet's flag word (material index and class in its upper bits, dev_scene.h).
+template <bool SPH> PT_DEV uint32_t fill_hit_pkt(const DeviceScene &s, uint32_t pkt, uint32_t inst, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(s.leaf) + 3 * (size_t)pkt;
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const uint32_t sh = q2.z, fl = q2.w;
+    const V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+    const V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+    const V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+    if (SPH && inst != PT_NONE) {  // TransformedPrimitive::intersect (primitive.rs:58-80): object-space interaction, then to world
+        const DevInstance &I = s.instances[inst];
+        const M4 w2i = ldm4g(I.world_to_instance), i2w = ldm4g(I.instance_to_world);
+        V3 oerr; V3 o2 = xf_point_err(w2i, ro, oerr); const V3 d2 = xf_vector(w2i, rd);
+        const float l2 = length_squared(d2);
+        if (l2 > 0.0f) { const float dt = dot(vabs(d2), oerr) / l2; o2 = o2 + d2 * dt; }
+        if ((sh >> 30) == PT_SHAPE_SPHERE) sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], o2, d2, si);
+        else tri_fill_from(s, sh & 0x3fffffffu, fl & 0xffu, p0, p1, p2, d2, b0, b1, b2, true, si);
+        if (!I.identity) {  // transform_surface_interaction (transform.rs:607-636)
+            V3 perr;
+            si.p = xf_point_abs_err(i2w, si.p, si.p_error, perr); si.p_error = perr;
+            si.n = normalize(xf_normal_inv(w2i, si.n));
+            si.wo = normalize(xf_vector(i2w, si.wo));
+            si.dpdu = xf_vector(i2w, si.dpdu); si.dpdv = xf_vector(i2w, si.dpdv);
+            si.sh_n = face_forward(normalize(xf_normal_inv(w2i, si.sh_n)), si.n);
+            si.sh_dpdu = xf_vector(i2w, si.sh_dpdu); si.sh_dpdv = xf_vector(i2w, si.sh_dpdv);
+            si.sh_dndu = xf_normal_inv(w2i, si.sh_dndu); si.sh_dndv = xf_normal_inv(w2i, si.sh_dndv);
+        }
+        return fl;
+    }
+    if (SPH && (sh >> 30) == PT_SHAPE_SPHERE) { sphere_fill_interaction(s.spheres[sh & 0x3fffffffu], ro, rd, si); return fl; }
+    tri_fill_from(s, sh & 0x3fffffffu, fl & 0xffu, p0, p1, p2, rd, b0, b1, b2, true, si);
+    return fl;
+}
+PT_DEV uint32_t packet_material(const DeviceScene &s, uint32_t pflags, uint32_t prim) {
+    const uint32_t m = pflags >> kTpMatShift;
+    return m != kTpMatNone ? m : s.prim_material[prim];
+}

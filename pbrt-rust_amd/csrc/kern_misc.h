@@ -17,6 +17,9 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
     }
     uint32_t shape = s.prim_shape[prim];
     p.prim = prim; p.shape = shape; p.flags = 0;
+    // material index + its shade-queue class ride in the flag word (dev_scene.h: kTpClassShift / kTpMatShift)
+    const uint32_t mat = s.prim_material[prim];
+    const uint32_t hi = ((mat == PT_NONE ? 0u : (uint32_t)s.mat_class[mat]) << kTpClassShift) | ((mat == PT_NONE || mat >= kTpMatNone ? kTpMatNone : mat) << kTpMatShift);
     if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
         uint32_t tri = shape & 0x3fffffffu;
         uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
@@ -26,11 +29,11 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
         bool ok = tri_partials(p0, p1, p2, uv, dpdu, dpdv);
         p.p0[0] = p0.x; p.p0[1] = p0.y; p.p0[2] = p0.z; p.p1x = p1.x;
         p.p1yz[0] = p1.y; p.p1yz[1] = p1.z; p.p2xy[0] = p2.x; p.p2xy[1] = p2.y; p.p2z = p2.z;
-        p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS);
+        p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS) | hi;
         if ((s.tri_alpha && s.tri_alpha[tri] >= 0) || (s.tri_shadow_alpha && s.tri_shadow_alpha[tri] >= 0)) p.flags |= TP_ALPHA;
     } else {
         p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
-        p.flags = TP_SPHERE;
+        p.flags = TP_SPHERE | hi;
     }
     out[i] = p;
 }
@@ -74,8 +77,7 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
         uint32_t pid = 0, cls = (uint32_t)kMissClass;   // escaped rays: their own light kernel (k_shade_miss)
         if (valid) {
             pid = queue[qi];
-            const uint32_t hp = ps.hit_prim(pid);
-            if (hp != PT_NONE) { const uint32_t m = s.prim_material[hp]; cls = (m == PT_NONE) ? 0u : (uint32_t)s.mat_class[m]; }
+            cls = (ps.hit_pflags(pid) >> kTpClassShift) & 7u;   // written by k_trace with the hit: the packet's class bits, kMissClass for a miss
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
         lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
@@ -123,6 +125,17 @@ PT_DEV void camera_ray(const RenderConst &rc, float pfx, float pfy, float time_u
     o = ow; d = dw;
 }
 
+// A fresh path: the whole core record and the ray record as full quads (consecutive lanes own consecutive path ids, so a wave writes
+// whole 64-byte lines). meta = dimension 5 after the camera sample, bounces 0, flags: camera ray.
+PT_DEV void init_path(const PathSoA &ps, uint32_t pid, float pfx, float pfy, V3 o, V3 d, uint64_t index) {
+    float4 *c = reinterpret_cast<float4 *>(ps.core) + 4 * (size_t)pid;
+    c[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                               // L, etascale
+    c[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(5u | (PF_CAMERA_RAY << 24)));        // beta, meta
+    c[2] = make_float4(__uint_as_float((uint32_t)index), __uint_as_float((uint32_t)(index >> 32)), pfx, pfy);
+    float4 *r = reinterpret_cast<float4 *>(ps.ray) + 2 * (size_t)pid;
+    r[0] = make_float4(o.x, o.y, o.z, d.x); r[1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+}
+
 __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
     // LDS copies of what every lane needs: Sobol' rows of dimensions 0..4 and the two van-der-Corput matrices of m
     __shared__ uint32_t s_rows[5 * 52];
@@ -152,14 +165,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                     const P2 pl(halton_sample_dimension(tabs, rc.halton, index, 3u), halton_sample_dimension(tabs, rc.halton, index, 4u));
                     V3 o, d;
                     camera_ray(rc, pfx, pfy, tm, pl, o, d);
-                    ps.pfilm_x(pid) = pfx; ps.pfilm_y(pid) = pfy;
-                    ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
-                    ps.dx(pid) = d.x; ps.dy(pid) = d.y; ps.dz(pid) = d.z;
-                    ps.beta_r(pid) = 1.0f; ps.beta_g(pid) = 1.0f; ps.beta_b(pid) = 1.0f;
-                    ps.L_r(pid) = 0.0f; ps.L_g(pid) = 0.0f; ps.L_b(pid) = 0.0f;
-                    ps.etascale(pid) = 1.0f;
-                    ps.sobol_index(pid) = index;
-                    ps.meta(pid) = 5u | (PF_CAMERA_RAY << 24);
+                    init_path(ps, pid, pfx, pfy, o, d, index);
                     alive = true;
                 } else {
                 const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
@@ -177,14 +183,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 const float pfx = (float)px + fx, pfy = (float)py + fy;
                 V3 o, d;
                 camera_ray(rc, pfx, pfy, sobol_to_float(v2), P2(sobol_to_float(v3), sobol_to_float(v4)), o, d);
-                ps.pfilm_x(pid) = pfx; ps.pfilm_y(pid) = pfy;
-                ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
-                ps.dx(pid) = d.x; ps.dy(pid) = d.y; ps.dz(pid) = d.z;
-                ps.beta_r(pid) = 1.0f; ps.beta_g(pid) = 1.0f; ps.beta_b(pid) = 1.0f;
-                ps.L_r(pid) = 0.0f; ps.L_g(pid) = 0.0f; ps.L_b(pid) = 0.0f;
-                ps.etascale(pid) = 1.0f;
-                ps.sobol_index(pid) = index;
-                ps.meta(pid) = 5u | (PF_CAMERA_RAY << 24);  // dimension 5 after the camera sample, bounces 0, flags: camera ray
+                init_path(ps, pid, pfx, pfy, o, d, index);
                 alive = true;
                 }
             }
@@ -226,13 +225,14 @@ __global__ __launch_bounds__(256) void k_film(RenderConst rc, PathSoA ps, const 
         if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
         for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
             const uint32_t pid = sl * rc.n_pix_slots + slot;
-            RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
+            const float4 c0 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid], c2 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 2];
+            RGB L(c0.x, c0.y, c0.z);
             // integrator.rs:350-368
             if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
             else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
             else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
             if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
-            const float dx = ps.pfilm_x(pid) - 0.5f, dy = ps.pfilm_y(pid) - 0.5f;
+            const float dx = c2.z - 0.5f, dy = c2.w - 0.5f;   // pfilm
             int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
             int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
             for (int64_t y = p0y; y < p1y; ++y) {

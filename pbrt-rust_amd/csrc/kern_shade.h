@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
             const uint32_t hp = ps.hit_prim(pid);
             const bool found = hp != PT_NONE;
             SurfaceInteraction si;
-            if (found) fill_hit<SPH>(s, hp, SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
+            uint32_t pfl = 0;
+            if (found) pfl = fill_hit_pkt<SPH>(s, ps.hit_pkt(pid), SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
             // path.rs:106-117
             if (bounces == 0 || (flags & PF_SPECULAR)) {
                 if (found) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 smp.load_window();
                 PT_T(10);
                 Bsdf<MAXL, DIFF> bsdf;
-                const uint32_t mi = s.prim_material[hp];
+                const uint32_t mi = packet_material(s, pfl, hp);
                 bool has_bsdf = false;
                 if (TEX) {
                     // compute_scattering_functions -> compute_differentials(ray) (interaction.rs:262-342): only the camera ray

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
     bool nx = false, ny = false, nz = false, found = false;
     float t_max = 0.0f;
-    uint32_t hit_prim = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
+    // closest hit so far: its packet (index in DeviceScene::leaf, PT_NONE = no hit yet) -- the primitive id and the flag word are
+    // read back from that packet when the ray retires instead of being carried through the loop
+    uint32_t hit_pkt = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
     uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
     uint32_t xf_arg = 0;   // ST_INST: instance index | TP_LAST of its packet in bit 31; ST_RET: word 0 of the popped marker entry
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                 if (retire) {   // one step of the chain loop of bssrdf.rs:373-395, in world space (every instance marker is popped)
                     const V3 target(job.bs.target_x[pid], job.bs.target_y[pid], job.bs.target_z[pid]);
                     bool finish = false, next_seg = false, chain_end = false;
-                    if (hit_prim != PT_NONE) {
+                    if (hit_pkt != PT_NONE) {
                         SurfaceInteraction si;
-                        fill_hit<INST>(s, hit_prim, INST ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
-                        if (s.prim_material[hit_prim] == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
+                        const uint32_t pfl = fill_hit_pkt<INST>(s, hit_pkt, INST ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
+                        if (packet_material(s, pfl, s.leaf[hit_pkt].prim) == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
                             if (!rewalk) {
                                 const uint32_t k = nfound % (uint32_t)kProbeRing;
-                                ring[(3 * k + 0) * 64] = make_uint4(hit_prim, hit_inst, __float_as_uint(hb0), __float_as_uint(hb1));
+                                ring[(3 * k + 0) * 64] = make_uint4(hit_pkt, hit_inst, __float_as_uint(hb0), __float_as_uint(hb1));
                                 ring[(3 * k + 1) * 64] = make_uint4(__float_as_uint(hb2), __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z));
                                 ring[(3 * k + 2) * 64] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), 0u);
                                 if (nfound == 0xffffffffu) atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); else nfound++;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                             if (nfound - selected <= (uint32_t)kProbeRing) {
                                 const uint32_t k = selected % (uint32_t)kProbeRing;
                                 const uint4 e0 = ring[(3 * k + 0) * 64], e1 = ring[(3 * k + 1) * 64], e2 = ring[(3 * k + 2) * 64];
-                                hit_prim = e0.x; hit_inst = e0.y; hb0 = __uint_as_float(e0.z); hb1 = __uint_as_float(e0.w); hb2 = __uint_as_float(e1.x);
+                                hit_pkt = e0.x; hit_inst = e0.y; hb0 = __uint_as_float(e0.z); hb1 = __uint_as_float(e0.w); hb2 = __uint_as_float(e1.x);
                                 ro = V3(__uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w));
                                 rd = V3(__uint_as_float(e2.x), __uint_as_float(e2.y), __uint_as_float(e2.z));
                                 finish = true;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                                 ro = V3(job.bs.start_x[pid], job.bs.start_y[pid], job.bs.start_z[pid]); rd = target - ro;
                                 next_seg = true;
                             }
-                        } else { hit_prim = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
+                        } else { hit_pkt = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
                     }
                     if (next_seg || finish) {   // the segment's ray goes back to the path state: k_bssrdf rebuilds the exit point from it
                         float4 *rw = const_cast<float4 *>(job.ray) + (size_t)pid * job.ray_stride;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                         nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                         tray = tri_ray_setup(rd);
                         sp = 0; pending = 0; found = false;
-                        hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                        hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                         in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
                         n_rays++;                                  // Scene::intersect of the next segment
                         state = ST_DONE;                           // (a segment that misses the world bound is a miss: resolved at the next refill round)
@@ -185,10 +187,12 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
             if (retire) {
                 if (ANY) job.out_word[(size_t)pid * job.out_word_stride] = found ? 1u : 0u;
                 else {
+                    uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
+                    if (hit_pkt != PT_NONE) { const uint4 hq = leaf4[3 * (size_t)hit_pkt + 2]; hit_prim = hq.y; hit_fl = hq.w; }   // {p2.z, prim, shape, flags}
                     if (job.out_hit) job.out_hit[(size_t)pid * job.out_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
                     else job.out_word[(size_t)pid * job.out_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
+                    if (job.out_hit2) job.out_hit2[(size_t)pid * job.out_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), hit_t, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
                     if (job.out_t) job.out_t[(size_t)pid * job.out_t_stride] = hit_t;
-                    if (INST && job.out_inst) job.out_inst[(size_t)pid * job.out_inst_stride] = hit_inst;
                 }
             }
             if (retire) state = ST_IDLE;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                     tray = tri_ray_setup(rd);
                     sp = 0; pending = 0; found = false;
-                    hit_prim = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                    hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                     in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
                     if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; }
                     n_rays++;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                             if (ANY) { state = ST_DONE; advance = false; }
                             else {
                                 t_max = t;
-                                hit_prim = q2.y; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
+                                hit_pkt = li; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
                                 hit_inst = in_inst; inst_hit = in_inst != PT_NONE;
                             }
                         }
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                         if (ANY) { found = true; state = ST_DONE; advance = false; }
                         else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
                             found = true; t_max = t;  // primitive.rs:137
-                            hit_prim = q2.y; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                            hit_pkt = li; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
                             if (INST) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
                         }
                     }

@@ -28,7 +28,7 @@ enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DE
 // instruction per field and fetched a 64-byte sector for every 4 bytes once the surviving paths were scattered.
 //   core  64 B  {L.rgb, etascale} {beta.rgb, meta} {sobol_index, pfilm.xy} {medium, mis_medium, -, -}      generate / shade / film
 //   ray   32 B  {o.xyz, d.x} {d.yz, (t_max), -}                                                            continuation ray: shade -> trace
-//   hit   32 B  {prim, b0, b1, b2} {inst, t, -, -}                                                         trace -> route / shade
+//   hit   32 B  {prim, b0, b1, b2} {inst, t, packet, packet flags}                                         trace -> route / shade
 //   nee   64 B  {sh_o.xyz, sh_d.x} {sh_d.yz, occluded | sh_prim, nee_light} {A.rgb, choice_pdf} {nb.rgb, -}  pending shadow ray + its terms
 //   mis   64 B  {mis_o.xyz, mis_d.x} {mis_d.yz, w, spdf} {mis_prim, b0, b1, b2} {f.rgb, mis_t}              pending MIS ray + its hit
 // The accessors below name single words of those records; adjacent words accessed together merge into dwordx2/x4 instructions.
@@ -47,7 +47,9 @@ struct PathSoA {
     PT_REC_F(ox, ray, 8, 0) PT_REC_F(oy, ray, 8, 1) PT_REC_F(oz, ray, 8, 2) PT_REC_F(dx, ray, 8, 3) PT_REC_F(dy, ray, 8, 4) PT_REC_F(dz, ray, 8, 5)   // continuation ray (t_max = inf)
     PT_REC_U(hit_prim, hit, 8, 0) PT_REC_F(hit_b0, hit, 8, 1) PT_REC_F(hit_b1, hit, 8, 2) PT_REC_F(hit_b2, hit, 8, 3)   // closest hit of the continuation ray
     PT_REC_U(hit_inst, hit, 8, 4)                        // instance the hit went through (PT_NONE: top level)
-    PT_REC_F(hit_t, hit, 8, 5)                           // volpath: ray.t_max after Scene::intersect; then the medium vertex's parameter
+    PT_REC_F(hit_t, hit, 8, 5)                           // ray.t_max after Scene::intersect (volpath: later the medium vertex's parameter)
+    PT_REC_U(hit_pkt, hit, 8, 6)                         // index of the hit's TriPacket in DeviceScene::leaf (vertices, ids and flags in one 48-byte line)
+    PT_REC_U(hit_pflags, hit, 8, 7)                      // that packet's flag word (class bits: kMissClass for a miss) -- all k_route reads
     // pending next-event estimation of the previous vertex
     PT_REC_F(sh_ox, nee, 16, 0) PT_REC_F(sh_oy, nee, 16, 1) PT_REC_F(sh_oz, nee, 16, 2) PT_REC_F(sh_dx, nee, 16, 3) PT_REC_F(sh_dy, nee, 16, 4) PT_REC_F(sh_dz, nee, 16, 5)   // shadow ray (t_max = 1 - eps)
     PT_REC_U(occluded, nee, 16, 6)                       // any-hit result of the shadow ray ...
@@ -133,8 +135,8 @@ struct TraceJob {
     // outputs (indexed by path id; strides in their own units)
     float4 *out_hit; uint32_t out_hit_stride;       // closest hit {prim, b0, b1, b2} as one quad (NULL: not wanted)
     uint32_t *out_word; uint32_t out_word_stride;   // any-hit: occluded flag; closest hit without out_hit: the primitive (volpath shadow rays)
-    float *out_t; uint32_t out_t_stride;            // may be NULL
-    uint32_t *out_inst; uint32_t out_inst_stride;   // may be NULL
+    float4 *out_hit2;                               // second quad of a hit record {inst, t, packet index, packet flags | miss class}, stride out_hit_stride (NULL: not wanted)
+    float *out_t; uint32_t out_t_stride;            // may be NULL (volpath MIS rays: mis_t)
     uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - kLdsStack)]
     uint32_t *error;
     DevCounters *counters;
