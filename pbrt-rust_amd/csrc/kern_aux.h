@@ -164,19 +164,23 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < count; qi += gridDim.x * blockDim.x) {
         n_valid++;
-        n_bytes += 4 + 4 + 12 + 12 + /* write back */ 12 + 4;
+        n_bytes += 4 + 32 + /* write back */ 16 + 4;
         const uint32_t pid = job.queue[qi];
-        const uint32_t meta = ps.meta(pid);
+        float4 *cq = reinterpret_cast<float4 *>(ps.core) + 4 * (size_t)pid;   // {L, etascale} {beta, meta}
+        const float4 c0 = cq[0], c1 = cq[1];
+        const uint32_t meta = __float_as_uint(c1.w);
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
-        RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
+        RGB L(c0.x, c0.y, c0.z);
         resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
         if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
-            n_bytes += 12 + 12;
-            const RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
-            const V3 rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
+            n_bytes += 32;
+            const RGB beta(c1.x, c1.y, c1.z);
+            const float4 *rq = reinterpret_cast<const float4 *>(ps.ray) + 2 * (size_t)pid;
+            const float4 r0 = rq[0], r1 = rq[1];
+            const V3 rd(r0.w, r1.x, r1.y);
             for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
         }
-        ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
+        cq[0] = make_float4(L.r, L.g, L.b, c0.w);
         ps.meta(pid) = (meta & 0x00ffffffu) | ((flags & ~PF_CAMERA_RAY) << 24);
         atomicAdd(&s_hist[bounces > 15u ? 15u : bounces], 1u);   // path.rs:219
     }

@@ -125,15 +125,25 @@ PT_DEV void camera_ray(const RenderConst &rc, float pfx, float pfy, float time_u
     o = ow; d = dw;
 }
 
-// A fresh path: the whole core record and the ray record as full quads (consecutive lanes own consecutive path ids, so a wave writes
-// whole 64-byte lines). meta = dimension 5 after the camera sample, bounces 0, flags: camera ray.
-PT_DEV void init_path(const PathSoA &ps, uint32_t pid, float pfx, float pfy, V3 o, V3 d, uint64_t index) {
-    float4 *c = reinterpret_cast<float4 *>(ps.core) + 4 * (size_t)pid;
-    c[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                               // L, etascale
-    c[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(5u | (PF_CAMERA_RAY << 24)));        // beta, meta
-    c[2] = make_float4(__uint_as_float((uint32_t)index), __uint_as_float((uint32_t)(index >> 32)), pfx, pfy);
-    float4 *r = reinterpret_cast<float4 *>(ps.ray) + 2 * (size_t)pid;
-    r[0] = make_float4(o.x, o.y, o.z, d.x); r[1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+// A fresh path's core record (64 B) and ray record (32 B) are staged in LDS by the lane that computed them and written by the block
+// TRANSPOSED: thread t stores quad (t & 3) of path (t >> 2), so every store instruction of a wave covers 1 KB of consecutive HBM
+// (a lane writing its own record quad by quad strides 64 B between lanes: measured 2.5 TB/s against 3.6 TB/s for the old 4-byte arrays).
+// meta = dimension 5 after the camera sample, bounces 0, flags: camera ray.
+constexpr int kGenPlane = 257;   // quads per LDS plane (256 paths + 1: the four planes of a path land in different banks)
+struct GenStage { float4 core[4 * kGenPlane]; float4 ray[2 * kGenPlane]; uint32_t alive[256]; };
+PT_DEV void stage_path(GenStage &g, uint32_t t, float pfx, float pfy, V3 o, V3 d, uint64_t index, uint32_t medium) {
+    g.core[0 * kGenPlane + t] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);                                               // L, etascale
+    g.core[1 * kGenPlane + t] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(5u | (PF_CAMERA_RAY << 24)));        // beta, meta
+    g.core[2 * kGenPlane + t] = make_float4(__uint_as_float((uint32_t)index), __uint_as_float((uint32_t)(index >> 32)), pfx, pfy);
+    g.core[3 * kGenPlane + t] = make_float4(__uint_as_float(medium), __uint_as_float(PT_NONE), 0.0f, 0.0f);        // medium (volpath: the camera's, perspective.rs:114), mis_medium
+    g.ray[0 * kGenPlane + t] = make_float4(o.x, o.y, o.z, d.x); g.ray[1 * kGenPlane + t] = make_float4(d.y, d.z, 0.0f, 0.0f);
+}
+PT_DEV void flush_paths(const GenStage &g, const PathSoA &ps, uint32_t pid0, uint32_t t) {   // all 256 threads; pid0 = first path id of the block's batch
+    float4 *core = reinterpret_cast<float4 *>(ps.core) + 4 * (size_t)pid0, *ray = reinterpret_cast<float4 *>(ps.ray) + 2 * (size_t)pid0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) { const uint32_t gq = j * 256u + t, p = gq >> 2, q = gq & 3u; if (g.alive[p]) core[gq] = g.core[q * kGenPlane + p]; }
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) { const uint32_t gq = j * 256u + t, p = gq >> 1, q = gq & 1u; if (g.alive[p]) ray[gq] = g.ray[q * kGenPlane + p]; }
 }
 
 __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
     __shared__ uint32_t s_rows[5 * 52];
     __shared__ uint64_t s_vdc[2 * 52];
     __shared__ LdsQueue<1024> s_q;
+    __shared__ GenStage s_gen;
     lq_init(s_q);
     const uint32_t m = (uint32_t)rc.sobol.log2_resolution;
     for (uint32_t i = threadIdx.x; i < 5 * 52; i += blockDim.x) s_rows[i] = tabs.m32[i];
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                     const P2 pl(halton_sample_dimension(tabs, rc.halton, index, 3u), halton_sample_dimension(tabs, rc.halton, index, 4u));
                     V3 o, d;
                     camera_ray(rc, pfx, pfy, tm, pl, o, d);
-                    init_path(ps, pid, pfx, pfy, o, d, index);
+                    stage_path(s_gen, threadIdx.x, pfx, pfy, o, d, index, rc.volpath ? rc.camera_medium : PT_NONE);
                     alive = true;
                 } else {
                 const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
@@ -183,12 +194,14 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                 const float pfx = (float)px + fx, pfy = (float)py + fy;
                 V3 o, d;
                 camera_ray(rc, pfx, pfy, sobol_to_float(v2), P2(sobol_to_float(v3), sobol_to_float(v4)), o, d);
-                init_path(ps, pid, pfx, pfy, o, d, index);
+                stage_path(s_gen, threadIdx.x, pfx, pfy, o, d, index, rc.volpath ? rc.camera_medium : PT_NONE);
                 alive = true;
                 }
             }
         }
-        if (alive && rc.volpath) ps.medium(pid) = rc.camera_medium;   // the camera ray starts in the camera's medium (perspective.rs:114)
+        s_gen.alive[threadIdx.x] = alive ? 1u : 0u;
+        __syncthreads();
+        flush_paths(s_gen, ps, pid - threadIdx.x, threadIdx.x);   // (the queue flush below holds the barrier that protects s_gen for the next round)
         lq_push(s_q, pid, alive);
         lq_sync_flush(s_q, q_ext_count, q_ext, 256u, false);
         n_alive += alive ? 1ull : 0ull;

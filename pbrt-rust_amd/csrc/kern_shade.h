@@ -36,14 +36,18 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
     PT_T(0);
     if (valid) {
         n_valid++;
-        n_bytes += 4 + 4 + 8 + 12 + 12 + /* write back */ 12 + 12 + 4;   // queue, meta, sobol index, L, beta
+        n_bytes += 4 + 48 + /* write back */ 32;   // queue entry, three quads of the core record read, two written
         pid = job.queue[qi];
-        uint32_t meta = ps.meta(pid);
+        // the core record as whole quads: {L, etascale} {beta, meta} {sobol index, pfilm}
+        const float4 *cq = reinterpret_cast<const float4 *>(ps.core) + 4 * (size_t)pid;
+        const float4 c0 = cq[0], c1 = cq[1], c2 = cq[2];
+        uint32_t meta = __float_as_uint(c1.w);
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-        Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+        float etascale = c0.w;
+        Sampler smp; smp.index = (uint64_t)__float_as_uint(c2.x) | ((uint64_t)__float_as_uint(c2.y) << 32); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
         smp.base = 0xffffffffu;
-        RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
-        RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
+        RGB L(c0.x, c0.y, c0.z);
+        RGB beta(c1.x, c1.y, c1.z);
 
         // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
         resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
@@ -52,13 +56,17 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         if (flags & PF_DEAD) {
             finished_bounces = (int)bounces;
         } else {
-            n_bytes += 24 + 16;  // ray + hit record
-            V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
-            const uint32_t hp = ps.hit_prim(pid);
+            n_bytes += 32 + 32;  // ray + hit record
+            float4 *rq = reinterpret_cast<float4 *>(ps.ray) + 2 * (size_t)pid;                  // {o, d.x} {d.yz, -, -}
+            const float4 *hq = reinterpret_cast<const float4 *>(ps.hit) + 2 * (size_t)pid;      // {prim, b0, b1, b2} {inst, t, packet, packet flags}
+            const float4 r0 = rq[0], r1 = rq[1], h0 = hq[0], h1 = hq[1];
+            V3 ro(r0.x, r0.y, r0.z), rd(r0.w, r1.x, r1.y);
+            const uint32_t hp = __float_as_uint(h0.x);
             const bool found = hp != PT_NONE;
             SurfaceInteraction si;
             uint32_t pfl = 0;
-            if (found) pfl = fill_hit_pkt<SPH>(s, ps.hit_pkt(pid), SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
+            if (found) n_bytes += 48;   // the hit's TriPacket: vertices, ids, flags
+            if (found) pfl = fill_hit_pkt<SPH>(s, __float_as_uint(h1.z), SPH ? __float_as_uint(h1.x) : PT_NONE, ro, rd, h0.y, h0.z, h0.w, si);
             // path.rs:106-117
             if (bounces == 0 || (flags & PF_SPECULAR)) {
                 if (found) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         P2 plens_u(0.0f, 0.0f);
                         if (rc.lens_radius > 0.0f) plens_u = rc.halton.enabled ? P2(halton_sample_dimension(tabs, rc.halton, smp.index, 3u), halton_sample_dimension(tabs, rc.halton, smp.index, 4u))
                                                                               : P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
-                        rdiff = camera_ray_differentials(rc, ps.pfilm_x(pid), ps.pfilm_y(pid), plens_u, ro, rd);
+                        rdiff = camera_ray_differentials(rc, c2.z, c2.w, plens_u, ro, rd);
                     }
                     const TexCtx tctx = compute_differentials(si, rdiff);
                     if (mi != PT_NONE && s.materials[mi].tex[PT_MP_BUMP] >= 0) {   // bump() (core/material.rs:46-87)
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 if (VOL) mif = surface_iface(s, hp, ps.medium(pid));   // primitive.rs:139-145
                 if (!has_bsdf) {  // path.rs:124-129: skip the surface, bounces unchanged
                     V3 o; spawn_ray(it, rd, o);
-                    ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
+                    rq[0] = make_float4(o.x, o.y, o.z, rd.x);
                     if (VOL) {   // volpath.rs:127-131 `bounces -= 1; continue`: the count drops by one and wraps below zero
                         ps.medium(pid) = medium_toward(mif, si.n, rd);
                         bounces = (bounces - 1u) & 0xffu;
@@ -137,11 +145,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                     else {
                         beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
-                        float etascale = ps.etascale(pid);
                         if ((sflags & BSDF_SPECULAR) && (sflags & BSDF_TRANSMISSION)) {
                             const float eta = bsdf.eta;
                             etascale *= (dot(wo, si.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
-                            ps.etascale(pid) = etascale;
                         }
                         V3 o; spawn_ray(it, wi, o);
                         bool rr_kill = false, to_probe = false;
@@ -166,8 +172,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                                         bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
                                         bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
                                         // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
-                                        ps.ox(pid) = start.x; ps.oy(pid) = start.y; ps.oz(pid) = start.z;
-                                        ps.dx(pid) = pd.x; ps.dy(pid) = pd.y; ps.dz(pid) = pd.z;
+                                        rq[0] = make_float4(start.x, start.y, start.z, pd.x); rq[1] = make_float4(pd.y, pd.z, 0.0f, 0.0f);
                                         to_probe = true; push_probe = true; n_bytes += 18 * 4 + 24 + 4;
                                     }
                                 }
@@ -183,10 +188,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                         if (rr_kill) terminated = true;
                         else if (!to_probe) {
                             bounces += 1;
-                            ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
-                            ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
+                            rq[0] = make_float4(o.x, o.y, o.z, wi.x); rq[1] = make_float4(wi.y, wi.z, 0.0f, 0.0f);
                             if (VOL) ps.medium(pid) = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
-                            push_ext = true; n_bytes += 24 + 4 + 4;  // new ray, etascale, ext queue entry
+                            push_ext = true; n_bytes += 32 + 4;  // new ray record, ext queue entry
                         }
                     }
                 }
@@ -198,9 +202,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
         }
         PT_T(12);
         if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
-        ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
-        ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
-        ps.meta(pid) = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
+        float4 *cw = reinterpret_cast<float4 *>(ps.core) + 4 * (size_t)pid;
+        cw[0] = make_float4(L.r, L.g, L.b, etascale);
+        cw[1] = make_float4(beta.r, beta.g, beta.b, __uint_as_float((smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24)));
     }
     PT_T(13);
     lq_push(s_qext, pid, push_ext);

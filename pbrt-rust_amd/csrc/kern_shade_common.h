@@ -23,35 +23,40 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
                                                 unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
     PT_T(1);
-    n_bytes += 4 + 4 + 12 + ((flags & PF_PEND_SHADOW) ? 1 + 12 : 0) + ((flags & PF_PEND_MIS) ? 12 + 4 + 12 + 12 + 8 : 0);  // nee_light, choice pdf, nb, occluded+A, MIS record
+    // the pending records as whole quads: nee {sh_d.yz, occluded | sh_prim, nee_light} {A, choice_pdf} {nb, -}; mis {o, d.x} {d.yz, w, spdf} {prim, b} {f, t}
+    const float4 *nq = reinterpret_cast<const float4 *>(ps.nee) + 4 * (size_t)pid;
+    const float4 n1 = nq[1], n2 = nq[2], n3 = nq[3];
+    n_bytes += 48 + ((flags & PF_PEND_MIS) ? 64 : 0);
     RGB Ld(0.0f);
-    const uint32_t li = ps.nee_light(pid);
+    const uint32_t li = __float_as_uint(n1.w);
     // volpath: VisibilityTester::tr intersects (closest hit) and every surface is opaque; the segment's transmittance is already in A
-    if ((flags & PF_PEND_SHADOW) && (VOL ? ps.sh_prim(pid) == PT_NONE : !ps.occluded(pid))) Ld = Ld + RGB(ps.A_r(pid), ps.A_g(pid), ps.A_b(pid));
+    if ((flags & PF_PEND_SHADOW) && (VOL ? __float_as_uint(n1.z) == PT_NONE : __float_as_uint(n1.z) == 0u)) Ld = Ld + RGB(n2.x, n2.y, n2.z);
     if (flags & PF_PEND_MIS) {
+        const float4 *mq = reinterpret_cast<const float4 *>(ps.mis) + 4 * (size_t)pid;
+        const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
         const PtLight &Lt = s.lights[li];
-        V3 wi(ps.mis_dx(pid), ps.mis_dy(pid), ps.mis_dz(pid));
+        V3 wi(m0.w, m1.x, m1.y);
         RGB lrad(0.0f);
-        const uint32_t mp = ps.mis_prim(pid);
+        const uint32_t mp = __float_as_uint(m2.x);
         if (mp != PT_NONE) {
             if (s.prim_light[mp] == li) {  // Arc::ptr_eq(light), integrator.rs:222-228
                 SurfaceInteraction lsi;
-                fill_hit<SPH>(s, mp, PT_NONE, V3(ps.mis_ox(pid), ps.mis_oy(pid), ps.mis_oz(pid)), wi, ps.mis_b0(pid), ps.mis_b1(pid), ps.mis_b2(pid), lsi);  // lights are never inside instances (api.rs:1605-1608)
+                fill_hit<SPH>(s, mp, PT_NONE, V3(m0.x, m0.y, m0.z), wi, m2.y, m2.z, m2.w, lsi);  // lights are never inside instances (api.rs:1605-1608)
                 lrad = area_l(Lt, lsi.n, -wi);
             }
         } else { PT_T(2); lrad = light_le(s, Lt, wi); PT_T(1); }
         if (!lrad.is_black()) {
-            RGB f(ps.mis_f_r(pid), ps.mis_f_g(pid), ps.mis_f_b(pid));
+            RGB f(m3.x, m3.y, m3.z);
             RGB Tr(1.0f);
             if (VOL) {   // Scene::intersect_tr (scene.rs:68-87): transmittance of the MIS ray's medium up to its hit (or to infinity)
                 const uint32_t mm = ps.mis_medium(pid);
-                if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? ps.mis_t(pid) : PT_INF, wi);
+                if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? m3.w : PT_INF, wi);
             }
-            Ld = Ld + f * lrad * Tr * ps.mis_w(pid) / ps.mis_spdf(pid);
+            Ld = Ld + f * lrad * Tr * m1.z / m1.w;
         }
     }
-    RGB nb(ps.nb_r(pid), ps.nb_g(pid), ps.nb_b(pid));
-    RGB Ldb = nb * (Ld / ps.nee_choice_pdf(pid));
+    RGB nb(n3.x, n3.y, n3.z);
+    RGB Ldb = nb * (Ld / n2.w);
     if (!VOL && Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
     L = L + Ldb;
     flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
@@ -78,6 +83,7 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
             // estimate_direct (integrator.rs:109-237), flags = All & !Specular
             const int bf = BSDF_ALL & ~BSDF_SPECULAR;
             V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
+            RGB A(0.0f); V3 sh_o(0.0f, 0.0f, 0.0f), sh_d(0.0f, 0.0f, 0.0f);   // the shadow ray and its term, stored with the rest of the nee record below
             PT_T(6);
             RGB Li = light_sample_li<SPH>(s, li, it, ulight, wi, lightpdf, p1);
             PT_T(7);
@@ -91,11 +97,9 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                         const uint32_t sm = medium_toward(mif, it.n, sd);
                         if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
                     }
-                    RGB A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
-                    ps.sh_ox(pid) = so.x; ps.sh_oy(pid) = so.y; ps.sh_oz(pid) = so.z;
-                    ps.sh_dx(pid) = sd.x; ps.sh_dy(pid) = sd.y; ps.sh_dz(pid) = sd.z;
-                    ps.A_r(pid) = A.r; ps.A_g(pid) = A.g; ps.A_b(pid) = A.b;
-                    flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 24 + 12 + 4;
+                    A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
+                    sh_o = so; sh_d = sd;
+                    flags |= PF_PEND_SHADOW; push_shadow = true; nee_pending = true; n_bytes += 16 + 4;   // first quad of the nee record + the shadow queue entry
                 }
             }
             if (!delta) {
@@ -116,18 +120,18 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                     }
                     if (!skip) {
                         V3 mo; spawn_ray(it, wi, mo);
-                        ps.mis_ox(pid) = mo.x; ps.mis_oy(pid) = mo.y; ps.mis_oz(pid) = mo.z;
-                        ps.mis_dx(pid) = wi.x; ps.mis_dy(pid) = wi.y; ps.mis_dz(pid) = wi.z;
-                        ps.mis_f_r(pid) = f.r; ps.mis_f_g(pid) = f.g; ps.mis_f_b(pid) = f.b;
-                        ps.mis_w(pid) = weight; ps.mis_spdf(pid) = scattpdf;
+                        float4 *mq = reinterpret_cast<float4 *>(ps.mis) + 4 * (size_t)pid;   // {o, d.x} {d.yz, w, spdf} . {f, -}; the third quad is the MIS ray's hit (k_trace)
+                        mq[0] = make_float4(mo.x, mo.y, mo.z, wi.x); mq[1] = make_float4(wi.y, wi.z, weight, scattpdf); mq[3] = make_float4(f.r, f.g, f.b, 0.0f);
                         if (VOL) ps.mis_medium(pid) = medium_toward(mif, it.n, wi);
-                        flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 24 + 12 + 8 + 4;
+                        flags |= PF_PEND_MIS; push_mis = true; nee_pending = true; n_bytes += 48 + 4;
                     }
                 }
             }
-            if (nee_pending) {
-                ps.nee_light(pid) = li; ps.nee_choice_pdf(pid) = choice_pdf;
-                ps.nb_r(pid) = beta.r; ps.nb_g(pid) = beta.g; ps.nb_b(pid) = beta.b; n_bytes += 8 + 12;
+            if (nee_pending) {   // the nee record {sh_o, sh_d.x} {sh_d.yz, occluded (k_trace), nee_light} {A, choice_pdf} {nb, -}
+                float4 *nq = reinterpret_cast<float4 *>(ps.nee) + 4 * (size_t)pid;
+                if (flags & PF_PEND_SHADOW) nq[0] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_d.x);
+                nq[1] = make_float4(sh_d.y, sh_d.z, 0.0f, __uint_as_float(li)); nq[2] = make_float4(A.r, A.g, A.b, choice_pdf); nq[3] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                n_bytes += 48;
             }
         }
     }

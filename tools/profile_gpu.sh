@@ -9,17 +9,19 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "== bench (headline config, unprofiled)"
-python3 $REPO/bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.json
 echo "== rocprofv3 --kernel-trace --stats (spp $PSPP)"
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PSPP --cpu-seconds 0 > $OUT/stats_bench.json 2> $OUT/stats.err
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PSPP --cpu-seconds 0 > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "== rocprofv3 --pmc FETCH_SIZE (spp $PPASS = one pass)"
-timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+echo "== rocprofv3 --pmc TCC_EA0_RDREQ by request size (spp $PPASS = one pass): exact read bytes = 128 a + 64 b + 32 c (profiles/r2_gather_calibration.json)"
+timeout -k 5 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $OUT/pmc_rd -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_rd_bench.json 2> $OUT/pmc_rd.err
 echo "== rocprofv3 --pmc WRITE_SIZE (spp $PPASS = one pass)"
-timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
 echo "== rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum (spp $PPASS = one pass)"
-timeout -k 5 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_l2_bench.json 2> $OUT/pmc_l2.err
-python3 $REPO/tools/summarize_profile.py $OUT $PPASS > $OUT/summary.txt 2>&1
+timeout -k 5 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/pmc_l2_bench.json 2> $OUT/pmc_l2.err
+python3 $REPO/tools/summarize_profile.py $OUT $PPASS ${CONFIG:-C2} > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep the merged-back payload small: drop the raw traces, keep stats + summaries
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
