@@ -6,11 +6,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+SAN = bool(os.environ.get("PT_SAN"))   # ASan/UBSan build of the oracle (tools/san_cpu_tests.sh preloads the sanitizer runtimes)
+LIB_PATH = os.path.join(_HERE, "liboracle_san.so" if SAN else "liboracle.so")
 
 
 def build(verbose=False):
-    r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", _HERE] + (["SAN=1"] if SAN else []), capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-3000:]); print(r.stderr[-3000:])
     if r.returncode != 0:

@@ -5,12 +5,13 @@ import subprocess
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "frontend", "libmi355front.so")
+SAN = bool(os.environ.get("PT_SAN"))   # ASan/UBSan build of the front end (tools/san_cpu_tests.sh)
+LIB_PATH = os.path.join(_HERE, "frontend", "libmi355front_san.so" if SAN else "libmi355front.so")
 CLI_PATH = os.path.join(_HERE, "frontend", "mi355pbrt")
 
 
 def build(verbose=False):
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "frontend")], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "frontend")] + (["SAN=1"] if SAN else []), capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-3000:]); print(r.stderr[-3000:])
     if r.returncode != 0:

@@ -34,6 +34,7 @@ inline Image read_hdr(const std::string &path) {
     const std::string dims = line();
     if (std::sscanf(dims.c_str(), "%c%c %d %c%c %d", &sy, &ay, &h, &sx, &ax, &w) != 6 || ay != 'Y' || ax != 'X' || w <= 0 || h <= 0)
         throw std::runtime_error("\"" + path + "\": unsupported HDR orientation line \"" + dims + "\"");
+    if ((uint64_t)w * (uint64_t)h > (1ull << 28)) throw std::runtime_error("\"" + path + "\": HDR image of " + std::to_string(w) + " x " + std::to_string(h) + " pixels is larger than 2^28 pixels");
     std::vector<unsigned char> rgbe((size_t)w * h * 4);
     for (int y = 0; y < h; ++y) {
         unsigned char *row = rgbe.data() + (size_t)y * w * 4;
@@ -53,8 +54,9 @@ inline Image read_hdr(const std::string &path) {
                 if (p + 4 > d.size()) throw std::runtime_error("HDR \"" + path + "\" is truncated");
                 const unsigned char *px = d.data() + p; p += 4;
                 if (px[0] == 1 && px[1] == 1 && px[2] == 1 && x > 0) {
-                    const int n = (int)px[3] << shift;
-                    for (int i = 0; i < n && x < w; ++i, ++x) std::memcpy(row + x * 4, row + (x - 1) * 4, 4);
+                    if (shift > 24) throw std::runtime_error("HDR \"" + path + "\": bad run");   // a fifth consecutive repeat record: the count no longer fits 32 bits
+                    const int64_t n = (int64_t)px[3] << shift;
+                    for (int64_t i = 0; i < n && x < w; ++i, ++x) std::memcpy(row + x * 4, row + (x - 1) * 4, 4);
                     shift += 8;
                 } else { std::memcpy(row + x * 4, px, 4); x++; shift = 0; }
             }
@@ -84,7 +86,11 @@ inline Image read_png(const std::string &path) {
         const uint32_t len = be32(p); const std::string type((const char *)d.data() + p + 4, 4);
         if (p + 12 + len > d.size()) throw std::runtime_error("PNG \"" + path + "\" is truncated");
         const unsigned char *body = d.data() + p + 8;
-        if (type == "IHDR") { w = be32(p + 8); h = be32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (type == "IHDR") {
+            if (len != 13) throw std::runtime_error("PNG \"" + path + "\": IHDR chunk of " + std::to_string(len) + " bytes");
+            w = be32(p + 8); h = be32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12];
+            if ((uint64_t)w * (uint64_t)h > (1ull << 28)) throw std::runtime_error("PNG \"" + path + "\": larger than 2^28 pixels");
+        }
         else if (type == "PLTE") plte.assign(body, body + len);
         else if (type == "IDAT") idat.insert(idat.end(), body, body + len);
         else if (type == "IEND") break;

@@ -630,7 +630,8 @@ int ptf_write_image(const char *path, int width, int height, const float *rgb) {
 int ptf_read_image(const char *path, int *width, int *height, float *rgb, size_t capacity_floats) {
     try {
         const fe::Image im = fe::read_image(path);
-        if (width) *width = im.w; if (height) *height = im.h;
+        if (width) *width = im.w;
+        if (height) *height = im.h;
         if (rgb) { if (capacity_floats < im.rgb.size()) { fe::g_error = "buffer too small"; return PT_ERR_INVALID_ARG; } std::memcpy(rgb, im.rgb.data(), im.rgb.size() * 4); }
     } catch (const std::exception &e) { fe::g_error = e.what(); return PT_ERR_INVALID_ARG; }
     return PT_OK;

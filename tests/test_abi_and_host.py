@@ -24,7 +24,7 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(A.PtSphere) == 16 * 4 * 2 + 6 * 4 + 8 + 8
     assert C.sizeof(A.PtLight) == 4 + 12 + 4 + 4 + 12 + 12 + 8 + 128
     assert C.sizeof(A.PtMaterial) == 4 + 7 * 12 + 5 * 4 + 4 + 24 + 8 + 64 + 8 + 44 + 12
-    assert C.sizeof(A.PtKernelStat) == 32 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(A.PtKernelStat) == 32 + 8 + 8 + 8 + 8 + 8 + 48
 
 
 def test_no_device_fails_loudly(pkg):
@@ -88,7 +88,8 @@ def test_host_sah_builder_equals_oracle_builder(pkg, oracle):
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "hb.cpp"), "w").write(src)
         so = os.path.join(td, "hb.so")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-I", here, "-o", so,
+        san = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if os.environ.get("PT_SAN") else []
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", *san, "-I", here, "-o", so,
                                os.path.join(td, "hb.cpp"), os.path.join(here, "host_bvh.cpp")])
         hb = C.CDLL(so)
         A = pkg._abi
