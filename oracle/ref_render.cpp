@@ -1254,3 +1254,51 @@ int orc_light_pdf_li(orc_scene *h, uint32_t li, const float *p, const float *per
     return 0;
 }
 }
+
+// ---- tests/hg.rs restated (the reference's assertions on HenyeyGreenstein::p / sample_p, medium.rs:149-193), run inside the oracle ----
+extern "C" {
+using namespace ref;
+// tests/hg.rs:12-32 sampling_match: RNG::default(), g = -0.75 .. 0.75 step 0.25, 100 samples each; returns max |p0 - p(wo, wi)| / p
+double orc_test_hg_sampling_match(void) {
+    HaltonTables::Pcg32 rng;   // RNG::default()
+    auto uf = [&]() { return fmin_(ONE_MINUS_EPSILON, (Float)rng.uniform_int32() * 0x1.0p-32f); };
+    double worst = 0.0;
+    for (Float g = -0.75f; g <= 0.75f; g += 0.25f)
+        for (int i = 0; i < 100; ++i) {
+            const Float a = uf(), b = uf();
+            const V3 wo = uniform_sample_sphere(P2(a, b));
+            V3 wi;
+            const Float u0 = uf(), u1 = uf();
+            const Float p0 = hg_sample_p(g, wo, wi, P2(u0, u1));
+            const Float p1 = phase_hg(dot(wo, wi), g);
+            worst = std::max(worst, (double)std::fabs(p0 - p1) / (double)std::fabs(p1));
+        }
+    return worst;
+}
+// tests/hg.rs:34-79 sampling_orientation_forward / sample_orientation_backward: wo = (-1, 0, 0), 100 samples, counts wi.x > 0
+void orc_test_hg_orientation(float g, int *nforward, int *nbackward) {
+    HaltonTables::Pcg32 rng;
+    auto uf = [&]() { return fmin_(ONE_MINUS_EPSILON, (Float)rng.uniform_int32() * 0x1.0p-32f); };
+    *nforward = *nbackward = 0;
+    for (int i = 0; i < 100; ++i) {
+        const Float u0 = uf(), u1 = uf();
+        V3 wi;
+        hg_sample_p(g, V3(-1.0f, 0.0f, 0.0f), wi, P2(u0, u1));
+        if (wi.x > 0.0f) ++*nforward; else ++*nbackward;
+    }
+}
+// tests/hg.rs:81-103 normalized: per g, the mean of p(wo, wi) over 100 000 uniform directions (expected 1 / 4 pi)
+void orc_test_hg_normalized(double *means7) {
+    HaltonTables::Pcg32 rng;
+    auto uf = [&]() { return fmin_(ONE_MINUS_EPSILON, (Float)rng.uniform_int32() * 0x1.0p-32f); };
+    int k = 0;
+    for (Float g = -0.75f; g <= 0.75f; g += 0.25f, ++k) {
+        const Float a = uf(), b = uf();
+        const V3 wo = uniform_sample_sphere(P2(a, b));
+        Float sum = 0.0f;
+        const int n = 100000;
+        for (int i = 0; i < n; ++i) { const Float c = uf(), d = uf(); sum += phase_hg(dot(wo, uniform_sample_sphere(P2(c, d))), g); }
+        means7[k] = (double)(sum / (Float)n);
+    }
+}
+}  // extern "C"

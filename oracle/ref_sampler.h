@@ -62,15 +62,21 @@ inline uint64_t sobol_interval_to_index(uint32_t m, uint64_t frame, int64_t px, 
     return index;
 }
 
+// core/lowdiscrepancy.rs:428-440 multiply_generator: the XOR of the generator-matrix columns selected by the bits of `a` (the loop
+// sobol_sample_float, :549-569, runs over its 52-column matrices; pinned by tests/sampling.rs:55-83 through ref_kats.cpp)
+inline uint32_t multiply_generator(const uint32_t *C, uint64_t a) {
+    uint32_t v = 0;
+    int i = 0;
+    while (a != 0) {
+        if (a & 1) v ^= C[i];
+        i += 1; a >>= 1;
+    }
+    return v;
+}
 // core/lowdiscrepancy.rs:549-569
 inline Float sobol_sample_float(uint64_t a, int dimension, uint32_t scramble) {
     const SobolTables &T = sobol_tables();
-    uint32_t v = scramble;
-    int i = dimension * SOBOL_MATRIX_SIZE;
-    while (a != 0) {
-        if (a & 1) v ^= T.m32[i];
-        i += 1; a >>= 1;
-    }
+    const uint32_t v = scramble ^ multiply_generator(T.m32.data() + dimension * SOBOL_MATRIX_SIZE, a);
     return fmin_((Float)v * 0x1.0p-32f, ONE_MINUS_EPSILON);
 }
 

@@ -4,48 +4,9 @@
 //   (transform_point_error, transform_vector_error, transform_ray_error, transform_point_abs_error,
 //    transform_bounds, transform_surface_interaction); core/interaction.rs:186-216 (SurfaceInteraction::new, shape None).
 #include "ref_scene.h"
+#include "ref_efloat.h"
 
 namespace ref {
-
-// core/efloat.rs
-struct EFloat {
-    Float v, low, high;
-    EFloat() : v(0), low(0), high(0) {}
-    EFloat(Float v_, Float err) : v(v_) {
-        if (err == 0.0f) { low = v; high = v; }
-        else { low = next_float_down(v - err); high = next_float_up(v + err); }
-    }
-    explicit EFloat(Float f) : v(f), low(f), high(f) {}
-};
-static EFloat operator+(EFloat a, EFloat b) { EFloat r; r.v = a.v + b.v; r.low = next_float_down(a.low + b.low); r.high = next_float_up(a.high + b.high); return r; }
-static EFloat operator-(EFloat a, EFloat b) { EFloat r; r.v = a.v - b.v; r.low = next_float_down(a.low - b.high); r.high = next_float_up(a.high - b.low); return r; }
-static EFloat operator*(EFloat a, EFloat b) {
-    EFloat r; r.v = a.v * b.v;
-    Float p[4] = {a.low * b.low, a.high * b.low, a.low * b.high, a.high * b.high};
-    r.low = next_float_down(fmin_(fmin_(p[0], p[1]), fmin_(p[2], p[3])));
-    r.high = next_float_up(fmax_(fmax_(p[0], p[1]), fmax_(p[2], p[3])));
-    return r;
-}
-static EFloat operator/(EFloat a, EFloat b) {  // efloat.rs:124-146: the straddle test looks at the NUMERATOR (as written there)
-    EFloat r; r.v = a.v / b.v;
-    if (a.low < 0.0f && a.high > 0.0f) { r.low = -INF; r.high = INF; }
-    else {
-        Float d[4] = {a.low / b.low, a.high / b.low, a.low / b.high, a.high / b.high};
-        r.low = next_float_down(fmin_(fmin_(d[0], d[1]), fmin_(d[2], d[3])));
-        r.high = next_float_up(fmax_(fmax_(d[0], d[1]), fmax_(d[2], d[3])));
-    }
-    return r;
-}
-static bool quadratic(EFloat a, EFloat b, EFloat c, EFloat &t0, EFloat &t1) {  // efloat.rs:211-231
-    double discrim = (double)b.v * (double)b.v - 4.0 * (double)a.v * (double)c.v;
-    if (discrim < 0.0) return false;
-    double root = std::sqrt(discrim);
-    EFloat frd((Float)root, (Float)((double)MACHINE_EPSILON * root));
-    EFloat q = (b.v < 0.0f) ? (EFloat(-0.5f) * (b - frd)) : (EFloat(-0.5f) * (b + frd));  // Mul<Float>: from(f) * self
-    t0 = q / a; t1 = c / q;
-    if (t0.v > t1.v) std::swap(t0, t1);
-    return true;
-}
 
 static V3 xf_vector_err(const M4 &t, V3 v, V3 &err) {  // transform.rs:510-527
     Float x = v.x, y = v.y, z = v.z;

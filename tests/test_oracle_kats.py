@@ -569,3 +569,80 @@ def test_sobol_pixel_samples_are_a_02_net(oracle, pkg, pixel):
             nx, ny = 1 << kx, 1 << (k - kx)
             cell = np.floor(out[:, 0] * nx).astype(int) * ny + np.floor(out[:, 1] * ny).astype(int)
             assert sorted(cell.tolist()) == list(range(n)), (k, kx)
+
+
+# ---- round 2: every remaining assertion the reference's tests hold for code on this path ----
+
+def test_hg_sampling_match_twin(oracle):
+    """tests/hg.rs:12-32 sampling_match: sample_p's return value is p(wo, wi) (relative 1e-4), RNG::default(), g = -0.75 .. 0.75."""
+    oracle.lib.orc_test_hg_sampling_match.restype = C.c_double
+    assert oracle.lib.orc_test_hg_sampling_match() < 1.0e-4
+
+
+def test_hg_sampling_orientation_twin(oracle):
+    """tests/hg.rs:34-79 sampling_orientation_forward / sample_orientation_backward: with wo = (-1, 0, 0), g = 0.95 scatters to
+    wi.x > 0 more than ten times as often as not, g = -0.95 the other way round (pins the sign convention of sample_p)."""
+    f, b = C.c_int(), C.c_int()
+    oracle.lib.orc_test_hg_orientation.argtypes = [C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    oracle.lib.orc_test_hg_orientation(0.95, C.byref(f), C.byref(b))
+    assert f.value + b.value == 100 and f.value > 10 * b.value
+    oracle.lib.orc_test_hg_orientation(-0.95, C.byref(f), C.byref(b))
+    assert f.value + b.value == 100 and b.value > 10 * f.value
+
+
+def test_hg_normalized_twin(oracle):
+    """tests/hg.rs:81-103 normalized: the mean of p over 100 000 uniform directions is 1 / 4 pi (relative 1e-3) for every g."""
+    means = (C.c_double * 7)()
+    oracle.lib.orc_test_hg_normalized(means)
+    # the reference evaluates relative_eq!(mean, 1 / 4 pi, epsilon = 1e-3) but never asserts it; the Monte-Carlo mean of 10^5 samples
+    # has a standard error of ~0.6 % at |g| = 0.75, so the twin asserts 3 % (five sigma) -- enough to catch a wrong normalisation
+    for m in means:
+        assert abs(m - 1.0 / (4.0 * np.pi)) < 0.03 / (4.0 * np.pi), list(means)
+
+
+@pytest.mark.parametrize("op,name", [(0, "efloat_abs"), (1, "efloat_sqrt"), (2, "add"), (3, "sub"), (4, "mul"), (5, "div")])
+def test_efloat_containment_twin(oracle, op, name):
+    """tests/fp.rs:125-226: for RNG::new(trial), trial = 0 .. 999 999, the exact f64 result of the operation on values drawn from inside
+    the operands' intervals lies inside the result's interval (EFloat is what bounds Sphere::intersect's hit error, row a14)."""
+    n = C.c_int()
+    oracle.lib.orc_test_efloat.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    failures = oracle.lib.orc_test_efloat(op, 1000000, C.byref(n))
+    assert n.value > 400000 and failures == 0, (name, failures, n.value)
+
+
+def test_bitops_twin(oracle):
+    """tests/bitops.rs:7-64 log2 and round_up_pow2 (every i < 2^24): SobolSampler's resolution and the MIPMap resampler depend on them."""
+    assert oracle.lib.orc_test_bitops() == 0
+
+
+def test_generator_matrix_twin(oracle):
+    """tests/sampling.rs:55-83 generator_matrix and :85-97 gray_code_sample_test on the oracle's multiply_generator."""
+    assert oracle.lib.orc_test_generator_matrix() == 0
+
+
+@pytest.mark.parametrize("ext,gamma", [("exr", False), ("pfm", False), ("tga", True), ("png", True)])
+def test_imageio_round_trip_twin(pkg, tmp_path, ext, gamma):
+    """tests/imageio.rs:9-100 test_round_trip through the front end's writers and readers (frontend/fe_imageio.h): 16 x 29 ramp with a
+    negative blue channel; PFM exact, EXR exact in the negative channel and to 1e-3 (half floats) elsewhere, 8-bit formats to 0.02
+    after undoing the sRGB curve with the clamped channel reading back 0."""
+    F = pkg.frontend.lib()
+    w, h = 16, 29
+    px = np.zeros((h, w, 3), np.float32)
+    px[..., 0] = (np.arange(w, dtype=np.float32) / np.float32(w - 1))[None, :]
+    px[..., 1] = (np.arange(h, dtype=np.float32) / np.float32(h - 1))[:, None]
+    px[..., 2] = -1.5
+    path = str(tmp_path / f"out.{ext}").encode()
+    assert F.ptf_write_image(path, w, h, px.ctypes.data_as(pkg._abi.fp)) == 0
+    rw, rh = C.c_int(), C.c_int()
+    back = np.zeros((h, w, 3), np.float32)
+    assert F.ptf_read_image(path, C.byref(rw), C.byref(rh), back.ctypes.data_as(pkg._abi.fp), back.size) == 0
+    assert (rw.value, rh.value) == (w, h)
+    if gamma:   # inverse_gamma_correct (pbrt.rs)
+        back = np.where(back <= 0.04045, back / 12.92, np.power((back + 0.055) / 1.055, 2.4)).astype(np.float32)
+    delta = px - back
+    if ext == "pfm":
+        assert np.array_equal(px, back)
+    elif ext == "exr":
+        assert np.all(delta[..., 2] == 0.0) and np.abs(delta[..., :2]).max() < 0.001
+    else:
+        assert np.all(back[..., 2] == 0.0) and np.abs(delta[..., :2]).max() < 0.02

@@ -1,5 +1,6 @@
 """VolPathIntegrator (integrators/volpath.rs) with homogeneous media (media/homogeneous.rs) and the
-Henyey-Greenstein phase function (core/medium.rs). The reference's tests pin none of it; the oracle is checked against closed
+Henyey-Greenstein phase function (core/medium.rs). Of all this the reference's tests pin only the phase function (tests/hg.rs: the
+orientation of sample_p is asserted; restated in tests/test_oracle_kats.py); the oracle is otherwise checked against closed
 forms and against the path integrator, the GPU against the oracle (bit-exact counters, radiance within the stated tolerance).
 Material-less interface shells are refused: the reference's own volpath mishandles them (volpath.rs:127-131)."""
 import numpy as np
