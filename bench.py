@@ -14,7 +14,7 @@ N > 1: one process per GPU (torch.distributed, backend nccl == RCCL). The 16x16 
 integrator.rs:276-283 are dealt round-robin to ranks (tile_rank/tile_world in PtRenderParams), every
 rank renders all spp of its tiles into a device film, and the films are summed onto rank 0 with one
 dist.reduce -- total work is fixed, so scaling is "strong". `--in-process` instead drives all N devices from ONE
-process through pt_render_multi (the C ABI's own multi-device path, include/mi355pt.h).
+process through pt_multi_render (the C ABI's own multi-device path, include/mi355pt.h).
 """
 import argparse
 import json
@@ -43,7 +43,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 disables)")
     ap.add_argument("--dump-image", default="")
     ap.add_argument("--sim-world", type=int, default=0, help="single-GPU study: render rank 0's shard of an N-rank job (value is then this rank's share only)")
-    ap.add_argument("--in-process", action="store_true", help="N > 1 without torchrun: one process drives --gpus devices through pt_render_multi")
+    ap.add_argument("--in-process", action="store_true", help="N > 1 without torchrun: one process drives --gpus devices through pt_multi_render (include/mi355pt.h)")
+    ap.add_argument("--devices", default="", help="--in-process: explicit device ordinals, e.g. 0,1,2,3 (an ordinal may repeat: replicas share the device; default 0..gpus-1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -51,7 +52,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    in_process = args.in_process and world == 1 and args.gpus > 1
+    devices = [int(x) for x in args.devices.split(",") if x != ""] or list(range(args.gpus))
+    in_process = args.in_process and world == 1 and len(devices) > 1
+    if in_process:
+        args.gpus = len(set(devices))
 
     import numpy as np
     import torch
@@ -90,11 +94,11 @@ def main():
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     pb = rp.pixel_bounds
     n_samples = (pb[2] - pb[0]) * (pb[3] - pb[1]) * spp
-    n_slots = (-(-(rp.sample_bounds[2] - rp.sample_bounds[0]) // 16)) * (-(-(rp.sample_bounds[3] - rp.sample_bounds[1]) // 16)) * 256 // max(1, world if not in_process else args.gpus)
+    n_slots = (-(-(rp.sample_bounds[2] - rp.sample_bounds[0]) // 16)) * (-(-(rp.sample_bounds[3] - rp.sample_bounds[1]) // 16)) * 256 // max(1, world if not in_process else len(devices))
     eff_spp_per_pass = min(spp, args.spp_per_pass if args.spp_per_pass else max(1, (1 << 26) // max(1, n_slots)))
     multi = None
     if in_process:
-        multi = pkg.MultiScene(lib, sd, list(range(args.gpus)))   # scene replicated on every device, one host thread + stream each
+        multi = pkg.MultiScene(lib, sd, devices)   # scene replicated on every device, one host thread + stream each
 
     def step():
         film.zero_()
@@ -204,7 +208,7 @@ def main():
                                f", {args.xres}x{args.yres}x{spp}spp, path maxdepth 5, sobol, box filter, spatial light sampling",
                    "name": args.config, "triangles": n_tris, "instances": n_inst, "spp": spp, "spp_per_pass": eff_spp_per_pass, "resolution": [args.xres, args.yres],
                    "film": "stays on the device (no read-back in the timed region; 33 MB = 0.6 ms over PCIe)",
-                   "parallelism": (f"16x16 sample tiles round-robin over {n_gpus} GPU(s); " + ("one process, pt_render_multi (peer film sum)" if in_process else "RCCL film reduce")) if n_gpus > 1 else "1 GPU"},
+                   "parallelism": (f"16x16 sample tiles round-robin over {n_gpus} GPU(s); " + ("one process, pt_multi_render (peer film sum)" if in_process else "RCCL film reduce")) if n_gpus > 1 else "1 GPU"},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
         "kernels_ms_per_step": kernels,
         "rays_per_sample": round((counters["intersect_tests"] + counters["shadow_tests"]) / max(1, counters["camera_rays"]), 3) if counters else None,

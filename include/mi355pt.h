@@ -399,13 +399,19 @@ typedef struct PtKernelStat {
 } PtKernelStat;
 
 typedef struct pt_scene pt_scene;
+typedef struct pt_multi_scene pt_multi_scene;
 
 /* ---- entry points ------------------------------------------------------------------- */
 
-/* Select the HIP device used by this process (one process per GPU). */
+/* Select the default HIP device of this process and bind the calling thread to it. Every host thread that calls into the
+ * library is bound to one device at a time; a pt_scene lives on the device that was bound when it was created and re-binds
+ * the calling thread on use, so one process may hold scenes on several devices (or use pt_multi_* below). */
 int pt_init(int device_ordinal);
+int pt_device_count(int *n_devices);
 const char *pt_last_error(void);
 
+/* Limits: at most 2^25 - 1 interior BVH nodes and 2^25 - 1 leaf packets (primitives + instance references) per scene, all
+ * accelerators of the scene together (traversal stack entries keep 25-bit references); more returns PT_ERR_UNSUPPORTED. */
 int pt_scene_create(const PtSceneDesc *desc, pt_scene **out_scene);
 void pt_scene_destroy(pt_scene *scene);
 
@@ -423,6 +429,21 @@ int pt_render(pt_scene *scene, const PtRenderParams *params, float *film_xyzw, i
 /* Film::write_image normalisation (film.rs:217-258): rgb = max(0, xyz_to_rgb(xyz)/w) * scale.
  * Pure host arithmetic on a host buffer. */
 int pt_film_resolve(const float *film_xyzw, uint32_t n_pixels, float scale, float *rgb_out);
+
+/* One process, several GPUs -- the shape of the reference itself: ONE process fans the 16x16 tiles out over its workers
+ * (core/integrator.rs:294-296, rayon) and merges them into one Film (integrator.rs:392-396). pt_multi_scene_create replicates the
+ * scene on every listed device (an ordinal may repeat: the replicas then share that device); pt_multi_render renders, on one
+ * host thread + stream per replica, the tiles with tile_index % (tile_world * n) == tile_rank + i * tile_world on replica i
+ * (pt_multi_tile_shard: the caller's own shard split n ways, so it nests inside a multi-process launch), sums the replicas'
+ * films onto the first device (peer copies over xGMI + an add kernel) and ADDS the result to film_xyzw, which is a pointer on
+ * device_ordinals[0] (film_is_device != 0) or a host buffer. Counters are the sums over the replicas. */
+int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, uint32_t n_devices, pt_multi_scene **out_scene);
+void pt_multi_scene_destroy(pt_multi_scene *scene);
+int pt_multi_render(pt_multi_scene *scene, const PtRenderParams *params, float *film_xyzw, int film_is_device);
+int pt_multi_get_counters(const pt_multi_scene *scene, PtCounters *out);
+int pt_multi_get_kernel_stats(const pt_multi_scene *scene, uint32_t replica, PtKernelStat *out, uint32_t max_entries, uint32_t *n_out);
+/* The tile shard of replica `replica` of `n_replicas` inside the caller's shard (tile_rank of tile_world). Pure host arithmetic. */
+void pt_multi_tile_shard(uint32_t tile_rank, uint32_t tile_world, uint32_t replica, uint32_t n_replicas, uint32_t *rank_out, uint32_t *world_out);
 
 int pt_get_counters(const pt_scene *scene, PtCounters *out);
 /* Per-kernel statistics of the last pt_render with params->profile != 0. Returns the number

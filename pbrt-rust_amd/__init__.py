@@ -6,4 +6,5 @@ The directory name contains a '-', so import it through `import_pkg()` in the re
 `_pkg.py` (module name `pbrt_rust_amd`).
 """
 from . import _abi, host, scenes, frontend, textures, bssrdf  # noqa: F401
-from .runtime import Library, Scene, load_library, build_library  # noqa: F401
+from . import runtime  # noqa: F401
+from .runtime import Library, Scene, MultiScene, load_library, build_library  # noqa: F401

@@ -153,6 +153,13 @@ ENTRY_POINTS = {
     "pt_scene_bvh_read": (C.c_int, [VP, C.POINTER(PtBVHNode), u32p]),
     "pt_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),
     "pt_film_resolve": (C.c_int, [fp, u32, f32, fp]),
+    "pt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pt_multi_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(C.c_int), u32, C.POINTER(VP)]),
+    "pt_multi_scene_destroy": (None, [VP]),
+    "pt_multi_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),
+    "pt_multi_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
+    "pt_multi_get_kernel_stats": (C.c_int, [VP, u32, C.POINTER(PtKernelStat), u32, u32p]),
+    "pt_multi_tile_shard": (None, [u32, u32, u32, u32, u32p, u32p]),
     "pt_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
     "pt_get_kernel_stats": (C.c_int, [VP, C.POINTER(PtKernelStat), u32, u32p]),
     "pt_trace_closest": (C.c_int, [VP, u32, fp, fp, fp, u32p, fp, fp]),

@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "kern_decl.h"   // kernel declarations; the definitions are instantiated by the tu_*.hip translation units
 #include "host_bvh.h"
@@ -16,16 +19,25 @@ extern "C" const unsigned int pt_sobol_blob_size;
 
 namespace {
 
-std::string g_error;
-int g_device = -1;
-int g_num_cus = 256;
+// Device binding is per host thread (hipSetDevice is): every thread that enters the library is bound to one device, whose Sobol' /
+// Halton tables and CU count it sees through these thread-local views of the per-device contexts below. pt_init selects the
+// process-wide default; a scene remembers the device it was created on and re-binds the calling thread when needed, so one
+// process can drive several GPUs (pt_multi_*: one host thread + stream per device).
+thread_local std::string g_error;
+thread_local int g_device = -1;
+thread_local int g_num_cus = 256;
+std::atomic<int> g_default_device{-1};
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
 uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
 bool g_refill_from_env = false;
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
-SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+constexpr int kMaxDevices = 64;
+struct DevCtx { bool ready = false; int num_cus = 256; SobolTables tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+DevCtx g_ctx[kMaxDevices];
+std::mutex g_ctx_mutex;
 
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
 #define HIP_TRY(expr)                                                                                         \
@@ -41,14 +53,16 @@ struct DevTmp {
     ~DevTmp() { for (void *q : p) hipFree(q); }
 };
 
+int bind_device(int device);
 int ensure_device() {
     if (g_device >= 0) return PT_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
-    return pt_init(0);
+    const int def = g_default_device.load();
+    return def >= 0 ? bind_device(def) : pt_init(0);
 }
 
-int upload_tables() {
+int upload_tables(SobolTables &g_tabs) {   // (fills the per-device context passed in; the name shadows the thread-local view on purpose)
     if (g_tabs.m32) return PT_OK;
     if (pt_sobol_blob_size != 8 + 1024 * 52 * 4 + (25 + 26) * 52 * 8 || std::memcmp(pt_sobol_blob, "PTSOBOL1", 8) != 0)
         return fail(PT_ERR_INVALID_ARG, "embedded Sobol table blob is corrupt");
@@ -92,12 +106,33 @@ int upload_tables() {
     return PT_OK;
 }
 
+// Bind the calling thread to `device`: hipSetDevice + the device's context (created on first use: CU count, Sobol' / Halton tables).
+int bind_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(PT_ERR_INVALID_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    DevCtx &c = g_ctx[device];
+    if (!c.ready) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int st = upload_tables(c.tabs);
+        if (st) return st;
+        c.ready = true;
+    }
+    g_device = device; g_num_cus = c.num_cus; g_tabs = c.tabs;
+    return PT_OK;
+}
+
 struct Stat { std::string name, kernel; uint64_t launches = 0; double ms = 0; uint64_t items = 0, nodes = 0, tris = 0; };
 struct TimedLaunch { int stat; hipEvent_t a, b; bool closed; };
 
 }  // namespace
 
 struct pt_scene {
+    int device = 0;                    // the HIP device every allocation of this scene lives on
     std::vector<void *> allocs;
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
@@ -175,6 +210,16 @@ struct pt_scene {
         for (auto &t : timed) { event_pool.push_back(t.a); event_pool.push_back(t.b); }
         timed.clear(); last_stat = -1;
     }
+};
+
+// One process, several devices: a replica of the scene per device, one host thread per replica inside pt_multi_render.
+struct pt_multi_scene {
+    std::vector<pt_scene *> sc;       // replica i lives on dev[i] (a device may appear more than once: replicas then share it)
+    std::vector<int> dev;
+    std::vector<float *> film;        // per replica: XYZ + weight sums of its tiles, on its device
+    float *stage = nullptr;           // on dev[0]: landing buffer of the peer copies
+    size_t film_px = 0;
+    PtCounters counters{};
 };
 
 namespace {
@@ -598,17 +643,20 @@ int pt_init(int device_ordinal) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device_ordinal < 0 || device_ordinal >= n) return fail(PT_ERR_INVALID_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device_ordinal));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
-    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (g_device != device_ordinal) { g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; }
-    g_device = device_ordinal;
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; g_refill_from_env = true; } }
     if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
-    return upload_tables();
+    g_default_device.store(device_ordinal);
+    return bind_device(device_ordinal);
+}
+
+int pt_device_count(int *n_devices) {
+    if (!n_devices) return fail(PT_ERR_INVALID_ARG, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *n_devices = n;
+    return PT_OK;
 }
 
 const char *pt_last_error(void) { return g_error.c_str(); }
@@ -688,6 +736,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     int st = ensure_device();
     if (st) return st;
     pt_scene *sc = new pt_scene();
+    sc->device = g_device;
     auto bail = [&](int code) { pt_scene_destroy(sc); return code; };
     DeviceScene &ds = sc->ds;
     // ---- accelerators: one BVH per multi-primitive object (api.rs:1692-1700) + the top-level BVH (adopted or built)
@@ -962,6 +1011,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
 
 void pt_scene_destroy(pt_scene *sc) {
     if (!sc) return;
+    if (sc->device != g_device) bind_device(sc->device);
     for (void *p : sc->allocs) hipFree(p);
     if (sc->slab) hipFree(sc->slab);
     if (sc->qbuf) hipFree(sc->qbuf);
@@ -990,6 +1040,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     if (rp->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (!(rp->filter_radius[0] > 0.0f) || !(rp->filter_radius[1] > 0.0f)) return fail(PT_ERR_INVALID_ARG, "filter radius must be > 0");
     if (rp->tile_world > 1 && rp->tile_rank >= rp->tile_world) return fail(PT_ERR_INVALID_ARG, "tile_rank >= tile_world");
+    if (sc->device != g_device) { int bst = bind_device(sc->device); if (bst) return bst; }
     RenderConst rc;
     fill_render_const(rp, rc);
     if (rc.film_w == 0 || rc.film_h == 0 || rc.ntx == 0 || rc.nty == 0) return fail(PT_ERR_INVALID_ARG, "empty film or sample bounds");
@@ -1081,6 +1132,7 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     DevTmp scratch;
     if (!sc || !o || !d || !tmax) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (n == 0) return PT_OK;
+    if (sc->device != g_device) { int bst = bind_device(sc->device); if (bst) return bst; }
     int st = ensure_workspace(sc, 0, 0);
     if (st) return st;
     std::vector<float> recs(8 * (size_t)n, 0.0f);   // 32-byte ray records {o.xyz, d.x} {d.y, d.z, t_max, -}
@@ -1193,6 +1245,121 @@ int pt_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float 
     HIP_TRY(hipMemcpy(out_o, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_d, dout + 3 * (size_t)n, (size_t)n * 12, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+// ---- one process, several devices ---------------------------------------------------------------------------------------
+// The reference is ONE process that fans the 16x16 tiles out over its worker threads (integrator.rs:294-296) and merges the tiles
+// into one Film (integrator.rs:392-396). Same shape here with GPUs as the workers: the scene is replicated on every listed device,
+// replica i renders the tiles with tile % (world * n) == rank + i * world on its own host thread and stream, and the replicas'
+// films are summed onto the first device (peer copies over xGMI + an add kernel) before they are added to the caller's film.
+void pt_multi_tile_shard(uint32_t tile_rank, uint32_t tile_world, uint32_t replica, uint32_t n_replicas, uint32_t *rank_out, uint32_t *world_out) {
+    const uint32_t w = tile_world ? tile_world : 1u, n = n_replicas ? n_replicas : 1u;
+    *world_out = w * n; *rank_out = tile_rank + replica * w;    // t % (w n) == r + i w  =>  t % w == r : the caller's own shard, split n ways
+}
+
+int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, uint32_t n_devices, pt_multi_scene **out) {
+    if (!desc || !device_ordinals || !out || n_devices == 0 || n_devices > (uint32_t)kMaxDevices) return fail(PT_ERR_INVALID_ARG, "pt_multi_scene_create: bad arguments");
+    int st = ensure_device();
+    if (st) return st;
+    const int home = g_device;
+    pt_multi_scene *ms = new pt_multi_scene();
+    auto bail = [&](int code) { const std::string msg = g_error; pt_multi_scene_destroy(ms); bind_device(home); g_error = msg; return code; };
+    PtSceneDesc d = *desc;
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        if ((st = bind_device(device_ordinals[i]))) return bail(st);
+        pt_scene *sc = nullptr;
+        if ((st = pt_scene_create(&d, &sc))) return bail(st);
+        ms->sc.push_back(sc); ms->dev.push_back(device_ordinals[i]); ms->film.push_back(nullptr);
+        if (i == 0) {   // the replicas adopt the first replica's top-level tree instead of building it again
+            d.nodes = sc->nodes.data(); d.n_nodes = (uint32_t)sc->nodes.size(); d.ordered_prims = sc->ordered.data();
+        }
+    }
+    // peer access first device <-> the others (the film merge copies device to device; without access the runtime stages through the host)
+    if (bind_device(ms->dev[0]) == PT_OK)
+        for (uint32_t i = 1; i < n_devices; ++i) if (ms->dev[i] != ms->dev[0]) { int can = 0; if (hipDeviceCanAccessPeer(&can, ms->dev[0], ms->dev[i]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[i], 0); (void)hipGetLastError(); } }
+    if ((st = bind_device(home))) return bail(st);
+    *out = ms;
+    return PT_OK;
+}
+
+void pt_multi_scene_destroy(pt_multi_scene *ms) {
+    if (!ms) return;
+    const int home = g_device;
+    for (size_t i = 0; i < ms->sc.size(); ++i) {
+        if (bind_device(ms->dev[i]) == PT_OK) { if (ms->film[i]) hipFree(ms->film[i]); if (i == 0 && ms->stage) hipFree(ms->stage); }
+        pt_scene_destroy(ms->sc[i]);
+    }
+    if (home >= 0) bind_device(home);
+    delete ms;
+}
+
+int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xyzw, int film_is_device) {
+    if (!ms || !rp || !film_xyzw || ms->sc.empty()) return fail(PT_ERR_INVALID_ARG, "null argument");
+    const int home = g_device;
+    const uint32_t n = (uint32_t)ms->sc.size();
+    const int64_t fw = (int64_t)rp->cropped_pixel_bounds[2] - rp->cropped_pixel_bounds[0], fh = (int64_t)rp->cropped_pixel_bounds[3] - rp->cropped_pixel_bounds[1];
+    if (fw <= 0 || fh <= 0) return fail(PT_ERR_INVALID_ARG, "empty film");
+    const size_t film_px = (size_t)fw * (size_t)fh;
+    std::vector<int> status(n, PT_OK); std::vector<std::string> message(n);
+    auto worker = [&](uint32_t i) {
+        int st = bind_device(ms->dev[i]);
+        if (!st && (ms->film_px != film_px || !ms->film[i])) {
+            if (ms->film[i]) { hipFree(ms->film[i]); ms->film[i] = nullptr; }
+            if (hipMalloc((void **)&ms->film[i], film_px * 16) != hipSuccess) st = fail(PT_ERR_OUT_OF_MEMORY, "pt_multi_render: film replica");
+        }
+        if (!st && hipMemset(ms->film[i], 0, film_px * 16) != hipSuccess) st = fail(PT_ERR_HIP, "pt_multi_render: memset");
+        if (!st) {
+            PtRenderParams p = *rp;
+            pt_multi_tile_shard(rp->tile_rank, rp->tile_world, i, n, &p.tile_rank, &p.tile_world);
+            st = pt_render(ms->sc[i], &p, ms->film[i], 1);
+        }
+        status[i] = st; if (st) message[i] = g_error;
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t i = 1; i < n; ++i) threads.emplace_back(worker, i);
+    worker(0);                                   // the calling thread drives the first replica
+    for (auto &t : threads) t.join();
+    for (uint32_t i = 0; i < n; ++i) if (status[i]) { bind_device(home >= 0 ? home : ms->dev[0]); return fail(status[i], "replica " + std::to_string(i) + " (device " + std::to_string(ms->dev[i]) + "): " + message[i]); }
+    ms->film_px = film_px;
+    // merge_film_tile across devices: films of replicas 1.. are copied to the first device and added (float adds in replica order)
+    int st = bind_device(ms->dev[0]);
+    if (st) return st;
+    pt_scene *s0 = ms->sc[0];
+    const unsigned blocks = (unsigned)((film_px + 255) / 256);
+    if (n > 1 && !ms->stage) HIP_TRY(hipMalloc((void **)&ms->stage, film_px * 16));
+    for (uint32_t i = 1; i < n; ++i) {
+        if (ms->dev[i] == ms->dev[0]) HIP_TRY(hipMemcpyAsync(ms->stage, ms->film[i], film_px * 16, hipMemcpyDeviceToDevice, s0->stream));
+        else HIP_TRY(hipMemcpyPeerAsync(ms->stage, ms->dev[0], ms->film[i], ms->dev[i], film_px * 16, s0->stream));
+        hipLaunchKernelGGL(k_film_add, dim3(blocks), dim3(256), 0, s0->stream, (float4 *)ms->film[0], (const float4 *)ms->stage, film_px);
+    }
+    if (film_is_device) {
+        hipLaunchKernelGGL(k_film_add, dim3(blocks), dim3(256), 0, s0->stream, (float4 *)film_xyzw, (const float4 *)ms->film[0], film_px);
+        HIP_TRY(hipStreamSynchronize(s0->stream));
+    } else {
+        HIP_TRY(hipStreamSynchronize(s0->stream));
+        std::vector<float> host(film_px * 4);
+        HIP_TRY(hipMemcpy(host.data(), ms->film[0], film_px * 16, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < film_px * 4; ++k) film_xyzw[k] += host[k];
+    }
+    HIP_TRY(hipGetLastError());
+    // counters: the work of all replicas
+    PtCounters &c = ms->counters; std::memset(&c, 0, sizeof c);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&ms->sc[i]->counters); uint64_t *dst = reinterpret_cast<uint64_t *>(&c);
+        for (size_t k = 0; k < sizeof(PtCounters) / 8; ++k) dst[k] += src[k];
+    }
+    if (home >= 0 && home != ms->dev[0]) bind_device(home);
+    return PT_OK;
+}
+
+int pt_multi_get_counters(const pt_multi_scene *ms, PtCounters *out) {
+    if (!ms || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    *out = ms->counters;
+    return PT_OK;
+}
+int pt_multi_get_kernel_stats(const pt_multi_scene *ms, uint32_t replica, PtKernelStat *out, uint32_t max_entries, uint32_t *n_out) {
+    if (!ms || replica >= ms->sc.size()) return fail(PT_ERR_INVALID_ARG, "replica out of range");
+    return pt_get_kernel_stats(ms->sc[replica], out, max_entries, n_out);
 }
 
 }  // extern "C"

@@ -283,6 +283,14 @@ __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t
     rgb_to_xyz(rgb, xyz);
     film_xyzw[4 * i] += xyz[0]; film_xyzw[4 * i + 1] += xyz[1]; film_xyzw[4 * i + 2] += xyz[2]; film_xyzw[4 * i + 3] += film_rgbw[4 * i + 3];
 }
+// Film merge of the one-process multi-device path (pt_multi_render): dst += src, quad by quad.
+__global__ void k_film_add(float4 *dst, const float4 *src, size_t n_quads) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_quads) return;
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 // ---- spatial light distribution (lightdistrib.rs:151-228), all voxels precomputed ---------------------------
 __global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

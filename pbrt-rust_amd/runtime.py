@@ -13,7 +13,7 @@ TABLES_PATH = os.path.join(_HERE, "data", "sobol_tables.bin")
 
 def build_library(verbose=False):
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:]); print(r.stderr[-4000:])
     if r.returncode != 0:
@@ -120,3 +120,49 @@ class Scene:
         hit = np.zeros(n, np.uint8)
         self.L.check(self.L.lib.pt_trace_any(self.h, n, _fptr(o), _fptr(d), _fptr(tmax), hit.ctypes.data_as(A.u8p)))
         return hit
+
+
+class MultiScene:
+    """pt_multi_scene: the scene replicated on several devices of THIS process (one host thread + stream per replica inside
+    pt_multi_render); a device ordinal may repeat. The film comes back summed, on the first device or in a host array."""
+
+    def __init__(self, lib, scene_data, devices):
+        self.L = lib; self.data = scene_data; self.devices = list(devices)
+        self.h = C.c_void_p()
+        d = scene_data.desc()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        lib.check(lib.lib.pt_multi_scene_create(C.byref(d), devs, len(self.devices), C.byref(self.h)), "pt_multi_scene_create")
+
+    def close(self):
+        if self.h:
+            self.L.lib.pt_multi_scene_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def render(self, rp, film=None, device_ptr=None):
+        cb = rp.cropped_pixel_bounds
+        w, h = cb[2] - cb[0], cb[3] - cb[1]
+        if device_ptr is not None:
+            self.L.check(self.L.lib.pt_multi_render(self.h, C.byref(rp), C.c_void_p(device_ptr), 1), "pt_multi_render"); return None
+        if film is None:
+            film = np.zeros((h, w, 4), dtype=np.float32)
+        self.L.check(self.L.lib.pt_multi_render(self.h, C.byref(rp), film.ctypes.data_as(C.c_void_p), 0), "pt_multi_render")
+        return film
+
+    def counters(self):
+        c = A.PtCounters()
+        self.L.check(self.L.lib.pt_multi_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def kernel_stats(self, replica=0):
+        arr = (A.PtKernelStat * 32)(); n = C.c_uint32()
+        self.L.check(self.L.lib.pt_multi_get_kernel_stats(self.h, replica, arr, 32, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, items=arr[i].items, bvh_nodes=arr[i].bvh_nodes, triangle_tests=arr[i].triangle_tests, kernel=arr[i].kernel.decode()) for i in range(n.value)]
+
+
+def tile_shard(lib, rank, world, replica, n_replicas):
+    r, w = C.c_uint32(), C.c_uint32()
+    lib.lib.pt_multi_tile_shard(rank, world, replica, n_replicas, C.byref(r), C.byref(w))
+    return r.value, w.value

@@ -28,6 +28,10 @@ def oracle(pkg):
 @pytest.fixture(scope="session")
 def gpu(pkg):
     """The HIP product library on device 0. No fallback: a missing .so or device is a hard failure."""
+    try:
+        import torch  # noqa: F401  -- tests that also use torch need ITS bundled HIP/HSA runtime loaded before libmi355pt.so pulls in the system one
+    except ImportError:
+        pass
     lib = pkg.load_library()
     lib.init(0)
     return lib

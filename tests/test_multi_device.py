@@ -1,0 +1,68 @@
+"""One process, several devices (include/mi355pt.h: pt_multi_*).
+
+CPU: the tile-shard arithmetic behind pt_multi_render is a pure host function of the library (no GPU needed to call it): replicas
+partition the caller's own shard exactly, and nest inside a multi-process launch. GPU: three replicas of one scene on the single
+device of the test box (ordinals may repeat) render through one host thread + stream each, the films are merged on the device --
+the result must equal the plain single-scene render (weights bit for bit, radiance to float summation order) with the counters
+summing to the same totals."""
+import ctypes as C
+import numpy as np
+import pytest
+
+
+def test_replica_tile_shards_partition_the_callers_shard(pkg):
+    lib = pkg.load_library()      # dlopen only: pt_multi_tile_shard is host arithmetic
+    ntiles = 8160                 # 1920x1080 in 16x16 tiles
+    tiles = np.arange(ntiles)
+    for world in (1, 2, 8):
+        for rank in range(world):
+            mine = tiles[tiles % world == rank]
+            for n in (1, 2, 3, 8):
+                owned = []
+                for i in range(n):
+                    r, w = pkg.runtime.tile_shard(lib, rank, world, i, n)
+                    assert w == world * n and r < w
+                    owned.append(tiles[tiles % w == r])
+                allo = np.concatenate(owned)
+                assert len(allo) == len(mine) and np.array_equal(np.sort(allo), mine)          # exact partition of the caller's shard
+                assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1            # balanced to one tile
+
+
+def test_library_reports_no_devices_without_a_gpu_instead_of_crashing(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box")
+    lib = pkg.load_library()
+    n = C.c_int(-1)
+    assert lib.lib.pt_device_count(C.byref(n)) == 0 and n.value == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["ganesha", "garden"])
+def test_three_replicas_on_one_device_equal_the_plain_render(pkg, gpu, scene):
+    if scene == "ganesha":
+        sd, rp = pkg.scenes.ganesha_scale(n=48, xres=160, yres=96, spp=8).world_end()
+    else:
+        sd, rp = pkg.scenes.instanced_garden(xres=128, yres=80, spp=8).world_end()
+    single = pkg.Scene(gpu, sd)
+    ref = single.render(rp)
+    rc = single.counters()
+    multi = pkg.MultiScene(gpu, sd, [0, 0, 0])
+    film = multi.render(rp)
+    mc = multi.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+        assert mc[k] == rc[k], (k, mc[k], rc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+    # the device-pointer form adds into a film on the first device
+    import torch
+    dfilm = torch.zeros(film.shape, dtype=torch.float32, device="cuda:0")
+    multi.render(rp, device_ptr=dfilm.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dfilm.cpu().numpy(), film)
+    # nested inside a 2-process launch: rank 1 of 2, split over the three replicas
+    rp.tile_rank, rp.tile_world = 1, 2
+    a = multi.render(rp); b = single.render(rp)
+    assert np.array_equal(a[..., 3], b[..., 3])
+    np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-7)
+    assert len(multi.kernel_stats(2)) > 0
