@@ -1,7 +1,7 @@
 // fe_params.h -- tokenizer and parameter lists of the .pbrt front end.
 //   pbrtparser/lexer.rs:9-60 (token classes: directive keywords, "quoted strings", numbers, [ ], # comments),
 //   pbrtparser/pbrtparser.rs:163-330 (param_item: "type name" declarations; int|integer, bool, float, point2, vector2,
-//   point3|point, vector3|vector, normal, rgb|color, string, texture; xyz / blackbody / spectrum are rejected here),
+//   point3|point, vector3|vector, normal, rgb|color, xyz, blackbody, spectrum (all kept as RGB, fe_spectrum.h), string, texture),
 //   core/paramset.rs (find_one_*, find_* with defaults).
 #pragma once
 #include <cstdlib>
@@ -9,8 +9,12 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include "fe_spectrum.h"
 
 namespace fe {
+
+// directory that relative .spd file names of "spectrum" parameters resolve against (resolve_filename: the scene file's directory)
+inline std::string &spectrum_search_dir() { static thread_local std::string d; return d; }
 
 struct Token { enum Kind { Word, Str, Num, LBracket, RBracket, End } kind = End; std::string text; float num = 0; int line = 0; };
 
@@ -65,10 +69,32 @@ public:
         auto it = canon.find(p.type);
         if (it == canon.end()) throw std::runtime_error("unknown parameter type " + p.type);   // pbrtparser.rs:182
         p.type = it->second;
-        if (p.type == "xyz" || p.type == "blackbody" || p.type == "spectrum") throw std::runtime_error("parameter type \"" + p.type + "\" is not supported by this front end (RGB only)");
+        // Spectrum = RGBSpectrum: every spectral parameter type is stored as RGB, in ONE namespace with "rgb" (ParamSet::spectra), so a
+        // later `find_one_spectrum(name)` sees it whatever type it was declared with (pbrtparser.rs:325-377, paramset.rs:145-246)
+        if (p.type == "xyz") {
+            nums.resize(nums.size() - nums.size() % 3);
+            for (size_t i = 0; i + 2 < nums.size(); i += 3) { float rgb[3]; xyz_to_rgb(&nums[i], rgb); nums[i] = rgb[0]; nums[i + 1] = rgb[1]; nums[i + 2] = rgb[2]; }
+            p.type = "rgb";
+        } else if (p.type == "blackbody") {
+            nums.resize(nums.size() - nums.size() % 2);
+            std::vector<float> out;
+            for (size_t i = 0; i + 1 < nums.size(); i += 2) { float rgb[3]; rgb_from_blackbody(nums[i], nums[i + 1], rgb); out.insert(out.end(), rgb, rgb + 3); }
+            nums = std::move(out); p.type = "rgb";
+        } else if (p.type == "spectrum") {
+            std::vector<float> out;
+            if (!strs.empty()) { for (const std::string &fn : strs) { float rgb[3]; rgb_from_spd_file((!fn.empty() && fn[0] == '/') ? fn : spectrum_search_dir() + fn, rgb); out.insert(out.end(), rgb, rgb + 3); } strs.clear(); }
+            else {
+                nums.resize(nums.size() - nums.size() % 2);
+                std::vector<float> wl, v;
+                for (size_t i = 0; i + 1 < nums.size(); i += 2) { wl.push_back(nums[i]); v.push_back(nums[i + 1]); }
+                float rgb[3]; rgb_from_sampled(wl, v, rgb); out.assign(rgb, rgb + 3);
+            }
+            nums = std::move(out); p.type = "rgb";
+        }
         const size_t arity = (p.type == "vector3" || p.type == "point3" || p.type == "normal" || p.type == "rgb") ? 3 : (p.type == "vector2" || p.type == "point2") ? 2 : 1;
         if (arity > 1) nums.resize(nums.size() - nums.size() % arity);   // excess values are dropped with a warning (pbrtparser.rs:214-330)
         p.nums = std::move(nums); p.strs = std::move(strs);
+        for (size_t i = 0; i < items.size(); ++i) if (items[i].type == p.type && items[i].name == p.name) { items.erase(items.begin() + (long)i); break; }   // add_* erases an earlier item of the same kind and name
         items.push_back(std::move(p));
     }
     const Param *find(const std::string &type, const std::string &name) const {

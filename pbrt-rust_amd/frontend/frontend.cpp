@@ -588,6 +588,7 @@ struct ptf_scene { fe::Scene sc; };
 static int parse_text(const std::string &text, const std::string &base_dir, ptf_scene **out) {
     std::unique_ptr<ptf_scene> h(new ptf_scene());
     h->sc.base_dir = base_dir;
+    fe::spectrum_search_dir() = base_dir;
     try {
         fe::Lexer lx(text);
         fe::Api api(h->sc);

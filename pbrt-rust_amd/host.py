@@ -749,3 +749,84 @@ class SceneData:
         d.n_images = len(self.image_src); d.images = self.images
         d.ewa_weight_lut = ptr(self.ewa_lut, A.fp)
         return d
+
+
+# ---- spectral parameter values -> RGB (Spectrum = RGBSpectrum): the mirror of frontend/fe_spectrum.h, written with numpy float32 ----
+_CIE = None
+
+
+def _cie_tables():
+    """CIE_X / CIE_Y / CIE_Z / CIE_LAMBDA (471 samples) and CIE_Y_INTEGRAL from include/pt_cie_tables.h (DATA of core/cie.rs)."""
+    global _CIE
+    if _CIE is None:
+        import os, re
+        txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "pt_cie_tables.h")).read()
+        tabs = {}
+        for name in ("CIE_X", "CIE_Y", "CIE_Z", "CIE_LAMBDA"):
+            body = txt[txt.index("#define PT_%s_VALUES" % name):].split("\n#define")[0]
+            vals = re.findall(r"([-+0-9.eE]+)f", body.split("\\", 1)[1])
+            tabs[name] = np.array([float(v) for v in vals], dtype=F)
+            assert len(tabs[name]) == 471
+        tabs["Y_INT"] = F(float(re.search(r"PT_CIE_Y_INTEGRAL ([0-9.]+)f", txt).group(1)))
+        _CIE = tabs
+    return _CIE
+
+
+def xyz_to_rgb(xyz):   # spectrum.rs:485-493
+    x, y, z = (F(v) for v in xyz)
+    return np.array([F(3.240479) * x - F(1.537150) * y - F(0.498535) * z, F(-0.969256) * x + F(1.875991) * y + F(0.041556) * z,
+                     F(0.055648) * x - F(0.204043) * y + F(1.057311) * z], dtype=F)
+
+
+def rgb_from_sampled(lam, vals):
+    """RGBSpectrum::from_sampled (spectrum.rs:129-154) incl. its unsorted-input quirk (sorted wavelengths, unsorted values)."""
+    T = _cie_tables()
+    lam = np.asarray(lam, dtype=F); vals = np.asarray(vals, dtype=F)
+    if len(lam) == 0: return np.zeros(3, dtype=F)
+    if np.any(lam[:-1] > lam[1:]):
+        order = sorted(range(len(lam)), key=lambda i: (float(lam[i]), float(vals[i])))
+        lam = lam[order]
+    xyz = np.zeros(3, dtype=F)
+    n = len(lam)
+    for i in range(471):
+        l = T["CIE_LAMBDA"][i]
+        if l <= lam[0]: v = vals[0]
+        elif l >= lam[n - 1]: v = vals[n - 1]
+        else:
+            off = min(max(int(np.searchsorted(lam, l, side="right")) - 1, 0), n - 2)
+            t = F(F(l - lam[off]) / F(lam[off + 1] - lam[off]))
+            v = F(F(F(1) - t) * vals[off] + t * vals[off + 1])
+        xyz[0] = F(xyz[0] + F(v * T["CIE_X"][i])); xyz[1] = F(xyz[1] + F(v * T["CIE_Y"][i])); xyz[2] = F(xyz[2] + F(v * T["CIE_Z"][i]))
+    scale = F(F(T["CIE_LAMBDA"][470] - T["CIE_LAMBDA"][0]) / F(T["Y_INT"] * F(471)))
+    return xyz_to_rgb(xyz * scale)
+
+
+def rgb_from_blackbody(temperature, scale):
+    """paramset.rs:163-180 + black_body_normalized (spectrum.rs:36-70), float32 arithmetic as written."""
+    T = _cie_tables()
+    t = F(temperature)
+    def bb(lam):
+        lam = np.asarray(lam, dtype=F)
+        if t <= 0: return np.zeros_like(lam)
+        c, h, kb = F(299792458.0), F(6.62606957e-34), F(1.3806488e-23)
+        l = (lam.astype(np.float64) * np.float64(F(1.0e-9))).astype(F)
+        lambda5 = ((l * l) * (l * l) * l).astype(F)
+        e = np.exp(((h * c) / (l * kb * t)).astype(F)).astype(F)
+        return ((F(2.0) * h * c * c) / (lambda5 * (e - F(1.0)))).astype(F)
+    le = bb(T["CIE_LAMBDA"])
+    lmax = F(F(F(2.8977721e-3) / t) * F(1.0e9))
+    le = (le / bb([lmax])[0]).astype(F)
+    return (rgb_from_sampled(T["CIE_LAMBDA"], le) * F(scale)).astype(F)
+
+
+def rgb_from_spd_text(text):
+    """`"spectrum x" "file.spd"`: read_float_file pushes every number twice (floatfile.rs:21-29), see fe_spectrum.h."""
+    vals = []
+    for line in text.splitlines():
+        if not line or line.startswith("#"): continue
+        for tok in line.split():
+            try: v = float(np.float32(tok))
+            except ValueError: return np.zeros(3, dtype=F)
+            vals += [v, v]
+    half = len(vals) // 2
+    return rgb_from_sampled([vals[2 * j] for j in range(half)], [vals[2 * j + 1] for j in range(half)])

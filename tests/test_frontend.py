@@ -223,7 +223,7 @@ def test_feature_scene_matches_python_builder_and_renders(pkg, oracle, tmp_path)
     ('Sampler "stratified" "integer xsamples" 4\nWorldBegin WorldEnd', "only \"sobol\" and \"halton\""),
     ('Integrator "bdpt"\n', "only \"path\""),
     ('WorldBegin\nShape "cone"\n', "shape \"cone\""),
-    ('WorldBegin\nMaterial "matte" "blackbody Kd" [5500 1]\n', "blackbody"),
+    ('WorldBegin\nMaterial "matte" "wavelengths Kd" [5500 1]\n', "unknown parameter type wavelengths"),
     ('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 5] "point P" [0 0 0 1 0 0 0 1 0]\n', "out of-bounds vertex index"),
     ('WorldBegin\nNamedMaterial "nope"\n', "not defined"),
     ('WorldBegin\nAttributeEnd\n', "unmatched AttributeEnd"),
@@ -510,3 +510,151 @@ def test_disney_material_from_a_scene_file(pkg):
         pkg.frontend.FrontScene(text=head + 'Material "disney" "texture color" "c" "rgb scatterdistance" [.1 .1 .1]\nShape "sphere"\nWorldEnd\n')
     with pytest.raises(Exception, match="textured \"sheen\""):
         pkg.frontend.FrontScene(text=head + 'Texture "f" "float" "checkerboard"\nMaterial "disney" "texture sheen" "f"\nShape "sphere"\nWorldEnd\n')
+
+
+# ---- spectral parameter types: "xyz", "blackbody", "spectrum" (inline pairs and .spd files) -> RGB ----
+
+_SPECTRAL_HEAD = """LookAt 0 0 5 0 0 0 0 1 0
+Camera "perspective" "float fov" [30]
+Film "image" "integer xresolution" [16] "integer yresolution" [16]
+Sampler "sobol" "integer pixelsamples" [1]
+Integrator "path"
+WorldBegin
+"""
+
+
+def test_spectral_parameter_types_become_rgb_like_the_reference(pkg, tmp_path):
+    """pbrtparser.rs:325-377 + paramset.rs:145-246 + spectrum.rs:36-70,129-154: the front end against the numpy mirror (host.py)."""
+    H = pkg.host
+    (tmp_path / "green.spd").write_text("# wavelength value\n400 0.1\n500 0.2 550 0.9\n600 0.3\n700 0.05\n")
+    (tmp_path / "broken.spd").write_text("400 0.1\n500 oops\n")
+    txt = _SPECTRAL_HEAD + """
+LightSource "point" "blackbody I" [5500 125]
+LightSource "point" "blackbody I" [2800 3 6500 1]
+LightSource "point" "xyz I" [0.3 0.4 0.2]
+LightSource "point" "spectrum I" [400 0.2 500 0.5 600 0.9 700 0.3]
+LightSource "point" "spectrum I" [700 0.3 500 0.5 600 0.9 400 0.2]
+LightSource "point" "spectrum I" "green.spd"
+LightSource "point" "spectrum I" "broken.spd"
+LightSource "point" "rgb I" [1 2 3] "blackbody I" [4000 2]
+Material "matte" "spectrum Kd" [300 0.5 900 0.5] "float sigma" 0
+Shape "sphere"
+WorldEnd
+"""
+    d = pkg.frontend.FrontScene(text=txt, base_dir=str(tmp_path)).desc()
+    want = [H.rgb_from_blackbody(5500, 125), H.rgb_from_blackbody(2800, 3),        # find_one_spectrum: the first of several values
+            H.xyz_to_rgb((0.3, 0.4, 0.2)), H.rgb_from_sampled([400, 500, 600, 700], [0.2, 0.5, 0.9, 0.3]),
+            H.rgb_from_sampled([700, 500, 600, 400], [0.3, 0.5, 0.9, 0.2]),         # unsorted: sorted wavelengths, UNSORTED values (spectrum.rs:131-136)
+            H.rgb_from_spd_text((tmp_path / "green.spd").read_text()), np.zeros(3, np.float32),
+            H.rgb_from_blackbody(4000, 2)]                                           # same name declared twice: the later one replaces the earlier
+    assert d.n_lights == len(want)
+    for i, w in enumerate(want):
+        np.testing.assert_allclose(list(d.lights[i].L), w, rtol=2e-5, atol=1e-6, err_msg=str(i))
+    mat = d.materials[d.n_materials - 1]   # (index 0 is the graphics state's default matte)
+    np.testing.assert_allclose(list(mat.kd), H.rgb_from_sampled([300, 900], [0.5, 0.5]), rtol=2e-5)
+    # sanity of the conversion itself: a 6500 K blackbody is close to white in linear sRGB; a constant spectrum is the equal-energy
+    # white E, i.e. XYZ = (v, v, v) -> RGB = v * (row sums of the XYZ -> RGB matrix), slightly reddish
+    bb = H.rgb_from_blackbody(6500, 1); assert 0.8 < bb[0] / bb[1] < 1.25 and 0.8 < bb[2] / bb[1] < 1.25
+    np.testing.assert_allclose(list(mat.kd), 0.5 * np.array([3.240479 - 1.537150 - 0.498535, -0.969256 + 1.875991 + 0.041556, 0.055648 - 0.204043 + 1.057311]), rtol=5e-3)   # (the X and Z integrals of the tables differ from the Y integral by ~0.2 %)
+
+
+_REF_SCENES = "/root/reference/src/scenes"
+
+
+def _read_ply_numpy(path):
+    """Minimal PLY reader for the mirror side of the test below (ascii / binary_little_endian, float vertices, list faces)."""
+    raw = open(path, "rb").read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    head = raw[:end].decode().split("\n")
+    fmt = [l.split()[1] for l in head if l.startswith("format")][0]
+    elems = []; cur = None
+    for l in head:
+        t = l.split()
+        if not t: continue
+        if t[0] == "element": cur = [t[1], int(t[2]), []]; elems.append(cur)
+        elif t[0] == "property": cur[2].append(t[1:])
+    body = raw[end:]
+    verts = None; faces = []
+    tmap = {"float": "f4", "float32": "f4", "double": "f8", "uchar": "u1", "uint8": "u1", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "short": "i2", "ushort": "u2", "char": "i1"}
+    if fmt == "ascii":
+        toks = body.split(); k = 0
+        for name, n, props in elems:
+            if name == "vertex":
+                verts = {p[-1]: np.zeros(n, np.float32) for p in props}
+                for i in range(n):
+                    for p in props: verts[p[-1]][i] = float(toks[k]); k += 1
+            elif name == "face":
+                for i in range(n):
+                    c = int(toks[k]); k += 1
+                    faces.append([int(x) for x in toks[k:k + c]]); k += c
+    else:
+        off = 0
+        for name, n, props in elems:
+            if name == "vertex":
+                dt = np.dtype([(p[-1], "<" + tmap[p[0]]) for p in props])
+                a = np.frombuffer(body, dt, n, off); off += n * dt.itemsize
+                verts = {k2: a[k2].astype(np.float32) for k2 in a.dtype.names}
+            elif name == "face":
+                p = props[0]; ct, it = np.dtype("<" + tmap[p[1]]), np.dtype("<" + tmap[p[2]])
+                for i in range(n):
+                    c = int(np.frombuffer(body, ct, 1, off)[0]); off += ct.itemsize
+                    faces.append(np.frombuffer(body, it, c, off).tolist()); off += c * it.itemsize
+    tris = []
+    for f in faces:
+        if len(f) == 3: tris.append(f)
+        elif len(f) == 4: tris += [[f[0], f[1], f[3]], [f[1], f[2], f[3]]]   # shapes/plymesh.rs: a quad becomes (0,1,3) and (1,2,3)
+    P = np.stack([verts["x"], verts["y"], verts["z"]], axis=1)
+    N = np.stack([verts["nx"], verts["ny"], verts["nz"]], axis=1) if "nx" in verts else None
+    UV = np.stack([verts[a] for a in (("u", "v") if "u" in verts else ("s", "t"))], axis=1) if ("u" in verts or "s" in verts) else None
+    return P, np.array(tris, np.uint32), N, UV
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(_REF_SCENES, "caustic-glass.pbrt")), reason="the reference's shipped scenes exist in the build container only")
+def test_reference_authored_scene_loads_like_the_mirror(pkg, oracle, tmp_path):
+    """src/scenes/caustic-glass.pbrt (a scene the reference ships; its spot light is given as `"blackbody I" [5500 125]`) read in place
+    by libmi355front.so -- only its Integrator line is swapped for "path" (the file names sppm) and a sampler line added, in memory -- and
+    assembled independently through the Python mirror of api.rs with a numpy PLY reader: the flattened arrays must agree, and the
+    oracle renders both to the same image. Nothing of the file is copied into the repository; the test is skipped where the
+    reference is absent (the GPU box)."""
+    text = open(os.path.join(_REF_SCENES, "caustic-glass.pbrt")).read()
+    lines = []
+    for l in text.split("\n"):
+        if l.startswith("Integrator"): lines.append('Integrator "path" "integer maxdepth" [5]\nSampler "sobol" "integer pixelsamples" [1]'); continue
+        if l.startswith('    "integer xresolution"'): l = '    "integer xresolution" [70] "integer yresolution" [100]'
+        lines.append(l)
+    fs = pkg.frontend.FrontScene(text="\n".join(lines), base_dir=_REF_SCENES)
+    d, rp = fs.desc(), fs.render_params()
+    H = pkg.host
+    b = H.SceneBuilder()
+    b.film.update(xres=70, yres=100, scale=1.5); b.spp = 1
+    b.integ.update(maxdepth=5)
+    b.look_at((-5.5, 7.0, -5.5), (-4.75, 2.25, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=30.0)
+    b.world_begin()
+    b.light_source("spot", from_=(0.0, 5.0, 9.0), to=(-5.0, 2.75, 0.0), I=tuple(float(x) for x in H.rgb_from_blackbody(5500, 125)))
+    b.attribute_begin(); b.light_source("infinite", L=(0.1, 0.1, 0.1)); b.attribute_end()
+    for fn, (kind, kw) in (("geometry/mesh_00001.ply", ("glass", dict(eta=1.25))),
+                           ("geometry/mesh_00002.ply", ("uber", dict(roughness=0.0104080001, eta=1.0, Kd=(0.6399999857,) * 3, Ks=(0.1000000015,) * 3, Kt=(0.0, 0.0, 0.0), opacity=(1.0, 1.0, 1.0))))):
+        b.attribute_begin(); b.material(kind, **kw)
+        P, I, N, UV = _read_ply_numpy(os.path.join(_REF_SCENES, fn))
+        b.trianglemesh(P, I, N=N, UV=UV); b.attribute_end()
+    sd, rp2 = b.world_end()
+    d2 = sd.desc()
+    assert d.n_triangles == d2.n_triangles > 80000 and d.n_vertices == d2.n_vertices and d.n_lights == d2.n_lights == 2 and d.n_materials == d2.n_materials
+    np.testing.assert_array_equal(_arr(d.indices, 3 * d.n_triangles), _arr(d2.indices, 3 * d2.n_triangles))
+    np.testing.assert_allclose(_arr(d.P, 3 * d.n_vertices), _arr(d2.P, 3 * d2.n_vertices), rtol=1e-6, atol=1e-6)
+    for f in ("prim_shape", "prim_material", "prim_light"):
+        np.testing.assert_array_equal(_arr(getattr(d, f), d.n_prims), _arr(getattr(d2, f), d2.n_prims))
+    for i in range(d.n_lights):
+        assert d.lights[i].type == d2.lights[i].type
+        np.testing.assert_allclose(list(d.lights[i].L), list(d2.lights[i].L), rtol=2e-5)
+        np.testing.assert_allclose(list(d.lights[i].pos), list(d2.lights[i].pos), atol=1e-5)
+        assert abs(d.lights[i].cos_total_width - d2.lights[i].cos_total_width) < 1e-6
+    for i in range(d.n_materials):
+        for f in ("type", "eta", "roughness"): assert getattr(d.materials[i], f) == pytest.approx(getattr(d2.materials[i], f), rel=1e-6), (i, f)
+        for f in ("kd", "ks", "kt", "opacity"): np.testing.assert_allclose(list(getattr(d.materials[i], f)), list(getattr(d2.materials[i], f)), rtol=1e-6)
+    for f in ("full_resolution", "cropped_pixel_bounds", "sample_bounds"): assert list(getattr(rp, f)) == list(getattr(rp2, f)), f
+    assert rp.scale == rp2.scale == 1.5
+    a = oracle.scene(fs); c = oracle.scene(sd)
+    fa, fc = a.render(rp, nthreads=8), c.render(rp2, nthreads=8)
+    assert np.isfinite(fa).all() and fa[..., :3].max() > 0
+    np.testing.assert_allclose(a.resolve(fa), c.resolve(fc), rtol=1e-3, atol=1e-4)
