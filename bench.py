@@ -88,7 +88,7 @@ def main():
     rp.tile_rank, rp.tile_world = rank, world
     if args.sim_world > 1 and world == 1: rp.tile_rank, rp.tile_world = 0, args.sim_world
     rp.spp_per_pass = args.spp_per_pass
-    rp.profile = 1                    # HIP events around every launch, on the render stream
+    rp.profile = int(os.environ.get("PT_BENCH_PROFILE", "1"))   # 1: HIP events around every launch, on the render stream; 2: + exact per-class launch sizes
     cb = rp.cropped_pixel_bounds
     W, H = cb[2] - cb[0], cb[3] - cb[1]
     film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)

@@ -399,23 +399,61 @@ template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lo
 }
 
 // ---- BSDF (reflection.rs:1495-1689). MAXL = compile-time lobe capacity of the shade-queue class -----------
+// Lobe storage. A one-lobe BSDF keeps its lobe in registers. The two- and five-lobe classes keep theirs in LDS (19 words per lobe,
+// word w of lobe i of thread t at store[(i * 19 + w) * 256 + t]: conflict free) and walk them with rolled loops that hold ONE lobe
+// in registers at a time: with the lobes in a register array every loop over them was unrolled MAXL times around the big
+// per-kind switches, which cost the five-lobe kernel 256 VGPRs + 73 AGPRs + 632 bytes of scratch per lane at one wave per SIMD.
+constexpr int kLobeWords = 19, kLobeStride = 256;   // (k_shade runs 256-thread blocks)
+template <int MAXL> constexpr int lobe_store_words() { return MAXL > 1 ? MAXL * kLobeWords * kLobeStride : 1; }
+
 template <int MAXL, bool DIFF = false> struct Bsdf {
     float eta;
     V3 ns, ng, ss, ts;
     int n;
-    Lobe l[MAXL];
+    static constexpr bool LDS = MAXL > 1;
+    Lobe l1;               // MAXL == 1
+    float *store;          // MAXL > 1: this thread's column of the block's LDS lobe store
+    uint64_t types;        // BxDFType byte of lobe i in bits 8i .. 8i+7 (what `matches` and the reflect / transmit split read)
     // MixMaterial (mix.rs:25-50): lobes [0, n1) are ScaledBxDFs with scale s1, lobes [n1, n) with scale s2 (reflection.rs:466-517);
     // only the five-lobe class carries this. `frozen`: the second material's init() must not reset the frame / eta / lobes.
     static constexpr bool MIX = MAXL == 5, FULL = MAXL == 5;
     int n1; RGB s1, s2; bool frozen;
 
+    PT_DEV void bind(float *block_store) { store = LDS ? block_store + threadIdx.x : nullptr; }
     PT_DEV void init(const SurfaceInteraction &si, float eta_) {
         if (MIX && frozen) return;
-        eta = eta_; ns = si.sh_n; ss = normalize(si.sh_dpdu); ng = si.n; ts = cross(ns, ss); n = 0;
+        eta = eta_; ns = si.sh_n; ss = normalize(si.sh_dpdu); ng = si.n; ts = cross(ns, ss); n = 0; types = 0ull;
     }
     PT_DEV RGB scaled(int i, RGB v) const { if (MIX && n1 >= 0) return (i < n1 ? s1 : s2) * v; return v; }
-    PT_DEV void add(const Lobe &x) { if (n < MAXL) l[n++] = x; }
-    PT_DEV int num_components(int flags) const { int c = 0; for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) ++c; return c; }
+    PT_DEV int type_of(int i) const { return (int)((types >> (8 * i)) & 0xffull); }
+    PT_DEV bool matches(int i, int flags) const { const int t = type_of(i); return (t & flags) == t; }
+    PT_DEV Lobe get(int i) const {
+        if (!LDS) return l1;
+        const float *p = store + (size_t)i * (kLobeWords * kLobeStride);
+        Lobe b;
+        const uint32_t w0 = __float_as_uint(p[0]);
+        b.kind = (uint8_t)(w0 & 0xffu); b.type = (uint8_t)((w0 >> 8) & 0xffu); b.fresnel = (uint8_t)((w0 >> 16) & 0xffu); b.sepg = (uint8_t)(w0 >> 24);
+        b.r = RGB(p[1 * kLobeStride], p[2 * kLobeStride], p[3 * kLobeStride]); b.t = RGB(p[4 * kLobeStride], p[5 * kLobeStride], p[6 * kLobeStride]);
+        b.ax = p[7 * kLobeStride]; b.ay = p[8 * kLobeStride]; b.etaa = p[9 * kLobeStride]; b.etab = p[10 * kLobeStride];
+        b.ck = RGB(p[11 * kLobeStride], p[12 * kLobeStride], p[13 * kLobeStride]); b.ce = RGB(p[14 * kLobeStride], p[15 * kLobeStride], p[16 * kLobeStride]);
+        b.A = p[17 * kLobeStride]; b.B = p[18 * kLobeStride];
+        return b;
+    }
+    PT_DEV void add(const Lobe &x) {
+        if (n >= MAXL) return;
+        if (!LDS) l1 = x;
+        else {
+            float *p = store + (size_t)n * (kLobeWords * kLobeStride);
+            p[0] = __uint_as_float((uint32_t)x.kind | ((uint32_t)x.type << 8) | ((uint32_t)x.fresnel << 16) | ((uint32_t)x.sepg << 24));
+            p[1 * kLobeStride] = x.r.r; p[2 * kLobeStride] = x.r.g; p[3 * kLobeStride] = x.r.b; p[4 * kLobeStride] = x.t.r; p[5 * kLobeStride] = x.t.g; p[6 * kLobeStride] = x.t.b;
+            p[7 * kLobeStride] = x.ax; p[8 * kLobeStride] = x.ay; p[9 * kLobeStride] = x.etaa; p[10 * kLobeStride] = x.etab;
+            p[11 * kLobeStride] = x.ck.r; p[12 * kLobeStride] = x.ck.g; p[13 * kLobeStride] = x.ck.b; p[14 * kLobeStride] = x.ce.r; p[15 * kLobeStride] = x.ce.g; p[16 * kLobeStride] = x.ce.b;
+            p[17 * kLobeStride] = x.A; p[18 * kLobeStride] = x.B;
+        }
+        types |= (uint64_t)x.type << (8 * n);
+        n++;
+    }
+    PT_DEV int num_components(int flags) const { int c = 0; for (int i = 0; i < MAXL; ++i) if (i < n && matches(i, flags)) ++c; return c; }
     PT_DEV V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
     PT_DEV V3 to_world(V3 v) const {
         return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z, ss.z * v.x + ts.z * v.y + ns.z * v.z);
@@ -425,9 +463,10 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         if (wo.z == 0.0f) return RGB(0.0f);
         bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
         RGB res(0.0f);
-        for (int i = 0; i < MAXL; ++i)
-            if (i < n && l[i].matches(flags) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                res = res + scaled(i, lobe_f<DIFF, FULL>(l[i], wo, wi));
+#pragma unroll 1
+        for (int i = 0; i < n; ++i)
+            if (matches(i, flags) && ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))))
+                res = res + scaled(i, lobe_f<DIFF, FULL>(get(i), wo, wi));
         return res;
     }
     PT_DEV float pdf(V3 wow, V3 wiw, int flags) const {
@@ -435,7 +474,8 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         V3 wo = to_local(wow), wi = to_local(wiw);
         if (wo.z == 0.0f) return 0.0f;
         float p = 0.0f; int matching = 0;
-        for (int i = 0; i < MAXL; ++i) if (i < n && l[i].matches(flags)) { ++matching; p += lobe_pdf<DIFF, FULL>(l[i], wo, wi); }
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) if (matches(i, flags)) { ++matching; p += lobe_pdf<DIFF, FULL>(get(i), wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
     // `pdf` must hold the caller's previous value on entry (it is left untouched on the wo.z == 0 exit,
@@ -447,7 +487,7 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         int idx = 0, count = comp;
         for (int i = 0; i < MAXL; ++i) {
             if (i >= n) break;
-            bool m = l[i].matches(ty);
+            bool m = matches(i, ty);
             if (m && count == 0) { idx = i; break; }
             else if (m) --count;
         }
@@ -456,20 +496,23 @@ template <int MAXL, bool DIFF = false> struct Bsdf {
         if (wo.z == 0.0f) return RGB(0.0f);
         pdf = 0.0f;
         RGB fv(0.0f);
-        int btype = 0;
-        // select the lobe without dynamic register-array indexing
-        for (int i = 0; i < MAXL; ++i) if (i == idx) { btype = l[i].type; sampled = btype; fv = scaled(i, lobe_sample_f<DIFF, FULL>(l[i], wo, wi, ur, pdf, sampled)); }
+        const int btype = type_of(idx);
+        sampled = btype;
+        fv = scaled(idx, lobe_sample_f<DIFF, FULL>(get(idx), wo, wi, ur, pdf, sampled));
         if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
         wiw = to_world(wi);
-        if (!(btype & BSDF_SPECULAR) && matching > 1)
-            for (int i = 0; i < MAXL; ++i) if (i < n && i != idx && l[i].matches(ty)) pdf += lobe_pdf<DIFF, FULL>(l[i], wo, wi);
+        if (!(btype & BSDF_SPECULAR) && matching > 1) {
+#pragma unroll 1
+            for (int i = 0; i < n; ++i) if (i != idx && matches(i, ty)) pdf += lobe_pdf<DIFF, FULL>(get(i), wo, wi);
+        }
         if (matching > 1) pdf /= (float)matching;
         if (!(btype & BSDF_SPECULAR)) {
             bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
             fv = RGB(0.0f);
-            for (int i = 0; i < MAXL; ++i)
-                if (i < n && l[i].matches(ty) && ((refl && (l[i].type & BSDF_REFLECTION)) || (!refl && (l[i].type & BSDF_TRANSMISSION))))
-                    fv = fv + scaled(i, lobe_f<DIFF, FULL>(l[i], wo, wi));
+#pragma unroll 1
+            for (int i = 0; i < n; ++i)
+                if (matches(i, ty) && ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))))
+                    fv = fv + scaled(i, lobe_f<DIFF, FULL>(get(i), wo, wi));
         }
         return fv;
     }

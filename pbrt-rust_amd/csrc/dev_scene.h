@@ -105,8 +105,14 @@ PT_DEV TriRay tri_ray_setup(V3 rd) {
 }
 PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t_max, float &t, float &b0, float &b1, float &b2) {
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    if (tr.kz == 0) { p0t = V3(p0t.y, p0t.z, p0t.x); p1t = V3(p1t.y, p1t.z, p1t.x); p2t = V3(p2t.y, p2t.z, p2t.x); }
-    else if (tr.kz == 1) { p0t = V3(p0t.z, p0t.x, p0t.y); p1t = V3(p1t.z, p1t.x, p1t.y); p2t = V3(p2t.z, p2t.x, p2t.y); }
+    // permute(kx, ky, kz) as per-component selects (two v_cndmask each) instead of a three-way branch: lanes of a wave differ in kz, so
+    // the branch form executed every arm with its register shuffles under exec masks
+    {
+        const bool k0 = tr.kz == 0, k1 = tr.kz == 1;
+#define PT_PERM(v) v = V3(k0 ? v.y : (k1 ? v.z : v.x), k0 ? v.z : (k1 ? v.x : v.y), k0 ? v.x : (k1 ? v.y : v.z))
+        PT_PERM(p0t); PT_PERM(p1t); PT_PERM(p2t);
+#undef PT_PERM
+    }
     const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;

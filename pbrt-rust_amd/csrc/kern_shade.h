@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
     __shared__ uint32_t s_hist[16];
+    __shared__ float s_lobes[lobe_store_words<MAXL>()];   // the two- and five-lobe classes keep their BxDFs here (dev_bsdf.h)
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #ifdef PT_REGION_PROFILE
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATT
                 PT_T(4);
                 smp.load_window();
                 PT_T(10);
-                Bsdf<MAXL, DIFF> bsdf;
+                Bsdf<MAXL, DIFF> bsdf; bsdf.bind(s_lobes);
                 const uint32_t mi = packet_material(s, pfl, hp);
                 bool has_bsdf = false;
                 if (TEX) {
