@@ -178,7 +178,7 @@ def main():
         if traffic:
             hbm_achieved = traffic / (avg_ms * 1e-3) / 1e9
             hbm_frac = hbm_achieved / HBM_PEAK_GBS
-        roofline = dict(bound="hbm", limiter="latency/divergence (gathers mostly L1/L2-served; see hbm_frac)", kernel=name, launch_kinds=g["kinds"],
+        roofline = dict(bound="hbm", limiter="VALU issue at full per-lane divergence (SIMDs ~77 % busy, DESIGN.md section 7); gathers mostly L1/L2-served, HBM at hbm_frac", kernel=name, launch_kinds=g["kinds"],
                         achieved=round(achieved, 2), achieved_kind="algorithmic bytes (cache-inclusive) / launch time", peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                         hbm_achieved=None if hbm_achieved is None else round(hbm_achieved, 2), hbm_frac=None if hbm_frac is None else round(hbm_frac, 5),
@@ -241,16 +241,18 @@ def run_cpu_baseline(pkg, sd, rp_full, spp, args):
             k += 1
         return k
 
+    cpu_spp = min(spp, 64)   # bounded sample: the per-sample cost does not depend on how many samples a pixel gets (each has its own Sobol' index)
+
     def render(stride):
         rp = copy.copy(rp_full)
-        rp.tile_rank, rp.tile_world, rp.profile = 0, stride, 0
+        rp.tile_rank, rp.tile_world, rp.profile, rp.spp = 0, stride, 0, cpu_spp
         oscene.render(rp, nthreads=cores)
         n = oscene.counters()["camera_rays"]
         return n, oscene.seconds()
     # calibrate on ~ one tile per core, then size the sample for ~cpu_seconds
     n, secs = render(coprime_stride(ntiles // max(1, cores)))
     rate = n / max(1e-6, secs)
-    want_tiles = max(cores, int(rate * args.cpu_seconds / (256 * spp)))
+    want_tiles = max(cores, int(rate * args.cpu_seconds / (256 * cpu_spp)))
     stride = coprime_stride(max(1, ntiles // want_tiles))
     n, secs = render(stride)
     msps = n / secs / 1e6
@@ -262,7 +264,7 @@ def run_cpu_baseline(pkg, sd, rp_full, spp, args):
     except OSError:
         pass
     return dict(value=round(msps, 4), unit="Msamples/s", cores=cores, kind="port",
-                sample=f"every {stride}th 16x16 tile of the whole {args.xres}x{args.yres} frame ({-(-ntiles // stride)} of {ntiles} tiles) at {spp} spp "
+                sample=f"every {stride}th 16x16 tile of the whole {args.xres}x{args.yres} frame ({-(-ntiles // stride)} of {ntiles} tiles) at {cpu_spp} spp "
                        f"({n} samples, {secs:.1f} s), oracle = C++ restatement of pbrt-rust's path, one std::thread per core over 16x16 tiles",
                 cpu=model)
 
