@@ -7,7 +7,10 @@
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres and/or instances), 2 = general geometry + textures
 // DIFF: the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only)
 template <int MAXL, int MODE, bool DIFF>
-__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? 2 : 1) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 1   // experiment hook (tools/build_variant.sh -DPT_SHADE_WAVES=N): minimum waves per SIMD the one-lobe kernels are compiled for
+#endif
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large

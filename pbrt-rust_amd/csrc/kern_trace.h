@@ -18,6 +18,9 @@
 // Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
 
 // GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 5   // waves per SIMD the triangle-only / instanced traversal kernels are compiled for (experiment hook: tools/build_variant.sh -DPT_TRACE_WAVES=N)
+#endif
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
                         // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
@@ -29,7 +32,7 @@
 // (`selected = clamp((u1 * nfound) as usize, 0, nfound - 1)`), so that one launch replaces what used to be one wavefront
 // iteration (a trace launch, a k_bssrdf launch and a host round trip) per segment, twice over.
 template <bool ANY, int MODE, bool PROBE>
-__global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ? PT_TRACE_WAVES : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY && PROBE), "probe chains are closest-hit queries");
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)

@@ -130,24 +130,43 @@ inline Pyramid prepare_image(const Image &im, float scale, bool gamma, int chann
 }
 inline std::vector<float> ewa_weight_lut() { std::vector<float> l(128); for (int i = 0; i < 128; ++i) { const float r2 = (float)i / 127.0f; l[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); } return l; }
 
-// lights/infinite.rs:62-81 for power-of-two maps with aspect <= 2:1 (level-0 bilinear lookup; see host.py _env_importance)
+// lights/infinite.rs:62-81: img[v][u] = map.lookup((u + .5) / W, (v + .5) / H, fwidth).y() * sin(theta) over the 2w x 2h grid, with
+// fwidth = 0.5 / min(2w, 2h). MIPMap::lookup (mipmap.rs:202-223) picks level = levels - 1 + log2(fwidth) = log2(max(w,h) / min(w,h)) - 2:
+// negative for aspects up to 2:1 -> triangle(0, st); otherwise lerp(delta, triangle(ilevel), triangle(ilevel + 1)) -- for power-of-two
+// maps delta is exactly 0, but the arithmetic is kept as written. `tex` is level 0 of the (already power-of-two) map, Repeat wrap.
 inline std::vector<float> env_importance(const std::vector<float> &tex, int w, int h) {
     auto pow2 = [](int n) { return n > 0 && (n & (n - 1)) == 0; };
-    if (!(pow2(w) && pow2(h) && std::max(w, h) <= 2 * std::min(w, h))) throw std::runtime_error("environment maps must have an aspect <= 2:1 after power-of-two resampling");
+    if (!(pow2(w) && pow2(h))) throw std::runtime_error("environment map must be resampled to powers of two first");
+    const Pyramid py = build_mipmap(tex, w, h, 3, 0);
+    std::vector<size_t> off(py.n_levels); { size_t o = 0; for (int l = 0; l < py.n_levels; ++l) { off[l] = o; o += (size_t)std::max(1, w >> l) * std::max(1, h >> l) * 3; } }
     const int W = 2 * w, H = 2 * h;
+    const float fwidth = 0.5f / (float)std::min(W, H);
+    const float level = (float)(py.n_levels - 1) + std::log2(std::max(fwidth, 1.0e-8f));
+    auto triangle = [&](int lv, float sx, float ty, float out[3]) {   // mipmap.rs:315-327
+        lv = std::min(std::max(lv, 0), py.n_levels - 1);
+        const int lw = std::max(1, w >> lv), lh = std::max(1, h >> lv);
+        const float *base = py.texels.data() + off[lv];
+        auto tx = [&](long s, long t, int k) { s %= lw; if (s < 0) s += lw; t %= lh; if (t < 0) t += lh; return base[((size_t)t * lw + s) * 3 + k]; };
+        const float s = sx * (float)lw - 0.5f, t = ty * (float)lh - 0.5f;
+        const long s0 = (long)std::floor(s), t0 = (long)std::floor(t);
+        const float ds = s - (float)s0, dt = t - (float)t0;
+        for (int k = 0; k < 3; ++k)
+            out[k] = tx(s0, t0, k) * ((1.0f - ds) * (1.0f - dt)) + tx(s0, t0 + 1, k) * ((1.0f - ds) * dt) + tx(s0 + 1, t0, k) * (ds * (1.0f - dt)) + tx(s0 + 1, t0 + 1, k) * (ds * dt);
+    };
     std::vector<float> img((size_t)W * H);
-    auto tx = [&](long s, long t, int k) { s %= w; if (s < 0) s += w; t %= h; if (t < 0) t += h; return tex[((size_t)t * w + s) * 3 + k]; };
     for (int v = 0; v < H; ++v) {
         const float vp = ((float)v + 0.5f) / (float)H;
         const float sin_theta = std::sin(3.14159265358979323846f * ((float)v + 0.5f) / (float)H);
         for (int u = 0; u < W; ++u) {
             const float up = ((float)u + 0.5f) / (float)W;
-            const float s = up * (float)w - 0.5f, t = vp * (float)h - 0.5f;
-            const long s0 = (long)std::floor(s), t0 = (long)std::floor(t);
-            const float ds = s - (float)s0, dt = t - (float)t0;
             float rgb[3];
-            for (int k = 0; k < 3; ++k)
-                rgb[k] = tx(s0, t0, k) * ((1.0f - ds) * (1.0f - dt)) + tx(s0, t0 + 1, k) * ((1.0f - ds) * dt) + tx(s0 + 1, t0, k) * (ds * (1.0f - dt)) + tx(s0 + 1, t0 + 1, k) * (ds * dt);
+            if (level < 0.0f) triangle(0, up, vp, rgb);
+            else if (level >= (float)(py.n_levels - 1)) { const float *top = py.texels.data() + off[py.n_levels - 1]; rgb[0] = top[0]; rgb[1] = top[1]; rgb[2] = top[2]; }
+            else {
+                const float ilevel = std::floor(level), delta = level - ilevel;
+                float a[3], b[3]; triangle((int)ilevel, up, vp, a); triangle((int)ilevel + 1, up, vp, b);
+                for (int k = 0; k < 3; ++k) rgb[k] = a[k] * (1.0f - delta) + b[k] * delta;   // lerp (pbrt.rs:136-144)
+            }
             img[(size_t)v * W + u] = (0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2]) * sin_theta;
         }
     }

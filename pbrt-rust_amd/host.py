@@ -627,31 +627,43 @@ def _env_power_lookup(tex):
 def _env_importance(tex):
     """lights/infinite.rs:62-81 importance image (2w x 2h): `map.lookup(st, fwidth).y() * sin(theta)` with
     fwidth = 0.5 / min(2w, 2h).  MIPMap::lookup (mipmap.rs:202-223) picks level = levels - 1 + log2(fwidth)
-    = log2(max(w,h)/min(w,h)) - 2, which is < 0 for power-of-two maps with aspect <= 2:1 -> `triangle(0, st)`, the
-    level-0 bilinear lookup with Repeat wrap (mipmap.rs:295-327).  Non-power-of-two maps arrive here already resampled
-    (`add_light`), so `tex` is level 0 of the reference's pyramid; aspects above 2:1 would need pyramid levels > 0 and
-    are rejected."""
+    = log2(max(w,h)/min(w,h)) - 2: negative for power-of-two maps with aspect <= 2:1 -> `triangle(0, st)`, the level-0 bilinear
+    lookup with Repeat wrap (mipmap.rs:295-327); for wider maps `lerp(delta, triangle(ilevel), triangle(ilevel + 1))` on the pyramid
+    (delta is exactly 0 for power-of-two sizes; the arithmetic is kept as written).  Non-power-of-two maps arrive here already
+    resampled (`light_source`), so `tex` is level 0 of the reference's pyramid."""
+    from . import textures as T
     h, w, _ = tex.shape
     pow2 = lambda n: n > 0 and (n & (n - 1)) == 0
-    if not (pow2(w) and pow2(h) and max(w, h) <= 2 * min(w, h)):
-        raise NotImplementedError("environment maps must have an aspect <= 2:1 after power-of-two resampling (pyramid levels > 0 of the importance lookup are not restated)")
+    if not (pow2(w) and pow2(h)):
+        raise ValueError("environment map must be resampled to powers of two first")
+    levels, _, _ = T.build_mipmap(tex, "repeat")
     W, H = 2 * w, 2 * h
     y_w = np.array([0.212671, 0.715160, 0.072169], dtype=F)
-    lum = (y_w[0] * tex[..., 0] + y_w[1] * tex[..., 1] + y_w[2] * tex[..., 2]).astype(F)
     up = ((np.arange(W, dtype=F) + F(0.5)) / F(W)).astype(F)
     vp = ((np.arange(H, dtype=F) + F(0.5)) / F(H)).astype(F)
-    sx = (up * F(w) - F(0.5)).astype(F); ty = (vp * F(h) - F(0.5)).astype(F)
-    s0 = np.floor(sx).astype(np.int64); t0 = np.floor(ty).astype(np.int64)
-    ds = (sx - s0.astype(F)).astype(F)[None, :]; dt = (ty - t0.astype(F)).astype(F)[:, None]
-    tx = lambda si, ti: tex[np.mod(ti, h)[:, None], np.mod(si, w)[None, :]].astype(F)   # texel(level 0, s, t), Repeat
     one = F(1.0)
-    # RGBSpectrum arithmetic first (tmp4 + tmp3 + tmp2 + tmp1), then y(), exactly as `triangle(..).y()`
-    rgb = ((tx(s0, t0) * ((one - ds) * (one - dt))[..., None] + tx(s0, t0 + 1) * ((one - ds) * dt)[..., None]).astype(F)
-           + tx(s0 + 1, t0) * (ds * (one - dt))[..., None]).astype(F)
-    rgb = (rgb + tx(s0 + 1, t0 + 1) * (ds * dt)[..., None]).astype(F)
+
+    def triangle(lv):
+        lv = min(max(lv, 0), len(levels) - 1)
+        L = levels[lv]; lh, lw, _ = L.shape
+        sx = (up * F(lw) - F(0.5)).astype(F); ty = (vp * F(lh) - F(0.5)).astype(F)
+        s0 = np.floor(sx).astype(np.int64); t0 = np.floor(ty).astype(np.int64)
+        ds = (sx - s0.astype(F)).astype(F)[None, :]; dt = (ty - t0.astype(F)).astype(F)[:, None]
+        tx = lambda si, ti: L[np.mod(ti, lh)[:, None], np.mod(si, lw)[None, :]].astype(F)   # texel(level, s, t), Repeat
+        # RGBSpectrum arithmetic first (tmp4 + tmp3 + tmp2 + tmp1), then y(), exactly as `triangle(..).y()`
+        rgb = ((tx(s0, t0) * ((one - ds) * (one - dt))[..., None] + tx(s0, t0 + 1) * ((one - ds) * dt)[..., None]).astype(F)
+               + tx(s0 + 1, t0) * (ds * (one - dt))[..., None]).astype(F)
+        return (rgb + tx(s0 + 1, t0 + 1) * (ds * dt)[..., None]).astype(F)
+
+    fwidth = F(F(0.5) / F(min(W, H)))
+    level = F(F(len(levels) - 1) + F(np.log2(max(fwidth, F(1.0e-8)))))
+    if level < 0: rgb = triangle(0)
+    elif level >= len(levels) - 1: rgb = np.broadcast_to(levels[-1][0, 0].astype(F), (H, W, 3)).copy()
+    else:
+        il = int(np.floor(level)); delta = F(level - F(il))
+        rgb = (triangle(il) * F(one - delta) + triangle(il + 1) * delta).astype(F)
     img = ((y_w[0] * rgb[..., 0] + y_w[1] * rgb[..., 1]).astype(F) + y_w[2] * rgb[..., 2]).astype(F)
     sin_theta = np.sin(F(math.pi) * (np.arange(H, dtype=F) + F(0.5)) / F(H)).astype(F)
-    del lum
     return np.ascontiguousarray(img * sin_theta[:, None], dtype=F)
 
 

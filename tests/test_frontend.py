@@ -417,8 +417,39 @@ def test_non_power_of_two_environment_map_is_resampled(pkg, tmp_path):
     assert c.env["texels"].shape == (8, 16, 3) and np.allclose(c.env["texels"], 0.75, rtol=1e-6)
     sin_t = np.sin(np.pi * (np.arange(16) + 0.5) / 16)
     assert np.allclose(c.env["importance"], (0.75 * sin_t)[:, None] * np.ones((1, 32)), rtol=1e-5)
-    with pytest.raises(Exception, match="aspect"):
-        pkg.host.SceneBuilder().light_source("infinite", texels=np.ones((2, 9, 3), np.float32))
+
+
+@pytest.mark.parametrize("shape", [(2, 32), (32, 4), (1, 16)])
+def test_wide_environment_maps_read_the_importance_image_from_a_coarser_level(pkg, tmp_path, shape):
+    """Aspects beyond 2:1 (round 1 refused them): MIPMap::lookup's level = log2(max / min) - 2 is >= 0, so the importance image of
+    infinite.rs:62-81 is the bilinear lookup of pyramid level `level` (mipmap.rs:202-223). Front end == Python mirror, and the level
+    really is the coarser one: for an 8:1 map the importance rows are those of level 1 (half the width)."""
+    h, w = shape
+    rng = np.random.default_rng(5)
+    tex = rng.uniform(0.1, 3.0, (h, w, 3)).astype(np.float32)
+    _write_pfm(tmp_path / "wide.pfm", tex)
+    scene = 'WorldBegin\nLightSource "infinite" "string mapname" "wide.pfm"\nShape "sphere"\nWorldEnd\n'
+    d = pkg.frontend.FrontScene(text=scene, base_dir=str(tmp_path)).desc()
+    b = pkg.host.SceneBuilder(); b.light_source("infinite", texels=tex)
+    assert (d.env_width, d.env_height) == (w, h)
+    imp = np.ctypeslib.as_array(d.env_importance, shape=(2 * h, 2 * w))
+    np.testing.assert_allclose(imp, b.env["importance"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(list(d.env_power_lookup), b.env["power_lookup"], rtol=1e-5)
+    level = int(np.log2(max(w, h) / min(w, h))) - 2
+    assert level >= 1
+    levels, _, _ = pkg.textures.build_mipmap(tex, "repeat")
+    coarse = levels[level]
+    # a level-`level` texel spans 2^level level-0 texels: along the long axis the importance image changes only every 2^(level+1) samples
+    # where the bilinear weights are constant -- check against a direct bilinear evaluation at one interior sample
+    H, W = 2 * h, 2 * w
+    v, u = H // 2, W // 2
+    lh, lw, _ = coarse.shape
+    sx = np.float32((u + 0.5) / W) * np.float32(lw) - np.float32(0.5); ty = np.float32((v + 0.5) / H) * np.float32(lh) - np.float32(0.5)
+    s0, t0 = int(np.floor(sx)), int(np.floor(ty)); ds, dt = sx - s0, ty - t0
+    tx = lambda a, c: coarse[c % lh, a % lw].astype(np.float64)
+    rgb = tx(s0, t0) * (1 - ds) * (1 - dt) + tx(s0, t0 + 1) * (1 - ds) * dt + tx(s0 + 1, t0) * ds * (1 - dt) + tx(s0 + 1, t0 + 1) * ds * dt
+    want = (0.212671 * rgb[0] + 0.715160 * rgb[1] + 0.072169 * rgb[2]) * np.sin(np.pi * (v + 0.5) / H)
+    assert abs(imp[v, u] - want) < 1e-4 * max(1.0, want)
 
 
 def _exr_zip_half(img):   # (h, w, 3) float -> scan-line EXR, ZIP (16 lines per block), HALF channels B, G, R

@@ -309,10 +309,10 @@ def test_long_probe_chains_fall_back_to_an_uncounted_rewalk(pkg, gpu, oracle):
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("shape", [(16, 8), (8, 8)])
+@pytest.mark.parametrize("shape", [(16, 8), (8, 8), (32, 4), (2, 16)])
 def test_image_environment_map_matches_oracle(pkg, gpu, oracle, shape):
     """Row a21 InfiniteAreaLight with an image map: level-0 bilinear `le`, Distribution2D importance sampling / pdf, and the
-    spatial light grid built from it."""
+    spatial light grid built from it. (32, 4) and (2, 16): aspects beyond 2:1, whose importance image comes from a coarser level."""
     tex = pkg.scenes.sky_env(*shape)
     b = pkg.scenes.ganesha_scale(n=16, xres=64, yres=40, spp=8, env=False)
     b.rotate(-90.0, 1.0, 0.0, 0.0)

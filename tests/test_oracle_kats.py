@@ -135,11 +135,11 @@ def test_triangle_badcase(oracle, pkg):
 
 
 def test_triangle_reintersect_property(oracle):
-    # tests/shapes.rs:173-224 with the same seeds RNG::new(0..999); 2 000 spawned ray pairs per triangle here
-    # (the reference uses 10 000; the full count runs in tools/ when wanted).
+    # tests/shapes.rs:173-224 with the same seeds RNG::new(0..999) and the reference's 10 000 spawned ray pairs per triangle
+
     oracle.lib.orc_test_triangle_reintersect.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     n = C.c_int()
-    failures = oracle.lib.orc_test_triangle_reintersect(1000, 2000, C.byref(n))
+    failures = oracle.lib.orc_test_triangle_reintersect(1000, 10000, C.byref(n))
     assert n.value > 100
     assert failures == 0
 
