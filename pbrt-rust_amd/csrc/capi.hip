@@ -29,7 +29,9 @@ thread_local int g_num_cus = 256;
 std::atomic<int> g_default_device{-1};
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
-uint32_t g_leaf_quorum[4] = {24, 24, 24, 32};
+uint32_t g_leaf_quorum[4] = {1, 1, 1, 1};         // 1 = a lane at a leaf tests its packet at once. Round 1 shipped {24, 24, 24, 32}, but its ballot ran under the leaf
+                                                  // lanes' exec mask and the quorum never held a lane back; with the ballot fixed (round 2) every real quorum is slower
+                                                  // (C2 at 64 spp: 1 -> 1132, 8 -> 1084, 24 -> 1038, 48 -> 798 Msamples/s): a waiting lane costs more than a thin triangle step
 bool g_refill_from_env = false;
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
@@ -620,6 +622,7 @@ void read_counters(pt_scene *sc) {
     for (int k = 0; k < 5; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; if (k == 4) s.items = d.k_rays[k]; }   // probe chains: items = segments traced
     for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
 #ifdef PT_TRACE_UTIL
+    fprintf(stderr, "[trace-util] kernel saw leaf_quorum = %llu, refill_min = %llu (last launch)\n", d.dbg[0], d.dbg[1]);
     for (int k = 0; k < 4; ++k)
         fprintf(stderr, "[trace-util] %-14s node phase: %.3e wave iterations, %.1f %% lanes active; leaf phase: %.3e iterations, %.1f %% lanes active\n", kn[k], (double)d.regions[4 * k],
                 d.regions[4 * k] ? 100.0 * (double)d.regions[4 * k + 1] / (64.0 * (double)d.regions[4 * k]) : 0.0, (double)d.regions[4 * k + 2], d.regions[4 * k + 2] ? 100.0 * (double)d.regions[4 * k + 3] / (64.0 * (double)d.regions[4 * k + 2]) : 0.0);

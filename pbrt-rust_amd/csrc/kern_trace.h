@@ -249,7 +249,11 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
         // executed for a handful of lanes in every iteration
         const bool at_node = state == ST_ENTER;
         const unsigned long long leaf_m = __ballot(state == ST_LEAF);
-        const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || __ballot(at_node) == 0ull);
+        // (both ballots are taken by the whole wave BEFORE the per-lane test: inside `state == ST_LEAF && (.. || __ballot(at_node) == 0)` the
+        //  short-circuit ran the ballot under the leaf lanes' exec mask only, where it is always 0 -- the quorum never held anything back;
+        //  found in round 2 with the PT_TRACE_UTIL counters: 88 % of all wave iterations ran the triangle test for 5 lanes)
+        const bool no_node_lane = __ballot(at_node) == 0ull;
+        const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || no_node_lane);
         if constexpr (INST) {
             // ---- transform step: enter instances / return from them, once enough lanes wait (or nothing else can run)
             const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     counter_add(&job.counters->k_tris[job.kind], n_tris);
     counter_add(&job.counters->k_rays[job.kind], n_rays);
 #ifdef PT_TRACE_UTIL
+    if (blockIdx.x == 0 && threadIdx.x == 0) { job.counters->dbg[0] = job.leaf_quorum; job.counters->dbg[1] = job.refill_min; job.counters->dbg[2] = job.inst_quorum; }
     for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
     if (lane == 0) {
         atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 1], (unsigned long long)u_act1);

@@ -100,6 +100,7 @@ struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long regions[16];            // PT_REGION_PROFILE builds: wave cycles per k_shade region
+    unsigned long long dbg[4];                 // PT_TRACE_UTIL builds: scheduling knobs as the kernel saw them
     unsigned long long bss_items, bss_bytes;   // k_bssrdf: probe steps processed / state bytes moved
     unsigned long long k_nodes[5], k_tris[5], k_rays[5];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera, 4 extend_probe (segments)
 };
