@@ -218,8 +218,18 @@ typedef struct PtLight {
 
 /* accelerators/bvh.rs:89-95 LinearBVHNode: left child at index+1, right child at `offset`
  * for interior nodes (n_prims == 0); leaves index `ordered_prims[offset .. offset+n_prims]`. */
-/* HomogeneousMedium (media/homogeneous.rs:13-29): sigma_a, sigma_s after "scale" (api.rs:706-722), Henyey-Greenstein g. */
-typedef struct PtMedium { float sigma_a[3]; float sigma_s[3]; float g; } PtMedium;
+/* Participating media (api.rs make_medium :680-762). PT_MEDIUM_HOMOGENEOUS: HomogeneousMedium (media/homogeneous.rs:13-29): sigma_a,
+ * sigma_s after "scale", Henyey-Greenstein g. PT_MEDIUM_GRID: GridDensityMedium (media/grid.rs): the same three plus a density grid
+ * `density[(z * ny + y) * nx + x]` over the unit cube of medium space and `world_to_medium` = inverse(medium_to_world * translate(p0) *
+ * scale(p1 - p0)); sigma_t = (sigma_a + sigma_s)[0] and 1 / max density are derived by the library as grid.rs:46-60 does. */
+typedef enum PtMediumType { PT_MEDIUM_HOMOGENEOUS = 0, PT_MEDIUM_GRID = 1 } PtMediumType;
+typedef struct PtMedium {
+    float sigma_a[3]; float sigma_s[3]; float g;
+    uint32_t type;                 /* PtMediumType */
+    uint32_t nx, ny, nz;           /* grid media */
+    float world_to_medium[16];
+    const float *density;          /* nx * ny * nz values (host memory in PtSceneDesc) */
+} PtMedium;
 
 typedef enum PtSplitMethod { PT_SPLIT_SAH = 0, PT_SPLIT_HLBVH = 1 } PtSplitMethod;
 typedef struct PtBVHNode {

@@ -502,6 +502,76 @@ static RGB medium_tr(const PtMedium &m, Float t_max, V3 d) {   // homogeneous.rs
     return r;
 }
 struct MediumVertex { bool valid = false; V3 p, wo; uint32_t medium = PT_NONE; Float g = 0; };
+
+// ---- GridDensityMedium (media/grid.rs) -----------------------------------------------------------------------------------
+static Float grid_d(const PtMedium &m, const Scene::GridAux &g, int64_t x, int64_t y, int64_t z) {   // grid.rs:102-110
+    if (x < 0 || y < 0 || z < 0 || x >= (int64_t)m.nx || y >= (int64_t)m.ny || z >= (int64_t)m.nz) return 0.0f;
+    return g.density[((size_t)z * m.ny + (size_t)y) * m.nx + (size_t)x];
+}
+static Float grid_density(const PtMedium &m, const Scene::GridAux &g, V3 p) {   // grid.rs:77-100
+    const Float sx = p.x * (Float)m.nx - 0.5f, sy = p.y * (Float)m.ny - 0.5f, sz = p.z * (Float)m.nz - 0.5f;
+    const int64_t ix = f2i_sat(sx), iy = f2i_sat(sy), iz = f2i_sat(sz);   // Point3i::from(Point3f) is `x as isize` (point.rs:618-626): truncation towards zero, not floor
+    const Float dx = sx - (Float)ix, dy = sy - (Float)iy, dz = sz - (Float)iz;
+    auto lerp_ = [](Float t, Float a, Float b) { return a * (1.0f - t) + b * t; };   // pbrt.rs:136-144
+    const Float d00 = lerp_(dx, grid_d(m, g, ix, iy, iz), grid_d(m, g, ix + 1, iy, iz));
+    const Float d10 = lerp_(dx, grid_d(m, g, ix, iy + 1, iz), grid_d(m, g, ix + 1, iy + 1, iz));
+    const Float d01 = lerp_(dx, grid_d(m, g, ix, iy, iz + 1), grid_d(m, g, ix + 1, iy, iz + 1));
+    const Float d11 = lerp_(dx, grid_d(m, g, ix, iy + 1, iz + 1), grid_d(m, g, ix + 1, iy + 1, iz + 1));
+    return lerp_(dz, lerp_(dy, d00, d10), lerp_(dy, d01, d11));
+}
+// The ray of grid.rs:115-117 / :155-158 in medium space and its overlap [tmin, tmax] with the unit cube (Bounds3f::intersect_p,
+// bounds.rs:533-557). Returns false when the ray misses the medium's bounds.
+static bool grid_ray(const PtMedium &m, const Ray &ray, Ray &r, Float &tmin, Float &tmax) {
+    M4 w2m = m4_from(m.world_to_medium);
+    r = xf_ray(w2m, Ray(ray.o, normalize(ray.d), ray.t_max * length(ray.d), 0.0f));
+    Float t0 = 0.0f, t1 = r.t_max;
+    const Float o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+    for (int i = 0; i < 3; ++i) {
+        const Float inv = 1.0f / d[i];
+        Float tnear = (0.0f - o[i]) * inv, tfar = (1.0f - o[i]) * inv;
+        if (tnear > tfar) std::swap(tnear, tfar);
+        tfar *= 1.0f + 2.0f * gamma(3);
+        t0 = tnear > t0 ? tnear : t0;
+        t1 = tfar < t1 ? tfar : t1;
+        if (t0 > t1) return false;
+    }
+    tmin = t0; tmax = t1;
+    return true;
+}
+template <class S> static RGB grid_tr(const PtMedium &m, const Scene::GridAux &g, const Ray &ray, S &sampler) {   // grid.rs:113-147: ratio tracking
+    Ray r; Float tmin, tmax;
+    if (!grid_ray(m, ray, r, tmin, tmax)) return RGB(1.0f);
+    Float tr = 1.0f, t = tmin;
+    for (;;) {
+        t -= dm_logf(1.0f - sampler.get_1d()) * g.inv_max_density / g.sigma_t;
+        if (t >= tmax) break;
+        const Float density = grid_density(m, g, r.o + r.d * t);
+        tr *= 1.0f - fmax_(density * g.inv_max_density, 0.0f);
+        const Float rr_threshold = 0.1f;   // grid.rs:136-143: roulette on low transmittance
+        if (tr < rr_threshold) {
+            const Float q = fmax_(1.0f - tr, 0.05f);
+            if (sampler.get_1d() < q) return RGB(0.0f);
+            tr /= 1.0f - q;
+        }
+    }
+    return RGB(tr);
+}
+template <class S> static RGB grid_sample(const PtMedium &m, const Scene::GridAux &g, uint32_t mid, const Ray &ray, S &sampler, MediumVertex &mi) {   // grid.rs:149-182: delta tracking
+    Ray r; Float tmin, tmax;
+    if (!grid_ray(m, ray, r, tmin, tmax)) return RGB(1.0f);
+    Float t = tmin;
+    for (;;) {
+        t -= dm_logf(1.0f - sampler.get_1d()) * g.inv_max_density / g.sigma_t;
+        if (t >= tmax) break;
+        if (grid_density(m, g, r.o + r.d * t) * g.inv_max_density > sampler.get_1d()) {
+            // (the reference evaluates `ray.find_point(t)` with the medium-space parameter on the WORLD ray, as written in grid.rs:173)
+            mi.valid = true; mi.p = ray.o + ray.d * t; mi.wo = -ray.d; mi.medium = mid; mi.g = m.g;
+            return RGB(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) / g.sigma_t;
+        }
+    }
+    return RGB(1.0f);
+}
+
 static RGB medium_sample(const PtMedium &m, uint32_t mid, const Ray &ray, SobolSampler &sampler, MediumVertex &mi) {   // homogeneous.rs:37-68
     Float sigma_t[3] = {m.sigma_a[0] + m.sigma_s[0], m.sigma_a[1] + m.sigma_s[1], m.sigma_a[2] + m.sigma_s[2]};
     Float uc = sampler.get_1d() * 3.0f;
@@ -540,6 +610,15 @@ static Float hg_sample_p(Float g, V3 wo, V3 &wi, P2 u) {   // medium.rs:173-193
     wi = v1 * sin_theta * dm_cosf(phi) + v2 * sin_theta * dm_sinf(phi) + wo * cos_theta;   // spherical_direction_basis (geometry.rs:36-38)
     return phase_hg(cos_theta, g);
 }
+// Medium::tr / Medium::sample by medium type
+template <class S> static RGB medium_tr_any(const Scene &sc, uint32_t mid, const Ray &ray, S &sampler) {
+    const PtMedium &m = sc.media[mid];
+    return m.type == PT_MEDIUM_GRID ? grid_tr(m, sc.grid_aux[mid], ray, sampler) : medium_tr(m, ray.t_max, ray.d);
+}
+template <class S> static RGB medium_sample_any(const Scene &sc, uint32_t mid, const Ray &ray, S &sampler, MediumVertex &mi) {
+    const PtMedium &m = sc.media[mid];
+    return m.type == PT_MEDIUM_GRID ? grid_sample(m, sc.grid_aux[mid], mid, ray, sampler, mi) : medium_sample(m, mid, ray, sampler, mi);
+}
 // the interaction's MediumInterface: the primitive's own when it is a transition, else the ray's medium on both sides
 // (primitive.rs:139-145); get_medium_vec (interaction.rs:54-66)
 struct MedIface { uint32_t inside = PT_NONE, outside = PT_NONE; };
@@ -552,7 +631,7 @@ static inline uint32_t medium_toward(const MedIface &m, V3 n, V3 w) { return dot
 
 // estimate_direct with handle_media = true (integrator.rs:109-237) for a surface (bsdf != nullptr) or a medium vertex
 static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedIface &mif, const SurfaceInteraction *si, const BSDF *bsdf, Float g,
-                               P2 uscatt, uint32_t li, P2 ulight) {
+                               P2 uscatt, uint32_t li, P2 ulight, SobolSampler &sampler) {   // the sampler: grid media draw their tracking steps from it (grid.rs)
     const Scene &S = *ctx.scene;
     const int flags = BSDF_ALL & ~BSDF_SPECULAR;
     RGB Ld(0.0f);
@@ -570,7 +649,7 @@ static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedI
             SurfaceInteraction tmp;
             RGB Tr(1.0f);
             if (S.intersect(sr, tmp, *ctx.c)) Tr = RGB(0.0f);
-            else if (sr.medium != PT_NONE) Tr = Tr * medium_tr(S.media[sr.medium], sr.t_max, sr.d);
+            else if (sr.medium != PT_NONE) Tr = Tr * medium_tr_any(S, sr.medium, sr, sampler);
             Li = Li * Tr;
             if (!Li.is_black()) {
                 if (delta) Ld += f * Li / lightpdf;
@@ -599,7 +678,7 @@ static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedI
             // Scene::intersect_tr (scene.rs:68-87)
             bool found = S.intersect(ray, lisect, *ctx.c);
             RGB Tr(1.0f);
-            if (ray.medium != PT_NONE) Tr = Tr * medium_tr(S.media[ray.medium], ray.t_max, ray.d);
+            if (ray.medium != PT_NONE) Tr = Tr * medium_tr_any(S, ray.medium, ray, sampler);
             RGB li_(0.0f);
             if (found) { if (S.prim_light[lisect.prim] == li) li_ = isect_le(ctx, lisect, -wi); }
             else li_ = ctx.lights->light_le(li, ray);
@@ -616,7 +695,7 @@ static RGB vol_uniform_sample_onelight(const RenderCtx &ctx, const IData &it, co
     if (lightpdf == 0.0f) return RGB(0.0f);
     P2 ulight = sampler.get_2d();
     P2 uscatt = sampler.get_2d();
-    return vol_estimate_direct(ctx, it, mif, si, bsdf, g, uscatt, (uint32_t)lightnum, ulight) / lightpdf;
+    return vol_estimate_direct(ctx, it, mif, si, bsdf, g, uscatt, (uint32_t)lightnum, ulight, sampler) / lightpdf;
 }
 static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSampler &sampler, RayDiff rdiff = RayDiff()) {
     const Scene &S = *ctx.scene;
@@ -628,7 +707,7 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
         SurfaceInteraction isect;
         bool found = S.intersect(ray, isect, *ctx.c);
         MediumVertex mi;
-        if (ray.medium != PT_NONE) beta *= medium_sample(S.media[ray.medium], ray.medium, ray, sampler, mi);
+        if (ray.medium != PT_NONE) beta *= medium_sample_any(S, ray.medium, ray, sampler, mi);
         if (beta.is_black()) break;
         if (mi.valid) {
             if (bounces >= pp.max_depth) break;
@@ -917,7 +996,20 @@ int orc_scene_create(const PtSceneDesc *d, orc_scene **out) {
     }
     s.max_node_prims = d->max_node_prims ? d->max_node_prims : 4;
     s.split_method = d->split_method;
-    if (d->n_media && d->media) s.media.assign(d->media, d->media + d->n_media);
+    if (d->n_media && d->media) {
+        s.media.assign(d->media, d->media + d->n_media);
+        s.grid_aux.resize(d->n_media);
+        for (uint32_t i = 0; i < d->n_media; ++i) {
+            if (s.media[i].type != PT_MEDIUM_GRID) continue;
+            const PtMedium &m = s.media[i];
+            Scene::GridAux &g = s.grid_aux[i];
+            g.density.assign(m.density, m.density + (size_t)m.nx * m.ny * m.nz);
+            g.sigma_t = m.sigma_a[0] + m.sigma_s[0];
+            Float maxd = 0.0f;
+            for (Float v : g.density) maxd = fmax_(maxd, v);
+            g.inv_max_density = 1.0f / maxd;
+        }
+    }
     if (d->prim_medium_inside && d->prim_medium_outside) { s.prim_med_in.assign(d->prim_medium_inside, d->prim_medium_inside + d->n_prims); s.prim_med_out.assign(d->prim_medium_outside, d->prim_medium_outside + d->n_prims); }
     if (d->n_instances && d->top_refs) {
         s.objects.assign(d->objects, d->objects + d->n_objects);

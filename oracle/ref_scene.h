@@ -105,6 +105,9 @@ struct Scene {
     uint32_t max_node_prims = 4, split_method = PT_SPLIT_SAH;
     // participating media (volpath only): HomogeneousMedium table + per-primitive MediumInterface (PT_NONE = none)
     std::vector<PtMedium> media; std::vector<uint32_t> prim_med_in, prim_med_out;
+    // GridDensityMedium (media/grid.rs): own copy of each grid's densities, sigma_t = (sigma_a + sigma_s)[0], 1 / max density (grid.rs:46-60)
+    struct GridAux { std::vector<Float> density; Float sigma_t = 0, inv_max_density = 0; };
+    std::vector<GridAux> grid_aux;
     std::vector<PtBVHNode> nodes;       // top-level accelerator
     std::vector<uint32_t> ordered;      // positions in the top-level list (see top_ref)
     struct Accel { std::vector<PtBVHNode> nodes; std::vector<uint32_t> ordered; };

@@ -50,8 +50,12 @@ class PtMaterial(C.Structure):
                 ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32), ("disney_scatter", f32 * 3)]
 
 
+PT_MEDIUM_HOMOGENEOUS, PT_MEDIUM_GRID = 0, 1
+
+
 class PtMedium(C.Structure):
-    _fields_ = [("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("g", f32)]
+    _fields_ = [("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("g", f32), ("type", u32), ("nx", u32), ("ny", u32), ("nz", u32),
+                ("world_to_medium", f32 * 16), ("density", fp)]
 
 
 class PtLight(C.Structure):

@@ -200,6 +200,7 @@ class SceneBuilder:
         self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None, kind="path")   # kind: "path" | "volpath"
         # participating media (api.rs:706-722,1219-1253): named homogeneous media, the current MediumInterface, the camera's medium
         self.media = []; self.named_media = {}; self.medium_inside = None; self.medium_outside = None; self.camera_medium = None
+        self._keep = []
         self.prim_med_in = []; self.prim_med_out = []
         self.max_node_prims = 4
         self.split_method = "sah"   # accelerator "bvh" "string splitmethod": "sah" | "hlbvh" (bvh.rs:918-940)
@@ -220,13 +221,23 @@ class SceneBuilder:
 
     def toggle_reverse_orientation(self): self.reverse_orientation = not self.reverse_orientation   # ReverseOrientation (api.rs)
 
-    def make_named_medium(self, name, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0, preset=""):
-        """MakeNamedMedium "name" "string type" "homogeneous" (api.rs:706-722): preset from the subsurface table, then * scale."""
+    def make_named_medium(self, name, sigma_a=(0.0011, 0.0024, 0.014), sigma_s=(2.55, 3.21, 3.77), g=0.0, scale=1.0, preset="", density=None, p0=(0.0, 0.0, 0.0), p1=(1.0, 1.0, 1.0)):
+        """MakeNamedMedium "name" "string type" "homogeneous" | "heterogeneous" (api.rs:680-762): preset from the subsurface table, then
+        * scale; `density` (nz, ny, nx) makes it a GridDensityMedium over the box [p0, p1] of the current transform's space."""
         if preset:
             from . import bssrdf as B
             if preset in B.NAMED_MEDIA and sigma_a == (0.0011, 0.0024, 0.014) and sigma_s == (2.55, 3.21, 3.77): sigma_s, sigma_a = B.NAMED_MEDIA[preset]
         m = A.PtMedium()
         m.sigma_a = (C.c_float * 3)(*[float(F(x) * F(scale)) for x in sigma_a]); m.sigma_s = (C.c_float * 3)(*[float(F(x) * F(scale)) for x in sigma_s]); m.g = float(g)
+        m.type = A.PT_MEDIUM_HOMOGENEOUS
+        if density is not None:   # "heterogeneous" (api.rs:723-752): GridDensityMedium over [p0, p1] of the CTM's space
+            d = np.ascontiguousarray(density, dtype=F)
+            nz, ny, nx = d.shape          # density[z][y][x]
+            med2w = self.ctm * Transform.translate(tuple(float(x) for x in p0)) * Transform.scale(float(p1[0]) - float(p0[0]), float(p1[1]) - float(p0[1]), float(p1[2]) - float(p0[2]))
+            m.type = A.PT_MEDIUM_GRID; m.nx, m.ny, m.nz = nx, ny, nz
+            m.world_to_medium = (C.c_float * 16)(*med2w.m_inv.flatten())
+            m.density = d.ctypes.data_as(A.fp)
+            self._keep.append(d)         # the struct points into the array
         self.media.append(m); self.named_media[name] = len(self.media) - 1
 
     def medium_interface(self, inside="", outside=""):
@@ -691,7 +702,7 @@ class SceneData:
         self.spheres = (A.PtSphere * max(1, len(b.spheres)))(*b.spheres)
         self.n_materials, self.n_lights, self.n_spheres = len(b.materials), len(b.lights), len(b.spheres)
         self.env = b.env
-        self.media = (A.PtMedium * max(1, len(b.media)))(*b.media); self.n_media = len(b.media)
+        self.media = (A.PtMedium * max(1, len(b.media)))(*b.media); self.n_media = len(b.media); self._keep = b._keep   # (grid media point into numpy arrays)
         self.prim_med_in = c1(b.prim_med_in) if b.media else None; self.prim_med_out = c1(b.prim_med_out) if b.media else None
         self.max_node_prims = b.max_node_prims
         self.split_method = {"sah": A.PT_SPLIT_SAH, "hlbvh": A.PT_SPLIT_HLBVH}[b.split_method]

@@ -786,3 +786,28 @@ CONFIG_SCENES = {   # bench.py --config / tests: name -> (builder, spp named by 
     "C4": (ecosystem_s4, 2048, "S4 Ecosystem-scale: 2,000 object instances of three 50 k-triangle plants over a 500 k-triangle terrain, 512x256 environment map only"),
     "C5": (dragon_s5, 4096, "S5 Dragon-subsurface-scale: the 4,298,312-triangle S2 mesh x0.02 with subsurface Skin1 (scale 20, eta 1.5) over a matte plane, environment map"),
 }
+
+
+def smoke_room(xres=64, yres=48, spp=16, maxdepth=4, n=8, g=0.2, sampler="sobol"):
+    """media/grid.rs: the camera (and so the whole world) sits in a GridDensityMedium whose density -- a soft blob on an n^3 grid -- lives in the
+    box [-1.2, 1.2] x [-0.4, 2.0] x [-1.2, 1.2]; outside the box rays miss the medium's bounds (Tr = 1). Ratio tracking on shadow / MIS
+    rays and delta tracking on path segments draw a data-dependent number of sampler dimensions in the middle of a vertex."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth, kind="volpath")
+    b.sampler = sampler
+    z, y, x = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n), np.linspace(-1, 1, n), indexing="ij")
+    dens = (np.exp(-2.5 * (x * x + (y * 1.2) ** 2 + z * z)) * (1.0 + 0.3 * np.sin(5.0 * x) * np.cos(4.0 * z))).astype(F)
+    b.make_named_medium("smoke", sigma_a=(0.4, 0.4, 0.4), sigma_s=(1.6, 1.6, 1.6), g=g, density=dens, p0=(-1.2, -0.4, -1.2), p1=(1.2, 2.0, 1.2))
+    b.medium_interface("", "smoke")
+    b.look_at((0.0, 1.4, 5.0), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.05, 0.06, 0.08))
+    b.attribute_begin(); b.area_light_source(L=(25.0, 22.0, 18.0))
+    P, I = quad((-0.7, 3.4, -0.7), (0.7, 3.4, -0.7), (0.7, 3.4, 0.7), (-0.7, 3.4, 0.7)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("point", from_=(-2.5, 1.5, -2.5), I=(14.0, 12.0, 10.0))
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I)
+    b.material("plastic", Kd=(0.6, 0.2, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2)
+    b.attribute_begin(); b.translate(-1.9, 0.1, 0.3); b.sphere(radius=0.6); b.attribute_end()
+    return b

@@ -134,3 +134,96 @@ def test_gpu_volpath_refuses_what_it_cannot_render(pkg, gpu):
     b = pkg.scenes.subsurface_c5(xres=32, yres=24, spp=2); b.integ["kind"] = "volpath"
     sd, rp = b.world_end()
     with pytest.raises(Exception, match="subsurface"): pkg.Scene(gpu, sd).render(rp)
+
+
+# ---- GridDensityMedium (media/grid.rs) ----------------------------------------------------------------
+
+def _grid_wall(pkg, sigma_a, sigma_s, dist, density, p0, p1, maxdepth=2, spp=2048):
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=8, yres=8); b.spp = spp
+    b.integ.update(maxdepth=maxdepth, kind="volpath")
+    b.make_named_medium("smoke", sigma_a=(sigma_a,) * 3, sigma_s=(sigma_s,) * 3, density=density, p0=p0, p1=p1)
+    b.medium_interface("", "smoke")
+    b.look_at((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0)); b.camera(fov=2.0)
+    b.world_begin()
+    b.material("matte", Kd=(0.0, 0.0, 0.0))
+    b.area_light_source(L=(3.0, 2.0, 1.0))
+    P, I = pkg.scenes.quad((-5.0, -5.0, -dist), (5.0, -5.0, -dist), (5.0, 5.0, -dist), (-5.0, 5.0, -dist))
+    b.trianglemesh(P, I)
+    return b.world_end()
+
+
+def _grid_density_numpy(dens, p):
+    """grid.rs:77-110 restated with numpy for the closed forms below: samples at voxel centres, `Point3i::from` truncates towards zero
+    (`as isize`, point.rs:618-626 -- so below the first centre the weights extrapolate instead of fading out), zero outside the grid."""
+    nz, ny, nx = dens.shape
+    ps = np.asarray(p, np.float64) * np.array([nx, ny, nz]) - 0.5
+    pi = np.trunc(ps).astype(np.int64); d = ps - pi
+    def D(x, y, z):
+        ok = (x >= 0) & (x < nx) & (y >= 0) & (y < ny) & (z >= 0) & (z < nz)
+        return np.where(ok, dens[np.clip(z, 0, nz - 1), np.clip(y, 0, ny - 1), np.clip(x, 0, nx - 1)], 0.0)
+    lerp = lambda t, a, b: a * (1 - t) + b * t
+    x, y, z = pi[..., 0], pi[..., 1], pi[..., 2]
+    d00 = lerp(d[..., 0], D(x, y, z), D(x + 1, y, z)); d10 = lerp(d[..., 0], D(x, y + 1, z), D(x + 1, y + 1, z))
+    d01 = lerp(d[..., 0], D(x, y, z + 1), D(x + 1, y, z + 1)); d11 = lerp(d[..., 0], D(x, y + 1, z + 1), D(x + 1, y + 1, z + 1))
+    return lerp(d[..., 2], lerp(d[..., 1], d00, d10), lerp(d[..., 1], d01, d11))
+
+
+def _optical_depth_along_minus_z(dens, p0, p1, sigma_t):
+    """integral of sigma_t * density along the camera ray x = y = 0, z from p1.z down to p0.z (world units)."""
+    zs = np.linspace(p1[2], p0[2], 200001)
+    pm = np.stack([np.full_like(zs, (0.0 - p0[0]) / (p1[0] - p0[0])), np.full_like(zs, (0.0 - p0[1]) / (p1[1] - p0[1])), (zs - p0[2]) / (p1[2] - p0[2])], axis=-1)
+    return sigma_t * np.trapezoid(np.maximum(_grid_density_numpy(dens.astype(np.float64), pm), 0.0), -zs)
+
+
+@pytest.mark.parametrize("case", ["constant", "half_density_double_sigma", "ramp"])
+def test_grid_medium_closed_form(pkg, oracle, case):
+    """An absorbing GridDensityMedium between the camera and an emissive wall: delta tracking (grid.rs:149-182) lets a ray through with
+    probability exp(-integral of sigma_t * density), and an absorbed ray scatters with weight sigma_s / sigma_t = 0, so
+    E[L] = Le * exp(-optical depth), the depth integrated over an independent numpy restatement of `density()`. Halving the density
+    while doubling sigma_t changes the majorant, not the mean."""
+    p0, p1 = (-1.0, -1.0, -2.0), (1.0, 1.0, -0.5)
+    if case == "constant": dens, sig = np.full((2, 2, 2), 1.0, np.float32), 0.8
+    elif case == "half_density_double_sigma": dens, sig = np.full((2, 2, 2), 0.5, np.float32), 1.6
+    else:
+        rng = np.random.default_rng(3); dens = rng.uniform(0.1, 1.0, (5, 3, 4)).astype(np.float32); sig = 1.1
+    want = np.array([3.0, 2.0, 1.0]) * np.exp(-_optical_depth_along_minus_z(dens, p0, p1, sig))
+    sd, rp = _grid_wall(pkg, sig, 0.0, 3.0, dens, p0, p1, spp=4096)
+    s = oracle.scene(sd)
+    rgb = s.resolve(s.render(rp, nthreads=4)).reshape(-1, 3).mean(axis=0)
+    assert np.all(np.abs(rgb - want) < 0.03 * want), (case, rgb, want)
+
+
+def test_grid_medium_ratio_tracking_on_shadow_rays(pkg, oracle):
+    """Single scattering off a black-walled scene's matte floor lit through a constant-density absorbing slab: the shadow ray's transmittance
+    comes from ratio tracking (grid.rs:113-147, sampler dimensions drawn in the middle of estimate_direct). The floor point's radiance
+    is the unshadowed value times exp(-sigma_t * path length inside the slab)."""
+    def build(with_medium):
+        b = pkg.host.SceneBuilder()
+        b.film.update(xres=6, yres=6); b.spp = 4096
+        b.integ.update(maxdepth=1, kind="volpath")
+        if with_medium:
+            b.make_named_medium("slab", sigma_a=(0.9,) * 3, sigma_s=(0.0,) * 3, density=np.ones((2, 2, 2), np.float32), p0=(-50.0, 1.0, -50.0), p1=(50.0, 2.0, 50.0))
+            b.medium_interface("", "slab")
+        b.look_at((0.0, 0.5, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=1.0)
+        b.world_begin()
+        b.light_source("point", from_=(0.0, 4.0, 0.0), I=(30.0, 30.0, 30.0))
+        b.material("matte", Kd=(0.6, 0.6, 0.6))
+        P, I = pkg.scenes.quad((-20.0, 0.0, -20.0), (-20.0, 0.0, 20.0), (20.0, 0.0, 20.0), (20.0, 0.0, -20.0)); b.trianglemesh(P, I)
+        return b.world_end()
+    sd, rp = build(False); s = oracle.scene(sd); base = s.resolve(s.render(rp, nthreads=4)).mean()
+    sd, rp = build(True); s = oracle.scene(sd); got = s.resolve(s.render(rp, nthreads=4)).mean()
+    # the light is straight above the shaded point: the shadow ray crosses the slab along y (one unit), the camera ray stays below y = 1.
+    # optical depth of a constant 2x2x2 grid along an axis through its centre: the far half-voxel fades to d / 2, the near one does not
+    # (truncating Point3i::from, see _grid_density_numpy): 0.9375 of the nominal thickness
+    ys = np.linspace(0.0, 1.0, 100001)
+    depth = 0.9 * np.trapezoid(_grid_density_numpy(np.ones((2, 2, 2)), np.stack([np.full_like(ys, 0.5), ys, np.full_like(ys, 0.5)], axis=-1)), ys) * 1.0
+    want = base * np.exp(-depth)
+    assert abs(got - want) < 0.03 * want, (got, want, base)
+
+
+def test_smoke_room_renders_on_the_oracle(pkg, oracle):
+    sd, rp = pkg.scenes.smoke_room(xres=32, yres=24, spp=8, sampler="halton").world_end()
+    s = oracle.scene(sd)
+    film = s.render(rp, nthreads=4); c = s.counters()
+    assert np.isfinite(film).all() and c["camera_rays"] == 32 * 24 * 8 == sum(c["path_length_hist"]) and film[..., :3].max() > 0
