@@ -545,6 +545,7 @@ template <class S> static RGB grid_tr(const PtMedium &m, const Scene::GridAux &g
     for (;;) {
         t -= dm_logf(1.0f - sampler.get_1d()) * g.inv_max_density / g.sigma_t;
         if (t >= tmax) break;
+        if (sampler.dim_overflow) return RGB(0.0f);   // past the sampler's last dimension the reference panics; the render reports the error
         const Float density = grid_density(m, g, r.o + r.d * t);
         tr *= 1.0f - fmax_(density * g.inv_max_density, 0.0f);
         const Float rr_threshold = 0.1f;   // grid.rs:136-143: roulette on low transmittance
@@ -563,6 +564,7 @@ template <class S> static RGB grid_sample(const PtMedium &m, const Scene::GridAu
     for (;;) {
         t -= dm_logf(1.0f - sampler.get_1d()) * g.inv_max_density / g.sigma_t;
         if (t >= tmax) break;
+        if (sampler.dim_overflow) break;
         if (grid_density(m, g, r.o + r.d * t) * g.inv_max_density > sampler.get_1d()) {
             // (the reference evaluates `ray.find_point(t)` with the medium-space parameter on the WORLD ray, as written in grid.rs:173)
             mi.valid = true; mi.p = ray.o + ray.d * t; mi.wo = -ray.d; mi.medium = mid; mi.g = m.g;

@@ -476,7 +476,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 2^32 - 1 intersections" : "Sobol dimension overflow (>= 1024)");
         if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 65536 wavefront iterations");
         const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
-        if (n_ext == 0 && n_resolve == 0 && n_probe == 0) break;
+        // volpath with grid media: vertices that did their NEE set-up last iteration wait in their own shade class for stage B
+        uint32_t n_stage_b = 0;
+        if (rc.volpath && sc->ds.has_grid) for (int c = 0; c < kNumClasses; ++c) if (c != kMissClass) n_stage_b += h.shade[cur][c];
+        if (n_ext == 0 && n_resolve == 0 && n_probe == 0 && n_stage_b == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
         tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.scalar_tmax = INFINITY;
@@ -558,7 +561,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sc->end();
         }
         uint32_t class_n[kNumClasses];
-        const uint32_t upper = n_ext + n_resolve;
+        const uint32_t upper = n_ext + n_resolve + n_stage_b;
         if (rp_profile_exact) {  // exact per-class item counts for the statistics (costs one extra sync per iteration)
             QCounters h2;
             HIP_TRY(hipMemcpyAsync(&h2, qc, sizeof h2, hipMemcpyDeviceToHost, sc->stream));
@@ -573,6 +576,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; sj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
+            sj.self_next = sc->q.shade[1 - cur][c]; sj.self_next_count = &qc->shade[1 - cur][c];
             if (c == 3 && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c == kMediumClass) {
@@ -892,6 +896,22 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     UP(materials, d->materials, d->n_materials); ds.n_materials = d->n_materials;
     if (d->n_media && d->media) {   // participating media (volpath only)
         UP(media, d->media, d->n_media); ds.n_media = d->n_media;
+        std::vector<DevGridAux> aux(d->n_media, DevGridAux{nullptr, 0.0f, 0.0f});
+        for (uint32_t i = 0; i < d->n_media; ++i) {   // GridDensityMedium::new (grid.rs:40-72)
+            const PtMedium &m = d->media[i];
+            if (m.type > PT_MEDIUM_GRID) return bail(fail(PT_ERR_INVALID_ARG, "unknown medium type"));
+            if (m.type != PT_MEDIUM_GRID) continue;
+            const size_t nvox = (size_t)m.nx * m.ny * m.nz;
+            if (!m.density || nvox == 0 || nvox > ((size_t)1 << 31)) return bail(fail(PT_ERR_INVALID_ARG, "grid medium without a density grid"));
+            for (int k = 1; k < 3; ++k) if (m.sigma_a[k] + m.sigma_s[k] != m.sigma_a[0] + m.sigma_s[0]) return bail(fail(PT_ERR_UNSUPPORTED, "GridDensityMedium requires a spectrally uniform attenuation coefficient (grid.rs:49-52 reports an error)"));
+            float maxd = 0.0f;
+            for (size_t k = 0; k < nvox; ++k) maxd = std::fmax(maxd, m.density[k]);
+            if (!(maxd > 0.0f)) return bail(fail(PT_ERR_INVALID_ARG, "grid medium with no positive density"));
+            if ((st = sc->upload(&aux[i].density, m.density, nvox))) return bail(st);
+            aux[i].sigma_t = m.sigma_a[0] + m.sigma_s[0]; aux[i].inv_max_density = 1.0f / maxd;
+            ds.has_grid = 1u;
+        }
+        UP(grid_aux, aux.data(), aux.size());
         if (d->prim_medium_inside && d->prim_medium_outside) {
             for (uint32_t i = 0; i < d->n_prims; ++i)
                 if ((d->prim_medium_inside[i] != PT_NONE && d->prim_medium_inside[i] >= d->n_media) || (d->prim_medium_outside[i] != PT_NONE && d->prim_medium_outside[i] >= d->n_media))

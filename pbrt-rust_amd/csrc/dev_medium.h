@@ -32,6 +32,83 @@ PT_DEV RGB medium_sample(const PtMedium &m, float t_max, V3 d, float u_channel, 
     const RGB Tr(tr[0], tr[1], tr[2]);
     return sampled ? Tr * RGB(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) / pdf : Tr / pdf;
 }
+// ---- GridDensityMedium (media/grid.rs) --------------------------------------------------------------------------------------
+PT_DEV float grid_d(const PtMedium &m, const float *density, long long x, long long y, long long z) {   // grid.rs:102-110
+    if (x < 0 || y < 0 || z < 0 || x >= (long long)m.nx || y >= (long long)m.ny || z >= (long long)m.nz) return 0.0f;
+    return density[((size_t)z * m.ny + (size_t)y) * m.nx + (size_t)x];
+}
+PT_DEV float grid_lerp(float t, float a, float b) { return a * (1.0f - t) + b * t; }   // pbrt.rs:136-144
+PT_DEV float grid_density(const PtMedium &m, const float *density, V3 p) {   // grid.rs:77-100; Point3i::from is `x as isize` (truncates towards zero)
+    const float sx = p.x * (float)m.nx - 0.5f, sy = p.y * (float)m.ny - 0.5f, sz = p.z * (float)m.nz - 0.5f;
+    const long long ix = f2i_sat(sx), iy = f2i_sat(sy), iz = f2i_sat(sz);
+    const float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+    const float d00 = grid_lerp(dx, grid_d(m, density, ix, iy, iz), grid_d(m, density, ix + 1, iy, iz));
+    const float d10 = grid_lerp(dx, grid_d(m, density, ix, iy + 1, iz), grid_d(m, density, ix + 1, iy + 1, iz));
+    const float d01 = grid_lerp(dx, grid_d(m, density, ix, iy, iz + 1), grid_d(m, density, ix + 1, iy, iz + 1));
+    const float d11 = grid_lerp(dx, grid_d(m, density, ix, iy + 1, iz + 1), grid_d(m, density, ix + 1, iy + 1, iz + 1));
+    return grid_lerp(dz, grid_lerp(dy, d00, d10), grid_lerp(dy, d01, d11));
+}
+// The ray of grid.rs:115-117 / :155-158 in medium space (o + normalize(d) * t, t_max * |d|, through world_to_medium with the error-bound
+// shift of Transform::transform_ray) and its overlap [tmin, tmax] with the unit cube (Bounds3f::intersect_p, bounds.rs:533-557).
+PT_DEV bool grid_ray(const PtMedium &m, V3 o, V3 d, float t_max, V3 &ro, V3 &rd, float &tmin, float &tmax) {
+    const M4 w2m = ldm4g(m.world_to_medium);
+    const V3 dn = normalize(d);
+    float tm = t_max * length(d);
+    V3 oerr; ro = xf_point_err(w2m, o, oerr); rd = xf_vector(w2m, dn);
+    const float l2 = length_squared(rd);
+    if (l2 > 0.0f) { const float dt = dot(vabs(rd), oerr) / l2; ro = ro + rd * dt; tm -= dt; }
+    float t0 = 0.0f, t1 = tm;
+    const float oc[3] = {ro.x, ro.y, ro.z}, dc[3] = {rd.x, rd.y, rd.z};
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.0f / dc[i];
+        float tnear = (0.0f - oc[i]) * inv, tfar = (1.0f - oc[i]) * inv;
+        if (tnear > tfar) { const float tmp = tnear; tnear = tfar; tfar = tmp; }
+        tfar *= 1.0f + 2.0f * gammaf(3);
+        t0 = tnear > t0 ? tnear : t0;
+        t1 = tfar < t1 ? tfar : t1;
+        if (t0 > t1) return false;
+    }
+    tmin = t0; tmax = t1;
+    return true;
+}
+// GridDensityMedium::tr (grid.rs:113-147): ratio tracking with roulette on low transmittance; draws its steps from the path's sampler
+template <class S> PT_DEV float grid_tr(const PtMedium &m, const DevGridAux &g, V3 o, V3 d, float t_max, S &smp) {
+    V3 ro, rd; float tmin, tmax;
+    if (!grid_ray(m, o, d, t_max, ro, rd, tmin, tmax)) return 1.0f;
+    float tr = 1.0f, t = tmin;
+    for (;;) {
+        t -= dm_logf(1.0f - smp.get_1d()) * g.inv_max_density / g.sigma_t;
+        if (t >= tmax) break;
+        if (smp.overflow) return 0.0f;   // (dimension overflow is reported as an error by the caller; leave the loop)
+        const float density = grid_density(m, g.density, ro + rd * t);
+        tr *= 1.0f - maxf(density * g.inv_max_density, 0.0f);
+        if (tr < 0.1f) {
+            const float q = maxf(1.0f - tr, 0.05f);
+            if (smp.get_1d() < q) return 0.0f;
+            tr /= 1.0f - q;
+        }
+    }
+    return tr;
+}
+// GridDensityMedium::sample (grid.rs:149-182): delta tracking. Returns the beta factor; `sampled` + the vertex's parameter `t` (applied to
+// the WORLD ray as the reference does: `ray.find_point(t)`, grid.rs:173).
+template <class S> PT_DEV RGB grid_sample(const PtMedium &m, const DevGridAux &g, V3 o, V3 d, float t_max, S &smp, bool &sampled, float &t_out) {
+    sampled = false;
+    V3 ro, rd; float tmin, tmax;
+    if (!grid_ray(m, o, d, t_max, ro, rd, tmin, tmax)) return RGB(1.0f);
+    float t = tmin;
+    for (;;) {
+        t -= dm_logf(1.0f - smp.get_1d()) * g.inv_max_density / g.sigma_t;
+        if (t >= tmax) break;
+        if (smp.overflow) break;
+        if (grid_density(m, g.density, ro + rd * t) * g.inv_max_density > smp.get_1d()) {
+            sampled = true; t_out = t;
+            return RGB(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) / g.sigma_t;
+        }
+    }
+    return RGB(1.0f);
+}
+
 PT_DEV float phase_hg(float cos_theta, float g) {
     const float denom = 1.0f + g * g + 2.0f * g * cos_theta;
     return kInv4Pi * (1.0f - g * g) / (denom * sqrtf(denom));

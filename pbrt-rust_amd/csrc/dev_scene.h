@@ -47,6 +47,9 @@ struct DevInstance {
     uint32_t pad;
 };
 
+// media/grid.rs GridDensityMedium: what the device needs besides the PtMedium record
+struct DevGridAux { const float *density; float sigma_t, inv_max_density; };
+
 // core/bssrdf.rs:241-268 BSSRDFTable (device copy of PtBSSRDFTable)
 struct DevBssTable { int n_rho, n_radius; const float *rho_samples, *radius_samples, *profile, *rhoeff, *profile_cdf; };
 
@@ -68,7 +71,8 @@ struct DeviceScene {
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class
     const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)
-    const PtMedium *media; uint32_t n_media;                 // homogeneous media + per-primitive MediumInterface (volpath, dev_medium.h)
+    const PtMedium *media; uint32_t n_media;                 // media + per-primitive MediumInterface (volpath, dev_medium.h)
+    const DevGridAux *grid_aux; uint32_t has_grid;           // per medium: GridDensityMedium's device density array, sigma_t, 1 / max density (grid.rs:46-60); any grid medium in the scene
     const uint32_t *prim_med_in; const uint32_t *prim_med_out;
     // textures (8f-1): nodes, one postfix program per node (tex_prog[tex_prog_offset[i] .. tex_prog_offset[i+1])), images
     const PtTexture *textures; uint32_t n_textures; const uint32_t *tex_prog_offset; const uint32_t *tex_prog;

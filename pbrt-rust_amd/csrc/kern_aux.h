@@ -25,10 +25,16 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
                 uint32_t meta = ps.meta(pid);
                 Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
                 smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
-                const float u_channel = smp.get_1d(), u_dist = smp.get_1d();
                 const V3 rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
                 bool sampled; float t;
-                const RGB w = medium_sample(s.media[med], hp != PT_NONE ? ps.hit_t(pid) : PT_INF, rd, u_channel, u_dist, sampled, t);
+                RGB w(1.0f);
+                if (s.media[med].type == PT_MEDIUM_GRID) {   // delta tracking: a data-dependent number of dimensions (grid.rs:149-182)
+                    const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid));
+                    w = grid_sample(s.media[med], s.grid_aux[med], ro, rd, hp != PT_NONE ? ps.hit_t(pid) : PT_INF, smp, sampled, t);
+                } else {
+                    const float u_channel = smp.get_1d(), u_dist = smp.get_1d();
+                    w = medium_sample(s.media[med], hp != PT_NONE ? ps.hit_t(pid) : PT_INF, rd, u_channel, u_dist, sampled, t);
+                }
                 const RGB beta = RGB(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid)) * w;
                 ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
                 uint32_t flags = meta >> 24;
@@ -56,9 +62,9 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
 // the phase function; beta is unchanged (phase value / its pdf = 1) and the ray stays in the same medium.
 __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
-    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis, s_qself;
     __shared__ uint32_t s_hist[16];
-    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qself);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #ifdef PT_REGION_PROFILE
     __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
         const bool valid = qi < count;
-        bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
+        bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_self = false;
         int finished_bounces = -1;
         uint32_t pid = 0;
         if (valid) {
@@ -84,18 +90,26 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
             smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
             RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
-            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
-            flags &= ~PF_CAMERA_RAY;
+            const bool stage_b = (flags & PF_STAGE_B) != 0u;   // grid media: this vertex's own NEE rays are back (see k_shade)
+            if (stage_b) smp.load_window();
+            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+            flags &= ~(PF_CAMERA_RAY | PF_STAGE_B);
             bool terminated = bounces >= rc.max_depth;   // volpath.rs:108
             if (!terminated) {
-                smp.load_window();
+                if (!stage_b) smp.load_window();
                 const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
                 const uint32_t med = ps.medium(pid);
                 SurfaceInteraction si;   // only p and wo are read through the MediumInteraction
                 si.p = ro + rd * ps.hit_t(pid); si.wo = -rd; si.n = V3(0.0f, 0.0f, 0.0f); si.sh_n = V3(0.0f, 0.0f, 0.0f); si.p_error = V3(0.0f, 0.0f, 0.0f);
                 IData it; it.p = si.p; it.p_error = V3(0.0f, 0.0f, 0.0f); it.n = V3(0.0f, 0.0f, 0.0f);
                 const PhaseBsdf phase{s.media[med].g, si.wo};
-                nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med});
+                bool defer = false;
+                if (!stage_b) {
+                    nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med});
+                    defer = s.has_grid != 0u && (push_shadow || push_mis);
+                }
+                if (defer) { flags |= PF_STAGE_B; push_self = true; }
+                else {
                 V3 wi;
                 hg_sample_p(phase.g, si.wo, wi, smp.get_2d());
                 flags &= ~PF_SPECULAR;   // specular_bounce = false
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                     ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
                     push_ext = true;
                 }
+                }
             }
             if (terminated) {
                 if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
@@ -124,19 +139,21 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
             ps.beta_r(pid) = beta.r; ps.beta_g(pid) = beta.g; ps.beta_b(pid) = beta.b;
             ps.meta(pid) = (smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24);
         }
-        lq_push(s_qext, pid, push_ext); lq_push(s_qres, pid, push_resolve); lq_push(s_qsh, pid, push_shadow); lq_push(s_qmis, pid, push_mis);
+        lq_push(s_qext, pid, push_ext); lq_push(s_qres, pid, push_resolve); lq_push(s_qsh, pid, push_shadow); lq_push(s_qmis, pid, push_mis); lq_push(s_qself, pid, push_self);
         if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
         __syncthreads();
         lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
         lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
         lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
         lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+        lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 256u, false);
         __syncthreads();
     }
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 0u, true);
     __syncthreads();
     __syncthreads();
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);

@@ -17,9 +17,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
+    __shared__ LdsQueue<(MODE == 3) ? 1024 : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue
     __shared__ uint32_t s_hist[16];
     __shared__ float s_lobes[lobe_store_words<MAXL>()];   // the two- and five-lobe classes keep their BxDFs here (dev_bsdf.h)
-    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe);
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe); lq_init(s_qself);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #ifdef PT_REGION_PROFILE
     __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     unsigned long long zero_num = 0, zero_den = 0, n_valid = 0, n_bytes = 0;  // n_bytes: path-state + queue bytes
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
-    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false, push_self = false;
     int finished_bounces = -1;
     uint32_t pid = 0;
     PT_T(0);
@@ -53,8 +54,14 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
         RGB L(c0.x, c0.y, c0.z);
         RGB beta(c1.x, c1.y, c1.z);
 
-        // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233)
-        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+        // -- resolve the previous vertex's next-event estimation (integrator.rs:150-171,199-233). Volpath with grid media: the pending
+        //    estimate is THIS vertex's own (stage B): its shadow / MIS rays have been traced, their ratio-tracking transmittances draw
+        //    the sampler dimensions that follow the vertex's light and scattering samples, then the vertex goes on to sample its BSDF
+        const bool stage_b = VOL && (flags & PF_STAGE_B) != 0u;
+        const uint32_t camera_ray_flag = flags & PF_CAMERA_RAY;   // (a deferred vertex rebuilds its BSDF in stage B with the same differentials)
+        if (stage_b) smp.load_window();
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+        flags &= ~PF_STAGE_B;
 
         PT_T(3);
         if (flags & PF_DEAD) {
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
             if (found) n_bytes += 48;   // the hit's TriPacket: vertices, ids, flags
             if (found) pfl = fill_hit_pkt<SPH>(s, __float_as_uint(h1.z), SPH ? __float_as_uint(h1.x) : PT_NONE, ro, rd, h0.y, h0.z, h0.w, si);
             // path.rs:106-117
-            if (bounces == 0 || (flags & PF_SPECULAR)) {
+            if (!stage_b && (bounces == 0 || (flags & PF_SPECULAR))) {
                 if (found) {
                     const uint32_t al = s.prim_light[hp];
                     if (al != PT_NONE) L = L + area_l(s.lights[al], si.n, -rd) * beta;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
             bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
             if (!terminated) {
                 PT_T(4);
-                smp.load_window();
+                if (!stage_b) smp.load_window();
                 PT_T(10);
                 Bsdf<MAXL, DIFF> bsdf; bsdf.bind(s_lobes);
                 const uint32_t mi = packet_material(s, pfl, hp);
@@ -135,7 +142,13 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                 } else {
                     const V3 wo = -rd;  // path.rs:148; estimate_direct uses isect.wo (== -rd for triangles, triangle.rs:296)
                     // uniform_sample_onelight (integrator.rs:81-106)
-                    if (VOL) nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif);   // volpath.rs:136-138: unconditional
+                    bool defer = false;
+                    if (VOL) {
+                        if (!stage_b) {
+                            nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif);   // volpath.rs:136-138: unconditional
+                            defer = s.has_grid != 0u && (push_shadow || push_mis);   // wait for the traced rays before drawing any further dimension
+                        }
+                    }
                     else if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
                         zero_den++;
                         const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
@@ -144,8 +157,11 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     // path.rs:148-174: sample the BSDF for the next direction
                     PT_T(11);
                     V3 wi; float pdf = 0.0f; int sflags = 0;
-                    RGB f = bsdf.sample_f(wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
-                    if (f.is_black() || pdf == 0.0f) terminated = true;
+                    RGB f(0.0f);
+                    if (defer) { flags |= PF_STAGE_B | camera_ray_flag; push_self = true; }
+                    else f = bsdf.sample_f(wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
+                    if (defer) { /* stage B samples on */ }
+                    else if (f.is_black() || pdf == 0.0f) terminated = true;
                     else {
                         beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
@@ -217,12 +233,14 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)
     if constexpr (MAXL == 5) if (job.probe_next) lq_push(s_qprobe, pid, push_probe);
+    if constexpr (MODE == 3) lq_push(s_qself, pid, push_self);
     __syncthreads();
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
     if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    if constexpr (MODE == 3) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 256u, false);
     __syncthreads();
     }  // persistent loop over the queue
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
     if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    if constexpr (MODE == 3) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 0u, true);
     __syncthreads();
     __syncthreads();   // s_hist complete
 #ifdef PT_REGION_PROFILE

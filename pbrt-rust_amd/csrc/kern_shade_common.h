@@ -19,18 +19,33 @@ struct Prof { long long *t; int *r; unsigned long long *acc; };
 
 // Resolve the pending next-event estimation of the previous vertex once its shadow / MIS rays are traced
 // (integrator.rs:150-171,199-233): L += beta_at_nee * Ld / choice_pdf.
+// Grid media (VOL, DeviceScene::has_grid): the transmittance of the shadow ray and of the MIS ray is a ratio-tracking estimate that
+// draws sampler dimensions (grid.rs:113-147), in the reference right after the vertex's light / scattering samples and before its
+// continuation sample. Such vertices are therefore resolved in a second stage of the SAME vertex (PF_STAGE_B, kern_shade.h) and pass
+// their sampler here; `smp` is NULL everywhere else.
 template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
-                                                unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG) {
+                                                unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG, Sampler *smp = nullptr) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
     PT_T(1);
-    // the pending records as whole quads: nee {sh_d.yz, occluded | sh_prim, nee_light} {A, choice_pdf} {nb, -}; mis {o, d.x} {d.yz, w, spdf} {prim, b} {f, t}
+    // the pending records as whole quads: nee {sh_d.yz, occluded | sh_prim, nee_light} {A, choice_pdf} {nb, shadow grid medium}; mis {o, d.x} {d.yz, w, spdf} {prim, b} {f, t}
     const float4 *nq = reinterpret_cast<const float4 *>(ps.nee) + 4 * (size_t)pid;
     const float4 n1 = nq[1], n2 = nq[2], n3 = nq[3];
     n_bytes += 48 + ((flags & PF_PEND_MIS) ? 64 : 0);
     RGB Ld(0.0f);
     const uint32_t li = __float_as_uint(n1.w);
     // volpath: VisibilityTester::tr intersects (closest hit) and every surface is opaque; the segment's transmittance is already in A
-    if ((flags & PF_PEND_SHADOW) && (VOL ? __float_as_uint(n1.z) == PT_NONE : __float_as_uint(n1.z) == 0u)) Ld = Ld + RGB(n2.x, n2.y, n2.z);
+    if ((flags & PF_PEND_SHADOW) && (VOL ? __float_as_uint(n1.z) == PT_NONE : __float_as_uint(n1.z) == 0u)) {
+        RGB A(n2.x, n2.y, n2.z);
+        if (VOL) {   // VisibilityTester::tr (light.rs:125-150) through a grid medium: estimated now (homogeneous media were folded into A at the vertex)
+            const uint32_t sm = __float_as_uint(n3.w);
+            if (sm != PT_NONE && s.media[sm].type == PT_MEDIUM_GRID) {
+                const float4 n0 = nq[0];
+                if (smp) A = A * grid_tr(s.media[sm], s.grid_aux[sm], V3(n0.x, n0.y, n0.z), V3(n0.w, n1.x, n1.y), 1.0f - kShadowEps, *smp);
+                else A = RGB(0.0f);
+            }
+        }
+        Ld = Ld + A;
+    }
     if (flags & PF_PEND_MIS) {
         const float4 *mq = reinterpret_cast<const float4 *>(ps.mis) + 4 * (size_t)pid;
         const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
@@ -45,10 +60,18 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
                 lrad = area_l(Lt, lsi.n, -wi);
             }
         } else { PT_T(2); lrad = light_le(s, Lt, wi); PT_T(1); }
+        RGB Tr(1.0f);
+        bool tr_done = false;
+        if (VOL) {   // Scene::intersect_tr (scene.rs:68-87) always evaluates the medium's tr -- a grid medium draws its dimensions whether or not the light is seen
+            const uint32_t mm = ps.mis_medium(pid);
+            if (mm != PT_NONE && s.media[mm].type == PT_MEDIUM_GRID) {
+                Tr = smp ? RGB(grid_tr(s.media[mm], s.grid_aux[mm], V3(m0.x, m0.y, m0.z), wi, mp != PT_NONE ? m3.w : PT_INF, *smp)) : RGB(0.0f);
+                tr_done = true;
+            }
+        }
         if (!lrad.is_black()) {
             RGB f(m3.x, m3.y, m3.z);
-            RGB Tr(1.0f);
-            if (VOL) {   // Scene::intersect_tr (scene.rs:68-87): transmittance of the MIS ray's medium up to its hit (or to infinity)
+            if (VOL && !tr_done) {   // homogeneous: analytic transmittance of the MIS ray's medium up to its hit (or to infinity)
                 const uint32_t mm = ps.mis_medium(pid);
                 if (mm != PT_NONE) Tr = Tr * medium_tr(s.media[mm], mp != PT_NONE ? m3.w : PT_INF, wi);
             }
@@ -84,6 +107,7 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
             const int bf = BSDF_ALL & ~BSDF_SPECULAR;
             V3 wi; float lightpdf = 0.0f, scattpdf = 0.0f; IData p1;
             RGB A(0.0f); V3 sh_o(0.0f, 0.0f, 0.0f), sh_d(0.0f, 0.0f, 0.0f);   // the shadow ray and its term, stored with the rest of the nee record below
+            uint32_t sh_medium = PT_NONE;                                       // VOL: a grid medium the shadow ray travels in
             PT_T(6);
             RGB Li = light_sample_li<SPH>(s, li, it, ulight, wi, lightpdf, p1);
             PT_T(7);
@@ -95,7 +119,8 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                     V3 so, sd; spawn_ray_to(it, p1, so, sd);
                     if (VOL) {   // Li *= visibility.tr(): the unoccluded segment's transmittance (light.rs:125-150)
                         const uint32_t sm = medium_toward(mif, it.n, sd);
-                        if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
+                        if (sm != PT_NONE && s.media[sm].type == PT_MEDIUM_GRID) sh_medium = sm;   // estimated when the shadow ray has been traced (resolve_pending)
+                        else if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
                     }
                     A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;
                     sh_o = so; sh_d = sd;
@@ -130,7 +155,7 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
             if (nee_pending) {   // the nee record {sh_o, sh_d.x} {sh_d.yz, occluded (k_trace), nee_light} {A, choice_pdf} {nb, -}
                 float4 *nq = reinterpret_cast<float4 *>(ps.nee) + 4 * (size_t)pid;
                 if (flags & PF_PEND_SHADOW) nq[0] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_d.x);
-                nq[1] = make_float4(sh_d.y, sh_d.z, 0.0f, __uint_as_float(li)); nq[2] = make_float4(A.r, A.g, A.b, choice_pdf); nq[3] = make_float4(beta.r, beta.g, beta.b, 0.0f);
+                nq[1] = make_float4(sh_d.y, sh_d.z, 0.0f, __uint_as_float(li)); nq[2] = make_float4(A.r, A.g, A.b, choice_pdf); nq[3] = make_float4(beta.r, beta.g, beta.b, __uint_as_float(sh_medium));
                 n_bytes += 48;
             }
         }

@@ -20,7 +20,8 @@ constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersection
 
 // path flags (meta >> 24)
 enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
-                  PF_CAMERA_RAY = 32u };   // the ray still carries the camera's differentials (cleared at the first shaded vertex)
+                  PF_CAMERA_RAY = 32u,     // the ray still carries the camera's differentials (cleared at the first shaded vertex)
+                  PF_STAGE_B = 64u };      // volpath with grid media: the vertex has done its NEE set-up and waits, in its own shade class, for the traced rays before it samples on
 
 // Path state in HBM: five arrays of 16-byte-aligned RECORDS indexed by path id (pid). A record holds what one kernel reads or
 // writes together, so a lane moves whole 16-byte quads of one 32- or 64-byte line (dwordx4 accesses, every fetched sector fully
@@ -29,7 +30,7 @@ enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DE
 //   core  64 B  {L.rgb, etascale} {beta.rgb, meta} {sobol_index, pfilm.xy} {medium, mis_medium, -, -}      generate / shade / film
 //   ray   32 B  {o.xyz, d.x} {d.yz, (t_max), -}                                                            continuation ray: shade -> trace
 //   hit   32 B  {prim, b0, b1, b2} {inst, t, packet, packet flags}                                         trace -> route / shade
-//   nee   64 B  {sh_o.xyz, sh_d.x} {sh_d.yz, occluded | sh_prim, nee_light} {A.rgb, choice_pdf} {nb.rgb, -}  pending shadow ray + its terms
+//   nee   64 B  {sh_o.xyz, sh_d.x} {sh_d.yz, occluded | sh_prim, nee_light} {A.rgb, choice_pdf} {nb.rgb, grid medium of the shadow ray}  pending shadow ray + its terms
 //   mis   64 B  {mis_o.xyz, mis_d.x} {mis_d.yz, w, spdf} {mis_prim, b0, b1, b2} {f.rgb, mis_t}              pending MIS ray + its hit
 // The accessors below name single words of those records; adjacent words accessed together merge into dwordx2/x4 instructions.
 struct PathSoA {
@@ -158,6 +159,7 @@ struct ShadeJob {
     uint32_t *error;
     DevCounters *counters;
     uint32_t cls;            // material class of this launch (statistics)
+    uint32_t *self_next, *self_next_count;       // the SAME class's queue of the next iteration (volpath with grid media: stage B of a vertex)
     uint32_t *probe_next, *probe_next_count;     // paths starting a BSSRDF probe chain (class 3 only)
     BssSoA bs;
 };

@@ -227,3 +227,40 @@ def test_smoke_room_renders_on_the_oracle(pkg, oracle):
     s = oracle.scene(sd)
     film = s.render(rp, nthreads=4); c = s.counters()
     assert np.isfinite(film).all() and c["camera_rays"] == 32 * 24 * 8 == sum(c["path_length_hist"]) and film[..., :3].max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(sampler="halton"), dict(sampler="sobol", maxdepth=2, spp=4), dict(sampler="halton", g=-0.4, n=5)])
+def test_gpu_grid_medium_matches_oracle(pkg, gpu, oracle, kw):
+    """GridDensityMedium on the device: delta tracking in k_medium_route, ratio tracking on shadow / MIS rays in the second stage of
+    the vertex (PF_STAGE_B) -- same sampler dimensions in the same order as the oracle, so counters are exact and the film agrees."""
+    from test_gpu_parity import _compare_render
+    sd, rp = pkg.scenes.smoke_room(xres=48, yres=36, **kw).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp)
+    assert film[..., :3].sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_grid_medium_with_a_homogeneous_medium_and_closed_form(pkg, gpu, oracle):
+    """A grid medium next to a homogeneous one (the juice in foggy_room's glass sphere stays homogeneous, the room's fog becomes a grid),
+    and the absorbing-grid closed form evaluated on the device."""
+    from test_gpu_parity import _compare_render
+    b = pkg.scenes.foggy_room(xres=48, yres=36, spp=8)
+    b.sampler = "halton"
+    dens = np.random.default_rng(2).uniform(0.2, 1.0, (4, 4, 4)).astype(np.float32)
+    m = pkg._abi.PtMedium()
+    # replace the fog (medium 0) by a grid of the same coefficients over the room
+    fog = b.media[0]
+    b.ctm_saved = b.ctm
+    b.ctm = pkg.host.Transform()
+    b.make_named_medium("gridfog", sigma_a=(0.05, 0.05, 0.05), sigma_s=(0.2, 0.2, 0.2), g=0.3, density=dens, p0=(-6.0, -0.5, -6.0), p1=(6.0, 5.0, 6.0))
+    b.ctm = b.ctm_saved
+    b.media[0] = b.media[-1]; b.media.pop(); b.named_media.pop("gridfog")
+    _compare_render(pkg, gpu, oracle, *b.world_end())
+    dens = np.random.default_rng(3).uniform(0.1, 1.0, (5, 3, 4)).astype(np.float32)
+    p0, p1 = (-1.0, -1.0, -2.0), (1.0, 1.0, -0.5)
+    sd, rp = _grid_wall(pkg, 1.1, 0.0, 3.0, dens, p0, p1, spp=4096)
+    g = pkg.Scene(gpu, sd)
+    rgb = g.resolve(g.render(rp)).reshape(-1, 3).mean(axis=0)
+    want = np.array([3.0, 2.0, 1.0]) * np.exp(-_optical_depth_along_minus_z(dens, p0, p1, 1.1))
+    assert np.all(np.abs(rgb - want) < 0.03 * want), (rgb, want)
