@@ -43,6 +43,7 @@ struct Scene {
     std::vector<PtSphere> spheres;
     std::vector<uint32_t> prim_shape, prim_material, prim_light, prim_med_in, prim_med_out;
     std::vector<PtMedium> media; std::map<std::string, int> named_media; int camera_medium = -1; bool volpath = false;
+    std::vector<std::vector<float>> media_density; std::vector<int> media_density_of;   // grid media: density arrays and the medium each belongs to
     std::vector<PtMaterial> materials; std::vector<PtLight> lights;
     std::vector<PtTexture> textures; std::vector<Pyramid> pyramids; std::vector<PtImage> images; std::vector<float> ewa_lut;
     std::vector<std::unique_ptr<BssTable>> bss_tables; std::vector<std::pair<float, float>> bss_keys; std::vector<PtBSSRDFTable> bss_desc;
@@ -124,13 +125,28 @@ private:
         else if (w == "MakeNamedMedium") {   // api.rs:706-722,1219-1241
             std::string n = str_arg(lx, d); ParamSet p = read_params(lx);
             const std::string ty = p.one_string("type", "");
-            if (ty != "homogeneous") fail(d, "medium type \"" + ty + "\": only \"homogeneous\" media are supported");
+            if (ty != "homogeneous" && ty != "heterogeneous") fail(d, "medium type \"" + ty + "\" unknown (homogeneous, heterogeneous)");   // api.rs:753-756 warns and drops it
             float siga[3] = {0.0011f, 0.0024f, 0.014f}, sigs[3] = {2.55f, 3.21f, 3.77f};
             const std::string preset = p.one_string("preset", "");
             if (!preset.empty()) { auto it = named_media().find(preset); if (it != named_media().end()) { copy3(siga, it->second.sigma_a); copy3(sigs, it->second.sigma_prime_s); } }
             const float scale = p.one_float("scale", 1.0f);
             p.rgb("sigma_a", siga); p.rgb("sigma_s", sigs);
             PtMedium m{}; for (int k = 0; k < 3; ++k) { m.sigma_a[k] = siga[k] * scale; m.sigma_s[k] = sigs[k] * scale; } m.g = p.one_float("g", 0.0f);
+            m.type = PT_MEDIUM_HOMOGENEOUS;
+            if (ty == "heterogeneous") {   // api.rs:723-752: GridDensityMedium over [p0, p1] of the current transform's space
+                const std::vector<float> *dens = p.floats("float", "density");
+                if (!dens || dens->empty()) fail(d, "No \"density\" values provided for heterogeneous medium?");
+                const int nx = p.one_int("nx", 1), ny = p.one_int("ny", 1), nz = p.one_int("nz", 1);
+                if (nx <= 0 || ny <= 0 || nz <= 0 || dens->size() != (size_t)nx * ny * nz) fail(d, "GridDensityMedium has " + std::to_string(dens->size()) + " density values; expected nx*ny*nz = " + std::to_string((long long)nx * ny * nz));
+                float p0[3] = {0.0f, 0.0f, 0.0f}, p1[3] = {1.0f, 1.0f, 1.0f};
+                p.vec3("point3", "p0", p0); p.vec3("point3", "p1", p1);
+                const Transform med2w = gs.ctm * Transform::translate(Vec3{p0[0], p0[1], p0[2]}) * Transform::scale(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]);
+                m.type = PT_MEDIUM_GRID; m.nx = (uint32_t)nx; m.ny = (uint32_t)ny; m.nz = (uint32_t)nz;
+                med2w.flat(m.world_to_medium, true);
+                sc.media_density.emplace_back(*dens);
+                m.density = nullptr;   // patched when the scene description is assembled (the vectors may still move)
+                sc.media_density_of.push_back((int)sc.media.size());
+            }
             sc.media.push_back(m); sc.named_media[n] = (int)sc.media.size() - 1;
         }
         else if (w == "MediumInterface") {
@@ -537,6 +553,7 @@ static void finish(Scene &sc, const Api &api) {
     d.n_lights = (uint32_t)sc.lights.size(); d.lights = sc.lights.data();
     if (sc.env_w) { d.env_width = sc.env_w; d.env_height = sc.env_h; d.env_texels = sc.env_texels.data(); d.env_importance = sc.env_importance.data(); for (int k = 0; k < 3; ++k) d.env_power_lookup[k] = sc.env_power_lookup[k]; }
     d.max_node_prims = sc.max_node_prims; d.split_method = sc.split_method;
+    for (size_t i = 0; i < sc.media_density_of.size(); ++i) sc.media[(size_t)sc.media_density_of[i]].density = sc.media_density[i].data();
     if (!sc.media.empty()) { d.n_media = (uint32_t)sc.media.size(); d.media = sc.media.data(); d.prim_medium_inside = sc.prim_med_in.data(); d.prim_medium_outside = sc.prim_med_out.data(); }
     if (!sc.instances.empty()) { d.n_objects = (uint32_t)sc.objects.size(); d.objects = sc.objects.data(); d.n_instances = (uint32_t)sc.instances.size(); d.instances = sc.instances.data(); d.n_top = (uint32_t)sc.top_refs.size(); d.top_refs = sc.top_refs.data(); }
     for (auto &t : sc.bss_tables) { PtBSSRDFTable e{}; e.n_rho = (uint32_t)t->n_rho; e.n_radius = (uint32_t)t->n_radius; e.rho_samples = t->rho_samples.data(); e.radius_samples = t->radius_samples.data(); e.profile = t->profile.data(); e.rhoeff = t->rhoeff.data(); e.profile_cdf = t->profile_cdf.data(); sc.bss_desc.push_back(e); }

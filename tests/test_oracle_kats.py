@@ -344,7 +344,7 @@ def test_image_environment_map(oracle, pkg):
         rgb = (rgb.astype(F) + tx(s0 + 1, t0) * F(ds * F(1 - dt))).astype(F); rgb = (rgb + tx(s0 + 1, t0 + 1) * F(ds * dt)).astype(F)
         y = F(F(yw[0] * rgb[0] + yw[1] * rgb[1]) + yw[2] * rgb[2])
         assert img[v, u] == F(y * F(math.sin(F(math.pi) * (F(v) + F(.5)) / F(2 * h))))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         H._env_importance(np.ones((3, 5, 3), dtype=F))
     # a camera looking at the sky only: every pixel is the (bilinear) map value in its direction
     b = pkg.host.SceneBuilder()

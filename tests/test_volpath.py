@@ -92,8 +92,56 @@ WorldEnd
     assert d.n_media == 1 and list(d.media[0].sigma_a) == pytest.approx([.2, .4, .6]) and list(d.media[0].sigma_s) == pytest.approx([2, 4, 6]) and d.media[0].g == pytest.approx(.4)
     ins = [d.prim_medium_inside[i] for i in range(d.n_prims)]; outs = [d.prim_medium_outside[i] for i in range(d.n_prims)]
     assert ins == [A.PT_NONE, 0, A.PT_NONE] and outs == [0, A.PT_NONE, 0]
-    with pytest.raises(Exception, match="homogeneous"):
+    with pytest.raises(Exception, match="density"):
         pkg.frontend.FrontScene(text='MakeNamedMedium "m" "string type" "heterogeneous"\nWorldBegin\nWorldEnd\n')
+
+
+def test_front_end_heterogeneous_medium_equals_the_python_mirror(pkg, oracle):
+    """MakeNamedMedium "string type" "heterogeneous" (api.rs:723-752): density grid, nx / ny / nz, p0 / p1 under the current transform --
+    the front end and the Python mirror produce the same PtMedium (world_to_medium included) and the oracle renders both alike."""
+    A = pkg._abi
+    rng = np.random.default_rng(11)
+    dens = rng.uniform(0.0, 1.0, (3, 2, 4)).astype(np.float32)     # density[z][y][x]: nx = 4, ny = 2, nz = 3
+    txt = """Translate 0.5 0 0
+Rotate 30 0 1 0
+MakeNamedMedium "smoke" "string type" "heterogeneous" "rgb sigma_a" [.4 .4 .4] "rgb sigma_s" [1.6 1.6 1.6] "float g" .2 "float scale" 1.5
+  "integer nx" 4 "integer ny" 2 "integer nz" 3 "point p0" [-1 0 -1] "point p1" [1 2 1.5] "float density" [%s]
+Identity
+MediumInterface "" "smoke"
+LookAt 0 1.4 5  0 .7 0  0 1 0
+Camera "perspective" "float fov" 38
+Film "image" "integer xresolution" [24] "integer yresolution" [18]
+Sampler "halton" "integer pixelsamples" [4]
+Integrator "volpath" "integer maxdepth" 3
+WorldBegin
+LightSource "point" "point from" [-2.5 1.5 -2.5] "rgb I" [14 12 10]
+Material "matte" "rgb Kd" [.5 .5 .5]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-10 -.5 -10  -10 -.5 10  10 -.5 10  10 -.5 -10]
+WorldEnd
+""" % " ".join("%.9g" % v for v in dens.ravel())
+    fs = pkg.frontend.FrontScene(text=txt)
+    d, rp = fs.desc(), fs.render_params()
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=24, yres=18); b.spp = 4; b.sampler = "halton"
+    b.integ.update(maxdepth=3, kind="volpath")
+    b.translate(0.5, 0.0, 0.0); b.rotate(30.0, 0.0, 1.0, 0.0)
+    b.make_named_medium("smoke", sigma_a=(0.4,) * 3, sigma_s=(1.6,) * 3, g=0.2, scale=1.5, density=dens, p0=(-1.0, 0.0, -1.0), p1=(1.0, 2.0, 1.5))
+    b.identity()
+    b.medium_interface("", "smoke")
+    b.look_at((0.0, 1.4, 5.0), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("point", from_=(-2.5, 1.5, -2.5), I=(14.0, 12.0, 10.0))
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = pkg.scenes.quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I)
+    sd, rp2 = b.world_end()
+    d2 = sd.desc()
+    m, m2 = d.media[0], d2.media[0]
+    assert m.type == m2.type == A.PT_MEDIUM_GRID and (m.nx, m.ny, m.nz) == (m2.nx, m2.ny, m2.nz) == (4, 2, 3) and rp.camera_medium == rp2.camera_medium == 0
+    np.testing.assert_allclose(list(m.world_to_medium), list(m2.world_to_medium), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(list(m.sigma_a) + list(m.sigma_s), list(m2.sigma_a) + list(m2.sigma_s), rtol=1e-6)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(m.density, shape=(24,)), dens.ravel())
+    fa = oracle.scene(fs).render(rp, nthreads=4); fb = oracle.scene(sd).render(rp2, nthreads=4)
+    np.testing.assert_allclose(fa, fb, rtol=1e-3, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------------- GPU

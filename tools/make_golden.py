@@ -29,6 +29,12 @@ CASES = {   # name -> (scene function, kwargs); kept tiny: each film is 40x24x4 
     "disney_spheres": ("disney_spheres", dict(xres=40, yres=24, spp=4)),
     "foggy_room_volpath": ("foggy_room", dict(xres=40, yres=24, spp=4)),
     "ganesha_halton_hlbvh": ("ganesha_halton_hlbvh", dict(n=16, xres=40, yres=24, spp=4)),
+    # round 2
+    "smoke_room_grid_medium": ("smoke_room", dict(xres=40, yres=24, spp=4, sampler="halton")),
+    "subsurface_sheets_long_chains": ("subsurface_sheets", dict(xres=40, yres=24, spp=4)),
+    "country_kitchen_s3_mini": ("country_kitchen_s3", dict(xres=40, yres=24, spp=4, wall_n=10, box_n=4, obj_n=8)),
+    "ecosystem_s4_mini": ("ecosystem_s4", dict(xres=40, yres=24, spp=4, n_inst=40, terrain_n=16, plant_scale=0.07, env_size=(32, 16))),
+    "dragon_s5_mini": ("dragon_s5", dict(xres=40, yres=24, spp=4, n=24, env_size=(32, 16))),
 }
 COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests",
             "zero_radiance_paths_num", "zero_radiance_paths_den", "path_length_hist", "film_splats")
@@ -41,7 +47,9 @@ def main():
     orc = Oracle(pkg._abi, pkg.runtime.TABLES_PATH)
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
+    only = set(sys.argv[1:])     # optional: the names to (re)generate
     for name, (fn, kw) in CASES.items():
+        if only and name not in only: continue
         sd, rp = getattr(pkg.scenes, fn)(**kw).world_end()
         s = orc.scene(sd)
         film = s.render(rp, nthreads=1)
