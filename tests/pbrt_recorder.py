@@ -49,6 +49,11 @@ def make_recorder(pkg, out_dir):
         def toggle_reverse_orientation(self): self._emit("ReverseOrientation"); self.reverse_orientation = not self.reverse_orientation
 
         def make_named_medium(self, name, **kw):
+            if kw.get("density") is not None:   # "heterogeneous": nx ny nz, the density in x-fastest order, the box corners
+                d = np.asarray(kw["density"], dtype=np.float32); rest = {k: v for k, v in kw.items() if k not in ("density", "p0", "p1")}
+                self._emit('MakeNamedMedium "%s" "string type" "heterogeneous" %s "integer nx" %d "integer ny" %d "integer nz" %d "point p0" %s "point p1" %s "float density" %s'
+                           % (name, self._params(rest, spectrum=("sigma_a", "sigma_s")), d.shape[2], d.shape[1], d.shape[0], _vec(kw.get("p0", (0, 0, 0))), _vec(kw.get("p1", (1, 1, 1))), _vec(d.ravel())))
+                return super().make_named_medium(name, **kw)
             self._emit('MakeNamedMedium "%s" "string type" "homogeneous" %s' % (name, self._params(kw, spectrum=("sigma_a", "sigma_s"))))
             super().make_named_medium(name, **kw)
         def medium_interface(self, inside="", outside=""): self._emit('MediumInterface "%s" "%s"' % (inside, outside)); super().medium_interface(inside, outside)

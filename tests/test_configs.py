@@ -98,3 +98,19 @@ def test_c4_ecosystem_gate(pkg, gpu, oracle):
 def test_c5_dragon_subsurface_gate(pkg, gpu, oracle):
     """S5: the 4.3 M-triangle S2 mesh x0.02 with subsurface Skin1 (probe-ray chains of TabulatedBSSRDF::sample_sp)."""
     _gate(pkg, gpu, oracle, pkg.scenes.dragon_s5(spp=8), (832, 412))
+
+
+@pytest.mark.gpu
+def test_c1_spheres_full_config_gate(pkg, gpu, oracle):
+    """Config C1 at its BASELINE size (400x400, 64 spp; test_spheres_c1_matches_oracle runs it at 96x96x8): the whole frame against the
+    oracle -- exact counters incl. sphere tests, identical weights, normalised L-infinity < 1e-3."""
+    sd, rp = pkg.scenes.spheres_c1(xres=400, yres=400, spp=64).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=16)
+    gc, oc = g.counters(), orc.counters()
+    for k in COUNTERS + ("sphere_tests",):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert gc["camera_rays"] == 400 * 400 * 64
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-3
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)

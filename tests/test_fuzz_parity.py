@@ -23,7 +23,13 @@ def random_scene(pkg, seed, builder=None):
     volpath = rng.random() < 0.4
     b.integ.update(maxdepth=int(pick(1, 3, 5, 8)), rrthreshold=pick(1.0, 0.3, 0.0), strategy=pick("spatial", "power", "uniform"), kind="volpath" if volpath else "path")
     if volpath:
-        b.make_named_medium("fog", sigma_a=rgb(0.0, 0.1), sigma_s=rgb(0.02, 0.3), g=u(-0.7, 0.7))
+        if rng.random() < 0.35:   # the fog as a GridDensityMedium (media/grid.rs; spectrally uniform sigma_t as it requires), shallow paths: ratio / delta tracking draw many dimensions
+            nd = int(pick(2, 3, 5)); sa, ss = u(0.0, 0.06), u(0.03, 0.25)
+            b.integ.update(maxdepth=int(pick(1, 2, 3)))
+            b.make_named_medium("fog", sigma_a=(sa, sa, sa), sigma_s=(ss, ss, ss), g=u(-0.7, 0.7), density=rng.uniform(0.0, 1.0, (nd, int(pick(2, 4)), nd)).astype(np.float32),
+                                p0=(u(-8, -4), u(-2, -0.5), u(-8, -4)), p1=(u(4, 8), u(3, 6), u(4, 8)))
+        else:
+            b.make_named_medium("fog", sigma_a=rgb(0.0, 0.1), sigma_s=rgb(0.02, 0.3), g=u(-0.7, 0.7))
         b.make_named_medium("ink", sigma_a=rgb(0.1, 2.0), sigma_s=rgb(0.1, 2.0), g=u(-0.3, 0.3), scale=u(0.5, 2.0))
         if rng.random() < 0.7: b.medium_interface("", "fog")
     b.look_at((u(-1, 1), u(1.0, 2.5), u(4.5, 6.0)), (u(-0.3, 0.3), u(0.2, 0.8), 0.0), (0.0, 1.0, 0.0))
@@ -31,7 +37,7 @@ def random_scene(pkg, seed, builder=None):
     b.world_begin()
     # lights
     if rng.random() < 0.7: b.light_source("infinite", L=rgb(0.02, 0.5))
-    if rng.random() < 0.3: b.light_source("infinite", L=rgb(0.2, 1.0), texels=S.sky_env(16, 8), scale=u(0.2, 1.0))
+    if rng.random() < 0.3: b.light_source("infinite", L=rgb(0.2, 1.0), texels=S.sky_env(*pick((16, 8), (16, 8), (32, 4), (4, 16))), scale=u(0.2, 1.0))
     for _ in range(int(rng.integers(0, 3))):
         k = pick("point", "spot", "distant")
         # point lights sit at (x, y, x) (create_pointlight translates by (P.x, P.y, P.x), App. A #15)
