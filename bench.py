@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRACE_KINDS = ("extend", "extend_mis", "shadow", "extend_camera", "extend_probe")
+TRACE_KINDS = ("trace", "extend", "extend_mis", "shadow", "extend_camera", "extend_probe")   # "trace" = the mixed launch: continuation + MIS + shadow rays of one wavefront iteration
 
 
 def main():
@@ -190,6 +190,9 @@ def main():
     kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps, kernel=v["kernel"], **gbs(n, v),
                        **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in TRACE_KINDS else {}))
                for n, v in kstats.items() if v["launches"]}
+    # what the mixed traversal launches did per ray kind (counters only: the kinds share the launches' time)
+    trace_kinds = {n.split(":", 1)[1]: dict(Mrays_per_step=round(v["items"] / args.steps / 1e6, 2), nodes_per_ray=round(v["bvh_nodes"] / max(1, v["items"]), 1), tris_per_ray=round(v["triangle_tests"] / max(1, v["items"]), 2))
+                   for n, v in kstats.items() if n.startswith("trace:")}
 
     cpu_baseline = None
     if args.cpu_seconds > 0 and world == 1:
@@ -210,7 +213,7 @@ def main():
                    "film": "stays on the device (no read-back in the timed region; 33 MB = 0.6 ms over PCIe)",
                    "parallelism": (f"16x16 sample tiles round-robin over {n_gpus} GPU(s); " + ("one process, pt_multi_render (peer film sum)" if in_process else "RCCL film reduce")) if n_gpus > 1 else "1 GPU"},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
-        "kernels_ms_per_step": kernels,
+        "kernels_ms_per_step": kernels, **({"trace_kinds": trace_kinds} if trace_kinds else {}),
         "rays_per_sample": round((counters["intersect_tests"] + counters["shadow_tests"]) / max(1, counters["camera_rays"]), 3) if counters else None,
         "nodes_per_ray": round(counters["bvh_nodes_visited"] / max(1, counters["intersect_tests"] + counters["shadow_tests"]), 2) if counters else None,
         "setup_s": {"scene_gen": round(t_gen, 1), "bvh_build_upload": round(t_up, 1)},

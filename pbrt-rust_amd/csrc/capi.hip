@@ -33,6 +33,7 @@ uint32_t g_leaf_quorum[4] = {1, 1, 1, 1};         // 1 = a lane at a leaf tests 
                                                   // lanes' exec mask and the quorum never held a lane back; with the ballot fixed (round 2) every real quorum is slower
                                                   // (C2 at 64 spp: 1 -> 1132, 8 -> 1084, 24 -> 1038, 48 -> 798 Msamples/s): a waiting lane costs more than a thin triangle step
 bool g_refill_from_env = false;
+bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one traversal launch per ray kind (extend / extend_mis / shadow) instead of the mixed launch
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
 thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -246,25 +247,38 @@ void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func
     else { for (size_t i = 1; i < n + 1; ++i) cdf[i] /= func_int; }
 }
 
-int launch_trace(pt_scene *sc, bool any, TraceJob job, uint32_t n_upper, bool probe = false) {
+#ifdef PT_TRACE_UTIL
+__global__ void k_trace_util_fold(DevCounters *dc, uint32_t kind, uint32_t waves, int reset) {   // per launch: span x waves, then re-arm min / max
+    if (!reset) dc->tail[5 + 2 * kind] += (dc->tail[1] - dc->tail[0]) * waves;
+    dc->tail[0] = ~0ull; dc->tail[1] = 0ull;
+}
+#endif
+
+// any: 0 closest hit, 1 any hit (rays of job.sub[0]); 2 mixed: the queues of job.sub[0..2] in one launch (n_upper covers all three)
+int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe = false) {
     if (n_upper == 0) return PT_OK;
-    job.refill_min = g_refill_min[job.kind == 4 ? 0 : (job.kind & 3)]; job.leaf_quorum = g_leaf_quorum[job.kind == 4 ? 0 : (job.kind & 3)];
+    const uint32_t knob = job.sub[0].kind == 4 ? 0 : (job.sub[0].kind & 3);
+    job.refill_min = g_refill_min[knob]; job.leaf_quorum = g_leaf_quorum[knob];
     if (sc->ds.n_instances > 0 && !g_refill_from_env) job.refill_min = 8;   // rays through instanced scenes are long (S4: 200 node visits): idle lanes are refilled early (measured 24 -> 8: +9 %)
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
     const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : sc->ds.n_spheres > 0 ? 1 : sc->ds.n_instances > 0 ? 3 : 0;  // kern_trace.h: k_trace MODE
     job.inst_quorum = g_inst_quorum;
-    #define PT_LAUNCH_TRACE(A, M) hipLaunchKernelGGL((k_trace<A, M, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
-    if (probe) {
-        if (mode == 3) hipLaunchKernelGGL((k_trace<false, 3, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-        else if (mode == 2) hipLaunchKernelGGL((k_trace<false, 2, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-        else if (mode == 1) hipLaunchKernelGGL((k_trace<false, 1, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-        else hipLaunchKernelGGL((k_trace<false, 0, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job);
-    } else
-    if (any) { if (mode == 3) PT_LAUNCH_TRACE(true, 3); else if (mode == 2) PT_LAUNCH_TRACE(true, 2); else if (mode == 1) PT_LAUNCH_TRACE(true, 1); else PT_LAUNCH_TRACE(true, 0); }
-    else { if (mode == 3) PT_LAUNCH_TRACE(false, 3); else if (mode == 2) PT_LAUNCH_TRACE(false, 2); else if (mode == 1) PT_LAUNCH_TRACE(false, 1); else PT_LAUNCH_TRACE(false, 0); }
+#ifdef PT_TRACE_UTIL
+    hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, 0u, 1);
+#endif
+    #define PT_LAUNCH_TRACE(A, M, P) hipLaunchKernelGGL((k_trace<A, M, P>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
+    #define PT_LAUNCH_TRACE_MODE(A, P) do { if (mode == 3) PT_LAUNCH_TRACE(A, 3, P); else if (mode == 2) PT_LAUNCH_TRACE(A, 2, P); else if (mode == 1) PT_LAUNCH_TRACE(A, 1, P); else PT_LAUNCH_TRACE(A, 0, P); } while (0)
+    if (probe) PT_LAUNCH_TRACE_MODE(0, true);
+    else if (any == 2) PT_LAUNCH_TRACE_MODE(2, false);
+    else if (any == 1) PT_LAUNCH_TRACE_MODE(1, false);
+    else PT_LAUNCH_TRACE_MODE(0, false);
+    #undef PT_LAUNCH_TRACE_MODE
     #undef PT_LAUNCH_TRACE
-    sc->set_kernel(std::string("k_trace<") + (any ? "true" : "false") + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ">");
+#ifdef PT_TRACE_UTIL
+    hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, blocks * (kTraceBlock / 64), 0);
+#endif
+    sc->set_kernel(std::string("k_trace<") + std::to_string(any) + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ">");
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -482,18 +496,55 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         if (n_ext == 0 && n_resolve == 0 && n_probe == 0 && n_stage_b == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
-        tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.scalar_tmax = INFINITY;
+        tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.head = &qc->head[0];
         PathSoA &ps = sc->ps;
-        // continuation rays -> hit record + material-class routing
-        tj.queue = sc->q.ext[cur]; tj.count = &qc->ext[cur]; tj.head = &qc->head[0];
-        tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4; tj.per_ray_tmax = 0;
-        tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_word = nullptr; tj.out_word_stride = 0;
-        tj.out_hit2 = (float4 *)ps.hit + 1; tj.out_t = nullptr; tj.out_t_stride = 0;   // {inst, t, packet, packet flags}
-        tj.kind = (iter == 0) ? 3 : 0;
+        // continuation rays -> hit record (routed to the material classes below)
+        TraceSub ext{};
+        ext.queue = sc->q.ext[cur]; ext.count = &qc->ext[cur]; ext.scalar_tmax = INFINITY;
+        ext.ray = (const float4 *)ps.ray; ext.ray_stride = PathSoA::kRayWords / 4;
+        ext.out_hit = (float4 *)ps.hit; ext.out_hit_stride = PathSoA::kHitWords / 4; ext.out_hit2 = (float4 *)ps.hit + 1;   // {inst, t, packet, packet flags}
+        ext.kind = (iter == 0) ? 3 : 0;
+        // MIS rays of the previous vertex (closest hit, integrator.rs:215)
+        TraceSub mis{};
+        mis.queue = sc->q.mis; mis.count = &qc->mis; mis.scalar_tmax = INFINITY;
+        mis.ray = (const float4 *)ps.mis; mis.ray_stride = PathSoA::kMisWords / 4;
+        mis.out_hit = (float4 *)&ps.mis_prim(0); mis.out_hit_stride = PathSoA::kMisWords / 4;
+        mis.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; mis.out_t_stride = PathSoA::kMisWords;
+        mis.kind = 1;
+        // shadow rays (any hit, light.rs:120-123). volpath: VisibilityTester::tr (light.rs:125-150) calls Scene::intersect, a closest-hit
+        // query counted as one; without out_hit the primitive goes to out_word = nee.sh_prim, the slot `occluded` uses otherwise
+        TraceSub sh{};
+        sh.queue = sc->q.shadow; sh.count = &qc->shadow; sh.scalar_tmax = 1.0f - 0.0001f;
+        sh.ray = (const float4 *)ps.nee; sh.ray_stride = PathSoA::kNeeWords / 4;
+        sh.out_word = &ps.occluded(0); sh.out_word_stride = PathSoA::kNeeWords;
+        sh.kind = 2; sh.any = rc.volpath ? 0u : 1u;
         int st = PT_OK;
-        if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
-            sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
-            st = launch_trace(sc, false, tj, n_ext);
+        if (n_mis + n_shadow == 0 || g_trace_split) {   // camera rays (nothing else to trace in the first iteration) / PT_TRACE_SPLIT=1: one launch per kind
+            if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
+                tj.sub[0] = ext;
+                sc->begin(iter == 0 ? "extend_camera" : "extend", n_ext);
+                st = launch_trace(sc, 0, tj, n_ext);
+                sc->end();
+                if (st) return st;
+            }
+            if (n_mis) {
+                tj.sub[0] = mis; tj.head = &qc->head[1];
+                sc->begin("extend_mis", n_mis);
+                st = launch_trace(sc, 0, tj, n_mis);
+                sc->end();
+                if (st) return st;
+            }
+            if (n_shadow) {
+                tj.sub[0] = sh; tj.head = &qc->head[2];
+                sc->begin("shadow", n_shadow);
+                st = launch_trace(sc, (int)sh.any, tj, n_shadow);
+                sc->end();
+                if (st) return st;
+            }
+        } else {   // the three ray kinds of this iteration in one launch: one tail of straggling rays instead of three
+            tj.sub[0] = ext; tj.sub[1] = mis; tj.sub[2] = sh;
+            sc->begin("trace", (uint64_t)n_ext + n_mis + n_shadow);
+            st = launch_trace(sc, 2, tj, n_ext + n_mis + n_shadow);
             sc->end();
             if (st) return st;
         }
@@ -510,41 +561,16 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
                                sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4]);
             sc->end();
         }
-        // MIS rays of the previous vertex (closest hit, integrator.rs:215)
-        tj.queue = sc->q.mis; tj.count = &qc->mis; tj.head = &qc->head[1];
-        tj.ray = (const float4 *)ps.mis; tj.ray_stride = PathSoA::kMisWords / 4;
-        tj.out_hit = (float4 *)&ps.mis_prim(0); tj.out_hit_stride = PathSoA::kMisWords / 4;
-        tj.out_hit2 = nullptr; tj.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; tj.out_t_stride = PathSoA::kMisWords;
-        tj.kind = 1;
-        if (n_mis) {
-            sc->begin("extend_mis", n_mis);
-            st = launch_trace(sc, false, tj, n_mis);
-            sc->end();
-            if (st) return st;
-        }
-        // shadow rays (any hit, light.rs:120-123)
-        tj.queue = sc->q.shadow; tj.count = &qc->shadow; tj.head = &qc->head[2]; tj.scalar_tmax = 1.0f - 0.0001f;
-        tj.ray = (const float4 *)ps.nee; tj.ray_stride = PathSoA::kNeeWords / 4;
-        tj.out_hit = nullptr; tj.out_hit2 = nullptr; tj.out_word = &ps.occluded(0); tj.out_word_stride = PathSoA::kNeeWords; tj.out_t = nullptr;
-        tj.kind = 2;
-        if (n_shadow) {
-            sc->begin("shadow", n_shadow);
-            if (rc.volpath) {   // VisibilityTester::tr (light.rs:125-150) calls Scene::intersect: a closest-hit query, counted as one
-                // (closest-hit kernel without out_hit: the primitive goes to out_word = nee.sh_prim, the slot `occluded` uses otherwise)
-                st = launch_trace(sc, false, tj, n_shadow);
-            } else
-            st = launch_trace(sc, true, tj, n_shadow);
-            sc->end();
-            if (st) return st;
-        }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
         if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-402): each lane of k_trace<.., PROBE> walks a whole chain, then k_bssrdf
-            tj.queue = sc->q.probe[cur]; tj.count = &qc->probe[cur]; tj.head = &qc->head[3]; tj.scalar_tmax = 1.0f - 0.0001f;
-            tj.ray = (const float4 *)ps.ray; tj.ray_stride = PathSoA::kRayWords / 4;
-            tj.out_hit = (float4 *)ps.hit; tj.out_hit_stride = PathSoA::kHitWords / 4; tj.out_hit2 = (float4 *)ps.hit + 1; tj.out_word = nullptr; tj.out_t = nullptr;
-            tj.kind = 4; tj.bs = sc->bs; tj.ring = sc->probe_ring;
+            TraceSub pr{};
+            pr.queue = sc->q.probe[cur]; pr.count = &qc->probe[cur]; pr.scalar_tmax = 1.0f - 0.0001f;
+            pr.ray = (const float4 *)ps.ray; pr.ray_stride = PathSoA::kRayWords / 4;
+            pr.out_hit = (float4 *)ps.hit; pr.out_hit_stride = PathSoA::kHitWords / 4; pr.out_hit2 = (float4 *)ps.hit + 1;
+            pr.kind = 4;
+            tj.sub[0] = pr; tj.head = &qc->head[3]; tj.bs = sc->bs; tj.ring = sc->probe_ring;
             sc->begin("extend_probe", n_probe);
-            st = launch_trace(sc, false, tj, n_probe, true);
+            st = launch_trace(sc, 0, tj, n_probe, true);
             sc->end();
             if (st) return st;
             BssrdfJob bj{};
@@ -624,9 +650,16 @@ void read_counters(pt_scene *sc) {
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[5] = {"extend", "extend_mis", "shadow", "extend_camera", "extend_probe"};
     for (int k = 0; k < 5; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; if (k == 4) s.items = d.k_rays[k]; }   // probe chains: items = segments traced
+    for (auto &s : sc->stats) if (s.name == "trace") { s.nodes = d.k_nodes[0] + d.k_nodes[1] + d.k_nodes[2]; s.tris = d.k_tris[0] + d.k_tris[1] + d.k_tris[2]; }   // the mixed launches: all three kinds
+    if (!g_trace_split) {   // what the mixed launches did per ray kind (no time of their own: launches = 0)
+        for (int k = 0; k < 3; ++k) if (d.k_rays[k]) { bool have = false; for (auto &s : sc->stats) have = have || s.name == kn[k];
+            if (!have) { Stat s2{std::string("trace:") + kn[k]}; s2.items = d.k_rays[k]; s2.nodes = d.k_nodes[k]; s2.tris = d.k_tris[k]; sc->stats.push_back(s2); } }
+    }
     for (auto &s : sc->stats) if (s.name == "bssrdf") { s.items = d.bss_items; s.nodes = d.bss_bytes; }
 #ifdef PT_TRACE_UTIL
     fprintf(stderr, "[trace-util] kernel saw leaf_quorum = %llu, refill_min = %llu (last launch)\n", d.dbg[0], d.dbg[1]);
+    for (int k = 0; k < 4; ++k) if (d.tail[5 + 2 * k])
+        fprintf(stderr, "[trace-util] %-14s wave slots busy %.1f %% of launch span x resident waves (the rest: launch ramp + tail after the queue drained)\n", kn[k], 100.0 * (double)d.tail[4 + 2 * k] / (double)d.tail[5 + 2 * k]);
     for (int k = 0; k < 4; ++k)
         fprintf(stderr, "[trace-util] %-14s node phase: %.3e wave iterations, %.1f %% lanes active; leaf phase: %.3e iterations, %.1f %% lanes active\n", kn[k], (double)d.regions[4 * k],
                 d.regions[4 * k] ? 100.0 * (double)d.regions[4 * k + 1] / (64.0 * (double)d.regions[4 * k]) : 0.0, (double)d.regions[4 * k + 2], d.regions[4 * k + 2] ? 100.0 * (double)d.regions[4 * k + 3] / (64.0 * (double)d.regions[4 * k + 2]) : 0.0);
@@ -651,6 +684,7 @@ int pt_init(int device_ordinal) {
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device_ordinal < 0 || device_ordinal >= n) return fail(PT_ERR_INVALID_ARG, "device ordinal out of range");
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; g_refill_from_env = true; } }
+    if (const char *e = getenv("PT_TRACE_SPLIT")) g_trace_split = atoi(e) != 0;
     if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
@@ -1175,15 +1209,16 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
     HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
     HIP_TRY(hipMemsetAsync(sc->qc, 0, sizeof(QCounters), sc->stream));
     TraceJob tj{};
-    tj.queue = nullptr; tj.count = dcount; tj.head = &sc->qc->head[0];
-    tj.ray = (const float4 *)din; tj.ray_stride = 2; tj.per_ray_tmax = 1;
-    tj.out_hit = (float4 *)dout; tj.out_hit_stride = 1; tj.out_t = dt; tj.out_t_stride = 1;
-    tj.out_word = docc; tj.out_word_stride = 1; tj.out_hit2 = nullptr;
+    TraceSub &ts = tj.sub[0];
+    ts.queue = nullptr; ts.count = dcount; tj.head = &sc->qc->head[0];
+    ts.ray = (const float4 *)din; ts.ray_stride = 2; ts.per_ray_tmax = 1;
+    ts.out_hit = (float4 *)dout; ts.out_hit_stride = 1; ts.out_t = dt; ts.out_t_stride = 1;
+    ts.out_word = docc; ts.out_word_stride = 1; ts.out_hit2 = nullptr;
     tj.spill = sc->spill; tj.error = &sc->qc->error; tj.counters = sc->dc;
     sc->profile = true; sc->drop_timings(); sc->stats.clear();
-    tj.kind = any ? 2 : 0;
+    ts.kind = any ? 2 : 0; ts.any = any ? 1u : 0u;
     sc->begin(any ? "trace_any_api" : "trace_closest_api", n);
-    st = launch_trace(sc, any, tj, n);
+    st = launch_trace(sc, any ? 1 : 0, tj, n);
     sc->end();
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(sc->stream));

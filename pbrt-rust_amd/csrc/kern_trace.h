@@ -31,9 +31,14 @@
 // kProbeRing matching intersections in a per-lane ring in HBM, and retires with the SELECTED intersection as its hit record
 // (`selected = clamp((u1 * nfound) as usize, 0, nfound - 1)`), so that one launch replaces what used to be one wavefront
 // iteration (a trace launch, a k_bssrdf launch and a host round trip) per segment, twice over.
-template <bool ANY, int MODE, bool PROBE>
+// ANY: 0 = closest hit (Scene::intersect), 1 = any hit (Scene::intersect_p), 2 = mixed: the launch walks the queues of job.sub[0..2]
+// back to back and every lane carries the kind of its own ray (the continuation, MIS and shadow rays of one wavefront iteration in one
+// launch: one tail of straggling rays per iteration instead of three; measured with the PT_TRACE_UTIL build on S2: the wave slots of the three
+// separate launches were busy 73 / 53 / 62 % of launch span x resident waves, ~0.8 ms of tail each).
+template <int ANY, int MODE, bool PROBE>
 __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ? PT_TRACE_WAVES : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
-    static_assert(!(ANY && PROBE), "probe chains are closest-hit queries");
+    static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
+    constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
@@ -45,12 +50,21 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
     uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLdsStack)) + lane;
-    const uint32_t count = *job.count;
+    // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
+    const uint32_t c0 = *job.sub[0].count, c01 = c0 + (MIX ? *job.sub[1].count : 0u);
+    const uint32_t count = c01 + (MIX ? *job.sub[2].count : 0u);
+    uint32_t ksel = 0; bool lane_any = ANY == 1;   // the lane's ray: its sub and whether it is an any-hit query
+    uint32_t mk_nodes = 0, mk_tris = 0;             // MIX: counter values when the lane's current ray started (per-kind statistics)
+    __shared__ uint32_t lds_kcnt[MIX ? (kTraceBlock / 64) * 16 : 1];   // MIX: per wave {nodes, tris, rays} x 3 subs
+    uint32_t *kcnt = lds_kcnt + (MIX ? (threadIdx.x >> 6) * 16 : 0u);
+    if (MIX && lane_id() < 16u) kcnt[lane_id()] = 0u;
+#define PT_SUB(f) (MIX ? (ksel == 0u ? job.sub[0].f : (ksel == 1u ? job.sub[1].f : job.sub[2].f)) : job.sub[0].f)
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
     uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0;
+    const unsigned long long u_t0 = wall_clock64();
 #define PT_UTIL(it, act, pred) do { const unsigned long long m_ = __ballot(pred); if (pred) { act++; it += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } } while (0)
 #else
 #define PT_UTIL(it, act, pred) do { } while (0)
@@ -160,12 +174,12 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                         } else { hit_pkt = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
                     }
                     if (next_seg || finish) {   // the segment's ray goes back to the path state: k_bssrdf rebuilds the exit point from it
-                        float4 *rw = const_cast<float4 *>(job.ray) + (size_t)pid * job.ray_stride;
+                        float4 *rw = const_cast<float4 *>(job.sub[0].ray) + (size_t)pid * job.sub[0].ray_stride;
                         rw[0] = make_float4(ro.x, ro.y, ro.z, rd.x); rw[1] = make_float4(rd.y, rd.z, 0.0f, 0.0f);
                     }
                     if (next_seg) {
                         retire = false;
-                        t_max = job.scalar_tmax;
+                        t_max = job.sub[0].scalar_tmax;
                         inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                         tray = tri_ray_setup(rd);
@@ -188,14 +202,19 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                 }
             }
             if (retire) {
-                if (ANY) job.out_word[(size_t)pid * job.out_word_stride] = found ? 1u : 0u;
+                float4 *const o_hit = PT_SUB(out_hit), *const o_hit2 = PT_SUB(out_hit2); uint32_t *const o_word = PT_SUB(out_word); float *const o_t = PT_SUB(out_t);
+                const uint32_t o_hit_stride = PT_SUB(out_hit_stride), o_word_stride = PT_SUB(out_word_stride), o_t_stride = PT_SUB(out_t_stride);
+                if (lane_any) o_word[(size_t)pid * o_word_stride] = found ? 1u : 0u;
                 else {
                     uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
                     if (hit_pkt != PT_NONE) { const uint4 hq = leaf4[3 * (size_t)hit_pkt + 2]; hit_prim = hq.y; hit_fl = hq.w; }   // {p2.z, prim, shape, flags}
-                    if (job.out_hit) job.out_hit[(size_t)pid * job.out_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
-                    else job.out_word[(size_t)pid * job.out_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
-                    if (job.out_hit2) job.out_hit2[(size_t)pid * job.out_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), hit_t, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
-                    if (job.out_t) job.out_t[(size_t)pid * job.out_t_stride] = hit_t;
+                    if (o_hit) o_hit[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
+                    else o_word[(size_t)pid * o_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
+                    if (o_hit2) o_hit2[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), hit_t, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
+                    if (o_t) o_t[(size_t)pid * o_t_stride] = hit_t;
+                }
+                if constexpr (MIX) {   // per-kind work counters (LDS atomics of the wave's own slots)
+                    atomicAdd(&kcnt[3u * ksel], n_nodes - mk_nodes); atomicAdd(&kcnt[3u * ksel + 1u], n_tris - mk_tris); atomicAdd(&kcnt[3u * ksel + 2u], 1u);
                 }
             }
             if (retire) state = ST_IDLE;
@@ -217,11 +236,20 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                 const bool get = state == ST_IDLE && rank < take;
                 chunk_next += take; chunk_left -= take;
                 if (get) {
-                    pid = job.queue ? job.queue[qi] : qi;
-                    const float4 r0 = job.ray[(size_t)pid * job.ray_stride], r1 = job.ray[(size_t)pid * job.ray_stride + 1];   // one 32-byte record
+                    uint32_t qk = qi;
+                    if constexpr (MIX) {
+                        ksel = (qi >= c0 ? 1u : 0u) + (qi >= c01 ? 1u : 0u);
+                        qk = qi - (ksel == 0u ? 0u : (ksel == 1u ? c0 : c01));
+                        lane_any = PT_SUB(any) != 0u;
+                        mk_nodes = n_nodes; mk_tris = n_tris;
+                    }
+                    const uint32_t *const qp = PT_SUB(queue);
+                    pid = qp ? qp[qk] : qk;
+                    const float4 *const rp = PT_SUB(ray) + (size_t)pid * PT_SUB(ray_stride);
+                    const float4 r0 = rp[0], r1 = rp[1];   // one 32-byte record
                     ro = V3(r0.x, r0.y, r0.z);
                     rd = V3(r0.w, r1.x, r1.y);
-                    t_max = job.per_ray_tmax ? r1.z : job.scalar_tmax;
+                    t_max = PT_SUB(per_ray_tmax) ? r1.z : PT_SUB(scalar_tmax);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                     tray = tri_ray_setup(rd);
@@ -353,9 +381,9 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                     if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
                         n_sph++;
                         float t, phi; V3 ph, dobj;
-                        if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, ANY, t, ph, phi, dobj)) {
+                        if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, lane_any, t, ph, phi, dobj)) {
                             found = true;
-                            if (ANY) { state = ST_DONE; advance = false; }
+                            if (lane_any) { state = ST_DONE; advance = false; }
                             else {
                                 t_max = t;
                                 hit_pkt = li; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
@@ -381,11 +409,11 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                             c.uv = P2(uv[0].x * b0 + uv[1].x * b1 + uv[2].x * b2, uv[0].y * b0 + uv[1].y * b1 + uv[2].y * b2);
                             const int32_t a = s.tri_alpha ? s.tri_alpha[tri] : -1;
                             if (a >= 0 && tex_eval(s, a, c).r == 0.0f) hit = false;
-                            if (ANY && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
-                        } else if (ANY && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
+                            if (lane_any && hit) { const int32_t sa = s.tri_shadow_alpha ? s.tri_shadow_alpha[tri] : -1; if (sa >= 0 && tex_eval(s, sa, c).r == 0.0f) hit = false; }
+                        } else if (lane_any && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
                     }
                     if (hit) {
-                        if (ANY) { found = true; state = ST_DONE; advance = false; }
+                        if (lane_any) { found = true; state = ST_DONE; advance = false; }
                         else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
                             found = true; t_max = t;  // primitive.rs:137
                             hit_pkt = li; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
@@ -401,16 +429,32 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     counter_add(&job.counters->nodes, n_nodes);
     counter_add(&job.counters->tri_tests, n_tris);
     if (SPH) counter_add(&job.counters->sphere_tests, n_sph);
-    counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
-    counter_add(&job.counters->k_nodes[job.kind], n_nodes);
-    counter_add(&job.counters->k_tris[job.kind], n_tris);
-    counter_add(&job.counters->k_rays[job.kind], n_rays);
+    if constexpr (MIX) {   // rays per kind from the wave's LDS slots: shadow_tests counts Scene::intersect_p calls, intersect_tests Scene::intersect calls
+        if (lane < 3u) {
+            const uint32_t kd = lane == 0u ? job.sub[0].kind : (lane == 1u ? job.sub[1].kind : job.sub[2].kind);
+            const uint32_t is_any = lane == 0u ? job.sub[0].any : (lane == 1u ? job.sub[1].any : job.sub[2].any);
+            const uint32_t kn = kcnt[3u * lane], kt = kcnt[3u * lane + 1u], kr = kcnt[3u * lane + 2u];
+            if (kr) {
+                atomicAdd(is_any ? &job.counters->shadow_tests : &job.counters->intersect_tests, (unsigned long long)kr);
+                atomicAdd(&job.counters->k_nodes[kd], (unsigned long long)kn); atomicAdd(&job.counters->k_tris[kd], (unsigned long long)kt); atomicAdd(&job.counters->k_rays[kd], (unsigned long long)kr);
+            }
+        }
+    } else {
+        counter_add(ANY ? &job.counters->shadow_tests : &job.counters->intersect_tests, n_rays);
+        counter_add(&job.counters->k_nodes[job.sub[0].kind], n_nodes);
+        counter_add(&job.counters->k_tris[job.sub[0].kind], n_tris);
+        counter_add(&job.counters->k_rays[job.sub[0].kind], n_rays);
+    }
 #ifdef PT_TRACE_UTIL
     if (blockIdx.x == 0 && threadIdx.x == 0) { job.counters->dbg[0] = job.leaf_quorum; job.counters->dbg[1] = job.refill_min; job.counters->dbg[2] = job.inst_quorum; }
+    if (lane == 0) {   // how long the launch's wave slots were occupied: a wave leaves when the queue is drained and its own rays are done
+        const unsigned long long u_t1 = wall_clock64();
+        atomicMin(&job.counters->tail[0], u_t0); atomicMax(&job.counters->tail[1], u_t1); atomicAdd(&job.counters->tail[4 + 2 * (job.sub[0].kind & 3)], u_t1 - u_t0);
+    }
     for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
     if (lane == 0) {
-        atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 1], (unsigned long long)u_act1);
-        atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * (job.kind & 3) + 3], (unsigned long long)u_act2);
+        atomicAdd(&job.counters->regions[4 * (job.sub[0].kind & 3) + 0], (unsigned long long)u_it1); atomicAdd(&job.counters->regions[4 * (job.sub[0].kind & 3) + 1], (unsigned long long)u_act1);
+        atomicAdd(&job.counters->regions[4 * (job.sub[0].kind & 3) + 2], (unsigned long long)u_it2); atomicAdd(&job.counters->regions[4 * (job.sub[0].kind & 3) + 3], (unsigned long long)u_act2);
     }
 #endif
 }

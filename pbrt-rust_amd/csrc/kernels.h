@@ -101,6 +101,7 @@ struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long regions[16];            // PT_REGION_PROFILE builds: wave cycles per k_shade region
+    unsigned long long tail[16];               // PT_TRACE_UTIL builds: [0] first wave start, [1] last wave exit of the launch in flight; per kind k: [4+2k] sum of wave busy time, [5+2k] sum of launch span x waves (wall_clock64 ticks)
     unsigned long long dbg[4];                 // PT_TRACE_UTIL builds: scheduling knobs as the kernel saw them
     unsigned long long bss_items, bss_bytes;   // k_bssrdf: probe steps processed / state bytes moved
     unsigned long long k_nodes[5], k_tris[5], k_rays[5];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera, 4 extend_probe (segments)
@@ -126,10 +127,10 @@ struct RenderConst {
     uint32_t film_w, film_h;
 };
 
-struct TraceJob {
+// One kind of ray of a traversal launch: where its rays come from and where its results go.
+struct TraceSub {
     const uint32_t *queue;   // path ids (NULL => identity)
     const uint32_t *count;   // device count of queue entries
-    uint32_t *head;          // persistent-wave work head (zeroed before launch)
     // rays: 32-byte records {o.xyz, d.x} {d.y, d.z, t_max, -} at ray[pid * ray_stride] (stride in 16-byte quads: 2 = ray records, 4 = the
     // leading quads of nee / mis records); t_max is read from the record only if per_ray_tmax, else scalar_tmax
     const float4 *ray; uint32_t ray_stride; uint32_t per_ray_tmax;
@@ -139,10 +140,19 @@ struct TraceJob {
     uint32_t *out_word; uint32_t out_word_stride;   // any-hit: occluded flag; closest hit without out_hit: the primitive (volpath shadow rays)
     float4 *out_hit2;                               // second quad of a hit record {inst, t, packet index, packet flags | miss class}, stride out_hit_stride (NULL: not wanted)
     float *out_t; uint32_t out_t_stride;            // may be NULL (volpath MIS rays: mis_t)
+    uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera, 4 probe chains (per-kind work counters)
+    uint32_t any;            // k_trace<2, ..> (mixed launch): this kind's rays are any-hit queries (Scene::intersect_p)
+};
+
+// A traversal launch. k_trace<0 | 1, ..> walks the rays of sub[0] (closest hit | any hit); k_trace<2, ..> walks the queues of
+// sub[0..2] back to back -- the continuation, MIS and shadow rays of one wavefront iteration in ONE launch, so that the iteration
+// has one tail of straggling rays instead of three (run_pass in capi.hip).
+struct TraceJob {
+    TraceSub sub[3];
+    uint32_t *head;          // persistent-wave work head (zeroed before launch)
     uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - kLdsStack)]
     uint32_t *error;
     DevCounters *counters;
-    uint32_t kind;           // 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera (per-kind work counters)
     uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)
     uint32_t leaf_quorum;    // lanes waiting at a leaf join the record fetch once this many wait (or no lane is at a node)
     uint32_t inst_quorum;    // lanes waiting to enter / leave an object instance run the transform step once this many wait
