@@ -95,7 +95,7 @@ def main():
     pb = rp.pixel_bounds
     n_samples = (pb[2] - pb[0]) * (pb[3] - pb[1]) * spp
     n_slots = (-(-(rp.sample_bounds[2] - rp.sample_bounds[0]) // 16)) * (-(-(rp.sample_bounds[3] - rp.sample_bounds[1]) // 16)) * 256 // max(1, world if not in_process else len(devices))
-    eff_spp_per_pass = min(spp, args.spp_per_pass if args.spp_per_pass else max(1, (1 << 26) // max(1, n_slots)))
+    eff_spp_per_pass = None   # what the library chose (0 = as many samples per pass as the free memory holds, up to 2^28 paths): from the number of k_generate launches below
     multi = None
     if in_process:
         multi = pkg.MultiScene(lib, sd, devices)   # scene replicated on every device, one host thread + stream each
@@ -135,6 +135,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if kstats.get("generate", {}).get("launches"):
+        n_pass = max(1, kstats["generate"]["launches"] // args.steps)
+        eff_spp_per_pass = -(-spp // n_pass)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -365,7 +365,8 @@ typedef struct PtRenderParams {
     /* Sharding of the 16x16 sample tiles of integrator.rs:276-283: this call renders the
      * tiles with (tile_index % tile_world) == tile_rank. (1 GPU: rank 0 of 1.) */
     uint32_t tile_rank, tile_world;
-    /* Samples per pixel traced per wavefront pass (0 => library default). */
+    /* Samples per pixel traced per wavefront pass. 0 => the library chooses: as many as fit 60 % of the device's free
+     * memory, at most 2^28 paths in flight (~90 GB at 1920x1080 x 128 samples), in passes of equal size. */
     uint32_t spp_per_pass;
     /* 1 => record per-kernel HIP-event timings (see pt_get_kernel_stats); 2 => also exact per-class launch sizes
      * (one extra host sync per iteration). */

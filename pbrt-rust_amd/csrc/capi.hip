@@ -472,6 +472,23 @@ template <int MAXL, bool DIFF = false> void launch_shade(pt_scene *sc, const Ren
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
 
+// Samples per pass when the caller leaves the choice to the library (PtRenderParams.spp_per_pass = 0): as many paths in flight as the
+// memory allows, up to 2^28 (69 GB of path state + 17-36 GB of queues / probe state out of 288 GB). Every wavefront iteration ends
+// in a tail of straggling rays (~0.8 ms on S2, whatever the launch size), so fewer, larger iterations spend less of the render in tails:
+// S2 at 1080p x 256 spp: 32 samples per pass 1267, 64: 1367, 128: 1439, 256: 1468 Msamples/s. `share` = renders that will hold a
+// workspace on this device at the same time (pt_multi_render with a device listed more than once).
+uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share) {
+    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    // (the present workspace is freed before a larger one is allocated)
+    const size_t afford = std::max(sc->capacity, (size_t)((double)(free_b / std::max(1u, share) + sc->capacity * per_path) * 0.6) / per_path);
+    const size_t paths = std::min(afford, ((size_t)1 << 28) / std::max(1u, share));
+    uint32_t S = (uint32_t)std::min<size_t>(spp, std::max<size_t>(1, paths / std::max(1u, n_pix_slots)));
+    const uint32_t n_pass = (spp + S - 1) / S;
+    return (spp + n_pass - 1) / n_pass;   // passes of equal size
+}
+
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
     const uint32_t total = rc.n_pix_slots * rc.s_count;
     QCounters *qc = sc->qc;
@@ -1118,7 +1135,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
         uint32_t S = rp->spp_per_pass;
-        if (S == 0) S = (uint32_t)std::max<size_t>(1, ((size_t)1 << 26) / rc.n_pix_slots);  // ~67 M paths in flight (14 GB of state; 288 GB HBM)
+        if (S == 0) S = choose_pass_size(sc, rc.n_pix_slots, rp->spp, 1);
         S = std::min(S, rp->spp);
         if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
@@ -1359,6 +1376,18 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
     if (fw <= 0 || fh <= 0) return fail(PT_ERR_INVALID_ARG, "empty film");
     const size_t film_px = (size_t)fw * (size_t)fh;
     std::vector<int> status(n, PT_OK); std::vector<std::string> message(n);
+    // replicas that share a device share its memory: their pass sizes are chosen here, before any of them allocates
+    std::vector<uint32_t> pass_size(n, rp->spp_per_pass);
+    if (rp->spp_per_pass == 0) for (uint32_t i = 0; i < n; ++i) {
+        uint32_t share = 0; for (uint32_t k = 0; k < n; ++k) share += ms->dev[k] == ms->dev[i];
+        if (share > 1 && bind_device(ms->dev[i]) == PT_OK) {
+            PtRenderParams p = *rp; RenderConst rc;
+            pt_multi_tile_shard(rp->tile_rank, rp->tile_world, i, n, &p.tile_rank, &p.tile_world);
+            fill_render_const(&p, rc);
+            const uint32_t ntiles = rc.ntx * rc.nty, slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world * 256u : 0u;
+            if (slots) pass_size[i] = choose_pass_size(ms->sc[i], slots, rp->spp, share);
+        }
+    }
     auto worker = [&](uint32_t i) {
         int st = bind_device(ms->dev[i]);
         if (!st && (ms->film_px != film_px || !ms->film[i])) {
@@ -1369,6 +1398,7 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
         if (!st) {
             PtRenderParams p = *rp;
             pt_multi_tile_shard(rp->tile_rank, rp->tile_world, i, n, &p.tile_rank, &p.tile_world);
+            p.spp_per_pass = pass_size[i];
             st = pt_render(ms->sc[i], &p, ms->film[i], 1);
         }
         status[i] = st; if (st) message[i] = g_error;

@@ -77,7 +77,11 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5 };
     uint32_t state = ST_IDLE;
     bool exhausted = false;
-    constexpr int kChunk = 256;
+#ifndef PT_TRACE_CHUNK
+#define PT_TRACE_CHUNK 256   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
+                             // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
+#endif
+    constexpr int kChunk = PT_TRACE_CHUNK;
     uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
     V3 ro, rd, inv_dir;
