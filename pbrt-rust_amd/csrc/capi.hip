@@ -29,9 +29,12 @@ thread_local int g_num_cus = 256;
 std::atomic<int> g_default_device{-1};
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
 uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
-uint32_t g_leaf_quorum[4] = {1, 1, 1, 1};         // 1 = a lane at a leaf tests its packet at once. Round 1 shipped {24, 24, 24, 32}, but its ballot ran under the leaf
-                                                  // lanes' exec mask and the quorum never held a lane back; with the ballot fixed (round 2) every real quorum is slower
-                                                  // (C2 at 64 spp: 1 -> 1132, 8 -> 1084, 24 -> 1038, 48 -> 798 Msamples/s): a waiting lane costs more than a thin triangle step
+uint32_t g_leaf_quorum[4] = {8, 8, 8, 8};         // lanes at a leaf wait until this many of them do, then all of them run until none is left (sticky). History: round 1
+                                                  // shipped {24, 24, 24, 32}, but its ballot ran under the leaf lanes' exec mask and never held a lane back; with the ballot
+                                                  // fixed, a quorum that has to form again for every packet of a leaf lost (C2 at 64 spp: 1 -> 1132, 8 -> 1084, 24 -> 1038);
+                                                  // the sticky form is a small gain (C2 trace 166.4 -> 163.4 ms per step at 8, flat to 24; C3 349 -> 345; C4 unchanged). That a
+                                                  // step which runs the 149-instruction triangle test seven times less often gains 2 % says the loop is bound by the latency
+                                                  // of its dependent gathers (~2 us under load, six waves per SIMD), not by instruction issue.
 bool g_refill_from_env = false;
 bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one traversal launch per ray kind (extend / extend_mis / shadow) instead of the mixed launch
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)

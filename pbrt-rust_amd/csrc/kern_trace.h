@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5 };
     uint32_t state = ST_IDLE;
     bool exhausted = false;
+    bool draining = false;    // wave-uniform: the leaf lanes are being served (see leaf_quorum below)
 #ifndef PT_TRACE_CHUNK
 #define PT_TRACE_CHUNK 256   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
                              // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
@@ -285,7 +286,11 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
         //  short-circuit ran the ballot under the leaf lanes' exec mask only, where it is always 0 -- the quorum never held anything back;
         //  found in round 2 with the PT_TRACE_UTIL counters: 88 % of all wave iterations ran the triangle test for 5 lanes)
         const bool no_node_lane = __ballot(at_node) == 0ull;
-        const bool at_leaf = state == ST_LEAF && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || no_node_lane);
+        // The quorum is sticky: once it is met the leaf lanes keep running until none is left (a leaf holds up to max_node_prims packets,
+        // one per iteration -- without the hysteresis a lane in a three-packet leaf waits for three quorums).
+        if (leaf_m == 0ull) draining = false;
+        else if ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || no_node_lane) draining = true;
+        const bool at_leaf = state == ST_LEAF && draining;
         if constexpr (INST) {
             // ---- transform step: enter instances / return from them, once enough lanes wait (or nothing else can run)
             const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);

@@ -12,7 +12,7 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read().strip().split("\n")[-1])
     k = d["kernels_ms_per_step"]
-    print(f"{sys.argv[1]:60s} {d['value']:9.2f} Msamples/s  " + " ".join(f"{n}={k[n]['ms']:.1f}" for n in ("extend_camera", "extend", "extend_mis", "shadow", "extend_probe") if n in k))
+    print(f"{sys.argv[1]:60s} {d['value']:9.2f} Msamples/s  " + " ".join(f"{n}={k[n]['ms']:.1f}" for n in ("extend_camera", "trace", "extend", "extend_mis", "shadow", "extend_probe") if n in k))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
