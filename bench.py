@@ -191,6 +191,7 @@ def main():
         ab = algo_bytes(n, v)
         return {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
     kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps, kernel=v["kernel"], **gbs(n, v),
+                       **({"Mitems": round(v["items"] / args.steps / 1e6, 2), "ns_per_item": round(v["total_ms"] * 1e6 / v["items"], 3)} if v["items"] and n not in TRACE_KINDS else {}),
                        **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in TRACE_KINDS else {}))
                for n, v in kstats.items() if v["launches"]}
     # what the mixed traversal launches did per ray kind (counters only: the kinds share the launches' time)

@@ -38,7 +38,7 @@ uint32_t g_leaf_quorum[4] = {8, 8, 8, 8};         // lanes at a leaf wait until 
 bool g_refill_from_env = false;
 bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one traversal launch per ray kind (extend / extend_mis / shadow) instead of the mixed launch
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
-uint32_t g_trace_waves_per_cu = 24;               // persistent trace waves per CU = 6 per SIMD: k_trace<*, 0> needs 80 VGPRs and 6 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %)
+uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU = 7 per SIMD: k_trace<*, 0> needs 71 VGPRs and 5 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %, 24 -> 28: +3 %)
 thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 constexpr int kMaxDevices = 64;
 struct DevCtx { bool ready = false; int num_cus = 256; SobolTables tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
@@ -143,7 +143,7 @@ struct pt_scene {
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
-    bool class_used[kNumClasses] = {true, false, false, false, true, false};
+    bool class_used[kNumClasses] = {true, false, false, false, true, false, false};
     bool has_null_material = false;   // a primitive without a material (refused by the volumetric integrator)   // matte (default material) and the miss class always exist
     bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
     void *bss_slab = nullptr; BssSoA bs{};
@@ -230,12 +230,24 @@ struct pt_multi_scene {
 
 namespace {
 
+// Shade class of a material = the kernel its vertices are shaded by (kernels.h: kNumClasses): by the number of BxDFs the material
+// can produce, decided from its constant parameters (a textured parameter can take any value).
 uint8_t material_class(const PtMaterial &m) {
+    auto textured = [&](int slot) { return m.tex[slot] >= 0; };
+    auto black = [](const float c[3]) { return !(c[0] > 0.0f) && !(c[1] > 0.0f) && !(c[2] > 0.0f); };   // .clamps(0, inf).is_black()
     switch (m.type) {
     case PT_MAT_MATTE: return 0;
-    case PT_MAT_MIRROR: case PT_MAT_METAL: case PT_MAT_SUBSTRATE: return 1;
-    case PT_MAT_GLASS: return (m.u_roughness == 0.0f && m.v_roughness == 0.0f) ? 1 : 2;
+    case PT_MAT_MIRROR: return (uint8_t)kSpecClass;
+    case PT_MAT_METAL: case PT_MAT_SUBSTRATE: return 1;
+    case PT_MAT_GLASS:   // glass.rs:57-92: one FresnelSpecular lobe when both roughnesses are 0, else up to two microfacet lobes
+        if (textured(PT_MP_U_ROUGHNESS) || textured(PT_MP_V_ROUGHNESS)) return 2;
+        return (m.u_roughness == 0.0f && m.v_roughness == 0.0f) ? (uint8_t)kSpecClass : 2;
     case PT_MAT_PLASTIC: return 2;
+    case PT_MAT_UBER: {   // uber.rs:40-106: without specular reflection / transmission and fully opaque it is Lambertian + microfacet
+        const bool opaque = !textured(PT_MP_OPACITY) && m.opacity[0] >= 1.0f && m.opacity[1] >= 1.0f && m.opacity[2] >= 1.0f;
+        const bool no_spec = !textured(PT_MP_KR) && !textured(PT_MP_KT) && black(m.kr) && black(m.kt);
+        return (opaque && no_spec) ? 2 : 3;
+    }
     default: return 3;
     }
 }
@@ -292,7 +304,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         int st;
         if ((st = sc->dalloc(&sc->qc, 1))) return st;
         if ((st = sc->dalloc(&sc->dc, 1))) return st;
-        sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 6 KB per wave)
+        sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 5 KB per wave)
         if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * (kMaxStack - kLdsStack)))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
         if (sc->has_bssrdf && (st = sc->dalloc(&sc->probe_ring, (size_t)sc->spill_waves * 64 * kProbeRing * 3))) return st;
@@ -465,11 +477,11 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
     if (mask & 8u) { qc->ext[cur] = 0; qc->probe[cur] = 0; for (int c = 0; c < kNumClasses; ++c) qc->shade[cur][c] = 0; }
 }
 
-template <int MAXL, bool DIFF = false> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
+template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
     const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
-    sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + (DIFF ? "true" : "false") + ">");
-    if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + std::to_string(DIFF) + ">");
+    if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF == 2 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
@@ -501,7 +513,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * 16u)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
-    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
+    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
     const int kMaxIterations = 65536;   // a path needs <= max_depth + null-surface skips + probe segments iterations
     for (int iter = 0; iter <= kMaxIterations; ++iter) {
         QCounters h;
@@ -578,7 +590,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sc->begin("route", n_ext); sc->set_kernel("k_route");
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * 8u)), dim3(256), 0, sc->stream, sc->ds,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0],
-                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4]);
+                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4], sc->q.shade[cur][kSpecClass]);
             sc->end();
         }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
@@ -615,7 +627,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             for (int c = 0; c < kNumClasses; ++c) class_n[c] = h2.shade[cur][c];
         } else for (int c = 0; c < kNumClasses; ++c) class_n[c] = upper;
         for (int c = 0; c < kNumClasses; ++c) {
-            if (!sc->class_used[c] || class_n[c] == 0) continue;
+            const bool used = sc->class_used[c] || (c == 1 && rc.volpath && sc->class_used[kSpecClass]);   // (the volumetric router folds class 6 into class 1)
+            if (!used || class_n[c] == 0 || (c == kSpecClass && rc.volpath)) continue;
             ShadeJob sj{};
             sj.queue = sc->q.shade[cur][c]; sj.count = &qc->shade[cur][c];
             sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
@@ -637,7 +650,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
                 else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_shade_miss<true, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
                 else hipLaunchKernelGGL((k_shade_miss<false, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sj);
             }
-            else if (c == 0) launch_shade<1, true>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 0) launch_shade<1, 1>(sc, rc, grid, sj, class_n[c]);
+            else if (c == kSpecClass) launch_shade<1, 2>(sc, rc, grid, sj, class_n[c]);
             else if (c == 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
             else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
@@ -666,7 +680,7 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages;
-    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium"};
+    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[5] = {"extend", "extend_mis", "shadow", "extend_camera", "extend_probe"};
     for (int k = 0; k < 5; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; if (k == 4) s.items = d.k_rays[k]; }   // probe chains: items = segments traced

@@ -175,12 +175,14 @@ template <bool FULL = true> PT_DEV float lobe_g(const Lobe &b, V3 wo, V3 wi) { r
 
 // FULL = the five-lobe class, the only one that can hold the Disney lobes (uber, subsurface, translucent, mix, disney materials): the
 // one- and two-lobe kernels narrow `kind` to the classic lobes so that they carry none of the Disney code.
-template <bool DIFF, bool FULL> PT_DEV uint8_t lobe_kind(const Lobe &b) {
-    if (DIFF) return b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R;
+// DIFF == 2: the class holds perfectly specular lobes only (class 6: mirror, smooth glass).
+template <int DIFF, bool FULL> PT_DEV uint8_t lobe_kind(const Lobe &b) {
+    if (DIFF == 1) return b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R;
+    if (DIFF == 2) return b.kind == LB_FRESNEL_SPEC ? (uint8_t)LB_FRESNEL_SPEC : (uint8_t)LB_SPEC_R;
     return FULL ? b.kind : (b.kind > LB_FRESNEL_BLEND ? (uint8_t)LB_FRESNEL_BLEND : b.kind);
 }
 
-template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
+template <int DIFF = 0, bool FULL = true> PT_DEV RGB lobe_f(const Lobe &b, V3 wo, V3 wi) {
     switch (lobe_kind<DIFF, FULL>(b)) {
     case LB_LAMBERT_R: return b.r * kInvPi;
     case LB_LAMBERT_T: return b.t * kInvPi;
@@ -265,7 +267,7 @@ template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_f(const Lobe &b, 
     }
 }
 
-template <bool DIFF = false, bool FULL = true> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
+template <int DIFF = 0, bool FULL = true> PT_DEV float lobe_pdf(const Lobe &b, V3 wo, V3 wi) {
     switch (lobe_kind<DIFF, FULL>(b)) {
     case LB_LAMBERT_R: case LB_OREN_NAYAR: case LB_FRESNEL_SPEC:  // reflection.rs:439-445, :788-794
     case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN:   // BxDF::pdf default
@@ -303,7 +305,7 @@ template <bool DIFF = false, bool FULL = true> PT_DEV float lobe_pdf(const Lobe 
     }
 }
 
-template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
+template <int DIFF = 0, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lobe &b, V3 wo, V3 &wi, P2 u, float &pdf, int &sampled) {
     switch (lobe_kind<DIFF, FULL>(b)) {
     case LB_DISNEY_CLEARCOAT: {  // disney.rs:257-274
         if (wo.z == 0.0f) return RGB(0.0f);
@@ -406,7 +408,7 @@ template <bool DIFF = false, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lo
 constexpr int kLobeWords = 19, kLobeStride = 256;   // (k_shade runs 256-thread blocks)
 template <int MAXL> constexpr int lobe_store_words() { return MAXL > 1 ? MAXL * kLobeWords * kLobeStride : 1; }
 
-template <int MAXL, bool DIFF = false> struct Bsdf {
+template <int MAXL, int DIFF = 0> struct Bsdf {
     float eta;
     V3 ns, ng, ss, ts;
     int n;
@@ -537,8 +539,9 @@ struct ConstMatEval {
 
 // Material::compute_scattering_functions. Returns false when the reference leaves si.bsdf == None. `E` evaluates the
 // (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
-template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf_leaf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
-    switch (DIFF ? (uint32_t)PT_MAT_MATTE : m.type) {   // class 0 holds matte materials only
+template <int MAXL, class ME, int DIFF> PT_DEV bool build_bsdf_leaf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
+    // class 0 holds matte materials only, class 6 mirrors and smooth glass: the other cases drop out of those kernels
+    switch (DIFF == 1 ? (uint32_t)PT_MAT_MATTE : DIFF == 2 ? (m.type == PT_MAT_MIRROR ? (uint32_t)PT_MAT_MIRROR : (uint32_t)PT_MAT_GLASS) : m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
         RGB r = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);
@@ -721,7 +724,7 @@ template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf_leaf(const PtMat
 
 // Material::compute_scattering_functions incl. MixMaterial (mix.rs:25-50): both materials' BxDFs in one BSDF (frame and eta of
 // the first), wrapped in ScaledBxDFs with scale = "amount" and 1 - "amount". `mats` = the scene's material array.
-template <int MAXL, class ME, bool DIFF> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E, const PtMaterial *mats) {
+template <int MAXL, class ME, int DIFF> PT_DEV bool build_bsdf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E, const PtMaterial *mats) {
     if constexpr (MAXL == 5) {
         bsdf.n1 = -1; bsdf.frozen = false;
         if (m.type == PT_MAT_MIX) {

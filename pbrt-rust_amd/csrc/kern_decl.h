@@ -4,7 +4,7 @@
 #include "kern_common.h"
 
 template <int ANY, int MODE, bool PROBE = false> __global__ void k_trace(DeviceScene s, TraceJob job);   // ANY: 0 closest hit, 1 any hit, 2 mixed (per-lane kind)
-template <int MAXL, int MODE, bool DIFF> __global__ void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);
+template <int MAXL, int MODE, int DIFF> __global__ void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);
 template <bool SPH, bool VOL> __global__ void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job);
 template <bool SPH> __global__ void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job);
 __global__ void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
@@ -14,7 +14,7 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
 __global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n);
 __global__ void k_light_area(DeviceScene s, float *area);
 __global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
-                        uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4);
+                        uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c6);
 __global__ void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters);
 __global__ void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
 __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix);

@@ -66,9 +66,9 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
 // material's class (escaped rays -> the miss class). Block-level staged appends: one global atomic per ~1000 entries per class.
 __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
-                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4) {
-    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4;
-    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4);
+                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c6) {
+    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4, q6;
+    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q6);
     __syncthreads();
     const uint32_t count = *count_ptr;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -81,15 +81,16 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
         lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
+        lq_push(q6, pid, valid && cls == (uint32_t)kSpecClass);
         __syncthreads();
         lq_flush_nosync(q0, class_count + 0, c0, 256u, false); lq_flush_nosync(q1, class_count + 1, c1, 256u, false);
         lq_flush_nosync(q2, class_count + 2, c2, 256u, false); lq_flush_nosync(q3, class_count + 3, c3, 256u, false);
-        lq_flush_nosync(q4, class_count + 4, c4, 256u, false);
+        lq_flush_nosync(q4, class_count + 4, c4, 256u, false); lq_flush_nosync(q6, class_count + kSpecClass, c6, 256u, false);
         __syncthreads();
     }
     lq_flush_nosync(q0, class_count + 0, c0, 0u, true); lq_flush_nosync(q1, class_count + 1, c1, 0u, true);
     lq_flush_nosync(q2, class_count + 2, c2, 0u, true); lq_flush_nosync(q3, class_count + 3, c3, 0u, true);
-    lq_flush_nosync(q4, class_count + 4, c4, 0u, true);
+    lq_flush_nosync(q4, class_count + 4, c4, 0u, true); lq_flush_nosync(q6, class_count + kSpecClass, c6, 0u, true);
 }
 // ---- camera rays -------------------------------------------------------------------------------------
 // pixel slot -> pixel: slot = tile_slot*256 + ty*16 + tx, tile index = tile_rank + tile_slot*tile_world

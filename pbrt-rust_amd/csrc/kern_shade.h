@@ -5,8 +5,9 @@
 #define PT_SHADE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(4,4)))
 #endif
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres and/or instances), 2 = general geometry + textures
-// DIFF: the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only)
-template <int MAXL, int MODE, bool DIFF>
+// DIFF: 1 = the launch serves class 0 (matte materials: Lambertian / Oren-Nayar lobes only); 2 = class 6 (mirror / smooth glass: perfectly
+//       specular lobes only, no next-event estimation); 0 = any material of the lobe budget MAXL
+template <int MAXL, int MODE, int DIFF>
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 1   // experiment hook (tools/build_variant.sh -DPT_SHADE_WAVES=N): minimum waves per SIMD the one-lobe kernels are compiled for
 #endif
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                             defer = s.has_grid != 0u && (push_shadow || push_mis);   // wait for the traced rays before drawing any further dimension
                         }
                     }
-                    else if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
+                    else if (DIFF != 2 && bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {   // (a specular-only BSDF has no such component: path.rs:131)
                         zero_den++;
                         const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
                         if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)

@@ -19,7 +19,9 @@
 
 // GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 5   // waves per SIMD the triangle-only / instanced traversal kernels are compiled for (experiment hook: tools/build_variant.sh -DPT_TRACE_WAVES=N)
+#define PT_TRACE_WAVES 7   // waves per SIMD the triangle-only traversal kernels are compiled for (experiment hook: tools/build_variant.sh -DPT_TRACE_WAVES=N).
+                           // Round 2: 71 VGPRs without scratch, and with a 10-entry LDS stack (kernels.h) seven workgroups share a CU's LDS: trace -3 %, camera
+                           // rays -6 % against six waves; eight waves need 64 VGPRs = 24 bytes of scratch per lane and lose 9 %. The loop waits on its gathers.
 #endif
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
@@ -36,25 +38,28 @@
 // launch: one tail of straggling rays per iteration instead of three; measured with the PT_TRACE_UTIL build on S2: the wave slots of the three
 // separate launches were busy 73 / 53 / 62 % of launch span x resident waves, ~0.8 ms of tail each).
 template <int ANY, int MODE, bool PROBE>
-__global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ? PT_TRACE_WAVES : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
     constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
-    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLdsStack * 2 * 64];
+    constexpr int kLds = MODE == 0 ? kLdsStack : kLdsStackGeneral;   // LDS stack entries per lane
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLds * 2 * 64];
     __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    uint32_t *stack = lds_stack + wave_in_block * (kLdsStack * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    uint32_t *stack = lds_stack + wave_in_block * (kLds * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
     float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
-    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLdsStack)) + lane;
+    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLds)) + lane;
     // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
+    // (measured and dropped, round 2: one work head per XCD group, each group draining "its" contiguous eighth of the queues first -- no
+    //  change on any config with the segments on or off, and the dozen wave-uniform words of segment state overflowed the SGPR file into
+    //  VGPRs: 75 -> 87, six -> five waves per SIMD, 7 % slower)
     const uint32_t c0 = *job.sub[0].count, c01 = c0 + (MIX ? *job.sub[1].count : 0u);
     const uint32_t count = c01 + (MIX ? *job.sub[2].count : 0u);
     uint32_t ksel = 0; bool lane_any = ANY == 1;   // the lane's ray: its sub and whether it is an any-hit query
-    uint32_t mk_nodes = 0, mk_tris = 0;             // MIX: counter values when the lane's current ray started (per-kind statistics)
     __shared__ uint32_t lds_kcnt[MIX ? (kTraceBlock / 64) * 16 : 1];   // MIX: per wave {nodes, tris, rays} x 3 subs
     uint32_t *kcnt = lds_kcnt + (MIX ? (threadIdx.x >> 6) * 16 : 0u);
     if (MIX && lane_id() < 16u) kcnt[lane_id()] = 0u;
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
             if (sp == 0) { state = ST_DONE; return; }
             sp--;
             uint32_t w0, w1;
-            if (sp < (uint32_t)kLdsStack) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
-            else { w0 = spill[(2 * (sp - kLdsStack)) * 64]; w1 = spill[(2 * (sp - kLdsStack) + 1) * 64]; }
+            if (sp < (uint32_t)kLds) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
+            else { w0 = spill[(2 * (sp - kLds)) * 64]; w1 = spill[(2 * (sp - kLds) + 1) * 64]; }
             if (INST && w1 == kMarker) {               // the object's BVH is exhausted: back to world space (primitive.rs:70-77), in the transform step
                 xf_arg = w0; state = ST_RET;
                 return;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                     if (o_t) o_t[(size_t)pid * o_t_stride] = hit_t;
                 }
                 if constexpr (MIX) {   // per-kind work counters (LDS atomics of the wave's own slots)
-                    atomicAdd(&kcnt[3u * ksel], n_nodes - mk_nodes); atomicAdd(&kcnt[3u * ksel + 1u], n_tris - mk_tris); atomicAdd(&kcnt[3u * ksel + 2u], 1u);
+                    atomicAdd(&kcnt[3u * ksel], n_nodes); atomicAdd(&kcnt[3u * ksel + 1u], n_tris); atomicAdd(&kcnt[3u * ksel + 2u], 1u);   // (MIX: n_nodes / n_tris count the lane's current ray only)
                 }
             }
             if (retire) state = ST_IDLE;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                         ksel = (qi >= c0 ? 1u : 0u) + (qi >= c01 ? 1u : 0u);
                         qk = qi - (ksel == 0u ? 0u : (ksel == 1u ? c0 : c01));
                         lane_any = PT_SUB(any) != 0u;
-                        mk_nodes = n_nodes; mk_tris = n_tris;
+                        n_nodes = 0u; n_tris = 0u;
                     }
                     const uint32_t *const qp = PT_SUB(queue);
                     pid = qp ? qp[qk] : qk;
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                     if (enter) {
                         // remember where to resume: the rest of this leaf (if any) and the outer skip count
                         const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
-                        if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
-                        else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = kMarker; }
+                        if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
+                        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = kMarker; }
                         sp++; pending = 0;
                         wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
@@ -370,8 +375,8 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
                     if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
                     else {
                         const uint32_t w0 = far_ref | (pending << 25), w1 = __float_as_uint(tmin_far);
-                        if (sp < (uint32_t)kLdsStack) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
-                        else { spill[(2 * (sp - kLdsStack)) * 64] = w0; spill[(2 * (sp - kLdsStack) + 1) * 64] = w1; }
+                        if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
+                        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
                         sp++; pending = 0;
                     }
                 } else pending++;
@@ -435,8 +440,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
             if (need_pop) pop_next();
         }
     }
-    counter_add(&job.counters->nodes, n_nodes);
-    counter_add(&job.counters->tri_tests, n_tris);
+    if (!MIX) { counter_add(&job.counters->nodes, n_nodes); counter_add(&job.counters->tri_tests, n_tris); }
     if (SPH) counter_add(&job.counters->sphere_tests, n_sph);
     if constexpr (MIX) {   // rays per kind from the wave's LDS slots: shadow_tests counts Scene::intersect_p calls, intersect_tests Scene::intersect calls
         if (lane < 3u) {
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(kTraceBlock, ((MODE == 0 || MODE == 3) && !PROBE) ?
             const uint32_t is_any = lane == 0u ? job.sub[0].any : (lane == 1u ? job.sub[1].any : job.sub[2].any);
             const uint32_t kn = kcnt[3u * lane], kt = kcnt[3u * lane + 1u], kr = kcnt[3u * lane + 2u];
             if (kr) {
+                atomicAdd(&job.counters->nodes, (unsigned long long)kn); atomicAdd(&job.counters->tri_tests, (unsigned long long)kt);
                 atomicAdd(is_any ? &job.counters->shadow_tests : &job.counters->intersect_tests, (unsigned long long)kr);
                 atomicAdd(&job.counters->k_nodes[kd], (unsigned long long)kn); atomicAdd(&job.counters->k_tris[kd], (unsigned long long)kt); atomicAdd(&job.counters->k_rays[kd], (unsigned long long)kr);
             }

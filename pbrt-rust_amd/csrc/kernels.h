@@ -1,5 +1,6 @@
 // kernels.h -- shared declarations between the HIP kernels (kernels.hip) and the host driver (capi.hip).
 #pragma once
+#include <cstddef>
 #include "dev_scene.h"
 #include "dev_sampler.h"
 #include "dev_light.h"
@@ -7,13 +8,19 @@
 
 namespace ptd {
 
-constexpr int kNumClasses = 6;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
-constexpr int kMissClass = 4, kMediumClass = 5;   // 5 = medium vertices of the volumetric integrator (k_shade_medium)
+constexpr int kNumClasses = 7;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
 //       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
+//       // 5 = medium vertices of the volumetric integrator (k_shade_medium)
+//       // 6 = perfectly specular materials (mirror, smooth glass): no next-event estimation at their vertices (path.rs:131-146);
+//       //     the volumetric integrator estimates direct light at every vertex, so its router folds this class into class 1
+constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6;
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 12
+#define PT_LDS_STACK 10
 #endif
-constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM
+constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM. Triangle-only scenes: 10, so
+                                              // that seven workgroups fit a CU's LDS; scenes with instances push a marker entry per instance entered and run five
+                                              // waves per SIMD: 12 (C4 with 10: trace +2.3 %)
+constexpr int kLdsStackGeneral = PT_LDS_STACK > 12 ? PT_LDS_STACK : 12;
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
@@ -150,7 +157,7 @@ struct TraceSub {
 struct TraceJob {
     TraceSub sub[3];
     uint32_t *head;          // persistent-wave work head (zeroed before launch)
-    uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - kLdsStack)]
+    uint32_t *spill;         // [waves_in_grid][64 lanes][2 * (kMaxStack - the kernel's LDS stack entries)], allocated for the smaller LDS stack
     uint32_t *error;
     DevCounters *counters;
     uint32_t refill_min;     // refill idle lanes from the queue once this many are idle (64 => only when the wave is empty)

@@ -6,7 +6,10 @@
 #endif
 #define PT_INST_SHADE(L, S, D) template __global__ void k_shade<L, S, D>(DeviceScene, RenderConst, SobolTables, LightGrid, PathSoA, ShadeJob);
 #if PT_TU_MAXL == 1
-PT_INST_SHADE(1, PT_TU_MODE, true) PT_INST_SHADE(1, PT_TU_MODE, false)
+PT_INST_SHADE(1, PT_TU_MODE, 1) PT_INST_SHADE(1, PT_TU_MODE, 0)
+#if PT_TU_MODE != 3   // (the volumetric integrator has no specular-only class: it estimates direct light at every vertex)
+PT_INST_SHADE(1, PT_TU_MODE, 2)
+#endif
 #else
-PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, false)
+PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, 0)
 #endif
