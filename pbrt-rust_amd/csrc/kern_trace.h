@@ -68,8 +68,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
-    uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0;
-    const unsigned long long u_t0 = wall_clock64();
+    uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0, u_it3 = 0, u_act3 = 0;
+    unsigned long long u_cxf = 0, u_cmain = 0;   // wave cycles inside the transform step / the record step
+    const unsigned long long u_t0 = wall_clock64(); const long long u_t0c = clock64();
 #define PT_UTIL(it, act, pred) do { const unsigned long long m_ = __ballot(pred); if (pred) { act++; it += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } } while (0)
 #else
 #define PT_UTIL(it, act, pred) do { } while (0)
@@ -301,6 +302,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
             const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);
             if (xf_m != 0ull && ((uint32_t)__popcll(xf_m) >= job.inst_quorum || __ballot(at_node || at_leaf) == 0ull)) {
                 bool need_pop = false;
+#ifdef PT_TRACE_UTIL
+                PT_UTIL(u_it3, u_act3, state == ST_INST || state == ST_RET);
+                const long long u_c0 = clock64();
+#endif
                 if (state == ST_RET) {
                     const uint32_t w0 = xf_arg;
                     pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
@@ -344,11 +349,17 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     else need_pop = true;
                 }
                 if (need_pop) pop_next();
+#ifdef PT_TRACE_UTIL
+                u_cxf += (unsigned long long)(clock64() - u_c0);
+#endif
                 continue;   // states changed: re-evaluate which step runs next
             }
         }
         PT_UTIL(u_it1, u_act1, at_node || at_leaf);
         PT_UTIL(u_it2, u_act2, at_leaf);
+#ifdef PT_TRACE_UTIL
+        const long long u_c1 = clock64();
+#endif
         if (at_node || at_leaf) {
             const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
             const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
@@ -439,6 +450,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
             }
             if (need_pop) pop_next();
         }
+#ifdef PT_TRACE_UTIL
+        u_cmain += (unsigned long long)(clock64() - u_c1);
+#endif
     }
     if (!MIX) { counter_add(&job.counters->nodes, n_nodes); counter_add(&job.counters->tri_tests, n_tris); }
     if (SPH) counter_add(&job.counters->sphere_tests, n_sph);
@@ -464,6 +478,11 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     if (lane == 0) {   // how long the launch's wave slots were occupied: a wave leaves when the queue is drained and its own rays are done
         const unsigned long long u_t1 = wall_clock64();
         atomicMin(&job.counters->tail[0], u_t0); atomicMax(&job.counters->tail[1], u_t1); atomicAdd(&job.counters->tail[4 + 2 * (job.sub[0].kind & 3)], u_t1 - u_t0);
+    }
+    for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); }
+    if (lane == 0) {
+        atomicAdd(&job.counters->tail[12], (unsigned long long)u_it3); atomicAdd(&job.counters->tail[13], (unsigned long long)u_act3);
+        atomicAdd(&job.counters->tail[14], u_cxf); atomicAdd(&job.counters->tail[15], u_cmain); atomicAdd(&job.counters->tail[2], (unsigned long long)(clock64() - (long long)u_t0c));
     }
     for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
     if (lane == 0) {

@@ -1,0 +1,137 @@
+"""How the wavefront is scheduled must not change what is computed: one traversal launch per iteration (k_trace<2, ..>: continuation, MIS
+and shadow rays together) against one launch per ray kind, any pass size, and the material classes a scene's vertices are shaded by
+(capi.hip: material_class). The reference has no counterpart of these choices (core/integrator.rs:263-403 is one loop per sample), so
+the checks are: identical films and counters between the schedules, and GPU == oracle for the scenes that exercise each class."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats",
+            "zero_radiance_paths_num", "zero_radiance_paths_den")
+
+_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from _pkg import import_pkg
+pkg = import_pkg()
+import torch   # before the library touches HIP (tests/conftest.py)
+torch.cuda.init()
+lib = pkg.load_library(); lib.init(0)
+out = {{}}
+for name in ("zoo", "spheres", "instances"):
+    b = {{"zoo": lambda: pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=8), "spheres": lambda: pkg.scenes.spheres_c1(xres=64, yres=64, spp=8),
+         "instances": lambda: pkg.scenes.instanced_garden(xres=64, yres=48, spp=4)}}[name]()
+    sd, rp = b.world_end()
+    g = pkg.Scene(lib, sd)
+    film = g.render(rp)
+    c = g.counters()
+    np.save({out!r} + "/" + name + ".npy", film)
+    out[name] = dict(counters={{k: c[k] for k in {counters!r}}}, stats=sorted(s["name"] for s in g.kernel_stats() if s["launches"]))
+json.dump(out, open({out!r} + "/out.json", "w"))
+"""
+
+
+def _scenes(pkg):
+    return {"zoo": lambda: pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=8), "spheres": lambda: pkg.scenes.spheres_c1(xres=64, yres=64, spp=8),
+            "instances": lambda: pkg.scenes.instanced_garden(xres=64, yres=48, spp=4)}
+
+
+def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_path):
+    """PT_TRACE_SPLIT=1 (read by pt_init, so in a process of its own) traces the three ray kinds of an iteration in three launches, as
+    round 1 did; the default traces them in one. Same films bit for bit (box filter), same counters; the launch kinds differ."""
+    env = dict(os.environ, PT_TRACE_SPLIT="1")
+    code = _CHILD.format(root=ROOT, out=str(tmp_path), counters=COUNTERS)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    split = json.load(open(tmp_path / "out.json"))
+    for name, make in _scenes(pkg).items():
+        sd, rp = make().world_end()
+        g = pkg.Scene(gpu, sd)
+        film = g.render(rp)
+        c = g.counters()
+        stats = sorted(s["name"] for s in g.kernel_stats() if s["launches"])
+        for k in COUNTERS:
+            assert c[k] == split[name]["counters"][k], (name, k)
+        assert np.array_equal(film, np.load(tmp_path / (name + ".npy"))), name
+        assert "trace" in stats and not {"extend", "extend_mis", "shadow"} & set(stats), stats
+        assert {"extend", "shadow"} <= set(split[name]["stats"]) and "trace" not in split[name]["stats"], split[name]["stats"]
+
+
+@pytest.mark.parametrize("per_pass", [1, 3, 5])
+def test_pass_size_does_not_change_the_image(pkg, gpu, per_pass):
+    """spp_per_pass = 0 lets the library size its passes from the free memory (here: one pass); explicit pass sizes that do not divide the
+    sample count give the same film (bit-identical weights and, with the box filter's one splat per sample in sample order, radiance)."""
+    sd, rp = pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=8).world_end()
+    g = pkg.Scene(gpu, sd)
+    rp.spp_per_pass = 0
+    a = g.render(rp); ca = g.counters()
+    n_pass_auto = [s["launches"] for s in g.kernel_stats() if s["name"] == "generate"][0]
+    rp.spp_per_pass = per_pass
+    b = g.render(rp); cb = g.counters()
+    n_pass = [s["launches"] for s in g.kernel_stats() if s["name"] == "generate"][0]
+    assert n_pass_auto == 1 and n_pass == -(-8 // per_pass)
+    for k in COUNTERS:
+        assert ca[k] == cb[k], k
+    assert np.array_equal(a[..., 3], b[..., 3])
+    np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-6, atol=1e-7)
+
+
+def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
+    """Mirror and smooth glass (C1's two spheres) are shaded by k_shade<1, MODE, 2>, the kernel without next-event estimation
+    (path.rs:131: a BSDF without non-specular components does not sample a light); rough glass and metal are not. GPU == oracle."""
+    sd, rp = pkg.scenes.spheres_c1(xres=64, yres=64, spp=8).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    st = {s["name"]: s for s in g.kernel_stats() if s["launches"]}
+    assert "shade_specular" in st and st["shade_specular"]["kernel"] == "k_shade<1, 1, 2>" and "shade_1lobe" not in st
+    gc, oc = g.counters(), orc.counters()
+    for k in COUNTERS:
+        assert gc[k] == oc[k], k
+    np.testing.assert_allclose(film, ref, rtol=3e-6, atol=1e-6)
+    # the zoo has metal + substrate (one lobe, with NEE), mirror + glass (specular), plastic + rough glass (two lobes) and an uber with a specular term (class 3)
+    sd, rp = pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=4).world_end()
+    g = pkg.Scene(gpu, sd); g.render(rp)
+    names = {s["name"] for s in g.kernel_stats() if s["launches"]}
+    assert {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_specular", "shade_miss"} <= names
+
+
+def _uber_ball(pkg, uber):
+    """A displaced ball of the given uber material over a matte floor, one area light and a dim constant environment."""
+    S = pkg.scenes
+    b = S.SceneBuilder()
+    b.film.update(xres=64, yres=48); b.spp = 8; b.integ.update(maxdepth=5)
+    b.look_at((0.0, 1.5, 5.0), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.2, 0.25, 0.3))
+    b.attribute_begin(); b.area_light_source(L=(20.0, 18.0, 15.0))
+    P, I = S.quad((-1.5, 4.0, -1.5), (1.5, 4.0, -1.5), (1.5, 4.0, 1.5), (-1.5, 4.0, 1.5)); b.trianglemesh(P, I); b.attribute_end()
+    b.material("matte", Kd=(0.6, 0.6, 0.55))
+    P, I = S.quad((-8.0, -0.5, -8.0), (-8.0, -0.5, 8.0), (8.0, -0.5, 8.0), (8.0, -0.5, -8.0)); b.trianglemesh(P, I)
+    b.attribute_begin(); b.material("uber", **uber); b.translate(0.0, 0.5, 0.0)
+    P, I, N = S.displaced_sphere(12); b.trianglemesh(P, I, N=N); b.attribute_end()
+    return b
+
+
+@pytest.mark.parametrize("uber,expect_class", [(dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2), "shade_2lobe"),
+                                               (dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), Kr=(0.1, 0.1, 0.1), roughness=0.2), "shade_uber"),
+                                               (dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), opacity=(0.6, 0.6, 0.6), roughness=0.2), "shade_uber")])
+def test_uber_without_specular_terms_is_a_two_lobe_material(pkg, gpu, oracle, uber, expect_class):
+    """uber.rs:40-106 adds its specular reflection / transmission lobes only for non-black Kr / Kt and its pass-through lobe only for
+    opacity < 1: an opaque uber with Kr = Kt = 0 is Lambertian + microfacet and is shaded by the two-lobe kernel. GPU == oracle either way."""
+    sd, rp = _uber_ball(pkg, uber).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    names = {s["name"] for s in g.kernel_stats() if s["launches"]}
+    assert expect_class in names and ({"shade_2lobe", "shade_uber"} - {expect_class}).isdisjoint(names), names
+    gc, oc = g.counters(), orc.counters()
+    for k in COUNTERS:
+        assert gc[k] == oc[k], k
+    np.testing.assert_allclose(film, ref, rtol=3e-6, atol=1e-6)

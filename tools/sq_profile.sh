@@ -6,9 +6,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq1_bench.json 2> $OUT/sq1.err
-timeout -k 5 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/sq2 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq2_bench.json 2> $OUT/sq2.err
-timeout -k 5 200 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_WAIT_INST_LDS SQ_INSTS_VALU_FMA_F64 --kernel-trace --output-format csv -d $OUT/sq3 -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq3_bench.json 2> $OUT/sq3.err
+timeout -k 5 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq1 -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq1_bench.json 2> $OUT/sq1.err
+timeout -k 5 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/sq2 -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq2_bench.json 2> $OUT/sq2.err
+timeout -k 5 200 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_WAIT_INST_LDS SQ_INSTS_VALU_FMA_F64 --kernel-trace --output-format csv -d $OUT/sq3 -- python3 $REPO/bench.py --config ${CONFIG:-C2} --steps 1 --warmup 0 --spp $PPASS --cpu-seconds 0 > $OUT/sq3_bench.json 2> $OUT/sq3.err
 python3 - $OUT <<'PY'
 import csv, glob, os, re, sys
 from collections import defaultdict
