@@ -401,11 +401,22 @@ template <int DIFF = 0, bool FULL = true> PT_DEV RGB lobe_sample_f(const Lobe &b
 }
 
 // ---- BSDF (reflection.rs:1495-1689). MAXL = compile-time lobe capacity of the shade-queue class -----------
-// Lobe storage. A one-lobe BSDF keeps its lobe in registers. The two- and five-lobe classes keep theirs in LDS (19 words per lobe,
-// word w of lobe i of thread t at store[(i * 19 + w) * 256 + t]: conflict free) and walk them with rolled loops that hold ONE lobe
+// Lobe storage. A one-lobe BSDF keeps its lobe in registers. The two- and five-lobe classes keep theirs in LDS (12 words per lobe,
+// word w of lobe i of thread t at store[(i * 12 + w) * 256 + t]: conflict free) and walk them with rolled loops that hold ONE lobe
 // in registers at a time: with the lobes in a register array every loop over them was unrolled MAXL times around the big
 // per-kind switches, which cost the five-lobe kernel 256 VGPRs + 73 AGPRs + 632 bytes of scratch per lane at one wave per SIMD.
-constexpr int kLobeWords = 19, kLobeStride = 256;   // (k_shade runs 256-thread blocks)
+// The 19 fields of a Lobe are never all live in one lobe, so the stored form overlays them (5 x 19 words x 256 threads = 95 KB kept the
+// five-lobe kernel at ONE workgroup per CU; 5 x 12 = 60 KB lets two share the 160 KB):
+//   word 0      kind | type << 8 | fresnel << 16 | sepg << 24
+//   words 1-3   r
+//   words 4-6   ce for the conductor / Disney Fresnel terms (lobes that have no t), else t
+//   words 7-9   ck for the conductor Fresnel term, else {etaa, etab, A}
+//   word 10     B for Oren-Nayar and the Disney clearcoat (lobes without a microfacet distribution), else ax
+//   word 11     ay
+// Fields a lobe does not store come back as mk_lobe() leaves them; no lobe kind reads a field it does not store.
+constexpr int kLobeWords = 12, kLobeStride = 256;   // (k_shade runs 256-thread blocks)
+PT_DEV bool lobe_stores_ce(uint8_t fresnel) { return fresnel == FR_CONDUCTOR || fresnel == FR_DISNEY; }
+PT_DEV bool lobe_stores_b(uint8_t kind) { return kind == LB_OREN_NAYAR || kind == LB_DISNEY_CLEARCOAT; }
 template <int MAXL> constexpr int lobe_store_words() { return MAXL > 1 ? MAXL * kLobeWords * kLobeStride : 1; }
 
 template <int MAXL, int DIFF = 0> struct Bsdf {
@@ -435,10 +446,14 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
         Lobe b;
         const uint32_t w0 = __float_as_uint(p[0]);
         b.kind = (uint8_t)(w0 & 0xffu); b.type = (uint8_t)((w0 >> 8) & 0xffu); b.fresnel = (uint8_t)((w0 >> 16) & 0xffu); b.sepg = (uint8_t)(w0 >> 24);
-        b.r = RGB(p[1 * kLobeStride], p[2 * kLobeStride], p[3 * kLobeStride]); b.t = RGB(p[4 * kLobeStride], p[5 * kLobeStride], p[6 * kLobeStride]);
-        b.ax = p[7 * kLobeStride]; b.ay = p[8 * kLobeStride]; b.etaa = p[9 * kLobeStride]; b.etab = p[10 * kLobeStride];
-        b.ck = RGB(p[11 * kLobeStride], p[12 * kLobeStride], p[13 * kLobeStride]); b.ce = RGB(p[14 * kLobeStride], p[15 * kLobeStride], p[16 * kLobeStride]);
-        b.A = p[17 * kLobeStride]; b.B = p[18 * kLobeStride];
+        b.r = RGB(p[1 * kLobeStride], p[2 * kLobeStride], p[3 * kLobeStride]);
+        const RGB x4(p[4 * kLobeStride], p[5 * kLobeStride], p[6 * kLobeStride]);
+        const float y7 = p[7 * kLobeStride], y8 = p[8 * kLobeStride], y9 = p[9 * kLobeStride], z10 = p[10 * kLobeStride];
+        b.t = RGB(0.0f); b.ce = RGB(0.0f); b.ck = RGB(0.0f); b.etaa = b.etab = 1.0f; b.A = b.B = 0.0f; b.ax = 0.001f;
+        if (lobe_stores_ce(b.fresnel)) b.ce = x4; else b.t = x4;
+        if (b.fresnel == FR_CONDUCTOR) b.ck = RGB(y7, y8, y9); else { b.etaa = y7; b.etab = y8; b.A = y9; }
+        if (lobe_stores_b(b.kind)) b.B = z10; else b.ax = z10;
+        b.ay = p[11 * kLobeStride];
         return b;
     }
     PT_DEV void add(const Lobe &x) {
@@ -447,10 +462,12 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
         else {
             float *p = store + (size_t)n * (kLobeWords * kLobeStride);
             p[0] = __uint_as_float((uint32_t)x.kind | ((uint32_t)x.type << 8) | ((uint32_t)x.fresnel << 16) | ((uint32_t)x.sepg << 24));
-            p[1 * kLobeStride] = x.r.r; p[2 * kLobeStride] = x.r.g; p[3 * kLobeStride] = x.r.b; p[4 * kLobeStride] = x.t.r; p[5 * kLobeStride] = x.t.g; p[6 * kLobeStride] = x.t.b;
-            p[7 * kLobeStride] = x.ax; p[8 * kLobeStride] = x.ay; p[9 * kLobeStride] = x.etaa; p[10 * kLobeStride] = x.etab;
-            p[11 * kLobeStride] = x.ck.r; p[12 * kLobeStride] = x.ck.g; p[13 * kLobeStride] = x.ck.b; p[14 * kLobeStride] = x.ce.r; p[15 * kLobeStride] = x.ce.g; p[16 * kLobeStride] = x.ce.b;
-            p[17 * kLobeStride] = x.A; p[18 * kLobeStride] = x.B;
+            p[1 * kLobeStride] = x.r.r; p[2 * kLobeStride] = x.r.g; p[3 * kLobeStride] = x.r.b;
+            const RGB x4 = lobe_stores_ce(x.fresnel) ? x.ce : x.t;
+            p[4 * kLobeStride] = x4.r; p[5 * kLobeStride] = x4.g; p[6 * kLobeStride] = x4.b;
+            const bool cond = x.fresnel == FR_CONDUCTOR;
+            p[7 * kLobeStride] = cond ? x.ck.r : x.etaa; p[8 * kLobeStride] = cond ? x.ck.g : x.etab; p[9 * kLobeStride] = cond ? x.ck.b : x.A;
+            p[10 * kLobeStride] = lobe_stores_b(x.kind) ? x.B : x.ax; p[11 * kLobeStride] = x.ay;
         }
         types |= (uint64_t)x.type << (8 * n);
         n++;

@@ -11,14 +11,17 @@ template <int MAXL, int MODE, int DIFF>
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 1   // experiment hook (tools/build_variant.sh -DPT_SHADE_WAVES=N): minimum waves per SIMD the one-lobe kernels are compiled for
 #endif
-__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
-    __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
-    __shared__ LdsQueue<(MAXL == 5) ? 1024 : 1> s_qprobe;
-    __shared__ LdsQueue<(MODE == 3) ? 1024 : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue
+    // (the five-lobe class flushes its queues every round -- 256-entry buffers: with the 60 KB lobe store, two of its workgroups fit a CU's
+    //  LDS; its vertices cost ~0.8 ns each, so the extra global atomics, one per queue and 256 vertices, do not show)
+    constexpr int QCAP = MAXL == 5 ? 256 : 1024;
+    __shared__ LdsQueue<QCAP> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ LdsQueue<(MAXL == 5) ? QCAP : 1> s_qprobe;
+    __shared__ LdsQueue<(MODE == 3) ? QCAP : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue
     __shared__ uint32_t s_hist[16];
     __shared__ float s_lobes[lobe_store_words<MAXL>()];   // the two- and five-lobe classes keep their BxDFs here (dev_bsdf.h)
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe); lq_init(s_qself);
