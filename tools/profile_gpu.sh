@@ -2,8 +2,8 @@
 # Round profile recipe (run through gpurun): headline bench, rocprofv3 kernel stats, PMC traffic passes.
 # usage: tools/profile_gpu.sh <tag> [spp_for_profiles]
 TAG=${1:-r1}
-PSPP=${2:-64}
-PPASS=${3:-32}   # PMC runs: exactly one pass of the headline pass size, so per-launch numbers are comparable
+PSPP=${2:-128}
+PPASS=${3:-128}   # PMC runs: exactly one pass of the headline pass size (the library picks 128 samples per pass at 1080p on an idle 288 GB device), so per-launch numbers are comparable
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd $REPO
 echo "== GPU tests"; timeout -k 10 600 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; tail -n 2 $OUT/gpu_tests.log
-echo "== C2 profile recipe"; tools/profile_gpu.sh $TAG 64 32 > $OUT/profile.log 2>&1; head -12 $OUT/summary.txt
+echo "== C2 profile recipe"; tools/profile_gpu.sh $TAG 128 128 > $OUT/profile.log 2>&1; head -12 $OUT/summary.txt
 for C in C3 C4 C5; do
   echo "== $C at its named spp"
   timeout -k 10 400 python bench.py --config $C --steps 1 --warmup 1 --cpu-seconds 8 > $OUT/bench_$C.json 2> $OUT/bench_$C.err || { echo "$C failed"; tail -5 $OUT/bench_$C.err; }
