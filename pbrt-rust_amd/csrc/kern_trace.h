@@ -80,10 +80,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     // ST_INST (an instance packet at `cur` waits to be entered) and ST_RET (the instance's marker was popped, the world ray waits to
     // be restored) are the two transform steps of TransformedPrimitive (primitive.rs:58-88): ~200 instructions that only a few lanes
     // need in any one iteration, so they run in a step of their own once `inst_quorum` lanes wait for it (like leaves, below)
-    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5 };
+    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5, ST_LEAFS = 6 };   // ST_LEAFS: at a leaf and being served (leaf_quorum below)
     uint32_t state = ST_IDLE;
     bool exhausted = false;
-    bool draining = false;    // wave-uniform: the leaf lanes are being served (see leaf_quorum below)
 #ifndef PT_TRACE_CHUNK
 #define PT_TRACE_CHUNK 256   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
                              // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
     V3 ro, rd, inv_dir;
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
-    bool nx = false, ny = false, nz = false, found = false;
+    bool nx = false, ny = false, nz = false;
     float t_max = 0.0f;
     // closest hit so far: its packet (index in DeviceScene::leaf, PT_NONE = no hit yet) -- the primitive id and the flag word are
     // read back from that packet when the ray retires instead of being carried through the loop
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
         //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
         //      paid once per batch instead of once per ray.
         const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
-        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_INST || state == ST_RET);
+        const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_LEAFS || state == ST_INST || state == ST_RET);
         if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
             bool retire = state == ST_DONE;
             if constexpr (PROBE) {
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                         inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                         tray = tri_ray_setup(rd);
-                        sp = 0; pending = 0; found = false;
+                        sp = 0; pending = 0;
                         hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                         in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
                         n_rays++;                                  // Scene::intersect of the next segment
@@ -215,14 +214,16 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
             if (retire) {
                 float4 *const o_hit = PT_SUB(out_hit), *const o_hit2 = PT_SUB(out_hit2); uint32_t *const o_word = PT_SUB(out_word); float *const o_t = PT_SUB(out_t);
                 const uint32_t o_hit_stride = PT_SUB(out_hit_stride), o_word_stride = PT_SUB(out_word_stride), o_t_stride = PT_SUB(out_t_stride);
-                if (lane_any) o_word[(size_t)pid * o_word_stride] = found ? 1u : 0u;
+                if (lane_any) o_word[(size_t)pid * o_word_stride] = hit_pkt != PT_NONE ? 1u : 0u;   // (an any-hit ray records the packet that stopped it)
                 else {
                     uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
                     if (hit_pkt != PT_NONE) { const uint4 hq = leaf4[3 * (size_t)hit_pkt + 2]; hit_prim = hq.y; hit_fl = hq.w; }   // {p2.z, prim, shape, flags}
                     if (o_hit) o_hit[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
                     else o_word[(size_t)pid * o_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
-                    if (o_hit2) o_hit2[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), hit_t, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
-                    if (o_t) o_t[(size_t)pid * o_t_stride] = hit_t;
+                    // (triangle-only scenes: the closest hit's t IS the ray's t_max -- one register less in the loop; inside instances t_max is an object-space value)
+                    const float t_out = (INST || PROBE) ? hit_t : (hit_pkt != PT_NONE ? t_max : 0.0f);
+                    if (o_hit2) o_hit2[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), t_out, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
+                    if (o_t) o_t[(size_t)pid * o_t_stride] = t_out;
                 }
                 if constexpr (MIX) {   // per-kind work counters (LDS atomics of the wave's own slots)
                     atomicAdd(&kcnt[3u * ksel], n_nodes); atomicAdd(&kcnt[3u * ksel + 1u], n_tris); atomicAdd(&kcnt[3u * ksel + 2u], 1u);   // (MIX: n_nodes / n_tris count the lane's current ray only)
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
                     tray = tri_ray_setup(rd);
-                    sp = 0; pending = 0; found = false;
+                    sp = 0; pending = 0;
                     hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                     in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
                     if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; }
@@ -287,16 +288,17 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
         // lanes at a leaf join in once `leaf_quorum` of them wait (or no lane is at a node), so the triangle test is not
         // executed for a handful of lanes in every iteration
         const bool at_node = state == ST_ENTER;
-        const unsigned long long leaf_m = __ballot(state == ST_LEAF);
-        // (both ballots are taken by the whole wave BEFORE the per-lane test: inside `state == ST_LEAF && (.. || __ballot(at_node) == 0)` the
+        const unsigned long long leaf_m = __ballot(state == ST_LEAF);   // lanes waiting at a leaf
+        // (the ballots are taken by the whole wave BEFORE the per-lane test: inside `state == ST_LEAF && (.. || __ballot(at_node) == 0)` the
         //  short-circuit ran the ballot under the leaf lanes' exec mask only, where it is always 0 -- the quorum never held anything back;
         //  found in round 2 with the PT_TRACE_UTIL counters: 88 % of all wave iterations ran the triangle test for 5 lanes)
         const bool no_node_lane = __ballot(at_node) == 0ull;
-        // The quorum is sticky: once it is met the leaf lanes keep running until none is left (a leaf holds up to max_node_prims packets,
-        // one per iteration -- without the hysteresis a lane in a three-packet leaf waits for three quorums).
-        if (leaf_m == 0ull) draining = false;
-        else if ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || no_node_lane) draining = true;
-        const bool at_leaf = state == ST_LEAF && draining;
+        // The quorum is sticky: the lanes that formed it (ST_LEAFS) are served until each has left its leaf (a leaf holds up to
+        // max_node_prims packets, one per iteration -- without the hysteresis a lane in a three-packet leaf waits for three quorums); lanes
+        // that arrive meanwhile wait for the next quorum (in S4 some lane is at a leaf in 99 % of the iterations: "until none is left"
+        // would never end).
+        if (__ballot(state == ST_LEAFS) == 0ull && ((uint32_t)__popcll(leaf_m) >= job.leaf_quorum || (no_node_lane && leaf_m != 0ull))) { if (state == ST_LEAF) state = ST_LEAFS; }
+        const bool at_leaf = state == ST_LEAFS;
         if constexpr (INST) {
             // ---- transform step: enter instances / return from them, once enough lanes wait (or nothing else can run)
             const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);
@@ -407,8 +409,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                         n_sph++;
                         float t, phi; V3 ph, dobj;
                         if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, lane_any, t, ph, phi, dobj)) {
-                            found = true;
-                            if (lane_any) { state = ST_DONE; advance = false; }
+                            if (lane_any) { hit_pkt = li; state = ST_DONE; advance = false; }
                             else {
                                 t_max = t;
                                 hit_pkt = li; hit_t = t; hb0 = hb1 = hb2 = 0.0f;
@@ -438,10 +439,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                         } else if (lane_any && hit && (fl & TP_ALPHA) && (fl & TP_BOGUS)) hit = false;
                     }
                     if (hit) {
-                        if (lane_any) { found = true; state = ST_DONE; advance = false; }
+                        if (lane_any) { hit_pkt = li; state = ST_DONE; advance = false; }
                         else if (!(fl & TP_BOGUS)) {  // triangle.rs:258-261
-                            found = true; t_max = t;  // primitive.rs:137
-                            hit_pkt = li; hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
+                            t_max = t;  // primitive.rs:137
+                            hit_pkt = li; if (INST || PROBE) hit_t = t; hb0 = b0; hb1 = b1; hb2 = b2;
                             if (INST) { hit_inst = in_inst; inst_hit = in_inst != PT_NONE; }
                         }
                     }
