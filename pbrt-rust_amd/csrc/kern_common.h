@@ -58,6 +58,22 @@ template <int CAP> PT_DEV void lq_push(LdsQueue<CAP> &q, uint32_t value, bool pr
     base = __shfl(base, (int)leader);
     if (pred) q.buf[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
+// Block-wide append in bins: the entries one round of the block appends land grouped by `bin` (0..7: the direction octant of a new
+// ray), so the 64 consecutive entries a traversal wave takes point the same way more often. All threads of the block call it together;
+// `bins` is 16 words of shared memory. Three barriers; the order inside a bin is not defined (nothing depends on it).
+template <int CAP> PT_DEV void lq_push_binned(LdsQueue<CAP> &q, uint32_t *bins, uint32_t value, bool pred, uint32_t bin) {
+    if (threadIdx.x < 8) bins[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t rank = pred ? atomicAdd(&bins[bin], 1u) : 0u;
+    __syncthreads();
+    uint32_t start = 0, total = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 8; ++b) { const uint32_t c = bins[b]; if (b < bin) start += c; total += c; }
+    const uint32_t base = q.count;
+    if (pred) q.buf[base + start + rank] = value;
+    __syncthreads();
+    if (threadIdx.x == 0) q.count = base + total;
+}
 // Flush when fewer than `reserve` free slots remain (or force). Block-uniform; contains __syncthreads().
 template <int CAP> PT_DEV void lq_sync_flush(LdsQueue<CAP> &q, uint32_t *gcount, uint32_t *gbuf, uint32_t reserve, bool force) {
     __syncthreads();

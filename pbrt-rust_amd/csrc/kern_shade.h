@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     __shared__ LdsQueue<(MAXL == 5) ? QCAP : 1> s_qprobe;
     __shared__ LdsQueue<(MODE == 3) ? QCAP : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue
     __shared__ uint32_t s_hist[16];
+    __shared__ uint32_t s_bins[16];
     __shared__ float s_lobes[lobe_store_words<MAXL>()];   // the two- and five-lobe classes keep their BxDFs here (dev_bsdf.h)
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qprobe); lq_init(s_qself);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     const bool valid = qi < count;
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false, push_self = false;
     int finished_bounces = -1;
-    uint32_t pid = 0;
+    uint32_t pid = 0, ext_oct = 0;   // direction octant of the continuation ray
     PT_T(0);
     if (valid) {
         n_valid++;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                         ps.medium(pid) = medium_toward(mif, si.n, rd);
                         bounces = (bounces - 1u) & 0xffu;
                     }
-                    push_ext = true;
+                    push_ext = true; ext_oct = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
                 } else {
                     const V3 wo = -rd;  // path.rs:148; estimate_direct uses isect.wo (== -rd for triangles, triangle.rs:296)
                     // uniform_sample_onelight (integrator.rs:81-106)
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                             rq[0] = make_float4(o.x, o.y, o.z, wi.x); rq[1] = make_float4(wi.y, wi.z, 0.0f, 0.0f);
                             if (VOL) ps.medium(pid) = medium_toward(mif, si.n, wi);   // isect.spawn_ray(wi) (interaction.rs:32-36,54-66)
                             push_ext = true; n_bytes += 32 + 4;  // new ray record, ext queue entry
+                            ext_oct = (wi.x < 0.0f ? 1u : 0u) | (wi.y < 0.0f ? 2u : 0u) | (wi.z < 0.0f ? 4u : 0u);
                         }
                     }
                 }
@@ -231,7 +233,11 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
         cw[1] = make_float4(beta.r, beta.g, beta.b, __uint_as_float((smp.dim & 0xffffu) | ((bounces & 0xffu) << 16) | (flags << 24)));
     }
     PT_T(13);
+#ifdef PT_BIN_EXT
+    lq_push_binned(s_qext, s_bins, pid, push_ext, ext_oct);
+#else
     lq_push(s_qext, pid, push_ext);
+#endif
     lq_push(s_qres, pid, push_resolve);
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
