@@ -177,7 +177,7 @@ typedef struct PtMaterial {
     float u_roughness;      /* glass/substrate: uroughness; metal/uber: < 0 => use `roughness` */
     float v_roughness;
     uint32_t remap_roughness;
-    /* subsurface (materials/subsurface.rs:47-106): sigma_a/sigma_s (before `scale`), scale, and the index of the
+    /* subsurface (materials/subsurface.rs:47-106): sigma_a/sigma_s (before `scale`; tex[PT_MP_SIGMA_A / _S] may name spectrum textures), scale, and the index of the
      * material's BSSRDFTable in PtSceneDesc.bssrdf_tables (built by the host: compute_beam_diffusion_bssrdf). */
     float sigma_a[3];
     float sigma_s[3];

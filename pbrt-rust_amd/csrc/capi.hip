@@ -328,7 +328,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
             BssSoA &bs = sc->bs;
             float *bp = (float *)sc->bss_slab;
             float **ba[] = {&bs.start_x, &bs.start_y, &bs.start_z, &bs.target_x, &bs.target_y, &bs.target_z, &bs.po_x, &bs.po_y, &bs.po_z,
-                            &bs.ns_x, &bs.ns_y, &bs.ns_z, &bs.ss_x, &bs.ss_y, &bs.ss_z, &bs.u1n};
+                            &bs.ns_x, &bs.ns_y, &bs.ns_z, &bs.ss_x, &bs.ss_y, &bs.ss_z, &bs.u1n, &bs.sa_r, &bs.sa_g, &bs.sa_b, &bs.sc_r, &bs.sc_g, &bs.sc_b};
             for (float **f : ba) { *f = bp; bp += capacity; }
             bs.mat = (uint32_t *)bp; bp += capacity; bs.cnt = (uint32_t *)bp;
             static_assert(sizeof(ba) / sizeof(ba[0]) + 2 == kBssSoAArrays, "BssSoA layout");
@@ -803,7 +803,6 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if (d->n_textures == 0 && m.tex[k] > 0) return fail(PT_ERR_INVALID_ARG, "material references a texture but the scene has none");
             if (d->n_textures && m.tex[k] >= (int32_t)d->n_textures) return fail(PT_ERR_INVALID_ARG, "material texture index out of range");
         }
-        if (d->n_textures && m.type == PT_MAT_SUBSURFACE && (m.tex[PT_MP_SIGMA_A] >= 0 || m.tex[PT_MP_SIGMA_S] >= 0)) return fail(PT_ERR_UNSUPPORTED, "textured sigma_a / sigma_s");
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const PtLight &L = d->lights[i];

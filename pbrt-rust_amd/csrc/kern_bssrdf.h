@@ -56,10 +56,12 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
-                DevBssrdf bss; bss.init_material(m, s.bss_tables);   // tabulated (textured sigma_a / sigma_s are rejected at scene creation) or DisneyBSSRDF
+                DevBssrdf bss;   // the BSSRDF of the entry point: tabulated, with the sigma_a / sigma_s its textures gave there, or DisneyBSSRDF
+                if (m.type == PT_MAT_DISNEY) bss.init_disney(m);
+                else bss.init_medium(m, s.bss_tables, RGB(bs.sa_r[pid], bs.sa_g[pid], bs.sa_b[pid]), RGB(bs.sc_r[pid], bs.sc_g[pid], bs.sc_b[pid]));
                 bss.ns = V3(bs.ns_x[pid], bs.ns_y[pid], bs.ns_z[pid]); bss.ss = V3(bs.ss_x[pid], bs.ss_y[pid], bs.ss_z[pid]);
                 bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
-                n_bytes += 36;
+                n_bytes += 36 + 24;
                 // bssrdf.rs:403-405: pdf = pdf_sp(pi) / nfound ; Sp = sr(|po - pi|)
                 float pdf = bss.pdf_sp(si.p, si.n) / (float)nfound;
                 const RGB S = bss.sr(length(bss.po_p - si.p));

@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                 Bsdf<MAXL, DIFF> bsdf; bsdf.bind(s_lobes);
                 const uint32_t mi = packet_material(s, pfl, hp);
                 bool has_bsdf = false;
+                RGB bss_sa(0.0f), bss_ss(0.0f);   // subsurface.rs:100-101: sigma_a / sigma_s textures, evaluated with the BSDF's parameters
+                const bool is_sss = MAXL == 5 && mi != PT_NONE && s.materials[mi].type == PT_MAT_SUBSURFACE;
                 if (TEX) {
                     // compute_scattering_functions -> compute_differentials(ray) (interaction.rs:262-342): only the camera ray
                     // carries differentials; every spawned ray has none
@@ -131,7 +133,11 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     }
                     const TexMatEval E{s, tctx};
                     has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E, s.materials);
-                } else has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
+                    if (is_sss) { bss_sa = E.spec(s.materials[mi], PT_MP_SIGMA_A, s.materials[mi].sigma_a); bss_ss = E.spec(s.materials[mi], PT_MP_SIGMA_S, s.materials[mi].sigma_s); }
+                } else {
+                    has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
+                    if (is_sss) { bss_sa = rgb3(s.materials[mi].sigma_a); bss_ss = rgb3(s.materials[mi].sigma_s); }
+                }
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                 MedIface mif{PT_NONE, PT_NONE};
@@ -182,7 +188,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                             if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
                                 const P2 s2 = smp.get_2d();
                                 const float s1 = smp.get_1d();
-                                DevBssrdf bss; bss.init_material(s.materials[mi], s.bss_tables); bss.init_frame(si);
+                                DevBssrdf bss;
+                                if (is_sss) bss.init_medium(s.materials[mi], s.bss_tables, bss_sa, bss_ss); else bss.init_disney(s.materials[mi]);
+                                bss.init_frame(si);
                                 V3 start, target; float u1n = 0.0f;
                                 const BssSoA &bs = job.bs;
                                 if (!bss.probe_segment(s1, s2, start, target, u1n)) rr_kill = true;   // S is black: `break`
@@ -196,9 +204,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                                         bs.ns_x[pid] = bss.ns.x; bs.ns_y[pid] = bss.ns.y; bs.ns_z[pid] = bss.ns.z;
                                         bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
                                         bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
+                                        if (is_sss) { bs.sa_r[pid] = bss_sa.r; bs.sa_g[pid] = bss_sa.g; bs.sa_b[pid] = bss_sa.b; bs.sc_r[pid] = bss_ss.r; bs.sc_g[pid] = bss_ss.g; bs.sc_b[pid] = bss_ss.b; }
                                         // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
                                         rq[0] = make_float4(start.x, start.y, start.z, pd.x); rq[1] = make_float4(pd.y, pd.z, 0.0f, 0.0f);
-                                        to_probe = true; push_probe = true; n_bytes += 18 * 4 + 24 + 4;
+                                        to_probe = true; push_probe = true; n_bytes += 24 * 4 + 24 + 4;
                                     }
                                 }
                             }

@@ -81,10 +81,11 @@ struct BssSoA {
     float *start_x, *start_y, *start_z, *target_x, *target_y, *target_z;
     float *po_x, *po_y, *po_z, *ns_x, *ns_y, *ns_z, *ss_x, *ss_y, *ss_z;
     float *u1n;
+    float *sa_r, *sa_g, *sa_b, *sc_r, *sc_g, *sc_b;   // sigma_a / sigma_s as evaluated at the entry point (subsurface.rs:100-101: textures of the outgoing interaction)
     uint32_t *mat;   // material id of the BSSRDF (Arc::ptr_eq test of the chain, bssrdf.rs:385-391)
     uint32_t *cnt;   // nfound of the finished chain (written by k_trace<.., PROBE>, read by k_bssrdf)
 };
-constexpr int kBssSoAArrays = 18;
+constexpr int kBssSoAArrays = 24;
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)

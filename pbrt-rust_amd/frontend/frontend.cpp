@@ -319,8 +319,13 @@ private:
             if (kind == "subsurface") {   // subsurface.rs:108-139
                 std::string nm = p.one_string("name", "");
                 if (!nm.empty()) { auto it = named_media().find(nm); if (it != named_media().end()) { copy3(siga, it->second.sigma_a); copy3(sigs, it->second.sigma_prime_s); g = 0.0f; } }
-                if (!p.texture("sigma_a").empty() || !p.texture("sigma_s").empty()) throw std::runtime_error("textured sigma_a / sigma_s are not supported");
-                p.rgb("sigma_a", siga); p.rgb("sigma_s", sigs);
+                // get_spectrumtexture("sigma_a", siga) (subsurface.rs:127-128): a texture where one is named (evaluated at every hit), else the constant
+                for (int w = 0; w < 2; ++w) {
+                    const char *pn = w ? "sigma_s" : "sigma_a"; const int slot = w ? PT_MP_SIGMA_S : PT_MP_SIGMA_A;
+                    const std::string tn = p.texture(pn);
+                    if (!tn.empty()) { auto it = gs.spec_tex.find(tn); if (it == gs.spec_tex.end()) throw std::runtime_error("spectrum texture \"" + tn + "\" not declared"); m.tex[slot] = it->second; }
+                    else p.rgb(pn, w ? sigs : siga);
+                }
                 m.scale = scale; m.bssrdf_table = bss_table(g, m.eta);
             } else {                      // kdsubsurface.rs:96-126: constant Kd / mfp -> subsurface_from_diffuse on the host
                 if (!p.texture("Kd").empty() || !p.texture("mfp").empty()) throw std::runtime_error("textured kdsubsurface Kd / mfp are not supported");

@@ -307,7 +307,7 @@ class SceneBuilder:
             from . import bssrdf as B
             g = float(d["g"])
             if kind == "subsurface":
-                siga, sigs = d["sigma_a"], d["sigma_s"]
+                siga, sigs = d.get("sigma_a", (0.0011, 0.0024, 0.014)), d.get("sigma_s", (2.55, 3.21, 3.77))   # (a textured parameter keeps the default in the constant field)
                 if d["name"]:  # subsurface.rs:111-122: a named medium overrides the defaults and forces g = 0
                     if d["name"] in B.NAMED_MEDIA:
                         sigs, siga = B.NAMED_MEDIA[d["name"]]

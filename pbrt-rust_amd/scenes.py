@@ -187,7 +187,7 @@ def instanced_garden(n_inst=24, plant_n=10, xres=96, yres=64, spp=8, flatten=Fal
     return b
 
 
-def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False):
+def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textured_sigma=False):
     """Config C5: a displaced sphere with a `subsurface` material (skin-like medium, mm units
     scaled so the mean free path is a visible fraction of the object), a `kdsubsurface` sphere shape and a matte floor,
     lit by an area light and a dim environment.  Exercises path.rs:177-204 / bssrdf.rs sample_s."""
@@ -206,7 +206,12 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False):
     b.trianglemesh(P, I)
     b.attribute_begin()
     kw = dict(uroughness=0.2, vroughness=0.1) if rough else {}
-    b.material("subsurface", name="Skin1", scale=8.0, eta=1.33, **kw)
+    if textured_sigma:   # subsurface.rs:100-101,127-128: sigma_a / sigma_s as spectrum textures, evaluated at every entry point
+        b.texture("siga", "color", "checkerboard", dimension=3, tex1=(0.0011, 0.0024, 0.014), tex2=(0.02, 0.004, 0.002))
+        b.texture("sigs", "color", "checkerboard", mapping="planar", v1=(1.5, 0.0, 0.0), v2=(0.0, 1.5, 0.0), aamode="closedform", tex1=(2.55, 3.21, 3.77), tex2=(1.0, 1.4, 2.2))
+        b.material("subsurface", sigma_a="siga", sigma_s="sigs", scale=8.0, eta=1.33, **kw)
+    else:
+        b.material("subsurface", name="Skin1", scale=8.0, eta=1.33, **kw)
     b.translate(-1.1, 0.0, 0.0)
     P, I, N = displaced_sphere(n, with_normals=True)
     b.trianglemesh(P, I, N=N); b.attribute_end()

@@ -523,6 +523,42 @@ WorldEnd
     assert fb.type == A.PT_MAT_MATTE and list(fb.kd) == pytest.approx([.9, .8, .7]) and list(mixes[1].kd) == pytest.approx([.5] * 3)
 
 
+def test_subsurface_sigma_textures_from_a_scene_file(pkg, oracle):
+    """subsurface.rs:127-128: `sigma_a` / `sigma_s` are spectrum textures (get_spectrumtexture), evaluated at every hit; a scene file that
+    names textures for them flattens like the Python mirror's and renders the same image (oracle)."""
+    A = pkg._abi
+    fs = pkg.frontend.FrontScene(text='''LookAt 0 1.6 6  0 .2 0  0 1 0
+Camera "perspective" "float fov" 38
+Sampler "sobol" "integer pixelsamples" 4
+Integrator "path" "integer maxdepth" 5
+Film "image" "integer xresolution" 48 "integer yresolution" 32
+WorldBegin
+LightSource "infinite" "rgb L" [.25 .3 .35]
+Texture "siga" "spectrum" "checkerboard" "integer dimension" 3 "rgb tex1" [.0011 .0024 .014] "rgb tex2" [.02 .004 .002]
+Texture "sigs" "spectrum" "checkerboard" "float uscale" 4 "float vscale" 4 "rgb tex1" [2.55 3.21 3.77] "rgb tex2" [1 1.4 2.2]
+Material "subsurface" "texture sigma_a" "siga" "texture sigma_s" "sigs" "float scale" 8 "float eta" 1.33
+Shape "sphere" "float radius" 1
+WorldEnd
+''')
+    d = fs.desc()
+    m = [d.materials[i] for i in range(d.n_materials) if d.materials[i].type == A.PT_MAT_SUBSURFACE][0]
+    assert m.tex[A.PT_MP_SIGMA_A] >= 0 and m.tex[A.PT_MP_SIGMA_S] >= 0 and m.tex[A.PT_MP_SIGMA_A] != m.tex[A.PT_MP_SIGMA_S]
+    assert list(m.sigma_a) == pytest.approx([.0011, .0024, .014]) and m.scale == pytest.approx(8.0)   # the constant fields keep create_subsurface_material's defaults
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=48, yres=32); b.spp = 4; b.integ.update(maxdepth=5)
+    b.look_at((0, 1.6, 6), (0, .2, 0), (0, 1, 0)); b.camera(fov=38.0)
+    b.world_begin(); b.light_source("infinite", L=(.25, .3, .35))
+    b.texture("siga", "color", "checkerboard", dimension=3, tex1=(.0011, .0024, .014), tex2=(.02, .004, .002))
+    b.texture("sigs", "color", "checkerboard", uscale=4.0, vscale=4.0, tex1=(2.55, 3.21, 3.77), tex2=(1.0, 1.4, 2.2))
+    b.material("subsurface", sigma_a="siga", sigma_s="sigs", scale=8.0, eta=1.33)
+    b.sphere(radius=1.0)
+    sd, rp = b.world_end()
+    a = oracle.scene(sd).render(rp, nthreads=4); c = oracle.scene(fs).render(fs.render_params(), nthreads=4)
+    # the two hosts' float arithmetic differs by ulps (matrix inverses): a few samples land on the other side of a checker edge
+    assert (np.abs(a - c) > 2e-5 * np.maximum(np.abs(a), 1e-2)).mean() < 0.01
+    with pytest.raises(Exception): pkg.frontend.FrontScene(text='WorldBegin\nMaterial "kdsubsurface" "texture Kd" "nope"\nWorldEnd\n')   # still refused: the inversion per hit
+
+
 def test_disney_material_from_a_scene_file(pkg):
     """disney.rs:842-887 parameter names and defaults; the BSSRDF branch (scatterdistance) and textured scalar parameters other
     than eta / roughness are refused by name."""

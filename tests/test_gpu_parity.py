@@ -293,6 +293,24 @@ def test_subsurface_matches_oracle(pkg, gpu, oracle, rough):
     assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-4
 
 
+@pytest.mark.parametrize("rough", [False, True])
+def test_subsurface_with_sigma_textures_matches_oracle(pkg, gpu, oracle, rough):
+    """subsurface.rs:100-101: sigma_a / sigma_s are textures evaluated on the outgoing interaction; the BSSRDF built there (its sigma_t and
+    albedo) is the one the probe chain, Sp / pdf_sp and the adapter lobe at the exit point use. The evaluated coefficients travel with the
+    path (BssSoA.sa_* / sc_*); a 3-D and a planar checkerboard drive them here."""
+    sd, rp = pkg.scenes.subsurface_c5(n=16, xres=96, yres=64, spp=8, rough=rough, textured_sigma=True).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
+              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+    plain, _ = pkg.scenes.subsurface_c5(n=16, xres=96, yres=64, spp=8, rough=rough).world_end()
+    assert not np.allclose(film[..., :3], pkg.Scene(gpu, plain).render(rp)[..., :3], rtol=1e-3)   # (the textures do change the image)
+
+
 def test_long_probe_chains_fall_back_to_an_uncounted_rewalk(pkg, gpu, oracle):
     """A stack of 40 thin sheets of one subsurface material: probe chains along the normal cross up to 40 matching surfaces, far more
     than the 8-entry ring of k_trace<.., PROBE>, so chains whose selected intersection has left the ring are walked a second
