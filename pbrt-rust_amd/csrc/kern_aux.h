@@ -43,6 +43,12 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
                 else if (sampled) { ps.hit_t(pid) = t; cls = (uint32_t)kMediumClass; }
                 if (smp.overflow) atomicMax(error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
                 ps.meta(pid) = (smp.dim & 0xffffu) | (meta & 0x00ff0000u) | (flags << 24);
+            } else if (RGB(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid)).is_black()) {
+                // volpath.rs:111 tests beta after the OPTIONAL medium sample: a throughput that two surfaces with disjoint colours
+                // multiplied to zero ends the path here too, after this ray's Scene::intersect (found by the fuzz sweep, seed 2005)
+                const uint32_t meta = ps.meta(pid);
+                ps.meta(pid) = (meta & 0x00ffffffu) | (((meta >> 24) | PF_DEAD) << 24);
+                cls = (uint32_t)kMissClass;
             }
         }
         lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u); lq_push(q2, pid, valid && cls == 2u);
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 const PhaseBsdf phase{s.media[med].g, si.wo};
                 bool defer = false;
                 if (!stage_b) {
-                    nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med});
+                    if (!nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med})) L = L + beta * RGB(0.0f);   // volpath.rs:120: `L += beta * Ld` with a black Ld
                     defer = s.has_grid != 0u && (push_shadow || push_mis);
                 }
                 if (defer) { flags |= PF_STAGE_B; push_self = true; }

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                     IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
                     if (nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS)) flags |= PF_NEE_UNCOUNTED;
+                    else L = L + beta * RGB(0.0f);   // path.rs:190-192 `L += beta * uniform_sample_one_light(..)` with a black estimate: 0, or NaN when pdf_sp was (an exit point a few ulps from po: inf x 0)
                     // path.rs:194-201: indirect component
                     V3 wi; int sflags = 0;
                     const RGB ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);

@@ -156,14 +156,16 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     bool defer = false;
                     if (VOL) {
                         if (!stage_b) {
-                            nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif);   // volpath.rs:136-138: unconditional
+                            // volpath.rs:136-138: unconditional. `L += beta * Ld` happens even when Ld is black: a throughput that has gone infinite or
+                            // NaN poisons the sample there (0 x inf), which integrator.rs:350-368 then zeroes and counts
+                            if (!nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) L = L + beta * RGB(0.0f);
                             defer = s.has_grid != 0u && (push_shadow || push_mis);   // wait for the traced rays before drawing any further dimension
                         }
                     }
                     else if (DIFF != 2 && bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {   // (a specular-only BSDF has no such component: path.rs:131)
                         zero_den++;
                         const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
-                        if (!nee_pending) zero_num++;  // Ld is black (path.rs:142)
+                        if (!nee_pending) { zero_num++; L = L + beta * RGB(0.0f); }  // Ld is black (path.rs:142); `L += beta * Ld` all the same (path.rs:140-145): NaN for a non-finite beta (fuzz seed 13269)
                     }
                     // path.rs:148-174: sample the BSDF for the next direction
                     PT_T(11);

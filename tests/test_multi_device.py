@@ -59,7 +59,10 @@ def test_three_replicas_on_one_device_equal_the_plain_render(pkg, gpu, scene):
     dfilm = torch.zeros(film.shape, dtype=torch.float32, device="cuda:0")
     multi.render(rp, device_ptr=dfilm.data_ptr())
     torch.cuda.synchronize()
-    assert np.array_equal(dfilm.cpu().numpy(), film)
+    # (weights bit for bit; radiance within the reordering of float atomics: a Sobol' sample that sits exactly on a pixel corner -- every
+    #  pixel's sample 0 -- splats onto four pixels, three of them through atomics whose order against the owner's additions is not defined)
+    assert np.array_equal(dfilm.cpu().numpy()[..., 3], film[..., 3])
+    np.testing.assert_allclose(dfilm.cpu().numpy()[..., :3], film[..., :3], rtol=2e-6, atol=1e-7)
     # nested inside a 2-process launch: rank 1 of 2, split over the three replicas
     rp.tile_rank, rp.tile_world = 1, 2
     a = multi.render(rp); b = single.render(rp)

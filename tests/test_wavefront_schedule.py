@@ -46,7 +46,7 @@ def _scenes(pkg):
 
 def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_path):
     """PT_TRACE_SPLIT=1 (read by pt_init, so in a process of its own) traces the three ray kinds of an iteration in three launches, as
-    round 1 did; the default traces them in one. Same films bit for bit (box filter), same counters; the launch kinds differ."""
+    round 1 did; the default traces them in one. Same counters, same weights bit for bit, same radiance up to the order of the film's float atomics; the launch kinds differ."""
     env = dict(os.environ, PT_TRACE_SPLIT="1")
     code = _CHILD.format(root=ROOT, out=str(tmp_path), counters=COUNTERS)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
@@ -60,7 +60,9 @@ def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_pat
         stats = sorted(s["name"] for s in g.kernel_stats() if s["launches"])
         for k in COUNTERS:
             assert c[k] == split[name]["counters"][k], (name, k)
-        assert np.array_equal(film, np.load(tmp_path / (name + ".npy"))), name
+        other = np.load(tmp_path / (name + ".npy"))
+        assert np.array_equal(film[..., 3], other[..., 3]), name
+        np.testing.assert_allclose(film[..., :3], other[..., :3], rtol=2e-6, atol=1e-7, err_msg=name)   # (corner samples reach their neighbours through float atomics: order not defined)
         assert "trace" in stats and not {"extend", "extend_mis", "shadow"} & set(stats), stats
         assert {"extend", "shadow"} <= set(split[name]["stats"]) and "trace" not in split[name]["stats"], split[name]["stats"]
 
