@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
             if (!stage_b && (bounces == 0 || (flags & PF_SPECULAR))) {
                 if (found) {
                     const uint32_t al = s.prim_light[hp];
-                    if (al != PT_NONE) L = L + area_l(s.lights[al], si.n, -rd) * beta;
+                    L = L + (al != PT_NONE ? area_l(s.lights[al], si.n, -rd) : RGB(0.0f)) * beta;   // isect.le() of a non-emissive primitive is 0, and `L += beta * 0` still happens (path.rs:110): NaN for a non-finite beta
                 } else {
                     for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
                 }
