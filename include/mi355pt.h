@@ -152,6 +152,7 @@ typedef enum PtMatParam {
     PT_MP_SIGMA_A = 7, PT_MP_SIGMA_S = 8,
     PT_MP_SIGMA = 9, PT_MP_ROUGHNESS = 10, PT_MP_U_ROUGHNESS = 11, PT_MP_V_ROUGHNESS = 12, PT_MP_ETA = 13,
     PT_MP_BUMP = 14,            /* "bumpmap" float texture (core/material.rs:46-87); -1 = none */
+    PT_MP_MFP = 15,             /* kdsubsurface "mfp" (see PtMaterial.kd_subsurface) */
     PT_MP_COUNT = 16
 } PtMatParam;
 
@@ -193,6 +194,11 @@ typedef struct PtMaterial {
     float disney[10];
     uint32_t disney_thin;
     float disney_scatter[3];   /* "scatterdistance": non-black (and not thin) => DisneyBSSRDF (disney.rs:442-704) with a constant color */
+    /* kdsubsurface with a textured "Kd" or "mfp" (materials/kdsubsurface.rs:96-99): kd_subsurface = 1 makes a PT_MAT_SUBSURFACE material take
+     * its coefficients from subsurface_from_diffuse(table, Kd, mfp * scale) at every hit -- Kd = kd / tex[PT_MP_KD], mfp = mfp / tex[PT_MP_MFP];
+     * sigma_a / sigma_s are ignored then. With constant Kd and mfp the host does that conversion once and leaves kd_subsurface = 0. */
+    float mfp[3];
+    uint32_t kd_subsurface;
 } PtMaterial;
 
 typedef enum PtLightType {

@@ -18,6 +18,35 @@ namespace ref {
 
 constexpr int kCatmullMaxIter = 100;
 
+// interpolation.rs:265-330 invert_catmull_rom: Newton-bisection on one spline segment (the loop is capped like the sampling one above)
+inline Float invert_catmull_rom(int n, const Float *x, const Float *values, Float u) {
+    if (!(u > values[0])) return x[0];
+    else if (!(u < values[n - 1])) return x[n - 1];
+    int i = find_interval(n, [&](int k) { return values[k] <= u; });
+    Float x0 = x[i], x1 = x[i + 1], f0 = values[i], f1 = values[i + 1], width = x1 - x0;
+    Float d0 = (i > 0) ? width * (f1 - values[i - 1]) / (x1 - x[i - 1]) : f1 - f0;
+    Float d1 = (i + 2 < n) ? width * (values[i + 2] - f0) / (x[i + 2] - x0) : f1 - f0;
+    Float a = 0.0f, b = 1.0f, t = 0.5f, Fhat, fhat;
+    for (int it = 0; it < kCatmullMaxIter; ++it) {
+        if (!(t > a && t < b)) t = 0.5f * (a + b);
+        Float t2 = t * t, t3 = t2 * t;
+        Fhat = (2.0f * t3 - 3.0f * t2 + 1.0f) * f0 + (-2.0f * t3 + 3.0f * t2) * f1 + (t3 - 2.0f * t2 + t) * d0 + (t3 - t2) * d1;
+        fhat = (6.0f * t2 - 6.0f * t) * f0 + (-6.0f * t2 + 6.0f * t) * f1 + (3.0f * t2 - 4.0f * t + 1.0f) * d0 + (3.0f * t2 - 2.0f * t) * d1;
+        if (std::fabs(Fhat - u) < 1.0e-6f || b - a < 1.0e-6f) break;
+        if (Fhat - u < 0.0f) a = t; else b = t;
+        t -= (Fhat - u) / fhat;
+    }
+    return x0 + t * width;
+}
+// bssrdf.rs:186-198 subsurface_from_diffuse
+inline void subsurface_from_diffuse(const BssrdfTable &t, RGB rho_eff, RGB mfp, RGB &sigma_a, RGB &sigma_s) {
+    for (int c = 0; c < 3; ++c) {
+        Float rho = invert_catmull_rom(t.n_rho, t.rho_samples.data(), t.rhoeff.data(), rho_eff.c[c]);
+        sigma_s.c[c] = rho / mfp.c[c];
+        sigma_a.c[c] = (1.0f - rho) / mfp.c[c];
+    }
+}
+
 inline bool catmull_rom_weights(int size, const Float *nodes, Float x, int &offset, Float w[4]) {
     if (!(x >= nodes[0] && x < nodes[size - 1])) return false;
     int idx = find_interval(size, [&](int i) { return nodes[i] <= x; });

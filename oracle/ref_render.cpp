@@ -310,6 +310,10 @@ static bool material_scattering_functions(const Scene &scene, uint32_t mi, Surfa
         }
         if (bssrdf) {
             RGB siga = E.spec(PT_MP_SIGMA_A, m.sigma_a).clamps(0.0f, INF) * m.scale, sigs = E.spec(PT_MP_SIGMA_S, m.sigma_s).clamps(0.0f, INF) * m.scale;
+            if (m.kd_subsurface) {   // kdsubsurface.rs:96-99: textured Kd / mfp, converted at this hit
+                RGB mfree = E.spec(PT_MP_MFP, m.mfp).clamps(0.0f, INF) * m.scale, kd = E.spec(PT_MP_KD, m.kd).clamps(0.0f, INF).clamps(0.0f, INF);
+                subsurface_from_diffuse(scene.bssrdf_tables[m.bssrdf_table], kd, mfree, siga, sigs);
+            }
             bssrdf->init(si, mi, eta, siga, sigs, &scene.bssrdf_tables[m.bssrdf_table]);
             *has_bssrdf = true;
         }

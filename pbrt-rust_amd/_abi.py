@@ -47,7 +47,7 @@ class PtMaterial(C.Structure):
     _fields_ = [("type", u32), ("kd", f32 * 3), ("ks", f32 * 3), ("kr", f32 * 3), ("kt", f32 * 3),
                 ("opacity", f32 * 3), ("eta_rgb", f32 * 3), ("k_rgb", f32 * 3), ("sigma", f32), ("eta", f32),
                 ("roughness", f32), ("u_roughness", f32), ("v_roughness", f32), ("remap_roughness", u32),
-                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32), ("disney_scatter", f32 * 3)]
+                ("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("scale", f32), ("bssrdf_table", u32), ("tex", C.c_int32 * 16), ("mix", u32 * 2), ("disney", f32 * 10), ("disney_thin", u32), ("disney_scatter", f32 * 3), ("mfp", f32 * 3), ("kd_subsurface", u32)]
 
 
 PT_MEDIUM_HOMOGENEOUS, PT_MEDIUM_GRID = 0, 1
@@ -84,7 +84,7 @@ PT_TOP_INSTANCE = 0x80000000
 PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_CYLINDRICAL = range(4)
 PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
 (PT_MP_KD, PT_MP_KS, PT_MP_KR, PT_MP_KT, PT_MP_OPACITY, PT_MP_ETA_RGB, PT_MP_K_RGB, PT_MP_SIGMA_A, PT_MP_SIGMA_S,
- PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA, PT_MP_BUMP) = range(15)
+ PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA, PT_MP_BUMP, PT_MP_MFP) = range(16)
 
 
 class PtTexture(C.Structure):

@@ -93,6 +93,40 @@ PT_DEV float bssrdf_sw(float eta, V3 w) {
     return (1.0f - fr_dielectric(cos_theta(w), 1.0f, eta)) / (c * kPi);
 }
 
+// interpolation.rs:265-330 invert_catmull_rom (Newton-bisection on one spline segment, capped like the sampling loop) and
+// bssrdf.rs:186-198 subsurface_from_diffuse: a kdsubsurface material whose Kd / mfp are textures converts at every hit.
+PT_DEV float invert_catmull_rom(int n, const float *x, const float *values, float u) {
+    if (!(u > values[0])) return x[0];
+    else if (!(u < values[n - 1])) return x[n - 1];
+    const int i = find_interval_pred(n, [&](int k) { return values[k] <= u; });
+    const float x0 = x[i], x1 = x[i + 1], f0 = values[i], f1 = values[i + 1], width = x1 - x0;
+    const float d0 = (i > 0) ? width * (f1 - values[i - 1]) / (x1 - x[i - 1]) : f1 - f0;
+    const float d1 = (i + 2 < n) ? width * (values[i + 2] - f0) / (x[i + 2] - x0) : f1 - f0;
+    float a = 0.0f, b = 1.0f, t = 0.5f;
+#pragma unroll 1
+    for (int it = 0; it < kCatmullMaxIter; ++it) {
+        if (!(t > a && t < b)) t = 0.5f * (a + b);
+        const float t2 = t * t, t3 = t2 * t;
+        const float Fhat = (2.0f * t3 - 3.0f * t2 + 1.0f) * f0 + (-2.0f * t3 + 3.0f * t2) * f1 + (t3 - 2.0f * t2 + t) * d0 + (t3 - t2) * d1;
+        const float fhat = (6.0f * t2 - 6.0f * t) * f0 + (-6.0f * t2 + 6.0f * t) * f1 + (3.0f * t2 - 4.0f * t + 1.0f) * d0 + (3.0f * t2 - 2.0f * t) * d1;
+        if (fabsf(Fhat - u) < 1.0e-6f || b - a < 1.0e-6f) break;
+        if (Fhat - u < 0.0f) a = t; else b = t;
+        t -= (Fhat - u) / fhat;
+    }
+    return x0 + t * width;
+}
+PT_DEV void subsurface_from_diffuse(const DevBssTable &t, RGB rho_eff, RGB mfp, RGB &sigma_a, RGB &sigma_s) {
+    const float re[3] = {rho_eff.r, rho_eff.g, rho_eff.b}, mf[3] = {mfp.r, mfp.g, mfp.b};
+    float sa[3], ss[3];
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        const float rho = invert_catmull_rom(t.n_rho, t.rho_samples, t.rhoeff, re[c]);
+        ss[c] = rho / mf[c];
+        sa[c] = (1.0f - rho) / mf[c];
+    }
+    sigma_a = RGB(sa[0], sa[1], sa[2]); sigma_s = RGB(ss[0], ss[1], ss[2]);
+}
+
 struct DevBssrdf {
     DevBssTable tb;
     float sigma_t[3], rho[3];
@@ -102,11 +136,13 @@ struct DevBssrdf {
 
     // subsurface.rs:100-103 (sigma * scale) + TabulatedBSSRDF::new
     // siga / sigs: the evaluated sigma_a / sigma_s textures (constants: the material fields)
+    // m.kd_subsurface: siga / sigs are what subsurface_from_diffuse gave at the hit (kdsubsurface.rs:96-99): taken as they are
     PT_DEV void init_medium(const PtMaterial &m, const DevBssTable *tables, RGB siga, RGB sigs) {
         tb = tables[m.bssrdf_table]; eta = m.eta;
         const float sa3[3] = {siga.r, siga.g, siga.b}, ss3[3] = {sigs.r, sigs.g, sigs.b};
+        const bool raw = m.kd_subsurface != 0u;
         for (int i = 0; i < 3; ++i) {
-            float sa = clampf(sa3[i], 0.0f, PT_INF) * m.scale, ss_ = clampf(ss3[i], 0.0f, PT_INF) * m.scale;
+            float sa = raw ? sa3[i] : clampf(sa3[i], 0.0f, PT_INF) * m.scale, ss_ = raw ? ss3[i] : clampf(ss3[i], 0.0f, PT_INF) * m.scale;
             sigma_t[i] = sa + ss_;
             rho[i] = (sigma_t[i] != 0.0f) ? ss_ / sigma_t[i] : 0.0f;
         }

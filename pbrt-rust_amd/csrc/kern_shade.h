@@ -133,10 +133,20 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     }
                     const TexMatEval E{s, tctx};
                     has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, E, s.materials);
-                    if (is_sss) { bss_sa = E.spec(s.materials[mi], PT_MP_SIGMA_A, s.materials[mi].sigma_a); bss_ss = E.spec(s.materials[mi], PT_MP_SIGMA_S, s.materials[mi].sigma_s); }
+                    if (is_sss) {
+                        const PtMaterial &sm = s.materials[mi];
+                        if (sm.kd_subsurface) {   // kdsubsurface.rs:96-99: mfp * scale and Kd from their textures, converted here
+                            const RGB mfree = E.spec(sm, PT_MP_MFP, sm.mfp).clamps(0.0f, PT_INF) * RGB(sm.scale), kd = E.spec(sm, PT_MP_KD, sm.kd).clamps(0.0f, PT_INF);
+                            subsurface_from_diffuse(s.bss_tables[sm.bssrdf_table], kd, mfree, bss_sa, bss_ss);
+                        } else { bss_sa = E.spec(sm, PT_MP_SIGMA_A, sm.sigma_a); bss_ss = E.spec(sm, PT_MP_SIGMA_S, sm.sigma_s); }
+                    }
                 } else {
                     has_bsdf = (mi != PT_NONE) && build_bsdf(s.materials[mi], si, bsdf, ConstMatEval(), s.materials);
-                    if (is_sss) { bss_sa = rgb3(s.materials[mi].sigma_a); bss_ss = rgb3(s.materials[mi].sigma_s); }
+                    if (is_sss) {
+                        const PtMaterial &sm = s.materials[mi];
+                        if (sm.kd_subsurface) subsurface_from_diffuse(s.bss_tables[sm.bssrdf_table], rgb3(sm.kd).clamps(0.0f, PT_INF), rgb3(sm.mfp).clamps(0.0f, PT_INF) * RGB(sm.scale), bss_sa, bss_ss);
+                        else { bss_sa = rgb3(sm.sigma_a); bss_ss = rgb3(sm.sigma_s); }
+                    }
                 }
                 flags &= ~PF_CAMERA_RAY;
                 IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;

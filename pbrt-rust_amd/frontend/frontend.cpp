@@ -327,8 +327,11 @@ private:
                     else p.rgb(pn, w ? sigs : siga);
                 }
                 m.scale = scale; m.bssrdf_table = bss_table(g, m.eta);
+            } else if (!p.texture("Kd").empty() || !p.texture("mfp").empty()) {   // kdsubsurface.rs:96-99 with a textured Kd / mfp: the library converts at every hit
+                spec("Kd", PT_MP_KD, m.kd, 0.5f); spec("mfp", PT_MP_MFP, m.mfp, 1.0f);
+                m.kd_subsurface = 1; m.scale = scale; m.bssrdf_table = bss_table(g, m.eta);
+                siga[0] = siga[1] = siga[2] = sigs[0] = sigs[1] = sigs[2] = 0.0f;
             } else {                      // kdsubsurface.rs:96-126: constant Kd / mfp -> subsurface_from_diffuse on the host
-                if (!p.texture("Kd").empty() || !p.texture("mfp").empty()) throw std::runtime_error("textured kdsubsurface Kd / mfp are not supported");
                 float kd[3] = {0.5f, 0.5f, 0.5f}, mfp[3] = {1, 1, 1}; p.rgb("Kd", kd); p.rgb("mfp", mfp);
                 m.bssrdf_table = bss_table(g, m.eta);
                 for (int i = 0; i < 3; ++i) { kd[i] = std::fmax(kd[i], 0.0f); mfp[i] = std::fmax(mfp[i], 0.0f) * scale; }

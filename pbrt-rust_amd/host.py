@@ -283,7 +283,7 @@ class SceneBuilder:
         # a parameter given as a string names a texture ("texture Kd" "name"); the constant field then keeps the default
         m.tex = (C.c_int32 * 16)(*([-1] * 16))
         slots = dict(Kd=(A.PT_MP_KD, 0), Ks=(A.PT_MP_KS, 0), Kr=(A.PT_MP_KR, 0), Kt=(A.PT_MP_KT, 0), reflect=(A.PT_MP_KR, 0), transmit=(A.PT_MP_KT, 0), amount=(A.PT_MP_KD, 0), color=(A.PT_MP_KD, 0), opacity=(A.PT_MP_OPACITY, 0),
-                     eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0),
+                     eta_rgb=(A.PT_MP_ETA_RGB, 0), k=(A.PT_MP_K_RGB, 0), sigma_a=(A.PT_MP_SIGMA_A, 0), sigma_s=(A.PT_MP_SIGMA_S, 0), mfp=(A.PT_MP_MFP, 0),
                      sigma=(A.PT_MP_SIGMA, 1), roughness=(A.PT_MP_ROUGHNESS, 1), uroughness=(A.PT_MP_U_ROUGHNESS, 1),
                      vroughness=(A.PT_MP_V_ROUGHNESS, 1), eta=(A.PT_MP_ETA, 1), bumpmap=(A.PT_MP_BUMP, 1))
         for key in list(kw):
@@ -291,7 +291,7 @@ class SceneBuilder:
                 slot, is_float = slots[key]
                 table = self.float_textures if is_float else self.spectrum_textures
                 if kw[key] not in table: raise KeyError(f"texture {kw[key]!r} not declared ({'float' if is_float else 'spectrum'})")
-                if kind in ("kdsubsurface",) or (kind == "subsurface" and d.get("name")): raise NotImplementedError("textured kdsubsurface / named subsurface parameters")
+                if kind == "subsurface" and d.get("name") and key in ("sigma_a", "sigma_s"): pass   # (an explicit parameter overrides the named medium's value, subsurface.rs:127-128)
                 m.tex[slot] = table[kw[key]]
                 d.pop(key)   # keep the create_*_material default in the constant field
         if kind == "metal" and m.tex[A.PT_MP_ROUGHNESS] >= 0:   # metal.rs: uroughness/vroughness fall back to "roughness"
@@ -316,6 +316,11 @@ class SceneBuilder:
                         g = 0.0
                 table = B.compute_beam_diffusion_bssrdf(g, float(d["eta"]))
                 m.scale = float(d["scale"])
+            elif m.tex[A.PT_MP_KD] >= 0 or m.tex[A.PT_MP_MFP] >= 0:   # kdsubsurface.rs:96-99 with a textured Kd / mfp: the conversion runs at every hit
+                table = B.compute_beam_diffusion_bssrdf(g, float(d["eta"]))
+                m.kd_subsurface = 1; m.scale = float(d["scale"])
+                m.kd = three(d.get("Kd", 0.5)); m.mfp = three(d.get("mfp", 1.0))
+                siga, sigs = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
             else:  # kdsubsurface.rs:96-99: mfp * scale, then subsurface_from_diffuse (constant textures -> host side)
                 table = B.compute_beam_diffusion_bssrdf(g, float(d["eta"]))
                 three_np = lambda v: np.asarray([v] * 3 if np.isscalar(v) else v, dtype=F)

@@ -187,7 +187,7 @@ def instanced_garden(n_inst=24, plant_n=10, xres=96, yres=64, spp=8, flatten=Fal
     return b
 
 
-def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textured_sigma=False):
+def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textured_sigma=False, textured_kd=False):
     """Config C5: a displaced sphere with a `subsurface` material (skin-like medium, mm units
     scaled so the mean free path is a visible fraction of the object), a `kdsubsurface` sphere shape and a matte floor,
     lit by an area light and a dim environment.  Exercises path.rs:177-204 / bssrdf.rs sample_s."""
@@ -216,7 +216,12 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textu
     P, I, N = displaced_sphere(n, with_normals=True)
     b.trianglemesh(P, I, N=N); b.attribute_end()
     b.attribute_begin()
-    b.material("kdsubsurface", Kd=(0.7, 0.35, 0.2), mfp=(0.25, 0.15, 0.08), eta=1.4)
+    if textured_kd:   # kdsubsurface.rs:96-99 with textures: subsurface_from_diffuse at every hit
+        b.texture("kdtex", "color", "checkerboard", uscale=6.0, vscale=3.0, tex1=(0.7, 0.35, 0.2), tex2=(0.2, 0.5, 0.8))
+        b.texture("mfptex", "color", "checkerboard", dimension=3, tex1=(0.25, 0.15, 0.08), tex2=(0.1, 0.2, 0.3))
+        b.material("kdsubsurface", Kd="kdtex", mfp="mfptex", eta=1.4, scale=1.5)
+    else:
+        b.material("kdsubsurface", Kd=(0.7, 0.35, 0.2), mfp=(0.25, 0.15, 0.08), eta=1.4)
     b.translate(1.2, 0.0, 0.3); b.sphere(radius=0.9); b.attribute_end()
     return b
 

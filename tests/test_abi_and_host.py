@@ -23,7 +23,7 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(A.PtBVHNode) == 32           # bvh.rs:89-95 LinearBVHNode
     assert C.sizeof(A.PtSphere) == 16 * 4 * 2 + 6 * 4 + 8 + 8
     assert C.sizeof(A.PtLight) == 4 + 12 + 4 + 4 + 12 + 12 + 8 + 128
-    assert C.sizeof(A.PtMaterial) == 4 + 7 * 12 + 5 * 4 + 4 + 24 + 8 + 64 + 8 + 44 + 12
+    assert C.sizeof(A.PtMaterial) == 4 + 7 * 12 + 5 * 4 + 4 + 24 + 8 + 64 + 8 + 44 + 12 + 12 + 4
     assert C.sizeof(A.PtKernelStat) == 32 + 8 + 8 + 8 + 8 + 8 + 48
 
 

@@ -556,7 +556,41 @@ WorldEnd
     a = oracle.scene(sd).render(rp, nthreads=4); c = oracle.scene(fs).render(fs.render_params(), nthreads=4)
     # the two hosts' float arithmetic differs by ulps (matrix inverses): a few samples land on the other side of a checker edge
     assert (np.abs(a - c) > 2e-5 * np.maximum(np.abs(a), 1e-2)).mean() < 0.01
-    with pytest.raises(Exception): pkg.frontend.FrontScene(text='WorldBegin\nMaterial "kdsubsurface" "texture Kd" "nope"\nWorldEnd\n')   # still refused: the inversion per hit
+    with pytest.raises(Exception): pkg.frontend.FrontScene(text='WorldBegin\nMaterial "kdsubsurface" "texture Kd" "nope"\nWorldEnd\n')   # an undeclared texture is an error
+
+
+def test_kdsubsurface_textures_from_a_scene_file_and_constant_textures_equal_constants(pkg, oracle):
+    """kdsubsurface.rs:106-126: `Kd` and `mfp` are spectrum textures. With textures the library converts at every hit
+    (PtMaterial.kd_subsurface); with constants the host converts once. Two checks that pin the per-hit path: constant TEXTURES must
+    render exactly what constant PARAMETERS do (the oracle's f32 Newton inversion against the Python mirror's host-side one), and a
+    scene file with a real texture flattens like the Python mirror's."""
+    A = pkg._abi
+    def scene(kd, mfp, declare):
+        b = pkg.host.SceneBuilder()
+        b.film.update(xres=40, yres=28); b.spp = 4; b.integ.update(maxdepth=5)
+        b.look_at((0, 1.6, 6), (0, .2, 0), (0, 1, 0)); b.camera(fov=38.0)
+        b.world_begin(); b.light_source("infinite", L=(.4, .45, .5))
+        declare(b)
+        b.material("kdsubsurface", Kd=kd, mfp=mfp, eta=1.4, scale=1.5)
+        b.sphere(radius=1.0)
+        return b.world_end()
+    plain = scene((0.7, 0.35, 0.2), (0.25, 0.15, 0.08), lambda b: None)
+    def const_tex(b):
+        b.texture("kdc", "color", "constant", value=(0.7, 0.35, 0.2)); b.texture("mfpc", "color", "constant", value=(0.25, 0.15, 0.08))
+    tex = scene("kdc", "mfpc", const_tex)
+    mp = [plain[0].desc().materials[i] for i in range(plain[0].desc().n_materials)][-1]; mt = [tex[0].desc().materials[i] for i in range(tex[0].desc().n_materials)][-1]
+    assert mp.kd_subsurface == 0 and mt.kd_subsurface == 1 and mt.tex[A.PT_MP_KD] >= 0 and mt.tex[A.PT_MP_MFP] >= 0 and mt.scale == pytest.approx(1.5)
+    a = oracle.scene(plain[0]).render(plain[1], nthreads=4); c = oracle.scene(tex[0]).render(tex[1], nthreads=4)
+    np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
+    fs = pkg.frontend.FrontScene(text='''WorldBegin
+Texture "kdt" "spectrum" "checkerboard" "rgb tex1" [.7 .35 .2] "rgb tex2" [.2 .5 .8]
+Material "kdsubsurface" "texture Kd" "kdt" "rgb mfp" [.25 .15 .08] "float scale" 1.5 "float eta" 1.4
+Shape "sphere"
+WorldEnd
+''')
+    d = fs.desc()
+    m = [d.materials[i] for i in range(d.n_materials) if d.materials[i].type == A.PT_MAT_SUBSURFACE][0]
+    assert m.kd_subsurface == 1 and m.tex[A.PT_MP_KD] >= 0 and m.tex[A.PT_MP_MFP] < 0 and list(m.mfp) == pytest.approx([.25, .15, .08]) and m.scale == pytest.approx(1.5)
 
 
 def test_disney_material_from_a_scene_file(pkg):

@@ -311,6 +311,21 @@ def test_subsurface_with_sigma_textures_matches_oracle(pkg, gpu, oracle, rough):
     assert not np.allclose(film[..., :3], pkg.Scene(gpu, plain).render(rp)[..., :3], rtol=1e-3)   # (the textures do change the image)
 
 
+def test_kdsubsurface_with_textures_matches_oracle(pkg, gpu, oracle):
+    """kdsubsurface.rs:96-99 with textured `Kd` / `mfp`: subsurface_from_diffuse (invert_catmull_rom over the table's effective albedo,
+    interpolation.rs:265-330) runs at every hit -- in k_shade<5, 2> on the device, in the oracle's compute_scattering_functions -- and the
+    resulting coefficients travel with the path like the textured sigma_a / sigma_s of `subsurface`."""
+    sd, rp = pkg.scenes.subsurface_c5(n=16, xres=96, yres=64, spp=8, textured_kd=True).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    gc, oc = g.counters(), orc.counters()
+    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
+              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+
+
 def test_long_probe_chains_fall_back_to_an_uncounted_rewalk(pkg, gpu, oracle):
     """A stack of 40 thin sheets of one subsurface material: probe chains along the normal cross up to 40 matching surfaces, far more
     than the 8-entry ring of k_trace<.., PROBE>, so chains whose selected intersection has left the ring are walked a second
