@@ -94,6 +94,7 @@ def random_scene(pkg, seed, builder=None):
         if allow_mix: kinds.append("mix")
         if allow_sss: kinds += ["subsurface", "kdsubsurface", "disney_sss"]
         if allow_sss and gen2: kinds += ["subsurface_tex", "subsurface_tex"]
+        if allow_sss and seed >= 70000: kinds += ["kdsubsurface_tex", "kdsubsurface_tex"]   # kdsubsurface with a textured Kd / mfp (converted at every hit)
         k = pick(*kinds)
         bump = {"bumpmap": "bump"} if rng.random() < 0.25 else {}
         if rng.random() < 0.1: bump = {"bumpmap": pick("fbm", "wnd")}
@@ -114,6 +115,7 @@ def random_scene(pkg, seed, builder=None):
         elif k == "disney_sss": b.material("disney", color=rgb(0.3, 0.9), scatterdistance=rgb(0.02, 0.2), roughness=u(0.2, 0.8), eta=u(1.2, 1.6))
         elif k == "subsurface": b.material("subsurface", name=pick("", "Skin1", "Marble"), scale=u(5, 40), eta=u(1.2, 1.5), **({} if rng.random() < 0.5 else {"sigma_a": rgb(0.001, 0.02), "sigma_s": rgb(1, 4)}))
         elif k == "subsurface_tex": b.material("subsurface", sigma_a=pick("siga", rgb(0.001, 0.02)), sigma_s=pick("sigs", "sigs", rgb(1, 4)), scale=u(5, 40), eta=u(1.2, 1.5), **({} if rng.random() < 0.5 else dict(uroughness=u(0.05, 0.3), vroughness=u(0.05, 0.3))))
+        elif k == "kdsubsurface_tex": b.material("kdsubsurface", Kd=pick("chk", "img", "chk3", rgb(0.3, 0.9)), mfp=pick("sigs", rgb(0.05, 0.5)) if rng.random() < 0.5 else "sigs", eta=u(1.2, 1.5), scale=u(0.1, 0.4))
         elif k == "kdsubsurface": b.material("kdsubsurface", Kd=rgb(0.3, 0.9), mfp=u(0.05, 0.5), eta=u(1.2, 1.5))
         else:
             ids = []
@@ -167,7 +169,7 @@ def test_oracle_renders_random_scenes(pkg, oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(160)) + [2005, 13269] + list(range(50000, 50024)))   # found by a 14 000-seed sweep (tools/fuzz_sweep.py): 2005 volpath's `if beta.is_black() { break }` outside any medium; 13269 `L += beta * Ld` with a black Ld and a NaN beta (BSSRDF exit point a few ulps from the entry point)
+@pytest.mark.parametrize("seed", list(range(160)) + [2005, 13269] + list(range(50000, 50024)) + list(range(70000, 70016)))   # found by a 14 000-seed sweep (tools/fuzz_sweep.py): 2005 volpath's `if beta.is_black() { break }` outside any medium; 13269 `L += beta * Ld` with a black Ld and a NaN beta (BSSRDF exit point a few ulps from the entry point)
 def test_gpu_matches_oracle_on_random_scenes(pkg, gpu, oracle, seed):
     b = random_scene(pkg, seed)
     sd, rp = b.world_end()
