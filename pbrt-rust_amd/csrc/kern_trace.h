@@ -23,6 +23,10 @@
                            // Round 2: 71 VGPRs without scratch, and with a 10-entry LDS stack (kernels.h) seven workgroups share a CU's LDS: trace -3 %, camera
                            // rays -6 % against six waves; eight waves need 64 VGPRs = 24 bytes of scratch per lane and lose 9 %. The loop waits on its gathers.
 #endif
+#ifndef PT_TRACE_WAVES_INST
+#define PT_TRACE_WAVES_INST 5   // triangles + instances (MODE 3): 89 VGPRs. Six waves (-DPT_TRACE_WAVES_INST=6 -DPT_LDS_STACK_GENERAL=10: 80 VGPRs + 52 B of scratch per
+                                // lane, 161 KB of LDS per CU) measured on S4: mixed launches -2.4 %, camera rays +4 %, 94.0 -> 95.4 Msamples/s -- not worth the scratch
+#endif
 #ifndef PT_TRACE_ATTR
 #define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
                         // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
@@ -38,7 +42,7 @@
 // launch: one tail of straggling rays per iteration instead of three; measured with the PT_TRACE_UTIL build on S2: the wave slots of the three
 // separate launches were busy 73 / 53 / 62 % of launch span x resident waves, ~0.8 ms of tail each).
 template <int ANY, int MODE, bool PROBE>
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? 5 : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? PT_TRACE_WAVES_INST : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
     constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;

@@ -20,7 +20,10 @@ constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6;
 constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM. Triangle-only scenes: 10, so
                                               // that seven workgroups fit a CU's LDS; scenes with instances push a marker entry per instance entered and run five
                                               // waves per SIMD: 12 (C4 with 10: trace +2.3 %)
-constexpr int kLdsStackGeneral = PT_LDS_STACK > 12 ? PT_LDS_STACK : 12;
+#ifndef PT_LDS_STACK_GENERAL
+#define PT_LDS_STACK_GENERAL 12
+#endif
+constexpr int kLdsStackGeneral = PT_LDS_STACK_GENERAL;
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 constexpr int kTraceBlock = 256;
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
