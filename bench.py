@@ -181,7 +181,7 @@ def main():
         if traffic:
             hbm_achieved = traffic / (avg_ms * 1e-3) / 1e9
             hbm_frac = hbm_achieved / HBM_PEAK_GBS
-        roofline = dict(bound="hbm", limiter="instruction issue (VALU ~80 % of SIMD cycles, as many scalar as vector instructions) with the latency of the dependent gathers close behind (DESIGN.md section 7); gathers mostly L1/L2-served, HBM at hbm_frac", kernel=name, launch_kinds=g["kinds"],
+        roofline = dict(bound="hbm", limiter="instruction issue (VALU ~80 % of SIMD cycles, as many scalar as vector instructions) with the dependent gathers close behind: the L2 misses are ~70 % of the fabric's measured random-gather ceiling (54 G requests/s, profiles/r2_gather_calibration.json), HBM bytes at hbm_frac (DESIGN.md section 7)", kernel=name, launch_kinds=g["kinds"],
                         achieved=round(achieved, 2), achieved_kind="algorithmic bytes (cache-inclusive) / launch time", peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                         hbm_achieved=None if hbm_achieved is None else round(hbm_achieved, 2), hbm_frac=None if hbm_frac is None else round(hbm_frac, 5),
