@@ -478,7 +478,10 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 }
 
 template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
-    const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * 8u);  // persistent blocks: the LDS Sobol' table is staged once per block
+#ifndef PT_SHADE_BLOCKS_PER_CU
+#define PT_SHADE_BLOCKS_PER_CU 8u   // (experiment hook)
+#endif
+    const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);  // persistent blocks: the LDS Sobol' table is staged once per block
     const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
     sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + std::to_string(DIFF) + ">");
     if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF == 2 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
