@@ -175,7 +175,10 @@ def test_tile_sharding_sums_to_full_render(pkg, gpu):
         rp.tile_rank, rp.tile_world = r, 3
         g.render(rp, film=acc)
     rp.tile_rank, rp.tile_world = 0, 1
-    assert np.array_equal(acc, full)  # box filter: disjoint pixels, bit-identical sum
+    # box filter: disjoint pixels. Weights bit for bit; radiance too except where a sample sits exactly on a pixel corner and reaches its
+    # neighbours through float atomics, whose order against the owner's additions is not defined (see test_multi_device.py)
+    assert np.array_equal(acc[..., 3], full[..., 3]) and (acc == full).mean() > 0.99
+    np.testing.assert_allclose(acc[..., :3], full[..., :3], rtol=2e-6, atol=1e-7)
 
 
 def test_tile_sharding_with_halton_and_volpath(pkg, gpu):
