@@ -15,9 +15,9 @@
 //  * a far child whose t_max-independent part already fails is not pushed; the reference would pop, test and
 //    discard it later, so the number of such skipped entries lying directly below each pushed entry is carried along
 //    (6 bits in the stack word) and added to the node-visit counter at the moment the reference would pop them.
-// Node steps and leaf (triangle) work run in separate phases so that neither executes with a mostly idle wave.
+// Node steps and leaf (triangle) work share one loop: every iteration a lane fetches ONE record, an interior node's or a leaf packet's
+// ("if-if"); lanes at a leaf join once a quorum of them waits. Instance entry / exit is a step of its own (ST_INST / ST_RET).
 
-// GEN = the scene has spheres and/or object instances (lean triangle-only code otherwise).
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 7   // waves per SIMD the triangle-only traversal kernels are compiled for (experiment hook: tools/build_variant.sh -DPT_TRACE_WAVES=N).
                            // Round 2: 71 VGPRs without scratch, and with a 10-entry LDS stack (kernels.h) seven workgroups share a CU's LDS: trace -3 %, camera
