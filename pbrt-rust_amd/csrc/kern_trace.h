@@ -496,3 +496,5 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     }
 #endif
 }
+#undef PT_SUB
+#undef PT_UTIL
