@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json: Msamples/s at 1920x1080).
 
-A "step" is one full render (pt_render) of the named workload. Default: S2 / config C2, the Ganesha-scale
+A "step" is one full render (pt_render / pt_multi_render) of the named workload. Default: S2 / config C2, the Ganesha-scale
 synthetic scene (4,298,312-triangle displaced sphere, matte, quad area light + constant environment),
 1920x1080 x 256 spp, PathIntegrator maxdepth 5, Sobol sampler, box filter, spatial light sampling.
 `--config C3|C4|C5` selects the other BASELINE configs built to SURVEY 8(d)'s S3 / S4 / S5 specification
 (pbrt-rust_amd/scenes.py: country_kitchen_s3, ecosystem_s4, dragon_s5) at their named spp (override: --spp).
+The default C2 run on one GPU also renders C3 / C4 / C5 once each at a reduced spp AFTER the headline's timed region and reports
+them under "other_configs" of the same JSON line, so every BASELINE config has a number on the driver's record.
 Scene generation, BVH build and upload are outside the timed region. The film stays on the device
 (pt_render's film_is_device path): the 33 MB read-back of SURVEY 8(d)'s definition (0.6 ms over PCIe) is not in `value`;
-for N > 1 the RCCL film reduction is inside the timed region.
+for N > 1 the film merge is inside the timed region.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL). The 16x16 sample tiles of
-integrator.rs:276-283 are dealt round-robin to ranks (tile_rank/tile_world in PtRenderParams), every
-rank renders all spp of its tiles into a device film, and the films are summed onto rank 0 with one
-dist.reduce -- total work is fixed, so scaling is "strong". `--in-process` instead drives all N devices from ONE
-process through pt_multi_render (the C ABI's own multi-device path, include/mi355pt.h).
+N > 1, two launch forms on the same kernels and the same tile shards (16x16 sample tiles of integrator.rs:276-283 round-robin,
+every shard renders all spp of its tiles into a device film, the films are summed onto the first GPU; total work is fixed, so
+scaling is "strong"):
+  * under a launcher (WORLD_SIZE set: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): one process per
+    GPU, the merge is one dist.reduce (backend nccl == RCCL over xGMI);
+  * plain `python bench.py --gpus N` (no WORLD_SIZE): ONE process drives devices 0..N-1 through pt_multi_render, the C ABI's own
+    multi-device path (the reference is one process too: integrator.rs:294-296), the merge is N-1 concurrent peer copies + one sum
+    kernel. The line then carries per-device busy ms and the merge ms. `--devices 0,0,...` repeats ordinals (replicas share a GPU).
 """
 import argparse
 import json
@@ -25,8 +30,253 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+GATHER_CEILING_GREQ_S = 54.0  # profiles/r2_gather_calibration.json: dependent random 64-byte gathers, 128-byte fabric requests per ns, whole chip
 TRACE_KINDS = ("trace", "extend", "extend_mis", "shadow", "extend_camera", "extend_probe")   # "trace" = the mixed launch: continuation + MIS + shadow rays of one wavefront iteration
+OTHER_CONFIG_SPP = {"C3": 64, "C4": 32, "C5": 128}   # one step each after the headline (C4: 0.7 s, C3 0.4 s, C5 0.3 s of render)
+
+
+def algo_bytes(name, s):
+    """ALGORITHMIC bytes of a launch kind: trace kernels 32 B per reference BVH node visited + 48 B per shape
+    packet tested + 44 B per ray (pid 4, ray 24, hit record 16); shade kernels count their path-state / mesh / queue quads in-kernel."""
+    if name in TRACE_KINDS:
+        return 32 * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
+    if name.startswith("shade_") or name == "bssrdf":
+        return s["bvh_nodes"]
+    return None
+
+
+def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
+    """Dominant kernel = the kernel symbol (what rocprofv3 --stats reports) with the largest HIP-event time in the timed region.
+
+    `achieved` is ALGORITHMIC bytes / launch time: cache-inclusive, most of those bytes are served by L1 / L2, so against the HBM peak it
+    is NOT bounded by 1 (`algorithmic_over_hbm_peak`). `frac` is the fabric-side byte rate of the same kernel (L2 misses, counted by
+    request size, + writes; profiles/pmc_traffic.json, collected by tools/profile_gpu.sh in separate --pmc passes) over the HBM peak:
+    Infinity-Cache hits are included in those bytes, so it is an upper bound on the DRAM rate and a true fraction. It is null when
+    no committed PMC record matches this kernel / config / pass size. The byte counts come from the committed profile, only the
+    launch time is measured in this run."""
+    groups = {}
+    for n, v in kstats.items():
+        ab = algo_bytes(n, v)
+        if ab is None or v["launches"] == 0:
+            continue
+        g = groups.setdefault(v["kernel"] or n, dict(ms=0.0, launches=0, bytes=0, kinds=[]))
+        g["ms"] += v["total_ms"]; g["launches"] += v["launches"]; g["bytes"] += ab; g["kinds"].append(n)
+    if not groups:
+        return None
+    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = g["ms"] / max(1, g["launches"])
+    achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+    rec = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            data = json.load(open(tpath))
+            r = data.get(config, {}).get(name)
+            if r and r.get("spp_per_pass") == eff_spp_per_pass and r.get("workload") == workload_key:
+                rec = r
+        except Exception:
+            rec = None
+    traffic = hbm_achieved = hbm_frac = l2_hit = gather_frac = None
+    if rec:
+        traffic, l2_hit = rec.get("hbm_bytes_per_launch"), rec.get("l2_hit_rate")
+        hbm_achieved = traffic / (avg_ms * 1e-3) / 1e9
+        hbm_frac = hbm_achieved / HBM_PEAK_GBS
+        rd = rec.get("rdreq", {}).get("TCC_EA0_RDREQ_sum")
+        disp = rec.get("dispatches") or 1
+        if rd:
+            gather_frac = rd / disp / (avg_ms * 1e-3) / 1e9 / GATHER_CEILING_GREQ_S
+    is_trace = any(k in TRACE_KINDS for k in g["kinds"])
+    return dict(
+        bound="hbm", kernel=name, launch_kinds=g["kinds"], unit="GB/s", peak=HBM_PEAK_GBS,
+        achieved=round(achieved, 2),
+        achieved_kind="ALGORITHMIC bytes / launch time (cache-inclusive: mostly L1/L2-served, can exceed the HBM peak)",
+        algorithmic_over_hbm_peak=round(achieved / HBM_PEAK_GBS, 5),
+        frac=None if hbm_frac is None else round(hbm_frac, 5),
+        frac_kind="fabric-side bytes (L2 read misses by request size + writes; Infinity-Cache hits included, so an upper bound on DRAM bytes) / this run's launch time / 8 TB/s",
+        hbm_achieved=None if hbm_achieved is None else round(hbm_achieved, 2), hbm_frac=None if hbm_frac is None else round(hbm_frac, 5),
+        traffic=traffic, traffic_source="committed profile profiles/pmc_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ_{128B,64B,32B}_sum + WRITE_SIZE, separate passes), not this run" if traffic else None,
+        traffic_over_algorithmic=None if not traffic else round(traffic / (g["bytes"] / max(1, g["launches"])), 3),
+        l2_hit_rate=l2_hit,
+        frac_of_gather_ceiling=None if gather_frac is None else round(gather_frac, 4),
+        gather_ceiling="fabric read requests per second of this kernel / 54 G/s, the measured chip-wide rate of dependent random 64-byte gathers (profiles/r2_gather_calibration.json)",
+        limiter=("instruction issue + dependent-gather latency (per-lane BVH walk; DESIGN.md section 7 has the SQ counters)" if is_trace
+                 else "instruction count at 2 waves/SIMD (VGPR-limited), not bytes (DESIGN.md section 7)"),
+        launches=g["launches"], avg_launch_ms=round(avg_ms, 4),
+        algorithmic_bytes_per_launch=int(g["bytes"] / max(1, g["launches"])))
+
+
+def kernel_table(kstats, steps):
+    def gbs(n, v):
+        ab = algo_bytes(n, v)
+        return {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
+    kernels = {n: dict(ms=round(v["total_ms"] / steps, 3), launches=v["launches"] // steps, kernel=v["kernel"], **gbs(n, v),
+                       **({"Mitems": round(v["items"] / steps / 1e6, 2), "ns_per_item": round(v["total_ms"] * 1e6 / v["items"], 3)} if v["items"] and n not in TRACE_KINDS else {}),
+                       **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in TRACE_KINDS else {}))
+               for n, v in kstats.items() if v["launches"] and ":" not in n}
+    # what the mixed traversal launches did per ray kind (counters only: the kinds share the launches' time)
+    trace_kinds = {n.split(":", 1)[1]: dict(Mrays_per_step=round(v["items"] / steps / 1e6, 2), nodes_per_ray=round(v["bvh_nodes"] / max(1, v["items"]), 1), tris_per_ray=round(v["triangle_tests"] / max(1, v["items"]), 2))
+                   for n, v in kstats.items() if n.startswith("trace:")}
+    return kernels, trace_kinds
+
+
+def accumulate(kstats, entries):
+    for ks in entries:
+        a = kstats.setdefault(ks["name"], dict(launches=0, total_ms=0.0, items=0, bvh_nodes=0, triangle_tests=0, kernel=ks.get("kernel", "")))
+        for k in ("launches", "total_ms", "items", "bvh_nodes", "triangle_tests"):
+            a[k] += ks[k]
+
+
+def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, devices, in_process, rank, world, want_cpu_baseline):
+    """Build the config's scene, run `warmup` untimed + `steps` timed renders, return the result dict (rank 0) or None."""
+    builder_fn, named_spp, workload_desc = pkg.scenes.CONFIG_SCENES[config]
+    spp = spp if spp > 0 else named_spp
+    t_gen = time.time()
+    kw = dict(xres=args.xres, yres=args.yres, spp=spp)
+    if config in ("C2", "C5"):
+        kw["n"] = args.mesh_n
+    b = builder_fn(**kw)
+    sd, rp = b.world_end()
+    d = sd.desc()
+    n_tris, n_inst = int(d.n_triangles), int(d.n_instances)
+    t_gen = time.time() - t_gen
+    t_up = time.time()
+    scene = multi = None
+    if in_process:
+        multi = pkg.MultiScene(lib, sd, devices)   # scene replicated on every listed device, one host thread + stream each
+    else:
+        scene = pkg.Scene(lib, sd)                 # host SAH build + upload + packet build
+    t_up = time.time() - t_up
+    rp.tile_rank, rp.tile_world = rank, world
+    if args.sim_world > 1 and world == 1:
+        rp.tile_rank, rp.tile_world = 0, args.sim_world
+    rp.spp_per_pass = args.spp_per_pass
+    rp.profile = int(os.environ.get("PT_BENCH_PROFILE", "1"))   # 1: HIP events around every launch, on the render stream; 2: + exact per-class launch sizes
+    cb = rp.cropped_pixel_bounds
+    W, H = cb[2] - cb[0], cb[3] - cb[1]
+    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    pb = rp.pixel_bounds
+    n_samples = (pb[2] - pb[0]) * (pb[3] - pb[1]) * spp
+
+    def step():
+        film.zero_()
+        torch.cuda.synchronize()
+        if multi is not None:
+            multi.render(rp, device_ptr=film.data_ptr())          # tiles % n_replicas, films summed onto the first device inside the call
+        else:
+            scene.render(rp, device_ptr=film.data_ptr())
+        if dist is not None:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)        # merge_film_tile across ranks (RCCL over xGMI)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    nrep = len(devices) if multi is not None else 1
+    kstats = {}
+    rep_kernel_ms = [0.0] * nrep      # per replica: sum of its kernels' HIP-event times over the timed steps
+    rep_render_ms = [0.0] * nrep      # per replica: wall time of its pt_render
+    rep_copy_ms = [0.0] * nrep
+    merge_ms = 0.0
+    counters = None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if multi is not None:
+            for r in range(nrep):
+                ks = multi.kernel_stats(r)
+                rep_kernel_ms[r] += sum(k["total_ms"] for k in ks if ":" not in k["name"])
+                accumulate(kstats, ks)
+            tm = multi.timing()
+            merge_ms += tm["merge_ms"]
+            for r in range(nrep):
+                rep_render_ms[r] += tm["render_ms"][r]; rep_copy_ms[r] += tm["copy_ms"][r]
+            counters = multi.counters()
+        else:
+            ks = scene.kernel_stats()
+            rep_kernel_ms[0] += sum(k["total_ms"] for k in ks if ":" not in k["name"])
+            accumulate(kstats, ks)
+            counters = scene.counters()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    busy_all = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        busy = torch.tensor([rep_kernel_ms[0] / steps], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(busy) for _ in range(world)]
+        dist.all_gather(gathered, busy)
+        busy_all = [round(float(x.item()), 2) for x in gathered]
+    if rank != 0:
+        return None
+
+    eff_spp_per_pass = None   # what the library chose (0 = as many samples per pass as the free memory holds, up to 2^28 paths): from the number of k_generate launches
+    if kstats.get("generate", {}).get("launches"):
+        n_pass = max(1, kstats["generate"]["launches"] // (steps * nrep))
+        eff_spp_per_pass = -(-spp // n_pass)
+    n_gpus = len(set(devices)) if in_process else world
+    value = n_samples * steps / elapsed / 1e6
+    roofline = build_roofline(kstats, config, eff_spp_per_pass, [args.mesh_n, args.xres, args.yres]) if nrep == 1 or in_process else None
+    if roofline and nrep > 1:
+        roofline["note"] = f"launch times and bytes are summed over the {nrep} replicas (each renders 1/{nrep} of the tiles)"
+    kernels, trace_kinds = kernel_table(kstats, steps)
+
+    cpu_baseline = None
+    if want_cpu_baseline and args.cpu_seconds > 0 and world == 1:
+        cpu_baseline = run_cpu_baseline(pkg, sd, rp, spp, args)
+
+    if args.dump_image and config == args.config:
+        from tools.imgio import write_png
+        write_png(args.dump_image, (scene or multi).resolve(film.cpu().numpy()))
+
+    if n_gpus > 1 or nrep > 1:
+        if in_process:
+            par = (f"16x16 sample tiles round-robin over {nrep} replica(s) on {n_gpus} GPU(s) (devices {devices}); ONE process, pt_multi_render: one host thread + stream per "
+                   "replica, film merge = concurrent hipMemcpyPeerAsync (one xGMI link per source, issued as each replica finishes) + one sum kernel on the first device; "
+                   "no RCCL in this form (a single 33 MB reduction per render; the launcher form below uses RCCL)")
+        else:
+            par = f"16x16 sample tiles round-robin over {n_gpus} GPU(s); one process per GPU (torch.distributed), film merge = one RCCL reduce (dist.reduce SUM) onto rank 0"
+    else:
+        par = "1 GPU"
+    multi_gpu = None
+    if in_process:
+        multi_gpu = dict(form="one process, pt_multi_render", devices=devices,
+                         per_replica_kernel_busy_ms=[round(x / steps, 2) for x in rep_kernel_ms],
+                         per_replica_render_wall_ms=[round(x / steps, 2) for x in rep_render_ms],
+                         per_replica_peer_copy_ms=[round(x / steps, 3) for x in rep_copy_ms],
+                         merge_ms=round(merge_ms / steps, 3),
+                         merge_def="from the last replica's render end to the summed film on the first device (tail of the peer copies + the sum kernel)")
+    elif busy_all is not None:
+        multi_gpu = dict(form="one process per GPU, RCCL reduce", per_rank_kernel_busy_ms=busy_all)
+    out = {
+        "metric": "Msamples/s (camera rays x spp) at 1920x1080",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{config}: {workload_desc}; {n_tris} triangles" + (f", {n_inst} instances" if n_inst else "") +
+                               f", {args.xres}x{args.yres}x{spp}spp, path maxdepth 5, sobol, box filter, spatial light sampling",
+                   "name": config, "triangles": n_tris, "instances": n_inst, "spp": spp, "spp_per_pass": eff_spp_per_pass, "resolution": [args.xres, args.yres],
+                   "film": "stays on the device (no read-back in the timed region; 33 MB = 0.6 ms over PCIe)",
+                   "parallelism": par},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+        **({"multi_gpu": multi_gpu} if multi_gpu else {}),
+        "kernels_ms_per_step": kernels, **({"trace_kinds": trace_kinds} if trace_kinds else {}),
+        "rays_per_sample": round((counters["intersect_tests"] + counters["shadow_tests"]) / max(1, counters["camera_rays"]), 3) if counters else None,
+        "nodes_per_ray": round(counters["bvh_nodes_visited"] / max(1, counters["intersect_tests"] + counters["shadow_tests"]), 2) if counters else None,
+        "setup_s": {"scene_gen": round(t_gen, 1), "bvh_build_upload": round(t_up, 1)},
+    }
+    if args.sim_world > 1 and world == 1:
+        out["sim_world"] = args.sim_world
+        out["value_note"] = f"rank 0's shard of a {args.sim_world}-rank job only; ideal = full-frame ms_per_step / {args.sim_world}"
+    (scene or multi).close()
+    del film
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -43,186 +293,62 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 disables)")
     ap.add_argument("--dump-image", default="")
     ap.add_argument("--sim-world", type=int, default=0, help="single-GPU study: render rank 0's shard of an N-rank job (value is then this rank's share only)")
-    ap.add_argument("--in-process", action="store_true", help="N > 1 without torchrun: one process drives --gpus devices through pt_multi_render (include/mi355pt.h)")
-    ap.add_argument("--devices", default="", help="--in-process: explicit device ordinals, e.g. 0,1,2,3 (an ordinal may repeat: replicas share the device; default 0..gpus-1)")
+    ap.add_argument("--in-process", action="store_true", help="force the one-process pt_multi_render form (it is the default for --gpus N > 1 without a launcher)")
+    ap.add_argument("--devices", default="", help="one-process form: explicit device ordinals, e.g. 0,1,2,3 (an ordinal may repeat: replicas share the device; default 0..gpus-1)")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"], help="after the headline, one step each of C3 / C4 / C5 at reduced spp under 'other_configs' (auto: default C2 run on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world > 1:
         args.gpus = world
     devices = [int(x) for x in args.devices.split(",") if x != ""] or list(range(args.gpus))
-    in_process = args.in_process and world == 1 and len(devices) > 1
-    if in_process:
-        args.gpus = len(set(devices))
+    # no launcher and more than one device (or replica) asked for: ONE process drives them all through pt_multi_render
+    in_process = world == 1 and (len(devices) > 1 or args.in_process)
 
-    import numpy as np
     import torch
     from _pkg import import_pkg
     pkg = import_pkg()
     lib = pkg.load_library()          # raises if libmi355pt.so is missing: there is no CPU fallback
-    lib.init(local_rank)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if in_process:
+        import ctypes
+        n_dev = ctypes.c_int(0)
+        lib.check(lib.lib.pt_device_count(ctypes.byref(n_dev)), "pt_device_count")
+        if max(devices) >= n_dev.value:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} asks for device ordinals {devices}, but this process sees {n_dev.value} device(s)")
+    first = devices[0] if in_process else local_rank
+    lib.init(first)
+    torch.cuda.set_device(first)
+    dev = torch.device("cuda", first)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    builder_fn, named_spp, workload_desc = pkg.scenes.CONFIG_SCENES[args.config]
-    spp = args.spp if args.spp > 0 else named_spp
-    t_gen = time.time()
-    kw = dict(xres=args.xres, yres=args.yres, spp=spp)
-    if args.config in ("C2", "C5"):
-        kw["n"] = args.mesh_n
-    b = builder_fn(**kw)
-    sd, rp = b.world_end()
-    d = sd.desc()
-    n_tris, n_inst = int(d.n_triangles), int(d.n_instances)
-    t_gen = time.time() - t_gen
-    t_up = time.time()
-    scene = pkg.Scene(lib, sd)        # host SAH build + upload + packet build
-    t_up = time.time() - t_up
-    rp.tile_rank, rp.tile_world = rank, world
-    if args.sim_world > 1 and world == 1: rp.tile_rank, rp.tile_world = 0, args.sim_world
-    rp.spp_per_pass = args.spp_per_pass
-    rp.profile = int(os.environ.get("PT_BENCH_PROFILE", "1"))   # 1: HIP events around every launch, on the render stream; 2: + exact per-class launch sizes
-    cb = rp.cropped_pixel_bounds
-    W, H = cb[2] - cb[0], cb[3] - cb[1]
-    film = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    pb = rp.pixel_bounds
-    n_samples = (pb[2] - pb[0]) * (pb[3] - pb[1]) * spp
-    n_slots = (-(-(rp.sample_bounds[2] - rp.sample_bounds[0]) // 16)) * (-(-(rp.sample_bounds[3] - rp.sample_bounds[1]) // 16)) * 256 // max(1, world if not in_process else len(devices))
-    eff_spp_per_pass = None   # what the library chose (0 = as many samples per pass as the free memory holds, up to 2^28 paths): from the number of k_generate launches below
-    multi = None
-    if in_process:
-        multi = pkg.MultiScene(lib, sd, devices)   # scene replicated on every device, one host thread + stream each
-
-    def step():
-        film.zero_()
-        torch.cuda.synchronize()
-        if multi is not None:
-            multi.render(rp, device_ptr=film.data_ptr())          # tiles % n_devices, films summed onto device 0 inside the call
-        else:
-            scene.render(rp, device_ptr=film.data_ptr())
-        if dist is not None:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # merge_film_tile across ranks (RCCL over xGMI)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kstats = {}
-    counters = None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for ks in (multi.kernel_stats() if multi is not None else scene.kernel_stats()):
-            a = kstats.setdefault(ks["name"], dict(launches=0, total_ms=0.0, items=0, bvh_nodes=0, triangle_tests=0, kernel=ks.get("kernel", "")))
-            for k in ("launches", "total_ms", "items", "bvh_nodes", "triangle_tests"):
-                a[k] += ks[k]
-        counters = multi.counters() if multi is not None else scene.counters()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if kstats.get("generate", {}).get("launches"):
-        n_pass = max(1, kstats["generate"]["launches"] // args.steps)
-        eff_spp_per_pass = -(-spp // n_pass)
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    n_gpus = args.gpus if in_process else world
-    value = n_samples * args.steps / elapsed / 1e6
-    # --- roofline of the dominant kernel: ALGORITHMIC bytes / HIP-event time, next to the HBM bytes the
-    # PMC counters saw for the same kernel (profiles/pmc_traffic.json, collected by tools/profile_gpu.sh in separate passes).
-    # trace kernels: 32 B per BVH node visited + 48 B per shape packet tested + 44 B per ray (pid 4, ray 24, hit record 16)
-    def algo_bytes(name, s):
-        if name in TRACE_KINDS:
-            return 32 * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
-        if name.startswith("shade_") or name == "bssrdf":
-            return s["bvh_nodes"]  # path-state + mesh + queue bytes counted in-kernel (PtKernelStat.bvh_nodes for shade kernels)
-        return None
-    # Group the per-launch-kind statistics by kernel symbol (what rocprofv3 --stats reports; PtKernelStat.kernel) and take
-    # the symbol with the largest total time as the dominant kernel.
-    groups = {}
-    for n, v in kstats.items():
-        ab = algo_bytes(n, v)
-        if ab is None or v["launches"] == 0:
-            continue
-        g = groups.setdefault(v["kernel"] or n, dict(ms=0.0, launches=0, bytes=0, kinds=[]))
-        g["ms"] += v["total_ms"]; g["launches"] += v["launches"]; g["bytes"] += ab; g["kinds"].append(n)
-    roofline = None
-    if groups:
-        name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
-        avg_ms = g["ms"] / max(1, g["launches"])
-        achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        traffic = traffic_src = hbm_achieved = hbm_frac = l2_hit = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+    out = measure(pkg, lib, torch, dev, dist, args, args.config, args.spp, args.steps, args.warmup, devices, in_process, rank, world, want_cpu_baseline=True)
+    others = args.other_configs == "on" or (args.other_configs == "auto" and args.config == "C2" and world == 1 and not in_process and args.sim_world <= 1
+                                             and args.spp == 0 and (args.xres, args.yres, args.mesh_n) == (1920, 1080, 1466))
+    if out is not None and others and world == 1:
+        oc = {}
+        for cfg, cspp in OTHER_CONFIG_SPP.items():
+            if cfg == args.config:
+                continue
             try:
-                data = json.load(open(tpath))
-                rec = data.get(args.config, data if args.config == "C2" else {}).get(name)
-                if rec and rec.get("spp_per_pass") == eff_spp_per_pass and rec.get("workload") == [args.mesh_n, args.xres, args.yres]:
-                    traffic, traffic_src, l2_hit = rec.get("hbm_bytes_per_launch"), rec.get("source"), rec.get("l2_hit_rate")
-            except Exception:
-                traffic = None
-        if traffic:
-            hbm_achieved = traffic / (avg_ms * 1e-3) / 1e9
-            hbm_frac = hbm_achieved / HBM_PEAK_GBS
-        roofline = dict(bound="hbm", limiter="instruction issue (VALU ~80 % of SIMD cycles, as many scalar as vector instructions) with the dependent gathers close behind: the L2 misses are ~70 % of the fabric's measured random-gather ceiling (54 G requests/s, profiles/r2_gather_calibration.json), HBM bytes at hbm_frac (DESIGN.md section 7)", kernel=name, launch_kinds=g["kinds"],
-                        achieved=round(achieved, 2), achieved_kind="algorithmic bytes (cache-inclusive) / launch time", peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
-                        hbm_achieved=None if hbm_achieved is None else round(hbm_achieved, 2), hbm_frac=None if hbm_frac is None else round(hbm_frac, 5),
-                        l2_hit_rate=l2_hit, launches=g["launches"], avg_launch_ms=round(avg_ms, 4),
-                        algorithmic_bytes_per_launch=int(g["bytes"] / max(1, g["launches"])))
-    def gbs(n, v):
-        ab = algo_bytes(n, v)
-        return {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
-    kernels = {n: dict(ms=round(v["total_ms"] / args.steps, 3), launches=v["launches"] // args.steps, kernel=v["kernel"], **gbs(n, v),
-                       **({"Mitems": round(v["items"] / args.steps / 1e6, 2), "ns_per_item": round(v["total_ms"] * 1e6 / v["items"], 3)} if v["items"] and n not in TRACE_KINDS else {}),
-                       **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in TRACE_KINDS else {}))
-               for n, v in kstats.items() if v["launches"]}
-    # what the mixed traversal launches did per ray kind (counters only: the kinds share the launches' time)
-    trace_kinds = {n.split(":", 1)[1]: dict(Mrays_per_step=round(v["items"] / args.steps / 1e6, 2), nodes_per_ray=round(v["bvh_nodes"] / max(1, v["items"]), 1), tris_per_ray=round(v["triangle_tests"] / max(1, v["items"]), 2))
-                   for n, v in kstats.items() if n.startswith("trace:")}
-
-    cpu_baseline = None
-    if args.cpu_seconds > 0 and world == 1:
-        cpu_baseline = run_cpu_baseline(pkg, sd, rp, spp, args)
-
-    if args.dump_image:
-        from tools.imgio import write_png
-        write_png(args.dump_image, scene.resolve(film.cpu().numpy()))
-
-    out = {
-        "metric": "Msamples/s (camera rays x spp) at 1920x1080",
-        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {workload_desc}; {n_tris} triangles" + (f", {n_inst} instances" if n_inst else "") +
-                               f", {args.xres}x{args.yres}x{spp}spp, path maxdepth 5, sobol, box filter, spatial light sampling",
-                   "name": args.config, "triangles": n_tris, "instances": n_inst, "spp": spp, "spp_per_pass": eff_spp_per_pass, "resolution": [args.xres, args.yres],
-                   "film": "stays on the device (no read-back in the timed region; 33 MB = 0.6 ms over PCIe)",
-                   "parallelism": (f"16x16 sample tiles round-robin over {n_gpus} GPU(s); " + ("one process, pt_multi_render (peer film sum)" if in_process else "RCCL film reduce")) if n_gpus > 1 else "1 GPU"},
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
-        "kernels_ms_per_step": kernels, **({"trace_kinds": trace_kinds} if trace_kinds else {}),
-        "rays_per_sample": round((counters["intersect_tests"] + counters["shadow_tests"]) / max(1, counters["camera_rays"]), 3) if counters else None,
-        "nodes_per_ray": round(counters["bvh_nodes_visited"] / max(1, counters["intersect_tests"] + counters["shadow_tests"]), 2) if counters else None,
-        "setup_s": {"scene_gen": round(t_gen, 1), "bvh_build_upload": round(t_up, 1)},
-    }
-    print(json.dumps(out))
+                r = measure(pkg, lib, torch, dev, None, args, cfg, cspp, 1, 1, devices, in_process, 0, 1, want_cpu_baseline=False)
+                rf = r["roofline"] or {}
+                oc[cfg] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], steps=1, warmup=1, spp=cspp, named_spp=pkg.scenes.CONFIG_SCENES[cfg][1],
+                               workload=r["config"]["workload"], spp_per_pass=r["config"]["spp_per_pass"],
+                               dominant_kernel=rf.get("kernel"), dominant_avg_launch_ms=rf.get("avg_launch_ms"), algorithmic_GBs=rf.get("achieved"),
+                               hbm_frac=rf.get("hbm_frac"), rays_per_sample=r["rays_per_sample"], nodes_per_ray=r["nodes_per_ray"],
+                               kernels_ms_per_step={k: v["ms"] for k, v in r["kernels_ms_per_step"].items()})
+            except Exception as e:   # the headline line must not be lost to a side measurement
+                oc[cfg] = dict(error=f"{type(e).__name__}: {e}")
+        out["other_configs"] = oc
+        out["other_configs_note"] = "one timed step after one warm-up, at a reduced spp (the per-sample cost does not depend on the spp beyond the pass size); the value is Msamples/s of that step"
+    if out is not None:
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

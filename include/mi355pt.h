@@ -452,13 +452,21 @@ int pt_film_resolve(const float *film_xyzw, uint32_t n_pixels, float scale, floa
  * scene on every listed device (an ordinal may repeat: the replicas then share that device); pt_multi_render renders, on one
  * host thread + stream per replica, the tiles with tile_index % (tile_world * n) == tile_rank + i * tile_world on replica i
  * (pt_multi_tile_shard: the caller's own shard split n ways, so it nests inside a multi-process launch), sums the replicas'
- * films onto the first device (peer copies over xGMI + an add kernel) and ADDS the result to film_xyzw, which is a pointer on
- * device_ordinals[0] (film_is_device != 0) or a host buffer. Counters are the sums over the replicas. */
+ * films onto the first device and ADDS the result to film_xyzw, which is a pointer on device_ordinals[0] (film_is_device != 0) or
+ * a host buffer. The merge (Film::merge_film_tile across devices, integrator.rs:392-396): every replica on another device pushes
+ * its film into a landing buffer of its own on the first device as soon as it has finished (hipMemcpyPeerAsync from its own host
+ * thread: the copies of different replicas run concurrently, one xGMI link each), then ONE kernel sums all films in replica order
+ * and adds the sum to film_xyzw. Counters are the sums over the replicas. One pt_multi_scene may be rendered at any film size:
+ * the per-replica films and landing buffers grow on demand. */
 int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, uint32_t n_devices, pt_multi_scene **out_scene);
 void pt_multi_scene_destroy(pt_multi_scene *scene);
 int pt_multi_render(pt_multi_scene *scene, const PtRenderParams *params, float *film_xyzw, int film_is_device);
 int pt_multi_get_counters(const pt_multi_scene *scene, PtCounters *out);
 int pt_multi_get_kernel_stats(const pt_multi_scene *scene, uint32_t replica, PtKernelStat *out, uint32_t max_entries, uint32_t *n_out);
+/* Wall-clock times of the last pt_multi_render: per replica the duration of its pt_render (its device's busy time) and of its peer
+ * copy, and `merge_ms` = from the moment the LAST replica finished rendering to the summed film (copy tail + the sum kernel).
+ * render_ms / copy_ms hold max_replicas entries (either may be NULL). */
+int pt_multi_get_timing(const pt_multi_scene *scene, double *merge_ms, double *render_ms, double *copy_ms, uint32_t max_replicas);
 /* The tile shard of replica `replica` of `n_replicas` inside the caller's shard (tile_rank of tile_world). Pure host arithmetic. */
 void pt_multi_tile_shard(uint32_t tile_rank, uint32_t tile_world, uint32_t replica, uint32_t n_replicas, uint32_t *rank_out, uint32_t *world_out);
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -40,7 +41,7 @@ bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one 
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU = 7 per SIMD: k_trace<*, 0> needs 71 VGPRs and 5 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %, 24 -> 28: +3 %)
 thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-constexpr int kMaxDevices = 64;
+constexpr int kMaxDevices = kMaxReplicas;
 struct DevCtx { bool ready = false; int num_cus = 256; SobolTables tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
 DevCtx g_ctx[kMaxDevices];
 std::mutex g_ctx_mutex;
@@ -223,8 +224,11 @@ struct pt_multi_scene {
     std::vector<pt_scene *> sc;       // replica i lives on dev[i] (a device may appear more than once: replicas then share it)
     std::vector<int> dev;
     std::vector<float *> film;        // per replica: XYZ + weight sums of its tiles, on its device
-    float *stage = nullptr;           // on dev[0]: landing buffer of the peer copies
-    size_t film_px = 0;
+    std::vector<size_t> film_cap;     // pixels film[i] holds (0: not allocated); a failed or smaller render never leaves a stale size behind
+    std::vector<float *> stage;       // on dev[0], one landing buffer per replica that lives on ANOTHER device: the peer copies of all
+    std::vector<size_t> stage_cap;    // sources are in flight together (one xGMI link each), issued by the replicas' own host threads
+    std::vector<double> render_ms, copy_ms;   // last pt_multi_render, per replica: wall time of its pt_render / of its peer copy
+    double merge_ms = 0;              // last pt_multi_render: from the last replica's render end to the summed film (copy tails + the sum kernel)
     PtCounters counters{};
 };
 
@@ -1365,14 +1369,21 @@ int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, u
         if ((st = bind_device(device_ordinals[i]))) return bail(st);
         pt_scene *sc = nullptr;
         if ((st = pt_scene_create(&d, &sc))) return bail(st);
-        ms->sc.push_back(sc); ms->dev.push_back(device_ordinals[i]); ms->film.push_back(nullptr);
+        ms->sc.push_back(sc); ms->dev.push_back(device_ordinals[i]);
+        ms->film.push_back(nullptr); ms->film_cap.push_back(0); ms->stage.push_back(nullptr); ms->stage_cap.push_back(0);
+        ms->render_ms.push_back(0); ms->copy_ms.push_back(0);
         if (i == 0) {   // the replicas adopt the first replica's top-level tree instead of building it again
             d.nodes = sc->nodes.data(); d.n_nodes = (uint32_t)sc->nodes.size(); d.ordered_prims = sc->ordered.data();
         }
     }
     // peer access first device <-> the others (the film merge copies device to device; without access the runtime stages through the host)
-    if (bind_device(ms->dev[0]) == PT_OK)
-        for (uint32_t i = 1; i < n_devices; ++i) if (ms->dev[i] != ms->dev[0]) { int can = 0; if (hipDeviceCanAccessPeer(&can, ms->dev[0], ms->dev[i]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[i], 0); (void)hipGetLastError(); } }
+    for (uint32_t i = 1; i < n_devices; ++i) {
+        if (ms->dev[i] == ms->dev[0]) continue;
+        int can = 0;
+        if (bind_device(ms->dev[0]) == PT_OK && hipDeviceCanAccessPeer(&can, ms->dev[0], ms->dev[i]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[i], 0); (void)hipGetLastError(); }
+        can = 0;
+        if (bind_device(ms->dev[i]) == PT_OK && hipDeviceCanAccessPeer(&can, ms->dev[i], ms->dev[0]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[0], 0); (void)hipGetLastError(); }
+    }
     if ((st = bind_device(home))) return bail(st);
     *out = ms;
     return PT_OK;
@@ -1381,8 +1392,9 @@ int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, u
 void pt_multi_scene_destroy(pt_multi_scene *ms) {
     if (!ms) return;
     const int home = g_device;
+    if (!ms->dev.empty() && bind_device(ms->dev[0]) == PT_OK) for (float *p : ms->stage) if (p) hipFree(p);
     for (size_t i = 0; i < ms->sc.size(); ++i) {
-        if (bind_device(ms->dev[i]) == PT_OK) { if (ms->film[i]) hipFree(ms->film[i]); if (i == 0 && ms->stage) hipFree(ms->stage); }
+        if (bind_device(ms->dev[i]) == PT_OK && ms->film[i]) hipFree(ms->film[i]);
         pt_scene_destroy(ms->sc[i]);
     }
     if (home >= 0) bind_device(home);
@@ -1397,6 +1409,18 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
     if (fw <= 0 || fh <= 0) return fail(PT_ERR_INVALID_ARG, "empty film");
     const size_t film_px = (size_t)fw * (size_t)fh;
     std::vector<int> status(n, PT_OK); std::vector<std::string> message(n);
+    using clk = std::chrono::steady_clock;
+    auto ms_between = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    // landing buffers on the first device, one per replica that lives elsewhere (a replica sharing the first device is summed in place)
+    int st = bind_device(ms->dev[0]);
+    if (st) return st;
+    for (uint32_t i = 1; i < n; ++i) {
+        if (ms->dev[i] == ms->dev[0] || ms->stage_cap[i] >= film_px) continue;
+        if (ms->stage[i]) { hipFree(ms->stage[i]); ms->stage[i] = nullptr; }
+        ms->stage_cap[i] = 0;
+        if (hipMalloc((void **)&ms->stage[i], film_px * 16) != hipSuccess) { (void)hipGetLastError(); if (home >= 0) bind_device(home); return fail(PT_ERR_OUT_OF_MEMORY, "pt_multi_render: film landing buffer"); }
+        ms->stage_cap[i] = film_px;
+    }
     // replicas that share a device share its memory: their pass sizes are chosen here, before any of them allocates
     std::vector<uint32_t> pass_size(n, rp->spp_per_pass);
     if (rp->spp_per_pass == 0) for (uint32_t i = 0; i < n; ++i) {
@@ -1409,11 +1433,15 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
             if (slots) pass_size[i] = choose_pass_size(ms->sc[i], slots, rp->spp, share);
         }
     }
+    std::vector<clk::time_point> t_rendered(n);
     auto worker = [&](uint32_t i) {
+        const clk::time_point t0 = clk::now();
         int st = bind_device(ms->dev[i]);
-        if (!st && (ms->film_px != film_px || !ms->film[i])) {
+        if (!st && ms->film_cap[i] < film_px) {
             if (ms->film[i]) { hipFree(ms->film[i]); ms->film[i] = nullptr; }
-            if (hipMalloc((void **)&ms->film[i], film_px * 16) != hipSuccess) st = fail(PT_ERR_OUT_OF_MEMORY, "pt_multi_render: film replica");
+            ms->film_cap[i] = 0;
+            if (hipMalloc((void **)&ms->film[i], film_px * 16) != hipSuccess) { (void)hipGetLastError(); st = fail(PT_ERR_OUT_OF_MEMORY, "pt_multi_render: film replica"); }
+            else ms->film_cap[i] = film_px;
         }
         if (!st && hipMemset(ms->film[i], 0, film_px * 16) != hipSuccess) st = fail(PT_ERR_HIP, "pt_multi_render: memset");
         if (!st) {
@@ -1422,6 +1450,17 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
             p.spp_per_pass = pass_size[i];
             st = pt_render(ms->sc[i], &p, ms->film[i], 1);
         }
+        t_rendered[i] = clk::now();
+        ms->render_ms[i] = ms_between(t0, t_rendered[i]); ms->copy_ms[i] = 0;
+        // merge_film_tile across devices, first half: every replica pushes its film to its own landing buffer on the first device as soon
+        // as it has finished -- the copies of different replicas travel on different xGMI links at the same time, and an early
+        // finisher's copy hides behind the others' rendering.
+        if (!st && i > 0 && ms->dev[i] != ms->dev[0]) {
+            hipStream_t cs = ms->sc[i]->stream;
+            if (hipMemcpyPeerAsync(ms->stage[i], ms->dev[0], ms->film[i], ms->dev[i], film_px * 16, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess)
+                st = fail(PT_ERR_HIP, std::string("pt_multi_render: peer copy: ") + hipGetErrorString(hipGetLastError()));
+            ms->copy_ms[i] = ms_between(t_rendered[i], clk::now());
+        }
         status[i] = st; if (st) message[i] = g_error;
     };
     std::vector<std::thread> threads;
@@ -1429,28 +1468,27 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
     worker(0);                                   // the calling thread drives the first replica
     for (auto &t : threads) t.join();
     for (uint32_t i = 0; i < n; ++i) if (status[i]) { bind_device(home >= 0 ? home : ms->dev[0]); return fail(status[i], "replica " + std::to_string(i) + " (device " + std::to_string(ms->dev[i]) + "): " + message[i]); }
-    ms->film_px = film_px;
-    // merge_film_tile across devices: films of replicas 1.. are copied to the first device and added (float adds in replica order)
-    int st = bind_device(ms->dev[0]);
-    if (st) return st;
+    clk::time_point t_last = t_rendered[0];
+    for (uint32_t i = 1; i < n; ++i) if (t_rendered[i] > t_last) t_last = t_rendered[i];
+    // second half: ONE kernel on the first device sums all films pixel by pixel, float adds in replica order (so the result does not
+    // depend on which replica finished first), and adds the sum to the caller's film.
+    if ((st = bind_device(ms->dev[0]))) return st;
     pt_scene *s0 = ms->sc[0];
+    FilmSumArgs fa; fa.n = n;
+    for (uint32_t i = 0; i < n; ++i) fa.src[i] = (const float4 *)((i == 0 || ms->dev[i] == ms->dev[0]) ? ms->film[i] : ms->stage[i]);
     const unsigned blocks = (unsigned)((film_px + 255) / 256);
-    if (n > 1 && !ms->stage) HIP_TRY(hipMalloc((void **)&ms->stage, film_px * 16));
-    for (uint32_t i = 1; i < n; ++i) {
-        if (ms->dev[i] == ms->dev[0]) HIP_TRY(hipMemcpyAsync(ms->stage, ms->film[i], film_px * 16, hipMemcpyDeviceToDevice, s0->stream));
-        else HIP_TRY(hipMemcpyPeerAsync(ms->stage, ms->dev[0], ms->film[i], ms->dev[i], film_px * 16, s0->stream));
-        hipLaunchKernelGGL(k_film_add, dim3(blocks), dim3(256), 0, s0->stream, (float4 *)ms->film[0], (const float4 *)ms->stage, film_px);
-    }
     if (film_is_device) {
-        hipLaunchKernelGGL(k_film_add, dim3(blocks), dim3(256), 0, s0->stream, (float4 *)film_xyzw, (const float4 *)ms->film[0], film_px);
+        hipLaunchKernelGGL(k_film_sum, dim3(blocks), dim3(256), 0, s0->stream, fa, (float4 *)film_xyzw, 1, film_px);
         HIP_TRY(hipStreamSynchronize(s0->stream));
     } else {
+        hipLaunchKernelGGL(k_film_sum, dim3(blocks), dim3(256), 0, s0->stream, fa, (float4 *)ms->film[0], 0, film_px);
         HIP_TRY(hipStreamSynchronize(s0->stream));
         std::vector<float> host(film_px * 4);
         HIP_TRY(hipMemcpy(host.data(), ms->film[0], film_px * 16, hipMemcpyDeviceToHost));
         for (size_t k = 0; k < film_px * 4; ++k) film_xyzw[k] += host[k];
     }
     HIP_TRY(hipGetLastError());
+    ms->merge_ms = ms_between(t_last, clk::now());
     // counters: the work of all replicas
     PtCounters &c = ms->counters; std::memset(&c, 0, sizeof c);
     for (uint32_t i = 0; i < n; ++i) {
@@ -1458,6 +1496,13 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
         for (size_t k = 0; k < sizeof(PtCounters) / 8; ++k) dst[k] += src[k];
     }
     if (home >= 0 && home != ms->dev[0]) bind_device(home);
+    return PT_OK;
+}
+
+int pt_multi_get_timing(const pt_multi_scene *ms, double *merge_ms, double *render_ms, double *copy_ms, uint32_t max_replicas) {
+    if (!ms) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (merge_ms) *merge_ms = ms->merge_ms;
+    for (uint32_t i = 0; i < max_replicas && i < ms->sc.size(); ++i) { if (render_ms) render_ms[i] = ms->render_ms[i]; if (copy_ms) copy_ms[i] = ms->copy_ms[i]; }
     return PT_OK;
 }
 

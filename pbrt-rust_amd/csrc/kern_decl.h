@@ -18,7 +18,7 @@ __global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *co
 __global__ void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters);
 __global__ void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
 __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix);
-__global__ void k_film_add(float4 *dst, const float4 *src, size_t n_quads);
+__global__ void k_film_sum(FilmSumArgs a, float4 *dst, int accumulate, size_t n_quads);
 __global__ void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func);
 __global__ void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int);
 __global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,

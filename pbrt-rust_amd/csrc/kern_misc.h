@@ -284,12 +284,16 @@ __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t
     rgb_to_xyz(rgb, xyz);
     film_xyzw[4 * i] += xyz[0]; film_xyzw[4 * i + 1] += xyz[1]; film_xyzw[4 * i + 2] += xyz[2]; film_xyzw[4 * i + 3] += film_rgbw[4 * i + 3];
 }
-// Film merge of the one-process multi-device path (pt_multi_render): dst += src, quad by quad.
-__global__ void k_film_add(float4 *dst, const float4 *src, size_t n_quads) {
+// Film merge of the one-process multi-device path (pt_multi_render): the films of all replicas (the first device's own and the landing
+// buffers of the peer copies) are summed quad by quad in replica order; accumulate != 0 adds the sum to dst, else dst = sum (dst may
+// be src[0]).
+__global__ void k_film_sum(FilmSumArgs a, float4 *dst, int accumulate, size_t n_quads) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_quads) return;
-    const float4 a = dst[i], b = src[i];
-    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    float4 s = a.src[0][i];
+    for (uint32_t k = 1; k < a.n; ++k) { const float4 b = a.src[k][i]; s = make_float4(s.x + b.x, s.y + b.y, s.z + b.z, s.w + b.w); }
+    if (accumulate) { const float4 d = dst[i]; s = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w); }
+    dst[i] = s;
 }
 
 // ---- spatial light distribution (lightdistrib.rs:151-228), all voxels precomputed ---------------------------

@@ -107,6 +107,10 @@ struct QCounters {
     uint32_t pad;
 };
 
+// pt_multi_render's film merge: at most one film per replica (capi.hip: kMaxDevices)
+constexpr int kMaxReplicas = 64;
+struct FilmSumArgs { const float4 *src[kMaxReplicas]; uint32_t n; };
+
 struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;

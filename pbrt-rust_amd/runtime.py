@@ -156,6 +156,16 @@ class MultiScene:
         self.L.check(self.L.lib.pt_multi_get_counters(self.h, C.byref(c)))
         return c.as_dict()
 
+    def resolve(self, film, scale=1.0):
+        return Scene.resolve(self, film, scale)
+
+    def timing(self):
+        """Last render: merge_ms and, per replica, the wall time of its pt_render and of its peer copy."""
+        n = len(self.devices)
+        merge = C.c_double(); r = (C.c_double * n)(); c = (C.c_double * n)()
+        self.L.check(self.L.lib.pt_multi_get_timing(self.h, C.byref(merge), r, c, n))
+        return dict(merge_ms=merge.value, render_ms=list(r), copy_ms=list(c))
+
     def kernel_stats(self, replica=0):
         arr = (A.PtKernelStat * 32)(); n = C.c_uint32()
         self.L.check(self.L.lib.pt_multi_get_kernel_stats(self.h, replica, arr, 32, C.byref(n)))

@@ -69,3 +69,45 @@ def test_three_replicas_on_one_device_equal_the_plain_render(pkg, gpu, scene):
     assert np.array_equal(a[..., 3], b[..., 3])
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-7)
     assert len(multi.kernel_stats(2)) > 0
+    tm = multi.timing()
+    assert len(tm["render_ms"]) == 3 and all(x > 0 for x in tm["render_ms"]) and tm["merge_ms"] > 0 and tm["copy_ms"] == [0.0, 0.0, 0.0]   # replicas on the first device are summed in place
+
+
+@pytest.mark.gpu
+def test_eight_replicas_and_two_film_sizes_on_one_multiscene(pkg, gpu):
+    """The 8-way merge (one sum kernel over eight films, integrator.rs:392-396) and a pt_multi_scene rendered at a small, then a larger,
+    then the small film size again (the landing / replica buffers follow the film size instead of keeping the first one)."""
+    b = pkg.scenes.ganesha_scale(n=40, xres=96, yres=64, spp=4)
+    sd, rp_small = b.world_end()
+    _, rp_big = pkg.scenes.ganesha_scale(n=40, xres=208, yres=144, spp=4).world_end()
+    single = pkg.Scene(gpu, sd)
+    multi = pkg.MultiScene(gpu, sd, [0] * 8)
+    for rp in (rp_small, rp_big, rp_small):
+        ref = single.render(rp); rc = single.counters()
+        film = multi.render(rp); mc = multi.counters()
+        for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+            assert mc[k] == rc[k], (k, mc[k], rc[k])
+        assert film.shape == ref.shape and np.array_equal(film[..., 3], ref[..., 3])
+        np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_distinct_devices_equal_the_plain_render(pkg, gpu):
+    """Needs two or more visible GPUs (skipped on the one-GPU test box): peer access, hipMemcpyPeerAsync into the landing buffers and
+    the per-thread device binding, on really different devices."""
+    n = C.c_int(0)
+    assert gpu.lib.pt_device_count(C.byref(n)) == 0
+    if n.value < 2:
+        pytest.skip(f"{n.value} device(s) visible: the distinct-device path needs two")
+    devs = list(range(min(n.value, 8)))
+    sd, rp = pkg.scenes.ganesha_scale(n=48, xres=160, yres=96, spp=8).world_end()
+    single = pkg.Scene(gpu, sd)
+    ref = single.render(rp); rc = single.counters()
+    multi = pkg.MultiScene(gpu, sd, devs)
+    film = multi.render(rp); mc = multi.counters()
+    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+        assert mc[k] == rc[k], (k, mc[k], rc[k])
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
+    tm = multi.timing()
+    assert all(c > 0 for c in tm["copy_ms"][1:])
