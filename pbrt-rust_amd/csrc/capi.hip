@@ -979,7 +979,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if (m.type != PT_MEDIUM_GRID) continue;
             const size_t nvox = (size_t)m.nx * m.ny * m.nz;
             if (!m.density || nvox == 0 || nvox > ((size_t)1 << 31)) return bail(fail(PT_ERR_INVALID_ARG, "grid medium without a density grid"));
-            for (int k = 1; k < 3; ++k) if (m.sigma_a[k] + m.sigma_s[k] != m.sigma_a[0] + m.sigma_s[0]) return bail(fail(PT_ERR_UNSUPPORTED, "GridDensityMedium requires a spectrally uniform attenuation coefficient (grid.rs:49-52 reports an error)"));
+            // grid.rs:46-52: `sigma_t = (sigma_a + sigma_s)[0]`; a spectrally varying coefficient is reported with error!() and rendering goes on with the first channel
+            for (int k = 1; k < 3; ++k) if (m.sigma_a[k] + m.sigma_s[k] != m.sigma_a[0] + m.sigma_s[0]) { fprintf(stderr, "mi355pt: GridDensityMedium requires spectrally uniform attenuation coefficient (medium %u: using channel 0, as grid.rs:46-52 does)\n", i); break; }
             float maxd = 0.0f;
             for (size_t k = 0; k < nvox; ++k) maxd = std::fmax(maxd, m.density[k]);
             if (!(maxd > 0.0f)) return bail(fail(PT_ERR_INVALID_ARG, "grid medium with no positive density"));

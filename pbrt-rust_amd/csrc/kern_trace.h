@@ -138,6 +138,12 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
         // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
         //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
         //      paid once per batch instead of once per ray.
+#ifdef PT_DROP_TAIL   // EXPERIMENT (wrong results, timing only): what the tail of straggling rays costs -- a wave whose queue is drained abandons its last few rays
+        if (exhausted && count > 65536u) {
+            const unsigned long long b_ = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_LEAFS || state == ST_INST || state == ST_RET);
+            if (b_ != 0ull && (uint32_t)__popcll(b_) <= (uint32_t)(PT_DROP_TAIL) && state != ST_DONE) state = ST_IDLE;
+        }
+#endif
         const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
         const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_LEAFS || state == ST_INST || state == ST_RET);
         if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {

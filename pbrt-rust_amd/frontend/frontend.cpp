@@ -22,6 +22,7 @@
 #include <functional>
 #include <fstream>
 #include <memory>
+#include <set>
 #include <sstream>
 
 namespace fe {
@@ -33,7 +34,7 @@ struct GState {
     int material = -1;
     bool has_area = false; float area_L[3] = {1, 1, 1}; bool area_two_sided = false;
     std::map<std::string, int> float_tex, spec_tex, named_materials;
-    int medium_inside = -1, medium_outside = -1;   // MediumInterface (api.rs:1243-1253); -1 = none
+    std::string medium_inside, medium_outside;     // MediumInterface (api.rs:1243-1253) keeps the NAMES; they are looked up when a shape / the camera is made (api.rs:382-403)
 };
 
 struct Scene {
@@ -83,6 +84,16 @@ private:
     bool in_world = false;
 
     [[noreturn]] void fail(const Token &t, const std::string &msg) { throw std::runtime_error("line " + std::to_string(t.line) + ": " + msg); }
+    // what the reference reports with warn!() / error!() and then carries on with (api.rs:388-399,753-756)
+    static void warn(const Token &t, const std::string &msg) { std::fprintf(stderr, "mi355front: warning: line %d: %s\n", t.line, msg.c_str()); }
+    std::set<std::string> undefined_media_reported;
+    int medium_index(const std::string &nm) {   // GraphicsState::create_medium_interface (api.rs:382-403): an undefined name is an error message and no medium
+        if (nm.empty()) return -1;
+        auto it = sc.named_media.find(nm);
+        if (it != sc.named_media.end()) return it->second;
+        if (undefined_media_reported.insert(nm).second) std::fprintf(stderr, "mi355front: error: Named medium \"%s\" undefined\n", nm.c_str());
+        return -1;
+    }
     static std::string str_arg(Lexer &lx, const Token &d) { Token t = lx.next(); if (t.kind != Token::Str) throw std::runtime_error("line " + std::to_string(d.line) + ": " + d.text + " needs a quoted name"); return t.text; }
     static void nums(Lexer &lx, const Token &d, float *out, int n) {
         Token p = lx.peek(); bool br = p.kind == Token::LBracket; if (br) lx.next();
@@ -113,7 +124,7 @@ private:
         else if (w == "AttributeBegin") { stack.push_back(gs); tstack.push_back(gs.ctm); }
         else if (w == "AttributeEnd") { if (stack.empty()) fail(d, "unmatched AttributeEnd"); gs = stack.back(); stack.pop_back(); if (!tstack.empty()) tstack.pop_back(); }
         else if (w == "ReverseOrientation") gs.reverse = !gs.reverse;
-        else if (w == "Camera") { sc.camera_name = str_arg(lx, d); sc.camera_params = read_params(lx); sc.camera_to_world = gs.ctm.inverse(); named_cs["camera"] = sc.camera_to_world; sc.camera_medium = gs.medium_outside; }
+        else if (w == "Camera") { sc.camera_name = str_arg(lx, d); sc.camera_params = read_params(lx); sc.camera_to_world = gs.ctm.inverse(); named_cs["camera"] = sc.camera_to_world; }
         else if (w == "Film") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); film(d, n, p); }
         else if (w == "Sampler") { sc.sampler = str_arg(lx, d); ParamSet p = read_params(lx); sc.spp = p.one_int("pixelsamples", 16); sc.sample_at_center = p.one_bool("samplepixelcenter", false); }
         else if (w == "PixelFilter") { sc.filter = str_arg(lx, d); sc.filter_params = read_params(lx); }
@@ -121,11 +132,12 @@ private:
         else if (w == "Accelerator") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); if (n != "bvh") fail(d, "only the bvh accelerator is supported");
                                        { const std::string sm = p.one_string("splitmethod", "sah"); if (sm == "hlbvh") sc.split_method = PT_SPLIT_HLBVH; else if (sm != "sah") fail(d, "splitmethod \"" + sm + "\" is not supported (sah, hlbvh)"); } sc.max_node_prims = (uint32_t)p.one_int("maxnodeprims", 4); }
         else if (w == "WorldBegin") { in_world = true; gs.ctm = Transform(); named_cs["world"] = gs.ctm; }
-        else if (w == "WorldEnd") in_world = false;
+        else if (w == "WorldEnd") { in_world = false; sc.camera_medium = medium_index(gs.medium_outside); }   // api.rs:1738-1741: the camera's medium is the OUTSIDE medium of the graphics state at WorldEnd
         else if (w == "MakeNamedMedium") {   // api.rs:706-722,1219-1241
             std::string n = str_arg(lx, d); ParamSet p = read_params(lx);
             const std::string ty = p.one_string("type", "");
-            if (ty != "homogeneous" && ty != "heterogeneous") fail(d, "medium type \"" + ty + "\" unknown (homogeneous, heterogeneous)");   // api.rs:753-756 warns and drops it
+            if (ty.empty()) { warn(d, "No parameter string \"type\" found in MakeNamedMedium"); return; }                 // api.rs:1225-1226
+            if (ty != "homogeneous" && ty != "heterogeneous") { warn(d, "Medium \"" + ty + "\" unknown."); return; }       // api.rs:753-756: warns, the name stays undefined
             float siga[3] = {0.0011f, 0.0024f, 0.014f}, sigs[3] = {2.55f, 3.21f, 3.77f};
             const std::string preset = p.one_string("preset", "");
             if (!preset.empty()) { auto it = named_media().find(preset); if (it != named_media().end()) { copy3(siga, it->second.sigma_a); copy3(sigs, it->second.sigma_prime_s); } }
@@ -152,8 +164,7 @@ private:
         else if (w == "MediumInterface") {
             const std::string in = str_arg(lx, d); std::string out = in;
             { Token t = lx.peek(); if (t.kind == Token::Str) out = str_arg(lx, d); }   // one name = both sides (pbrtparser)
-            auto find = [&](const std::string &nm) { if (nm.empty()) return -1; auto it = sc.named_media.find(nm); if (it == sc.named_media.end()) fail(d, "named medium \"" + nm + "\" not defined"); return it->second; };
-            gs.medium_inside = find(in); gs.medium_outside = find(out);
+            gs.medium_inside = in; gs.medium_outside = out;
         }
         else if (w == "Material") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.material = (n.empty() || n == "none") ? -1 : new_material(n, p); }
         else if (w == "MakeNamedMaterial") { std::string n = str_arg(lx, d); ParamSet p = read_params(lx); gs.named_materials[n] = new_material(p.one_string("type", "matte"), p); }
@@ -451,7 +462,7 @@ private:
     void add_prim(uint32_t shape_ref) {
         const uint32_t prim = (uint32_t)sc.prim_shape.size();
         sc.prim_shape.push_back(shape_ref); sc.prim_material.push_back(gs.material < 0 ? PT_NONE : (uint32_t)gs.material);
-        sc.prim_med_in.push_back(gs.medium_inside < 0 ? PT_NONE : (uint32_t)gs.medium_inside); sc.prim_med_out.push_back(gs.medium_outside < 0 ? PT_NONE : (uint32_t)gs.medium_outside);
+        { const int mi = medium_index(gs.medium_inside), mo = medium_index(gs.medium_outside); sc.prim_med_in.push_back(mi < 0 ? PT_NONE : (uint32_t)mi); sc.prim_med_out.push_back(mo < 0 ? PT_NONE : (uint32_t)mo); }
         sc.prim_light.push_back((gs.has_area && !sc.in_object) ? new_area_light(prim) : PT_NONE);   // api.rs:1605-1608: area lights inside instances are dropped
         if (sc.in_object) sc.object_ranges[sc.current_object].second += 1; else sc.top_refs.push_back(prim);
     }

@@ -8,6 +8,7 @@ that the render path depends on besides the parameter set-up the reference also 
 """
 import ctypes as C
 import math
+import sys
 import numpy as np
 from . import _abi as A
 
@@ -199,7 +200,7 @@ class SceneBuilder:
         self.sample_at_pixel_center = False
         self.integ = dict(maxdepth=5, rrthreshold=1.0, strategy="spatial", pixelbounds=None, kind="path")   # kind: "path" | "volpath"
         # participating media (api.rs:706-722,1219-1253): named homogeneous media, the current MediumInterface, the camera's medium
-        self.media = []; self.named_media = {}; self.medium_inside = None; self.medium_outside = None; self.camera_medium = None
+        self.media = []; self.named_media = {}; self.medium_inside = ""; self.medium_outside = ""; self.camera_medium = None; self._undefined_media = set()
         self._keep = []
         self.prim_med_in = []; self.prim_med_out = []
         self.max_node_prims = 4
@@ -241,19 +242,28 @@ class SceneBuilder:
         self.media.append(m); self.named_media[name] = len(self.media) - 1
 
     def medium_interface(self, inside="", outside=""):
-        """MediumInterface "inside" "outside" (api.rs:1243-1253); "" = no medium."""
-        self.medium_inside = self.named_media[inside] if inside else None
-        self.medium_outside = self.named_media[outside] if outside else None
+        """MediumInterface "inside" "outside" (api.rs:1243-1253) keeps the NAMES; "" = no medium. They are looked up when a shape or
+        the camera is made (GraphicsState::create_medium_interface, api.rs:382-403)."""
+        self.medium_inside = inside; self.medium_outside = outside
+
+    def _medium_index(self, name):
+        """api.rs:388-399: an undefined name is reported (error!) and means no medium."""
+        if not name: return None
+        if name in self.named_media: return self.named_media[name]
+        if name not in self._undefined_media:
+            self._undefined_media.add(name); print(f'host: error: Named medium "{name}" undefined', file=sys.stderr)
+        return None
 
     def _prim_media(self, n):
         none = A.PT_NONE
-        self.prim_med_in.append(np.full(n, none if self.medium_inside is None else self.medium_inside, dtype=np.uint32))
-        self.prim_med_out.append(np.full(n, none if self.medium_outside is None else self.medium_outside, dtype=np.uint32))
+        mi, mo = self._medium_index(self.medium_inside), self._medium_index(self.medium_outside)
+        self.prim_med_in.append(np.full(n, none if mi is None else mi, dtype=np.uint32))
+        self.prim_med_out.append(np.full(n, none if mo is None else mo, dtype=np.uint32))
 
     # -- options
     def camera(self, fov=90.0, lensradius=0.0, focaldistance=1e6):
         self.cam.update(fov=fov, lensradius=lensradius, focaldistance=focaldistance, c2w=self.ctm.inverse())  # api.rs:1208
-        self.camera_medium = self.medium_outside   # the camera sits in the current outside medium (api.rs camera())
+        self.camera_medium = self._medium_index(self.medium_outside)   # provisional (what pbrt-v3 does); world_end() takes the state at WorldEnd as api.rs:1738-1741 does
 
     def world_begin(self): self.ctm = Transform()
 
@@ -580,6 +590,7 @@ class SceneBuilder:
 
     # -- WorldEnd (api.rs:1715-1748): flatten to the C ABI structs
     def world_end(self):
+        self.camera_medium = self._medium_index(self.medium_outside)   # api.rs:1738-1741: create_medium_interface() on the graphics state AT WorldEnd, camera = mi.outside (api.rs:830)
         return SceneData(self), self.render_params()
 
     def render_params(self):

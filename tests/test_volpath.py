@@ -144,6 +144,55 @@ WorldEnd
     np.testing.assert_allclose(fa, fb, rtol=1e-3, atol=1e-5)
 
 
+def test_undefined_and_unknown_media_are_reported_and_dropped_like_the_reference(pkg, oracle, capfd):
+    """api.rs:753-756: an unknown medium type is warned about and its name stays undefined; api.rs:382-403: MediumInterface keeps NAMES,
+    looked up when a shape is made -- an undefined name is an error message and no medium; api.rs:1738-1741 + :830: the camera's medium
+    is the OUTSIDE medium of the graphics state at WorldEnd (not at the Camera directive). ADVICE r2: such scenes used to fail to load."""
+    A = pkg._abi
+    txt = """MakeNamedMedium "plasma" "string type" "nonsense"
+MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.1 .1 .1] "rgb sigma_s" [.2 .2 .2]
+MediumInterface "" "plasma"
+LookAt 0 1.4 5  0 .7 0  0 1 0
+Camera "perspective" "float fov" 38
+Film "image" "integer xresolution" [16] "integer yresolution" [12]
+Sampler "sobol" "integer pixelsamples" [2]
+Integrator "volpath" "integer maxdepth" 2
+WorldBegin
+LightSource "point" "point from" [-2.5 1.5 -2.5] "rgb I" [14 12 10]
+Material "matte" "rgb Kd" [.5 .5 .5]
+AttributeBegin
+MediumInterface "ghost" "fog"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-10 -.5 -10  -10 -.5 10  10 -.5 10  10 -.5 -10]
+AttributeEnd
+MediumInterface "" "fog"
+WorldEnd
+"""
+    fs = pkg.frontend.FrontScene(text=txt)
+    err = capfd.readouterr().err
+    assert 'Medium "nonsense" unknown' in err and 'Named medium "ghost" undefined' in err
+    d, rp = fs.desc(), fs.render_params()
+    assert d.n_media == 1 and d.media[0].type == A.PT_MEDIUM_HOMOGENEOUS
+    assert [d.prim_medium_inside[i] for i in range(d.n_prims)] == [A.PT_NONE] * 2 and [d.prim_medium_outside[i] for i in range(d.n_prims)] == [0, 0]
+    assert rp.camera_medium == 0        # "fog": the state at WorldEnd, although the Camera directive saw the undefined "plasma"
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=16, yres=12); b.spp = 2
+    b.integ.update(maxdepth=2, kind="volpath")
+    b.make_named_medium("fog", sigma_a=(0.1,) * 3, sigma_s=(0.2,) * 3)
+    b.medium_interface("", "plasma")
+    b.look_at((0.0, 1.4, 5.0), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("point", from_=(-2.5, 1.5, -2.5), I=(14.0, 12.0, 10.0))
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    b.attribute_begin(); b.medium_interface("ghost", "fog")
+    P, I = pkg.scenes.quad((-10.0, -0.5, -10.0), (-10.0, -0.5, 10.0), (10.0, -0.5, 10.0), (10.0, -0.5, -10.0)); b.trianglemesh(P, I)
+    b.attribute_end()
+    b.medium_interface("", "fog")
+    sd, rp2 = b.world_end()
+    assert rp2.camera_medium == 0
+    fa = oracle.scene(fs).render(rp, nthreads=2); fb = oracle.scene(sd).render(rp2, nthreads=2)
+    np.testing.assert_allclose(fa, fb, rtol=1e-4, atol=1e-6)
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 
 @pytest.mark.gpu
@@ -312,3 +361,15 @@ def test_gpu_grid_medium_with_a_homogeneous_medium_and_closed_form(pkg, gpu, ora
     rgb = g.resolve(g.render(rp)).reshape(-1, 3).mean(axis=0)
     want = np.array([3.0, 2.0, 1.0]) * np.exp(-_optical_depth_along_minus_z(dens, p0, p1, 1.1))
     assert np.all(np.abs(rgb - want) < 0.03 * want), (rgb, want)
+
+@pytest.mark.gpu
+def test_gpu_grid_medium_with_spectrally_varying_coefficients_renders_with_channel_zero(pkg, gpu, oracle, capfd):
+    """grid.rs:46-52: `sigma_t = (sigma_a + sigma_s)[0]`, a spectrally varying coefficient is only reported (error!) -- the library used to
+    refuse such a scene; now it renders, and exactly what the oracle's restatement of grid.rs renders."""
+    from test_gpu_parity import _compare_render
+    b = pkg.scenes.smoke_room(xres=40, yres=30, spp=8)
+    for k in range(3):
+        b.media[0].sigma_a[k] = 0.3 + 0.2 * k; b.media[0].sigma_s[k] = 1.0 + 0.5 * k
+    film, ref = _compare_render(pkg, gpu, oracle, *b.world_end())
+    assert film[..., :3].sum() > 0
+    assert "spectrally uniform" in capfd.readouterr().err

@@ -137,3 +137,21 @@ def test_uber_without_specular_terms_is_a_two_lobe_material(pkg, gpu, oracle, ub
     for k in COUNTERS:
         assert gc[k] == oc[k], k
     np.testing.assert_allclose(film, ref, rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("knobs", [
+    {"PT_TRACE_SPLIT": "1"},
+    {"PT_TRACE_LEAF_QUORUM": "1", "PT_TRACE_REFILL_MIN": "4"},
+    {"PT_TRACE_LEAF_QUORUM": "40", "PT_TRACE_REFILL_MIN": "64"},
+    {"PT_TRACE_INST_QUORUM": "48", "PT_TRACE_LEAF_QUORUM": "40"},
+    {"PT_TRACE_INST_QUORUM": "1", "PT_TRACE_REFILL_MIN": "4", "PT_TRACE_SPLIT": "1"},
+], ids=lambda k: ",".join(f"{a[9:].lower()}={b}" for a, b in k.items()))
+def test_golden_vectors_hold_at_the_scheduling_knobs_extremes(knobs):
+    """the traversal's scheduling knobs (read once by pt_init, hence a fresh CHILD process per setting -- started with
+    subprocess, never an exec of this process) must not change a single counter or weight: the committed golden vectors (tests/golden,
+    every §8 row) through the HIP path at the extremes of leaf quorum / refill batch / instance quorum and with one launch per ray kind."""
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_golden.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (knobs, r.stdout[-3000:], r.stderr[-1500:])
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
