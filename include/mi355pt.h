@@ -402,6 +402,10 @@ typedef struct PtCounters {
     uint64_t sanitized_nan, sanitized_negative, sanitized_infinite; /* integrator.rs:350-368 */
     uint64_t film_splats;            /* film pixels touched by add_sample */
     uint64_t wavefront_stages;       /* sum over stages of lanes processed */
+    uint64_t reference_asserts;      /* assert!()s of the reference's li that would have fired (path.rs:143,162-163,184,201,213;
+                                        volpath.rs:176,194,210,223): the reference panics at the first one, a C ABI cannot -- the
+                                        sample is carried on (and sanitised by integrator.rs:350-368's rules); non-zero tells the
+                                        host "pbrt-rust would have aborted this render"                                          */
 } PtCounters;
 
 typedef struct PtKernelStat {

@@ -429,6 +429,7 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
             ctx.c->zero_den++;
             RGB Ld = beta * uniform_sample_onelight(ctx, isect, bsdf, sampler, distrib);
             if (Ld.is_black()) ctx.c->zero_num++;
+            if (!(Ld.y() >= 0.0f)) ctx.c->ref_asserts++;   // path.rs:143 assert!(Ld.y() >= 0.0)
             L += Ld;
         }
         V3 wo = -ray.d, wi;
@@ -436,6 +437,8 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
         RGB f = bsdf.sample_f(wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
         if (f.is_black() || pdf == 0.0f) break;
         beta *= f * abs_dot(wi, isect.sh_n) / pdf;
+        if (!(beta.y() >= 0.0f)) ctx.c->ref_asserts++;       // path.rs:162
+        if (std::isinf(beta.y())) ctx.c->ref_asserts++;      // path.rs:163
         specular_bounce = (flags & BSDF_SPECULAR) != 0;
         if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
             Float eta = bsdf.eta;
@@ -446,6 +449,7 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
         if (has_bssrdf && (flags & BSDF_TRANSMISSION)) {  // path.rs:177-204
             P2 s2 = sampler.get_2d();
             Float s1 = sampler.get_1d();
+            if (std::isinf(beta.y())) ctx.c->ref_asserts++;  // path.rs:184 (evaluated after sample_s whatever it returned)
             // TabulatedBSSRDF::sample_s -> sample_sp (bssrdf.rs:334-410)
             V3 start, target; Float u1n = 0.0f;
             if (!bssrdf.probe_segment(s1, s2, start, target, u1n)) break;   // S black
@@ -477,6 +481,7 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
             RGB ff = pibsdf.sample_f(pi.wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
             if (ff.is_black() || pdf == 0.0f) break;
             beta *= ff * abs_dot(wi, pi.sh_n) / pdf;
+            if (std::isinf(beta.y())) ctx.c->ref_asserts++;  // path.rs:201
             specular_bounce = (flags & BSDF_SPECULAR) != 0;
             IData pit; pit.p = pi.p; pit.p_error = pi.p_error; pit.n = pi.n;
             ray = spawn_ray(pit, wi);
@@ -486,6 +491,7 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
             Float q = fmax_(1.0f - rrbeta.max_component_value(), 0.05f);
             if (sampler.get_1d() < q) break;
             beta = beta / (1.0f - q);
+            if (std::isinf(beta.y())) ctx.c->ref_asserts++;  // path.rs:213 / volpath.rs:223
         }
         bounces += 1;
     }
@@ -755,6 +761,7 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
             RGB f = bsdf.sample_f(wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
             if (f.is_black() || pdf == 0.0f) break;
             beta *= f * abs_dot(wi, isect.sh_n) / pdf;
+            if (std::isinf(beta.y())) ctx.c->ref_asserts++;  // volpath.rs:176
             specular_bounce = (flags & BSDF_SPECULAR) != 0;
             if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
                 Float eta = bsdf.eta;
@@ -767,6 +774,7 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
             Float q = fmax_(1.0f - rrbeta.max_component_value(), 0.05f);
             if (sampler.get_1d() < q) break;
             beta = beta / (1.0f - q);
+            if (std::isinf(beta.y())) ctx.c->ref_asserts++;  // path.rs:213 / volpath.rs:223
         }
         bounces += 1;
     }
@@ -1073,7 +1081,7 @@ int orc_get_counters(const orc_scene *h, PtCounters *o) {
     o->zero_radiance_paths_num = c.zero_num; o->zero_radiance_paths_den = c.zero_den;
     for (int i = 0; i < 16; ++i) o->path_length_hist[i] = c.path_len[i];
     o->sanitized_nan = c.san_nan; o->sanitized_negative = c.san_neg; o->sanitized_infinite = c.san_inf;
-    o->film_splats = c.splats;
+    o->film_splats = c.splats; o->reference_asserts = c.ref_asserts;
     return PT_OK;
 }
 

@@ -52,11 +52,12 @@ struct Counters {
     uint64_t camera_rays = 0, intersect_tests = 0, shadow_tests = 0, nodes = 0, tri_tests = 0, sphere_tests = 0;
     uint64_t zero_num = 0, zero_den = 0, path_len[16] = {0};
     uint64_t san_nan = 0, san_neg = 0, san_inf = 0, splats = 0;
+    uint64_t ref_asserts = 0;   // assert!()s of PathIntegrator::li / VolPathIntegrator::li that would have fired (the reference panics there)
     void add(const Counters &o) {
         camera_rays += o.camera_rays; intersect_tests += o.intersect_tests; shadow_tests += o.shadow_tests;
         nodes += o.nodes; tri_tests += o.tri_tests; sphere_tests += o.sphere_tests; zero_num += o.zero_num;
         zero_den += o.zero_den; for (int i = 0; i < 16; ++i) path_len[i] += o.path_len[i];
-        san_nan += o.san_nan; san_neg += o.san_neg; san_inf += o.san_inf; splats += o.splats;
+        san_nan += o.san_nan; san_neg += o.san_neg; san_inf += o.san_inf; splats += o.splats; ref_asserts += o.ref_asserts;
     }
 };
 

@@ -132,7 +132,7 @@ class PtCounters(C.Structure):
                 ("triangle_tests", u64), ("sphere_tests", u64), ("zero_radiance_paths_num", u64),
                 ("zero_radiance_paths_den", u64), ("path_length_hist", u64 * 16), ("sanitized_nan", u64),
                 ("sanitized_negative", u64), ("sanitized_infinite", u64), ("film_splats", u64),
-                ("wavefront_stages", u64)]
+                ("wavefront_stages", u64), ("reference_asserts", u64)]
 
     def as_dict(self):
         d = {}

@@ -686,7 +686,7 @@ void read_counters(pt_scene *sc) {
     c.zero_radiance_paths_num = d.zero_num; c.zero_radiance_paths_den = d.zero_den;
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
-    c.film_splats = d.splats; c.wavefront_stages = d.stages;
+    c.film_splats = d.splats; c.wavefront_stages = d.stages; c.reference_asserts = d.ref_asserts;
     static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[5] = {"extend", "extend_mis", "shadow", "extend_camera", "extend_probe"};

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    uint32_t n_assert = 0;   // PtCounters::reference_asserts
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
         const bool valid = qi < count;
         bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_self = false;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             const bool stage_b = (flags & PF_STAGE_B) != 0u;   // grid media: this vertex's own NEE rays are back (see k_shade)
             if (stage_b) smp.load_window();
-            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
             flags &= ~(PF_CAMERA_RAY | PF_STAGE_B);
             bool terminated = bounces >= rc.max_depth;   // volpath.rs:108
             if (!terminated) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                     const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
                     if (smp.get_1d() < q) rr_kill = true;
-                    else beta = beta / (1.0f - q);
+                    else { beta = beta / (1.0f - q); if (__builtin_isinf(beta.y())) n_assert++; }   // volpath.rs:223
                 }
                 if (rr_kill) terminated = true;
                 else {
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
     counter_add(&job.counters->stages, n_valid);
     counter_add(&job.counters->shade_items[kMediumClass], n_valid);
     counter_add(&job.counters->shade_bytes[kMediumClass], n_bytes);
+    counter_add(&job.counters->ref_asserts, (unsigned long long)n_assert);
     (void)zero_num;
 }
 
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
     __syncthreads();
     const uint32_t count = *job.count;
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    uint32_t n_assert = 0;   // PtCounters::reference_asserts
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < count; qi += gridDim.x * blockDim.x) {
         n_valid++;
         n_bytes += 4 + 32 + /* write back */ 16 + 4;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
         const uint32_t meta = __float_as_uint(c1.w);
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
         RGB L(c0.x, c0.y, c0.z);
-        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
         if (!(flags & PF_DEAD) && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
             n_bytes += 32;
             const RGB beta(c1.x, c1.y, c1.z);
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst r
     __syncthreads();
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->ref_asserts, (unsigned long long)n_assert);
     counter_add(&job.counters->stages, n_valid);
     counter_add(&job.counters->shade_items[kMissClass], n_valid);
     counter_add(&job.counters->shade_bytes[kMissClass], n_bytes);

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;
     unsigned long long zero_num = 0, n_valid = 0, n_bytes = 0;
+    uint32_t n_assert = 0;   // PtCounters::reference_asserts
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
             // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
-            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS);
+            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                     if (ff.is_black() || pdf == 0.0f) terminated = true;
                     else {
                         beta = beta * (ff * abs_dot(wi, si.sh_n) / pdf);
+                        if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:201
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
                         V3 o; spawn_ray(it, wi, o);
                         // path.rs:206-214 Russian roulette
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
                         if (rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                             const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
                             if (smp.get_1d() < q) rr_kill = true;
-                            else beta = beta / (1.0f - q);
+                            else { beta = beta / (1.0f - q); if (__builtin_isinf(beta.y())) n_assert++; }   // path.rs:213
                         }
                         if (rr_kill) terminated = true;
                         else {
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, S
     __syncthreads();
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
+    counter_add(&job.counters->ref_asserts, (unsigned long long)n_assert);
     counter_add(&job.counters->stages, n_valid);
     counter_add(&job.counters->bss_items, n_valid);
     counter_add(&job.counters->bss_bytes, n_bytes);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;   // whole blocks iterate together
     unsigned long long zero_num = 0, zero_den = 0, n_valid = 0, n_bytes = 0;  // n_bytes: path-state + queue bytes
+    uint32_t n_assert = 0;   // assert!()s of the reference that would have fired at this thread's vertices (PtCounters::reference_asserts)
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
     bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_probe = false, push_self = false;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
         const bool stage_b = VOL && (flags & PF_STAGE_B) != 0u;
         const uint32_t camera_ray_flag = flags & PF_CAMERA_RAY;   // (a deferred vertex rebuilds its BSDF in stage B with the same differentials)
         if (stage_b) smp.load_window();
-        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
         flags &= ~PF_STAGE_B;
 
         PT_T(3);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     else if (DIFF != 2 && bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {   // (a specular-only BSDF has no such component: path.rs:131)
                         zero_den++;
                         const bool nee_pending = nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS);
-                        if (!nee_pending) { zero_num++; L = L + beta * RGB(0.0f); }  // Ld is black (path.rs:142); `L += beta * Ld` all the same (path.rs:140-145): NaN for a non-finite beta (fuzz seed 13269)
+                        if (!nee_pending) { zero_num++; const RGB Ld0 = beta * RGB(0.0f); if (!(Ld0.y() >= 0.0f)) n_assert++; /* path.rs:143 */ L = L + Ld0; }  // Ld is black (path.rs:142); `L += beta * Ld` all the same (path.rs:140-145): NaN for a non-finite beta (fuzz seed 13269)
                     }
                     // path.rs:148-174: sample the BSDF for the next direction
                     PT_T(11);
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                     else if (f.is_black() || pdf == 0.0f) terminated = true;
                     else {
                         beta = beta * (f * abs_dot(wi, si.sh_n) / pdf);
+                        { const float by = beta.y(); if (!VOL && !(by >= 0.0f)) n_assert++; if (__builtin_isinf(by)) n_assert++; }   // path.rs:162-163, volpath.rs:176
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
                         if ((sflags & BSDF_SPECULAR) && (sflags & BSDF_TRANSMISSION)) {
                             const float eta = bsdf.eta;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                             if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
                                 const P2 s2 = smp.get_2d();
                                 const float s1 = smp.get_1d();
+                                if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:184: evaluated after sample_s whatever it returned
                                 DevBssrdf bss;
                                 if (is_sss) bss.init_medium(s.materials[mi], s.bss_tables, bss_sa, bss_ss); else bss.init_disney(s.materials[mi]);
                                 bss.init_frame(si);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                         if (!to_probe && !rr_kill && rrbeta.max_component_value() < rc.rr_threshold && bounces > 3) {
                             const float q = maxf(1.0f - rrbeta.max_component_value(), 0.05f);
                             if (smp.get_1d() < q) rr_kill = true;
-                            else beta = beta / (1.0f - q);
+                            else { beta = beta / (1.0f - q); if (__builtin_isinf(beta.y())) n_assert++; }   // path.rs:213, volpath.rs:223
                         }
                         if (rr_kill) terminated = true;
                         else if (!to_probe) {
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);
     counter_add(&job.counters->zero_den, zero_den);
+    counter_add(&job.counters->ref_asserts, (unsigned long long)n_assert);
     counter_add(&job.counters->stages, n_valid);
     counter_add(&job.counters->shade_items[job.cls], n_valid);
     counter_add(&job.counters->shade_bytes[job.cls], n_bytes);

@@ -23,8 +23,9 @@ struct Prof { long long *t; int *r; unsigned long long *acc; };
 // draws sampler dimensions (grid.rs:113-147), in the reference right after the vertex's light / scattering samples and before its
 // continuation sample. Such vertices are therefore resolved in a second stage of the SAME vertex (PF_STAGE_B, kern_shade.h) and pass
 // their sampler here; `smp` is NULL everywhere else.
+// n_assert: the reference's `assert!(Ld.y() >= 0.0)` (path.rs:143) on the regular vertices' estimate, counted instead of panicking.
 template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
-                                                unsigned long long &zero_num, unsigned long long &n_bytes PT_PROF_ARG, Sampler *smp = nullptr) {
+                                                unsigned long long &zero_num, uint32_t &n_assert, unsigned long long &n_bytes PT_PROF_ARG, Sampler *smp = nullptr) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
     PT_T(1);
     // the pending records as whole quads: nee {sh_d.yz, occluded | sh_prim, nee_light} {A, choice_pdf} {nb, shadow grid medium}; mis {o, d.x} {d.yz, w, spdf} {prim, b} {f, t}
@@ -81,6 +82,7 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
     RGB nb(n3.x, n3.y, n3.z);
     RGB Ldb = nb * (Ld / n2.w);
     if (!VOL && Ldb.is_black() && !(flags & PF_NEE_UNCOUNTED)) zero_num++;   // path.rs:142 counts only the regular vertices' NEE
+    if (!VOL && !(flags & PF_NEE_UNCOUNTED) && !(Ldb.y() >= 0.0f)) n_assert++;   // path.rs:143 (a NaN estimate fails it too)
     L = L + Ldb;
     flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
 }

@@ -114,6 +114,7 @@ struct FilmSumArgs { const float4 *src[kMaxReplicas]; uint32_t n; };
 struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long camera_rays, intersect_tests, shadow_tests, nodes, tri_tests, sphere_tests;
     unsigned long long zero_num, zero_den, path_len[16], san_nan, san_neg, san_inf, splats, stages;
+    unsigned long long ref_asserts;            // assert!()s of the reference's li that would have fired (PtCounters::reference_asserts)
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long regions[16];            // PT_REGION_PROFILE builds: wave cycles per k_shade region
     unsigned long long tail[16];               // PT_TRACE_UTIL builds: [0] first wave start, [1] last wave exit of the launch in flight; per kind k: [4+2k] sum of wave busy time, [5+2k] sum of launch span x waves (wall_clock64 ticks)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats",
-            "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite")
+            "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts")
 
 
 def test_pcg32_matches_the_oracle_rng(pkg, oracle):

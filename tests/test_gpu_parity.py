@@ -108,7 +108,7 @@ def _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-6, atol=1e-7):
     ref = orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
     for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "zero_radiance_paths_num",
-              "zero_radiance_paths_den", "path_length_hist", "film_splats", "sanitized_nan", "sanitized_negative", "sanitized_infinite"):
+              "zero_radiance_paths_den", "path_length_hist", "film_splats", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts"):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=rtol, atol=atol)
@@ -502,3 +502,26 @@ def test_textured_triangle_only_scene(pkg, gpu, oracle):
     sd, rp = b.world_end()
     assert len(b.spheres) == 0 and not b.instances
     _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-5, atol=1e-6)
+
+
+def _negative_light_scene(pkg, spp=4):
+    """A matte floor under a point light with a NEGATIVE intensity (a .pbrt file may say so): every lit vertex's estimate has
+    Ld.y() < 0, where the reference's `assert!(Ld.y() >= 0.0)` (path.rs:143) panics."""
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=32, yres=24); b.spp = spp
+    b.integ.update(maxdepth=3, strategy="uniform")   # (the spatial strategy floors a light with a negative contribution at 0.001 x the average)
+    b.look_at((0.0, 2.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("point", from_=(0.0, 3.0, 0.0), I=(-5.0, -4.0, -3.0))
+    b.light_source("infinite", L=(0.2, 0.2, 0.2))
+    b.material("matte", Kd=(0.6, 0.5, 0.4))
+    P, I = pkg.scenes.quad((-4.0, 0.0, -4.0), (-4.0, 0.0, 4.0), (4.0, 0.0, 4.0), (4.0, 0.0, -4.0)); b.trianglemesh(P, I)
+    return b.world_end()
+
+
+@pytest.mark.gpu
+def test_reference_asserts_counter_matches_oracle(pkg, gpu, oracle):
+    sd, rp = _negative_light_scene(pkg, spp=8)
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp)      # compares reference_asserts exactly
+    g = pkg.Scene(gpu, sd); g.render(rp)
+    assert g.counters()["reference_asserts"] > 0

@@ -646,3 +646,75 @@ def test_imageio_round_trip_twin(pkg, tmp_path, ext, gamma):
         assert np.all(delta[..., 2] == 0.0) and np.abs(delta[..., :2]).max() < 0.001
     else:
         assert np.all(back[..., 2] == 0.0) and np.abs(delta[..., :2]).max() < 0.02
+
+
+# ---- tests/shapes.rs:226-419: the reference's sampling / solid-angle tests of the shapes behind the area lights ----
+
+def test_triangle_sampling_twin(oracle):
+    """tests/shapes.rs:226-299 triangle_sampling: for RNG::new(0..30) a random triangle (punif(10)) and a reference point 3 units outside
+    the cube, Sum 1 / (N pdf) over Triangle::sample + Shape::sample_interaction (the pdf LightSampler::sample_li uses) must agree with
+    the uniform-sphere Monte Carlo estimate over Triangle::intersect_p within 10 % -- N = 512 * 1024 radical-inverse points, every pdf
+    > 0 -- on the oracle's restatements (oracle/ref_kats_shapes.cpp runs the loops)."""
+    n = 30
+    out = (C.c_double * (4 * n))()
+    oracle.lib.orc_test_triangle_sampling.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_triangle_sampling(n, 512 * 1024, out) == 0
+    compared = sum(1 for i in range(n) if out[4 * i + 3] == 1.0)
+    assert compared >= 25                                                     # the reference skips only tiny solid angles
+    assert max(out[4 * i + 2] for i in range(n) if out[4 * i + 3] == 1.0) < 0.1
+
+
+def test_triangle_solid_angle_twin(oracle):
+    """tests/shapes.rs:301-352 triangle_solid_angle: the same sampling estimate (N = 64 * 1024, RNG::new(100..150)) against
+    Triangle::solid_angle -- Girard's theorem, triangle.rs:586-624 -- within 1.5 %."""
+    n = 50
+    out = (C.c_double * (3 * n))()
+    oracle.lib.orc_test_triangle_solid_angle.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_triangle_solid_angle(n, 64 * 1024, out) == 0
+    assert sum(1 for i in range(n) if out[3 * i] > 0.0) >= 45 and max(out[3 * i + 2] for i in range(n)) < 0.015
+
+
+def _test_transform(pkg):
+    """Transform::translate(1, .5, -.8) * Transform::rotate_x(30) and its inverse as the reference builds them (transform.rs:291-303:
+    m_inv of a rotation is the transpose; Mul: (m1 m2, m2_inv m1_inv), all in f32)."""
+    F32 = np.float32
+    T = pkg.host.Transform
+    th = F32(np.radians(F32(30.0)))
+    s, c = F32(np.sin(th)), F32(np.cos(th))
+    rot = np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]], dtype=F32)
+    return T.translate((1.0, 0.5, -0.8)) * T(rot, rot.T.copy())
+
+
+def test_sphere_solid_angle_twin(pkg, oracle):
+    """tests/shapes.rs:354-389 mc_solid_angle + sphere_solid_angle: uniform directions through Sphere::intersect_p of a rotated and
+    translated unit sphere give 4 pi from inside and Sphere::solid_angle (sphere.rs:397-407) to 1e-3 from outside, N = 128 * 1024."""
+    b = pkg.host.SceneBuilder()
+    b.ctm = _test_transform(pkg)
+    b.sphere(radius=1.0, zmin=-1.0, zmax=1.0, phimax=360.0)
+    out = (C.c_double * 4)()
+    oracle.lib.orc_test_sphere_solid_angle.argtypes = [C.POINTER(pkg._abi.PtSphere), C.c_int, C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_sphere_solid_angle(C.byref(b.spheres[0]), 128 * 1024, out) == 0
+    assert abs(out[0] - 4 * np.pi) < 0.01 and out[1] == np.float32(4.0) * np.float32(np.pi) and abs(out[2] - out[3]) < 0.001 and 0.2 < out[3] < 2.0
+
+
+def test_disk_solid_angle_twin(pkg, oracle):
+    """tests/shapes.rs:407-419 disk_solid_angle: Disk::intersect_p Monte Carlo against the default Shape::solid_angle (shape.rs:84-107:
+    Disk::sample through sample_interaction, the sample counted when the disk does not block its own segment), N = 128 * 1024, 1e-3."""
+    b = pkg.host.SceneBuilder()
+    b.ctm = _test_transform(pkg)
+    b.disk(height=0.0, radius=1.25, innerradius=0.0, phimax=360.0)
+    out = (C.c_double * 2)()
+    oracle.lib.orc_test_disk_solid_angle.argtypes = [C.POINTER(pkg._abi.PtSphere), C.c_int, C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_disk_solid_angle(C.byref(b.spheres[0]), 128 * 1024, out) == 0
+    assert abs(out[0] - out[1]) < 0.001 and out[0] > 0.1
+
+
+def test_oracle_counts_the_asserts_the_reference_would_panic_on(pkg, oracle):
+    """PtCounters::reference_asserts (VERDICT r2 item 5): 0 on an ordinary scene, > 0 where path.rs:143 would have aborted the render."""
+    from test_gpu_parity import _negative_light_scene
+    sd, rp = _negative_light_scene(pkg)
+    s = oracle.scene(sd); s.render(rp, nthreads=2); c = s.counters()
+    assert c["reference_asserts"] > 0 and c["sanitized_negative"] > 0
+    sd, rp = pkg.scenes.ganesha_scale(n=16, xres=32, yres=24, spp=2).world_end()
+    s = oracle.scene(sd); s.render(rp, nthreads=2)
+    assert s.counters()["reference_asserts"] == 0
