@@ -344,7 +344,15 @@ typedef struct PtSceneDesc {
 
 typedef enum PtIntegratorType { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_VOLPATH = 1 } PtIntegratorType;
 typedef enum PtSamplerType { PT_SAMPLER_SOBOL = 0, PT_SAMPLER_HALTON = 1 } PtSamplerType;
-typedef enum PtLightStrategy { PT_LS_UNIFORM = 0, PT_LS_POWER = 1, PT_LS_SPATIAL = 2 } PtLightStrategy;
+/* "lightsamplestrategy" (path.rs:236, lightdistrib.rs:14-34). PT_LS_SPATIAL is SpatialLightDistribution (lightdistrib.rs:105-340): one
+ * Distribution1D over ALL lights per voxel of a <= 64^3 grid. The reference fills a voxel on first touch (a lock-free hash,
+ * lightdistrib.rs:249-337); a voxel's content is a pure function of the voxel, so WHEN it is filled cannot be observed. The library
+ * fills every voxel up front when voxels x lights <= 2^25 (one launch, nothing in the render loop), and otherwise on first touch,
+ * once per wavefront iteration: the vertices about to be shaded name their voxels (k_light_touch), the new ones are computed by
+ * one k_light_grid_contrib launch (128 Halton points x every light, as compute_distribution does) and live until the scene is
+ * destroyed. There is no limit on the number of lights other than memory: a touched voxel costs 8 (n_lights + 3) bytes -- every
+ * emissive triangle is a light (api.rs:1531-1546). PT_LS_SPATIAL_EAGER / _LAZY force one of the two forms (tests; same result). */
+typedef enum PtLightStrategy { PT_LS_UNIFORM = 0, PT_LS_POWER = 1, PT_LS_SPATIAL = 2, PT_LS_SPATIAL_EAGER = 3, PT_LS_SPATIAL_LAZY = 4 } PtLightStrategy;
 
 typedef struct PtRenderParams {
     /* Film (core/film.rs:55-100). */

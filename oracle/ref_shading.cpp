@@ -581,7 +581,7 @@ void LightSampler::init(const Scene &s, int requested) {
     bounding_sphere(s.wb, world_center, world_radius);  // Light::preprocess (distant.rs:52-58, infinite.rs:111-116)
     if (s.env_w > 0) env_dist = Distribution2D(s.env_importance.data(), 2 * s.env_w, 2 * s.env_h);
     size_t nl = s.lights.size();
-    strategy = requested;
+    strategy = requested >= PT_LS_SPATIAL ? (int)PT_LS_SPATIAL : requested;   // (PT_LS_SPATIAL_EAGER / _LAZY: how the DEVICE fills its voxels; the same distribution)
     if (requested == PT_LS_UNIFORM || nl == 1) strategy = PT_LS_UNIFORM;  // lightdistrib.rs:21
     if (nl == 0) { strategy = PT_LS_UNIFORM; fixed = std::make_shared<Distribution1D>(std::vector<Float>()); return; }  // Distribution1D::new(vec![]) (lightdistrib.rs:79)
     if (strategy == PT_LS_UNIFORM) fixed = std::make_shared<Distribution1D>(std::vector<Float>(nl, 1.0f));

@@ -22,7 +22,7 @@ PT_MAT_MATTE, PT_MAT_MIRROR, PT_MAT_GLASS, PT_MAT_PLASTIC, PT_MAT_METAL, PT_MAT_
 (PT_DS_METALLIC, PT_DS_SPECULARTINT, PT_DS_ANISOTROPIC, PT_DS_SHEEN, PT_DS_SHEENTINT, PT_DS_CLEARCOAT, PT_DS_CLEARCOATGLOSS, PT_DS_SPECTRANS,
  PT_DS_FLATNESS, PT_DS_DIFFTRANS) = range(10)
 PT_LIGHT_DIFFUSE_AREA, PT_LIGHT_DISTANT, PT_LIGHT_POINT, PT_LIGHT_INFINITE, PT_LIGHT_SPOT = range(5)
-PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL = range(3)
+PT_LS_UNIFORM, PT_LS_POWER, PT_LS_SPATIAL, PT_LS_SPATIAL_EAGER, PT_LS_SPATIAL_LAZY = range(5)
 PT_SPLIT_SAH, PT_SPLIT_HLBVH = range(2)
 PT_SAMPLER_SOBOL, PT_SAMPLER_HALTON = range(2)
 PT_INTEGRATOR_PATH, PT_INTEGRATOR_VOLPATH = range(2)

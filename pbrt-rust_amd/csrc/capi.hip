@@ -152,7 +152,10 @@ struct pt_scene {
     uint32_t n_lights = 0;
     std::vector<PtLight> host_lights; uint32_t env_w = 0, env_h = 0; float env_texel0[3] = {0, 0, 0};
     // light grids (lazy, per effective strategy)
-    LightGrid grid[3]{}; bool grid_ready[3] = {false, false, false};
+    LightGrid grid[5]{}; bool grid_ready[5] = {false, false, false, false, false};   // by PtLightStrategy; PT_LS_SPATIAL itself resolves to _EAGER or _LAZY
+    // PT_LS_SPATIAL_LAZY: voxels are filled when a vertex first needs them (lightdistrib.rs:233-337), once per wavefront iteration
+    struct LazyGrid { unsigned long long *cell_ptr = nullptr; float *zero_block = nullptr; uint32_t *req_flag = nullptr, *req_list = nullptr, *req_count = nullptr, *missing = nullptr;
+                      size_t ncell = 0, stride = 0; uint64_t filled = 0; } lazy;
     // render workspace
     hipStream_t stream = nullptr;
     void *slab = nullptr; size_t capacity = 0; PathSoA ps{};
@@ -357,15 +360,33 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
     return PT_OK;
 }
 
+// SpatialLightDistribution::new's voxel counts (lightdistrib.rs:112-128)
+void spatial_voxels(const pt_scene *sc, uint32_t nvox[3]) {
+    float diag[3] = {sc->ds.wb_max[0] - sc->ds.wb_min[0], sc->ds.wb_max[1] - sc->ds.wb_min[1], sc->ds.wb_max[2] - sc->ds.wb_min[2]};
+    int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
+    float bmax = diag[me];
+    for (int i = 0; i < 3; ++i) {
+        float v = std::round(diag[i] / bmax * 64.0f);
+        uint32_t nv = (v > 0.0f) ? (uint32_t)v : 0u;  // `as usize` saturates, NaN -> 0
+        nvox[i] = std::max<uint32_t>(1u, nv);
+    }
+}
+constexpr size_t kEagerGridEntries = (size_t)1 << 25;   // voxels x lights up to which PT_LS_SPATIAL precomputes every voxel
+
 int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
     effective = requested;
     if (requested == PT_LS_UNIFORM || sc->n_lights == 1) effective = PT_LS_UNIFORM;  // lightdistrib.rs:21
-    if (requested > PT_LS_SPATIAL) effective = PT_LS_SPATIAL;
+    if (requested > PT_LS_SPATIAL_LAZY) effective = PT_LS_SPATIAL;
+    if (effective == PT_LS_SPATIAL) {   // the form is the library's choice (include/mi355pt.h: PtLightStrategy)
+        uint32_t nv[3]; spatial_voxels(sc, nv);
+        effective = (size_t)nv[0] * nv[1] * nv[2] * std::max(1u, sc->n_lights) <= kEagerGridEntries ? PT_LS_SPATIAL_EAGER : PT_LS_SPATIAL_LAZY;
+    }
     LightGrid &g = sc->grid[effective];
     if (sc->grid_ready[effective]) return PT_OK;
-    g.strategy = effective; g.n_lights = sc->n_lights; g.nvox[0] = g.nvox[1] = g.nvox[2] = 1;
+    g.strategy = effective >= PT_LS_SPATIAL ? (int)PT_LS_SPATIAL : effective; g.n_lights = sc->n_lights; g.nvox[0] = g.nvox[1] = g.nvox[2] = 1;
+    g.cell_ptr = nullptr; g.zero_block = 0; g.missing = nullptr;
     const uint32_t nl = sc->n_lights;
-    if (nl == 0) { g.func = g.cdf = g.func_int = nullptr; sc->grid_ready[effective] = true; return PT_OK; }
+    if (nl == 0) { g.strategy = PT_LS_UNIFORM; g.func = g.cdf = g.func_int = nullptr; sc->grid_ready[effective] = true; return PT_OK; }
     if (effective == PT_LS_UNIFORM || effective == PT_LS_POWER) {
         std::vector<float> func(nl, 1.0f), cdf; float fi;
         if (effective == PT_LS_POWER) {  // compute_light_power_distribution (integrator.rs:239-247): Light::power().y() per light
@@ -393,17 +414,29 @@ int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
         if ((st = sc->upload(&g.func, func.data(), nl))) return st;
         if ((st = sc->upload(&g.cdf, cdf.data(), nl + 1))) return st;
         if ((st = sc->upload(&g.func_int, &fi, 1))) return st;
+    } else if (effective == PT_LS_SPATIAL_LAZY) {   // voxels filled on first touch (lazy_light_fill, called from run_pass)
+        spatial_voxels(sc, g.nvox);
+        pt_scene::LazyGrid &z = sc->lazy;
+        z.ncell = (size_t)g.nvox[0] * g.nvox[1] * g.nvox[2];
+        z.stride = ((size_t)4 + nl + nl + 1 + 3) & ~(size_t)3;   // {func_int, -, -, -} func[nl] cdf[nl + 1], whole quads
+        int st;
+        if ((st = sc->dalloc(&z.cell_ptr, z.ncell))) return st;
+        if ((st = sc->dalloc(&z.zero_block, z.stride))) return st;
+        if ((st = sc->dalloc(&z.req_flag, z.ncell))) return st;
+        if ((st = sc->dalloc(&z.req_list, z.ncell))) return st;
+        if ((st = sc->dalloc(&z.req_count, 2))) return st;
+        z.missing = z.req_count + 1;
+        HIP_TRY(hipMemset(z.zero_block, 0, z.stride * 4));
+        HIP_TRY(hipMemset(z.req_flag, 0, z.ncell * 4));
+        HIP_TRY(hipMemset(z.req_count, 0, 8));
+        std::vector<unsigned long long> init(z.ncell, (unsigned long long)z.zero_block);
+        HIP_TRY(hipMemcpy(z.cell_ptr, init.data(), z.ncell * 8, hipMemcpyHostToDevice));
+        g.func = g.cdf = g.func_int = nullptr;
+        g.cell_ptr = z.cell_ptr; g.zero_block = (unsigned long long)z.zero_block; g.missing = z.missing;
     } else {  // SpatialLightDistribution::new (lightdistrib.rs:112-128), every voxel precomputed on device
-        float diag[3] = {sc->ds.wb_max[0] - sc->ds.wb_min[0], sc->ds.wb_max[1] - sc->ds.wb_min[1], sc->ds.wb_max[2] - sc->ds.wb_min[2]};
-        int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);
-        float bmax = diag[me];
-        for (int i = 0; i < 3; ++i) {
-            float v = std::round(diag[i] / bmax * 64.0f);
-            uint32_t nv = (v > 0.0f) ? (uint32_t)v : 0u;  // `as usize` saturates, NaN -> 0
-            g.nvox[i] = std::max<uint32_t>(1u, nv);
-        }
+        spatial_voxels(sc, g.nvox);
         size_t ncell = (size_t)g.nvox[0] * g.nvox[1] * g.nvox[2];
-        if (ncell * nl > ((size_t)1 << 31)) return fail(PT_ERR_UNSUPPORTED, "spatial light grid too large to precompute (voxels x lights > 2^31)");
+        if (ncell * nl > ((size_t)1 << 31)) return fail(PT_ERR_UNSUPPORTED, "PT_LS_SPATIAL_EAGER: voxels x lights > 2^31 (PT_LS_SPATIAL picks the first-touch form for such scenes)");
         float *func, *cdf, *fint; int st;
         if ((st = sc->dalloc(&func, ncell * nl))) return st;
         if ((st = sc->dalloc(&cdf, ncell * (nl + 1)))) return st;
@@ -411,8 +444,8 @@ int ensure_light_grid(pt_scene *sc, int requested, int &effective) {
         size_t total = ncell * nl;
         sc->begin("light_grid", total);
         sc->set_kernel("k_light_grid_contrib");
-        hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, g.nvox[0], g.nvox[1], g.nvox[2], func);
-        hipLaunchKernelGGL(k_light_grid_finish, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, sc->stream, nl, ncell, func, cdf, fint);
+        hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, g.nvox[0], g.nvox[1], g.nvox[2], func, (const uint32_t *)nullptr, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(k_light_grid_finish, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, sc->stream, nl, ncell, func, cdf, fint, (const uint32_t *)nullptr, (size_t)0, (unsigned long long *)nullptr);
         sc->end();
         HIP_TRY(hipGetLastError());
         g.func = func; g.cdf = cdf; g.func_int = fint;
@@ -511,6 +544,46 @@ uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp
     return (spp + n_pass - 1) / n_pass;   // passes of equal size
 }
 
+// First-touch voxels of PT_LS_SPATIAL_LAZY. touch: the vertices of one queue name their voxels; fill: the voxels named since the last fill are
+// computed (k_light_grid_contrib over the list: 128 Halton points x every light each, lightdistrib.rs:151-228) and published in cell_ptr.
+int lazy_light_touch(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const uint32_t *queue, const uint32_t *count, uint32_t n_upper, uint32_t kind) {
+    if (!grid.cell_ptr || n_upper == 0) return PT_OK;
+    pt_scene::LazyGrid &z = sc->lazy;
+    const unsigned blocks = std::min<uint32_t>((n_upper + 255) / 256, (uint32_t)g_num_cus * 16u);
+    const bool sph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;
+    sc->begin("light_touch", n_upper); sc->set_kernel(sph ? "k_light_touch<true>" : "k_light_touch<false>");
+    if (sph) hipLaunchKernelGGL((k_light_touch<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, grid, sc->ps, queue, count, kind, rc.max_depth, z.req_flag, z.req_list, z.req_count);
+    else hipLaunchKernelGGL((k_light_touch<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, grid, sc->ps, queue, count, kind, rc.max_depth, z.req_flag, z.req_list, z.req_count);
+    sc->end();
+    return PT_OK;
+}
+int lazy_light_fill(pt_scene *sc, const LightGrid &grid) {
+    if (!grid.cell_ptr) return PT_OK;
+    pt_scene::LazyGrid &z = sc->lazy;
+    uint32_t n_new = 0;
+    HIP_TRY(hipMemcpyAsync(&n_new, z.req_count, 4, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (n_new == 0) return PT_OK;
+    if (n_new > z.ncell) return fail(PT_ERR_HIP, "light grid: more voxels requested than the grid holds");
+    const uint32_t nl = grid.n_lights;
+    // in batches of at most 2^31 (voxel, light) pairs per launch and 1 GiB of blocks per allocation
+    const size_t per_batch = std::max<size_t>(1, std::min<size_t>(((size_t)1 << 31) / std::max(1u, nl), ((size_t)1 << 28) / z.stride));
+    for (size_t first = 0; first < n_new; first += per_batch) {
+        const size_t n = std::min<size_t>(per_batch, n_new - first);
+        float *blocks = nullptr; int st;
+        if ((st = sc->dalloc(&blocks, n * z.stride))) return st;
+        const size_t total = n * nl;
+        sc->begin("light_grid", total); sc->set_kernel("k_light_grid_contrib");
+        hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, grid.nvox[0], grid.nvox[1], grid.nvox[2], blocks, (const uint32_t *)(z.req_list + first), n, z.stride);
+        hipLaunchKernelGGL(k_light_grid_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sc->stream, nl, n, blocks, (float *)nullptr, (float *)nullptr, (const uint32_t *)(z.req_list + first), z.stride, z.cell_ptr);
+        sc->end();
+    }
+    HIP_TRY(hipMemsetAsync(z.req_count, 0, 4, sc->stream));
+    HIP_TRY(hipGetLastError());
+    z.filled += n_new;
+    return PT_OK;
+}
+
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
     const uint32_t total = rc.n_pix_slots * rc.s_count;
     QCounters *qc = sc->qc;
@@ -601,6 +674,14 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sc->end();
         }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
+        if (grid.cell_ptr) {   // first-touch voxels: the vertices of every shade class name theirs, then the new ones are computed
+            const uint32_t upper0 = n_ext + n_resolve;
+            for (int c = 0; c < kNumClasses; ++c) {
+                if (c == kMissClass) continue;
+                if ((st = lazy_light_touch(sc, rc, grid, sc->q.shade[cur][c], &qc->shade[cur][c], upper0 + n_stage_b, c == kMediumClass ? 1u : 0u))) return st;
+            }
+            if ((st = lazy_light_fill(sc, grid))) return st;
+        }
         if (n_probe) {  // subsurface probe chains (bssrdf.rs:367-402): each lane of k_trace<.., PROBE> walks a whole chain, then k_bssrdf
             TraceSub pr{};
             pr.queue = sc->q.probe[cur]; pr.count = &qc->probe[cur]; pr.scalar_tmax = 1.0f - 0.0001f;
@@ -612,6 +693,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             st = launch_trace(sc, 0, tj, n_probe, true);
             sc->end();
             if (st) return st;
+            if (grid.cell_ptr) {   // the chains' exit points look their voxels up in k_bssrdf
+                if ((st = lazy_light_touch(sc, rc, grid, sc->q.probe[cur], &qc->probe[cur], n_probe, 2u))) return st;
+                if ((st = lazy_light_fill(sc, grid))) return st;
+            }
             BssrdfJob bj{};
             bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
             bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
@@ -1174,6 +1259,12 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         for (uint32_t s0 = 0; s0 < rp->spp; s0 += S) {
             rc.s_begin = s0; rc.s_count = std::min(S, rp->spp - s0);
             if ((st = run_pass(sc, rc, sc->grid[eff], rp->profile >= 2))) return st;
+        }
+        if (sc->grid[eff].cell_ptr) {   // a vertex that looked up a voxel nobody had computed: cannot happen (k_light_touch names every voxel first)
+            uint32_t missing = 0;
+            HIP_TRY(hipMemcpyAsync(&missing, sc->lazy.missing, 4, hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+            if (missing) { HIP_TRY(hipMemset(sc->lazy.missing, 0, 4)); return fail(PT_ERR_HIP, "internal: " + std::to_string(missing) + " light-distribution lookups hit a voxel that had not been computed"); }
         }
         float *dst = film_xyzw, *tmp = nullptr; DevTmp film_tmp;
         std::vector<float> host;

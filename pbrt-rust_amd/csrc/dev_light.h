@@ -326,19 +326,34 @@ struct LightGrid {
     const float *func;       // [ncell][n_lights]     (uniform/power: ncell == 1)
     const float *cdf;        // [ncell][n_lights+1]
     const float *func_int;   // [ncell]
+    // Voxels filled on first touch (PT_LS_SPATIAL with many lights; include/mi355pt.h: PtLightStrategy): cell -> its block
+    // {func_int, -, -, -, func[n_lights], cdf[n_lights + 1]}, or the scene's all-zero block while the voxel has not been computed. Every
+    // vertex's voxel is computed before the vertex is shaded (k_light_touch), so a lookup that lands on the zero block is a bug: it is
+    // counted in *missing and the render fails.
+    const unsigned long long *cell_ptr;   // NULL: the dense arrays above
+    unsigned long long zero_block;
+    uint32_t *missing;
 };
-PT_DEV Dist1D light_distribution_lookup(const LightGrid &g, const DeviceScene &s, V3 p) {  // lightdistrib.rs:233-247
+PT_DEV size_t light_grid_cell(const LightGrid &g, const DeviceScene &s, V3 p) {  // lightdistrib.rs:233-247
+    float o[3] = {p.x - s.wb_min[0], p.y - s.wb_min[1], p.z - s.wb_min[2]};  // Bounds3::offset, bounds.rs:372-390
+    uint32_t pi[3];
+    for (int i = 0; i < 3; ++i) {
+        if (s.wb_max[i] > s.wb_min[i]) o[i] /= s.wb_max[i] - s.wb_min[i];
+        int64_t v = f2i_sat(o[i] * (float)g.nvox[i]);
+        int64_t hi = (int64_t)g.nvox[i] - 1;
+        pi[i] = (uint32_t)(v < 0 ? 0 : (v > hi ? hi : v));
+    }
+    return ((size_t)pi[2] * g.nvox[1] + pi[1]) * g.nvox[0] + pi[0];
+}
+PT_DEV Dist1D light_distribution_lookup(const LightGrid &g, const DeviceScene &s, V3 p) {
     size_t cell = 0;
-    if (g.strategy == PT_LS_SPATIAL) {
-        float o[3] = {p.x - s.wb_min[0], p.y - s.wb_min[1], p.z - s.wb_min[2]};  // Bounds3::offset, bounds.rs:372-390
-        uint32_t pi[3];
-        for (int i = 0; i < 3; ++i) {
-            if (s.wb_max[i] > s.wb_min[i]) o[i] /= s.wb_max[i] - s.wb_min[i];
-            int64_t v = f2i_sat(o[i] * (float)g.nvox[i]);
-            int64_t hi = (int64_t)g.nvox[i] - 1;
-            pi[i] = (uint32_t)(v < 0 ? 0 : (v > hi ? hi : v));
-        }
-        cell = ((size_t)pi[2] * g.nvox[1] + pi[1]) * g.nvox[0] + pi[0];
+    if (g.strategy == PT_LS_SPATIAL) cell = light_grid_cell(g, s, p);
+    if (g.cell_ptr) {
+        const unsigned long long b = g.cell_ptr[cell];
+        if (b == g.zero_block) atomicAdd(g.missing, 1u);
+        const float *blk = reinterpret_cast<const float *>(b);
+        Dist1D d{blk + 4, blk + 4 + g.n_lights, blk[0], (int)g.n_lights};
+        return d;
     }
     Dist1D d{g.func + cell * g.n_lights, g.cdf + cell * (g.n_lights + 1), g.func_int[cell], (int)g.n_lights};
     return d;

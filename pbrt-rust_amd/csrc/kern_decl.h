@@ -19,8 +19,9 @@ __global__ void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_
 __global__ void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
 __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix);
 __global__ void k_film_sum(FilmSumArgs a, float4 *dst, int accumulate, size_t n_quads);
-__global__ void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func);
-__global__ void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int);
+__global__ void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func, const uint32_t *cells, size_t n_cells, size_t stride);
+__global__ void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int, const uint32_t *cells, size_t stride, unsigned long long *cell_ptr);
+template <bool SPH> __global__ void k_light_touch(DeviceScene s, LightGrid g, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr, uint32_t kind, uint32_t max_depth, uint32_t *req_flag, uint32_t *req_list, uint32_t *req_count);
 __global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
                                  uint32_t n_dims, float *out, uint64_t *out_index);
 __global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,

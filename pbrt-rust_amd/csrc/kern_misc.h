@@ -297,12 +297,15 @@ __global__ void k_film_sum(FilmSumArgs a, float4 *dst, int accumulate, size_t n_
 }
 
 // ---- spatial light distribution (lightdistrib.rs:151-228), all voxels precomputed ---------------------------
-__global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func) {
+// `cells` == NULL: every voxel of the grid, func[cell][n_lights] (the eager form). Otherwise the n_cells voxels listed in `cells` (first
+// touched in this wavefront iteration), written into blocks of `stride` floats: {func_int, -, -, -, func[n_lights], cdf[n_lights + 1]}.
+__global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func, const uint32_t *cells, size_t n_cells, size_t stride) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t ncell = (size_t)nvx * nvy * nvz;
+    const size_t ncell = cells ? n_cells : (size_t)nvx * nvy * nvz;
     if (gid >= ncell * s.n_lights) return;
     const uint32_t j = (uint32_t)(gid % s.n_lights);
-    const size_t cell = gid / s.n_lights;
+    const size_t slot = gid / s.n_lights;
+    const size_t cell = cells ? (size_t)cells[slot] : slot;
     const uint32_t pi0 = (uint32_t)(cell % nvx), pi1 = (uint32_t)((cell / nvx) % nvy), pi2 = (uint32_t)(cell / ((size_t)nvx * nvy));
     V3 p0((float)pi0 / (float)nvx, (float)pi1 / (float)nvy, (float)pi2 / (float)nvz);
     V3 p1((float)(pi0 + 1) / (float)nvx, (float)(pi1 + 1) / (float)nvy, (float)(pi2 + 1) / (float)nvz);
@@ -319,13 +322,14 @@ __global__ __launch_bounds__(256) void k_light_grid_contrib(DeviceScene s, uint3
         RGB Li = light_sample_li<true>(s, j, intr, u, wi, pdf, vis);
         if (pdf > 0.0f) contrib += Li.y() / pdf;
     }
-    func[gid] = contrib;
+    func[cells ? slot * stride + 4 + j : gid] = contrib;
 }
 // Per voxel: floor at 0.001*avg, then Distribution1D::new (sampling.rs:12-34)
-__global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int) {
+// (`cells` != NULL: the blocks of k_light_grid_contrib's listed form; the finished block's address is published in cell_ptr[cell])
+__global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, size_t ncell, float *func, float *cdf, float *func_int, const uint32_t *cells, size_t stride, unsigned long long *cell_ptr) {
     const size_t cell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= ncell) return;
-    float *f = func + cell * n_lights, *c = cdf + cell * (n_lights + 1);
+    float *f = cells ? func + cell * stride + 4 : func + cell * n_lights, *c = cells ? f + n_lights : cdf + cell * (n_lights + 1);
     float sum = 0.0f;
     for (uint32_t j = 0; j < n_lights; ++j) sum += f[j];
     const float avg = sum / (128.0f * (float)n_lights);
@@ -336,7 +340,34 @@ __global__ __launch_bounds__(256) void k_light_grid_finish(uint32_t n_lights, si
     const float fi = c[n_lights];
     if (fi == 0.0f) { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] = (float)i / (float)n_lights; }
     else { for (uint32_t i = 1; i < n_lights + 1; ++i) c[i] /= fi; }
-    func_int[cell] = fi;
+    if (cells) { func[cell * stride] = fi; __threadfence(); cell_ptr[cells[cell]] = (unsigned long long)(func + cell * stride); }
+    else func_int[cell] = fi;
+}
+
+// SpatialLightDistribution::lookup's "first touch" (lightdistrib.rs:233-337), once per wavefront iteration: every vertex of `queue` that is
+// about to look its voxel up (kind 0: surface hits of a shade class below max_depth, path.rs:120-131; 1: medium vertices, volpath.rs:113-119;
+// 2: the exit points of finished BSSRDF probe chains, path.rs:188) names the voxel; voxels without a distribution are listed once.
+template <bool SPH>
+__global__ __launch_bounds__(256) void k_light_touch(DeviceScene s, LightGrid g, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr, uint32_t kind, uint32_t max_depth,
+                                                     uint32_t *req_flag, uint32_t *req_list, uint32_t *req_count) {
+    const uint32_t count = *count_ptr;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < count; qi += gridDim.x * blockDim.x) {
+        const uint32_t pid = queue[qi];
+        const uint32_t meta = ps.meta(pid);
+        if ((meta >> 24) & PF_DEAD) continue;
+        if (kind != 2u && ((meta >> 16) & 0xffu) >= max_depth) continue;
+        const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
+        V3 p;
+        if (kind == 1u) p = ro + rd * ps.hit_t(pid);
+        else {
+            if (ps.hit_prim(pid) == PT_NONE) continue;
+            SurfaceInteraction si;
+            fill_hit_pkt<SPH>(s, ps.hit_pkt(pid), SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
+            p = si.p;
+        }
+        const size_t cell = light_grid_cell(g, s, p);
+        if (g.cell_ptr[cell] == g.zero_block && atomicExch(&req_flag[cell], 1u) == 0u) req_list[atomicAdd(req_count, 1u)] = (uint32_t)cell;
+    }
 }
 // ---- parity helpers -------------------------------------------------------------------------------------------
 __global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,

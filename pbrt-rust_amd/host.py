@@ -630,7 +630,7 @@ class SceneBuilder:
         if pb is None: pb = sb
         else: pb = [max(pb[0], sb[0]), max(pb[2], sb[1]), min(pb[1], sb[2]), min(pb[3], sb[3])]  # path.rs:233-246
         rp.pixel_bounds = (C.c_int32 * 4)(*pb)
-        rp.light_strategy = dict(uniform=A.PT_LS_UNIFORM, power=A.PT_LS_POWER, spatial=A.PT_LS_SPATIAL)[self.integ["strategy"]]
+        rp.light_strategy = dict(uniform=A.PT_LS_UNIFORM, power=A.PT_LS_POWER, spatial=A.PT_LS_SPATIAL, spatial_eager=A.PT_LS_SPATIAL_EAGER, spatial_lazy=A.PT_LS_SPATIAL_LAZY)[self.integ["strategy"]]
         rp.tile_rank, rp.tile_world, rp.spp_per_pass, rp.profile = 0, 1, 0, 0
         return rp
 

@@ -119,6 +119,39 @@ def material_zoo(n=24, xres=96, yres=64, spp=16, maxdepth=5):
     return b
 
 
+def emissive_field(n_lights=50000, xres=24, yres=16, spp=2, maxdepth=2, strategy="spatial", seed=5):
+    """An emissive mesh: every triangle of an AreaLightSource shape is a light of its own (api.rs:1531-1546) -- n_lights small emissive
+    triangles, in warm and cold patches, hang over a matte floor with a blocker. Under "lightsamplestrategy" "spatial" each touched
+    voxel of SpatialLightDistribution holds a Distribution1D over ALL of them (lightdistrib.rs:151-228): the case the library's
+    first-touch voxel grid exists for (include/mi355pt.h: PtLightStrategy)."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp
+    b.integ.update(maxdepth=maxdepth, strategy=strategy)
+    b.look_at((0.0, 2.2, 7.0), (0.0, 0.4, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=42.0)
+    b.world_begin()
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n_lights)))
+    k = np.arange(n_lights)
+    cx = ((k % side) + 0.5) / side * 8.0 - 4.0 + rng.uniform(-0.3, 0.3, n_lights) * (8.0 / side)
+    cz = ((k // side) + 0.5) / side * 8.0 - 4.0 + rng.uniform(-0.3, 0.3, n_lights) * (8.0 / side)
+    cy = 3.0 + 0.4 * np.sin(cx * 1.7) * np.cos(cz * 1.3)
+    h = 0.35 * 8.0 / side
+    P = np.empty((n_lights, 3, 3), dtype=np.float32)
+    P[:, 0] = np.stack([cx - h, cy, cz - h], axis=1); P[:, 1] = np.stack([cx + h, cy, cz - h], axis=1); P[:, 2] = np.stack([cx, cy, cz + h], axis=1)
+    I = np.arange(3 * n_lights, dtype=np.uint32).reshape(-1, 3)
+    half = n_lights // 2
+    for lo, hi, L in ((0, half, (900.0, 500.0, 200.0)), (half, n_lights, (150.0, 400.0, 900.0))):   # two AreaLightSource blocks
+        if hi <= lo: continue
+        b.attribute_begin(); b.area_light_source(L=L, twosided=True)
+        b.trianglemesh(P[lo:hi].reshape(-1, 3), (I[lo:hi] - 3 * lo).astype(np.uint32))
+        b.attribute_end()
+    b.material("matte", Kd=(0.6, 0.6, 0.6))
+    Pq, Iq = quad((-4.0, 0.0, -4.0), (-4.0, 0.0, 4.0), (4.0, 0.0, 4.0), (4.0, 0.0, -4.0)); b.trianglemesh(Pq, Iq)
+    b.material("plastic", Kd=(0.7, 0.3, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2)
+    Pq, Iq = quad((-1.5, 0.0, -0.5), (-1.5, 1.6, -0.5), (1.5, 1.6, -0.5), (1.5, 0.0, -0.5)); b.trianglemesh(Pq, Iq)
+    return b
+
+
 def spheres_c1(xres=400, yres=400, spp=64, maxdepth=5):
     """S1 / config C1: LookAt 2 2 5 -> 0 -.4 0, fov 30, sobol, path maxdepth 5, box filter; matte ground quad
     (2 tris, Kd .5), mirror sphere r=1 at x=-1.3, glass sphere (index 1.5) r=1 at x=+1.3, one distant light L=pi from
