@@ -532,13 +532,18 @@ template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderCo
 // in a tail of straggling rays (~0.8 ms on S2, whatever the launch size), so fewer, larger iterations spend less of the render in tails:
 // S2 at 1080p x 256 spp: 32 samples per pass 1267, 64: 1367, 128: 1439, 256: 1468 Msamples/s. `share` = renders that will hold a
 // workspace on this device at the same time (pt_multi_render with a device listed more than once).
+#ifndef PT_PASS_MAX_PATHS_LOG2
+#define PT_PASS_MAX_PATHS_LOG2 29   // round 3: 2^29 paths = 256 samples per pixel at 1080p in ONE pass (137 GB of path state + 39 GB of queues of the 288 GB): half the iterations of 2^28
+#endif
+constexpr size_t kPassMaxPaths = (size_t)1 << PT_PASS_MAX_PATHS_LOG2;
+constexpr double kPassMemFraction = 0.65;   // of the device's free memory
 uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share) {
     const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     // (the present workspace is freed before a larger one is allocated)
-    const size_t afford = std::max(sc->capacity, (size_t)((double)(free_b / std::max(1u, share) + sc->capacity * per_path) * 0.6) / per_path);
-    const size_t paths = std::min(afford, ((size_t)1 << 28) / std::max(1u, share));
+    const size_t afford = std::max(sc->capacity, (size_t)((double)(free_b / std::max(1u, share) + sc->capacity * per_path) * kPassMemFraction) / per_path);
+    const size_t paths = std::min(afford, kPassMaxPaths / std::max(1u, share));
     uint32_t S = (uint32_t)std::min<size_t>(spp, std::max<size_t>(1, paths / std::max(1u, n_pix_slots)));
     const uint32_t n_pass = (spp + S - 1) / S;
     return (spp + n_pass - 1) / n_pass;   // passes of equal size
