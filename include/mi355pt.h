@@ -329,9 +329,12 @@ typedef struct PtSceneDesc {
     const float *ewa_weight_lut;   /* [128] = exp(-2 r2) - exp(-2), r2 = i/127 (mipmap.rs:40-50); required with EWA image maps */
     /* Participating media for the volumetric path integrator (media/homogeneous.rs, core/medium.rs). Ignored by
      * PT_INTEGRATOR_PATH exactly as the reference's PathIntegrator ignores Ray::medium. prim_medium_inside / _outside are the
-     * GeometricPrimitive's MediumInterface per primitive (PT_NONE = no medium; api.rs:1540-1560); NULL = no interfaces. Every
-     * primitive needs a material: the reference's own volpath mishandles material-less interface shapes (bounces underflow,
-     * volpath.rs:127-131), they are refused with PT_ERR_UNSUPPORTED. */
+     * GeometricPrimitive's MediumInterface per primitive (PT_NONE = no medium; api.rs:1540-1560); NULL = no interfaces. A
+     * primitive without a material (prim_material = PT_NONE: `Material "none"`, api.rs:597) is a medium-interface shell: shadow and
+     * MIS rays go on behind it, segment by segment (VisibilityTester::tr light.rs:125-150, Scene::intersect_tr scene.rs:68-87), and
+     * the path itself steps over it with the reference's `bounces -= 1; continue` (volpath.rs:152-156) -- which skips the loop's
+     * increment: the count DROPS at every shell and wraps below zero at a camera ray's first one (the release build has no overflow
+     * checks), so such a path ends at its next vertex. Reproduced as it is; maxdepth <= 254 keeps the 8-bit count equivalent. */
     uint32_t n_media; const PtMedium *media;
     const uint32_t *prim_medium_inside; const uint32_t *prim_medium_outside;
     /* bvh "splitmethod" (api.rs make_accelerator -> bvh.rs:918-940) for every accelerator the library builds (ignored for

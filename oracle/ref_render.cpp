@@ -501,9 +501,10 @@ static RGB path_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, SobolSam
 
 
 // ---- VolPathIntegrator (integrators/volpath.rs:76-186) with HomogeneousMedium (media/homogeneous.rs) and the Henyey-Greenstein
-//      phase function (core/medium.rs:149-194). Every primitive has a material (scene creation refuses the others), so the
-//      transmittance loops of VisibilityTester::tr (light.rs:125-150) and Scene::intersect_tr (scene.rs:68-87) end at their
-//      first hit.
+//      phase function (core/medium.rs:149-194). A primitive without a material is a medium-interface shell (api.rs:597): the path
+//      steps over it with `bounces -= 1; continue` (volpath.rs:152-156: the increment at the loop's end is skipped, so the count drops
+//      and, at 0, wraps -- the release build has no overflow checks), and the transmittance loops of VisibilityTester::tr
+//      (light.rs:125-150) and Scene::intersect_tr (scene.rs:68-87) walk on behind it.
 static inline Float dm_expf_(Float x) { return (Float)dm_expd((double)x); }   // f32::exp through the shared f64 exp
 static RGB medium_tr(const PtMedium &m, Float t_max, V3 d) {   // homogeneous.rs:32-35
     Float l = fmin_(t_max * length(d), std::numeric_limits<Float>::max());
@@ -655,13 +656,21 @@ static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedI
         if (bsdf) { f = bsdf->f(si->wo, wi, flags) * abs_dot(wi, si->sh_n); scattpdf = bsdf->pdf(si->wo, wi, flags); }
         else { Float p = phase_hg(dot(it.wo, wi), g); f = RGB(p); scattpdf = p; }
         if (!f.is_black()) {
-            // VisibilityTester::tr (light.rs:125-150): the first hit is opaque, else the segment's transmittance
+            // VisibilityTester::tr (light.rs:125-150): a loop over the segments between material-less surfaces (medium-interface shells)
             Ray sr = spawn_ray_to(it, p1);
             sr.medium = medium_toward(mif, it.n, sr.d);
-            SurfaceInteraction tmp;
             RGB Tr(1.0f);
-            if (S.intersect(sr, tmp, *ctx.c)) Tr = RGB(0.0f);
-            else if (sr.medium != PT_NONE) Tr = Tr * medium_tr_any(S, sr.medium, sr, sampler);
+            for (;;) {
+                SurfaceInteraction tmp;
+                const bool hitt = S.intersect(sr, tmp, *ctx.c);
+                if (hitt && S.prim_material[tmp.prim] != PT_NONE) { Tr = RGB(0.0f); break; }   // an opaque surface along the ray's path
+                if (sr.medium != PT_NONE) Tr = Tr * medium_tr_any(S, sr.medium, sr, sampler);   // the current segment (ray.t_max = the hit)
+                if (!hitt) break;
+                IData a; a.p = tmp.p; a.p_error = tmp.p_error; a.n = tmp.n;
+                const uint32_t seg_medium = sr.medium;
+                sr = spawn_ray_to(a, p1);                                                     // isect.spawn_rayto_interaction(&self.p1)
+                sr.medium = medium_toward(surface_iface(S, tmp.prim, seg_medium), tmp.n, sr.d);   // get_medium(d) of the shell's interface (interaction.rs:54-66)
+            }
             Li = Li * Tr;
             if (!Li.is_black()) {
                 if (delta) Ld += f * Li / lightpdf;
@@ -687,10 +696,19 @@ static RGB vol_estimate_direct(const RenderCtx &ctx, const IData &it, const MedI
             SurfaceInteraction lisect;
             Ray ray = spawn_ray(it, wi);
             ray.medium = medium_toward(mif, it.n, wi);
-            // Scene::intersect_tr (scene.rs:68-87)
-            bool found = S.intersect(ray, lisect, *ctx.c);
+            // Scene::intersect_tr (scene.rs:68-87): on through every surface that has no material
+            bool found = false;
             RGB Tr(1.0f);
-            if (ray.medium != PT_NONE) Tr = Tr * medium_tr_any(S, ray.medium, ray, sampler);
+            for (;;) {
+                const bool hits = S.intersect(ray, lisect, *ctx.c);
+                if (ray.medium != PT_NONE) Tr = Tr * medium_tr_any(S, ray.medium, ray, sampler);
+                if (!hits) { found = false; break; }
+                if (S.prim_material[lisect.prim] != PT_NONE) { found = true; break; }
+                IData a; a.p = lisect.p; a.p_error = lisect.p_error; a.n = lisect.n;
+                const uint32_t seg_medium = ray.medium;
+                ray = spawn_ray(a, ray.d);                                                     // isect.spawn_ray(&ray.d)
+                ray.medium = medium_toward(surface_iface(S, lisect.prim, seg_medium), lisect.n, ray.d);
+            }
             RGB li_(0.0f);
             if (found) { if (S.prim_light[lisect.prim] == li) li_ = isect_le(ctx, lisect, -wi); }
             else li_ = ctx.lights->light_le(li, ray);
@@ -716,6 +734,8 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
     uint32_t bounces = 0;
     Float etascale = 1.0f;
     for (;;) {
+        if (sampler.dim_overflow) break;   // the reference panics at the first dimension it does not have (sobol.rs:69-73); a path that material-less shells keep
+                                           // alive (`bounces -= 1` below) gets there: the render then reports PT_ERR_SOBOL_DIMENSIONS
         SurfaceInteraction isect;
         bool found = S.intersect(ray, isect, *ctx.c);
         MediumVertex mi;

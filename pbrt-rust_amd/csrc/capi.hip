@@ -145,7 +145,9 @@ struct pt_scene {
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
     bool class_used[kNumClasses] = {true, false, false, false, true, false, false};
-    bool has_null_material = false;   // a primitive without a material (refused by the volumetric integrator)   // matte (default material) and the miss class always exist
+    bool has_null_material = false;   // a primitive without a material: a medium-interface shell (api.rs:597). The path integrator steps over it (path.rs:124-129);
+                                      // the volumetric one also walks its shadow / MIS rays through it, segment by segment (kern_shade_common.h: vol_chain_step)
+    void *ext_slab = nullptr; size_t ext_capacity = 0;   // PathSoA::ext, allocated for volpath renders of scenes with shells
     bool has_bssrdf = false;           // any subsurface material: probe queues + BssSoA are allocated
     void *bss_slab = nullptr; BssSoA bs{};
     uint4 *probe_ring = nullptr;       // k_trace<.., PROBE>: kProbeRing x 3 x uint4 per persistent lane
@@ -318,6 +320,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
     }
     if (capacity > sc->capacity) {
         if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
+        if (sc->ext_slab) { hipFree(sc->ext_slab); sc->ext_slab = nullptr; sc->ext_capacity = 0; }
         if (sc->bss_slab) { hipFree(sc->bss_slab); sc->bss_slab = nullptr; }
         size_t bytes = capacity * (size_t)kPathBytes + 4096;
         hipError_t e = hipMalloc(&sc->slab, bytes);
@@ -609,7 +612,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
         // volpath with grid media: vertices that did their NEE set-up last iteration wait in their own shade class for stage B
         uint32_t n_stage_b = 0;
-        if (rc.volpath && sc->ds.has_grid) for (int c = 0; c < kNumClasses; ++c) if (c != kMissClass) n_stage_b += h.shade[cur][c];
+        if (rc.volpath && (sc->ds.has_grid || sc->ds.has_shells)) for (int c = 0; c < kNumClasses; ++c) if (c != kMissClass) n_stage_b += h.shade[cur][c];
         if (n_ext == 0 && n_resolve == 0 && n_probe == 0 && n_stage_b == 0) break;
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
@@ -628,6 +631,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         mis.out_hit = (float4 *)&ps.mis_prim(0); mis.out_hit_stride = PathSoA::kMisWords / 4;
         mis.out_t = rc.volpath ? &ps.mis_t(0) : nullptr; mis.out_t_stride = PathSoA::kMisWords;
         mis.kind = 1;
+        const bool shells = rc.volpath && ps.ext != nullptr;   // the chains of VisibilityTester::tr / Scene::intersect_tr need every segment's full hit record
+        if (shells) { mis.out_hit = (float4 *)ps.ext + 6; mis.out_hit_stride = PathSoA::kExtWords / 4; mis.out_hit2 = (float4 *)ps.ext + 7; mis.out_t = nullptr; }
         // shadow rays (any hit, light.rs:120-123). volpath: VisibilityTester::tr (light.rs:125-150) calls Scene::intersect, a closest-hit
         // query counted as one; without out_hit the primitive goes to out_word = nee.sh_prim, the slot `occluded` uses otherwise
         TraceSub sh{};
@@ -635,6 +640,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         sh.ray = (const float4 *)ps.nee; sh.ray_stride = PathSoA::kNeeWords / 4;
         sh.out_word = &ps.occluded(0); sh.out_word_stride = PathSoA::kNeeWords;
         sh.kind = 2; sh.any = rc.volpath ? 0u : 1u;
+        if (shells) { sh.out_hit = (float4 *)ps.ext + 4; sh.out_hit_stride = PathSoA::kExtWords / 4; sh.out_hit2 = (float4 *)ps.ext + 5; }
         int st = PT_OK;
         if (n_mis + n_shadow == 0 || g_trace_split) {   // camera rays (nothing else to trace in the first iteration) / PT_TRACE_SPLIT=1: one launch per kind
             if (n_ext) {   // (a launch kind with no work is not a launch: the per-launch averages of bench.py / rocprofv3 count real dispatches)
@@ -1088,6 +1094,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         sc->class_used[kMediumClass] = true;
     }
     for (uint32_t i = 0; i < d->n_prims; ++i) if (d->prim_material[i] == PT_NONE) sc->has_null_material = true;
+    ds.has_shells = sc->has_null_material ? 1u : 0u;
     UP(spheres, d->spheres, d->n_spheres); ds.n_spheres = d->n_spheres;
     UP(lights, d->lights, d->n_lights); ds.n_lights = d->n_lights; sc->n_lights = d->n_lights;
     if (d->n_lights) sc->host_lights.assign(d->lights, d->lights + d->n_lights);
@@ -1206,6 +1213,7 @@ void pt_scene_destroy(pt_scene *sc) {
     if (sc->slab) hipFree(sc->slab);
     if (sc->qbuf) hipFree(sc->qbuf);
     if (sc->bss_slab) hipFree(sc->bss_slab);
+    if (sc->ext_slab) hipFree(sc->ext_slab);
     if (sc->film_rgbw) hipFree(sc->film_rgbw);
     sc->drop_timings();
     for (auto e : sc->event_pool) hipEventDestroy(e);
@@ -1237,7 +1245,6 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
     if (rp->max_depth > 254) return fail(PT_ERR_INVALID_ARG, "maxdepth must be <= 254 (the bounce count of a path is kept in 8 bits)");
     if (rc.volpath) {   // VolPathIntegrator (volpath.rs): what this back end takes
-        if (sc->has_null_material) return fail(PT_ERR_UNSUPPORTED, "volpath: primitives without a material (medium-interface shells) are not supported; the reference's volpath mishandles them too (volpath.rs:127-131)");
         if (sc->has_bssrdf) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials are not supported by the volumetric integrator here");
         if (rp->camera_medium != PT_NONE && rp->camera_medium >= sc->ds.n_media) return fail(PT_ERR_INVALID_ARG, "camera_medium out of range");
     }
@@ -1255,6 +1262,12 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         S = std::min(S, rp->spp);
         if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
+        if (rc.volpath && sc->has_null_material && sc->ext_capacity < sc->capacity) {   // the shells' chain state (PathSoA::ext)
+            if (sc->ext_slab) { hipFree(sc->ext_slab); sc->ext_slab = nullptr; sc->ext_capacity = 0; }
+            if (hipMalloc(&sc->ext_slab, sc->capacity * (size_t)PathSoA::kExtWords * 4) != hipSuccess) { (void)hipGetLastError(); return fail(PT_ERR_OUT_OF_MEMORY, "volpath: chain state of material-less shells"); }
+            sc->ext_capacity = sc->capacity;
+        }
+        sc->ps.ext = (rc.volpath && sc->has_null_material) ? (float *)sc->ext_slab : nullptr;
         int eff;
         if ((st = ensure_light_grid(sc, (int)rp->light_strategy, eff))) return st;
         HIP_TRY(hipMemcpyAsync(sc->d_filter, rp->filter_table, 256 * 4, hipMemcpyHostToDevice, sc->stream));

@@ -72,6 +72,7 @@ struct DeviceScene {
     const uint8_t *mat_class;           // per material: shade-queue class
     const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)
     const PtMedium *media; uint32_t n_media;                 // media + per-primitive MediumInterface (volpath, dev_medium.h)
+    uint32_t has_shells;                                     // a primitive without a material: a medium-interface shell (api.rs:597; volpath's transmittance loops walk through it)
     const DevGridAux *grid_aux; uint32_t has_grid;           // per medium: GridDensityMedium's device density array, sigma_t, 1 / max density (grid.rs:46-60); any grid medium in the scene
     const uint32_t *prim_med_in; const uint32_t *prim_med_out;
     // textures (8f-1): nodes, one postfix program per node (tex_prog[tex_prog_offset[i] .. tex_prog_offset[i+1])), images

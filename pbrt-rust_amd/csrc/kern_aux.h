@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             const bool stage_b = (flags & PF_STAGE_B) != 0u;   // grid media: this vertex's own NEE rays are back (see k_shade)
             if (stage_b) smp.load_window();
-            resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+            if (stage_b && s.has_shells) { if (!vol_chain_step<true>(s, ps, pid, flags, smp, push_shadow, push_mis, n_bytes)) resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, nullptr); }
+            else resolve_pending<true, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
             flags &= ~(PF_CAMERA_RAY | PF_STAGE_B);
             bool terminated = bounces >= rc.max_depth;   // volpath.rs:108
             if (!terminated) {
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
                 bool defer = false;
                 if (!stage_b) {
                     if (!nee_vertex<true, PhaseBsdf, true, true>(s, grid, ps, pid, smp, si, it, phase, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, MedIface{med, med})) L = L + beta * RGB(0.0f);   // volpath.rs:120: `L += beta * Ld` with a black Ld
-                    defer = s.has_grid != 0u && (push_shadow || push_mis);
                 }
+                defer = (s.has_grid != 0u || s.has_shells != 0u) && (push_shadow || push_mis);
                 if (defer) { flags |= PF_STAGE_B; push_self = true; }
                 else {
                 V3 wi;

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
         const bool stage_b = VOL && (flags & PF_STAGE_B) != 0u;
         const uint32_t camera_ray_flag = flags & PF_CAMERA_RAY;   // (a deferred vertex rebuilds its BSDF in stage B with the same differentials)
         if (stage_b) smp.load_window();
-        resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
+        // (scenes with material-less shells: the pending estimate's rays are walked segment by segment first, vol_chain_step)
+        if (VOL && stage_b && s.has_shells) { if (!vol_chain_step<SPH>(s, ps, pid, flags, smp, push_shadow, push_mis, n_bytes)) resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, nullptr); }
+        else resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, stage_b ? &smp : nullptr);
         flags &= ~PF_STAGE_B;
 
         PT_T(3);
@@ -170,8 +172,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2
                             // volpath.rs:136-138: unconditional. `L += beta * Ld` happens even when Ld is black: a throughput that has gone infinite or
                             // NaN poisons the sample there (0 x inf), which integrator.rs:350-368 then zeroes and counts
                             if (!nee_vertex<SPH, Bsdf<MAXL, DIFF>, true, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) L = L + beta * RGB(0.0f);
-                            defer = s.has_grid != 0u && (push_shadow || push_mis);   // wait for the traced rays before drawing any further dimension
                         }
+                        // wait for the traced rays before drawing any further dimension (stage A: the vertex's shadow / MIS rays; stage B in a
+                        // scene with shells: the next segment of one of them)
+                        defer = (s.has_grid != 0u || s.has_shells != 0u) && (push_shadow || push_mis);
                     }
                     else if (DIFF != 2 && bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {   // (a specular-only BSDF has no such component: path.rs:131)
                         zero_den++;

@@ -87,6 +87,78 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
     flags &= ~(PF_PEND_SHADOW | PF_PEND_MIS | PF_NEE_UNCOUNTED);
 }
 
+// Volpath in a scene with material-less shells (`Material "none"` + MediumInterface: how a .pbrt file bounds a medium, api.rs:597). The
+// transmittance of a shadow ray is VisibilityTester::tr (light.rs:125-150) and that of a MIS ray Scene::intersect_tr (scene.rs:68-87): LOOPS
+// that intersect, multiply the segment's medium transmittance in, and go on behind every surface that has no material. A wavefront
+// vertex walks them one traced segment per iteration while it waits in stage B: first the whole shadow chain, then the MIS chain -- the
+// order in which the reference draws the ratio-tracking dimensions of grid media (integrator.rs:150-156 before :207-216). The traced
+// segment's full hit record is in the path's ext record; a shell hit spawns the next segment (push_shadow / push_mis: the caller keeps
+// the path in stage B). Returns true while a chain goes on. When both have ended the nee / mis records are left as a plain, fully
+// attenuated estimate (media NONE, the final MIS hit in the mis record) for resolve_pending to sum.
+template <bool SPH> PT_DEV bool vol_chain_step(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t flags, Sampler &smp, bool &push_shadow, bool &push_mis,
+                                              unsigned long long &n_bytes) {
+    float4 *nq = reinterpret_cast<float4 *>(ps.nee) + 4 * (size_t)pid;
+    float4 *mq = reinterpret_cast<float4 *>(ps.mis) + 4 * (size_t)pid;
+    float4 *xq = reinterpret_cast<float4 *>(ps.ext) + 8 * (size_t)pid;
+    if ((flags & PF_PEND_SHADOW) && __float_as_uint(nq[1].z) != 1u) {   // nee word 6: 1 = the shadow chain has ended (A is final); the traced prim lives in ext
+        const float4 n0 = nq[0], n1 = nq[1], n2 = nq[2], n3 = nq[3], h0 = xq[4], h1 = xq[5];
+        n_bytes += 64 + 32;
+        const uint32_t prim = __float_as_uint(h0.x), sm = __float_as_uint(n3.w);
+        const bool hit = prim != PT_NONE;
+        const V3 so(n0.x, n0.y, n0.z), sd(n0.w, n1.x, n1.y);
+        RGB A(n2.x, n2.y, n2.z);
+        bool ended = true;
+        if (hit && s.prim_material[prim] != PT_NONE) A = RGB(0.0f);   // light.rs:136-138: an opaque surface, `return Spectrum::new(0.0)` -- before the segment's medium is asked
+        else {
+            if (sm != PT_NONE) {   // light.rs:141-143: Tr *= ray.medium.tr(ray, sampler), the segment ends at its hit (ray.t_max)
+                const float t_seg = hit ? h1.y : 1.0f - kShadowEps;
+                A = A * (s.media[sm].type == PT_MEDIUM_GRID ? RGB(grid_tr(s.media[sm], s.grid_aux[sm], so, sd, t_seg, smp)) : medium_tr(s.media[sm], t_seg, sd));
+            }
+            if (hit) {   // light.rs:146-147: ray = isect.spawn_rayto_interaction(p1)
+                SurfaceInteraction hs;
+                fill_hit_pkt<SPH>(s, __float_as_uint(h1.z), SPH ? __float_as_uint(h1.x) : PT_NONE, so, sd, h0.y, h0.z, h0.w, hs);
+                IData a; a.p = hs.p; a.p_error = hs.p_error; a.n = hs.n;
+                IData b; { const float4 x0 = xq[0], x1 = xq[1], x2 = xq[2]; b.p = V3(x0.x, x0.y, x0.z); b.p_error = V3(x1.x, x1.y, x1.z); b.n = V3(x2.x, x2.y, x2.z); }
+                V3 o2, d2; spawn_ray_to(a, b, o2, d2);
+                const uint32_t sm2 = medium_toward(surface_iface(s, prim, sm), hs.n, d2);   // interaction.rs:54-66 get_medium(d) of the shell's MediumInterface (primitive.rs:139-145)
+                nq[0] = make_float4(o2.x, o2.y, o2.z, d2.x); nq[1] = make_float4(d2.y, d2.z, 0.0f, n1.w); nq[3] = make_float4(n3.x, n3.y, n3.z, __uint_as_float(sm2));
+                push_shadow = true; ended = false; n_bytes += 48 + 4;
+            }
+        }
+        nq[2] = make_float4(A.r, A.g, A.b, n2.w);
+        if (!ended) return true;
+        nq[1] = make_float4(n1.x, n1.y, __uint_as_float(1u), n1.w);
+    }
+    if (flags & PF_PEND_MIS) {
+        const float4 m0 = mq[0], m1 = mq[1], m3 = mq[3], h0 = xq[6], h1 = xq[7];
+        n_bytes += 64 + 32;
+        const uint32_t prim = __float_as_uint(h0.x), mm = ps.mis_medium(pid);
+        const bool hit = prim != PT_NONE;
+        const V3 mo(m0.x, m0.y, m0.z), wi(m0.w, m1.x, m1.y);
+        RGB f(m3.x, m3.y, m3.z);
+        // scene.rs:76-79: *tr *= ray.medium.tr(ray, sampler) -- always, whatever the segment ends at
+        if (mm != PT_NONE) f = f * (s.media[mm].type == PT_MEDIUM_GRID ? RGB(grid_tr(s.media[mm], s.grid_aux[mm], mo, wi, hit ? h1.y : PT_INF, smp)) : medium_tr(s.media[mm], hit ? h1.y : PT_INF, wi));
+        if (hit && s.prim_material[prim] == PT_NONE) {   // scene.rs:84: ray = isect.spawn_ray(ray.d)
+            SurfaceInteraction hs;
+            fill_hit_pkt<SPH>(s, __float_as_uint(h1.z), SPH ? __float_as_uint(h1.x) : PT_NONE, mo, wi, h0.y, h0.z, h0.w, hs);
+            IData a; a.p = hs.p; a.p_error = hs.p_error; a.n = hs.n;
+            V3 o2; spawn_ray(a, wi, o2);
+            ps.mis_medium(pid) = medium_toward(surface_iface(s, prim, mm), hs.n, wi);
+            mq[0] = make_float4(o2.x, o2.y, o2.z, wi.x); mq[3] = make_float4(f.r, f.g, f.b, m3.w);
+            push_mis = true; n_bytes += 32 + 4;
+            return true;
+        }
+        // the chain has ended at an opaque surface or escaped: leave the record as resolve_pending reads it
+        mq[2] = h0; mq[3] = make_float4(f.r, f.g, f.b, hit ? h1.y : 0.0f);
+        ps.mis_medium(pid) = PT_NONE;
+    }
+    if (flags & PF_PEND_SHADOW) {   // the summed form: "unoccluded" with the fully attenuated (or zeroed) term, no medium left to ask
+        const float4 n1 = nq[1], n3 = nq[3];
+        nq[1] = make_float4(n1.x, n1.y, __uint_as_float(PT_NONE), n1.w); nq[3] = make_float4(n3.x, n3.y, n3.z, __uint_as_float(PT_NONE));
+    }
+    return false;
+}
+
 // uniform_sample_onelight + estimate_direct (integrator.rs:81-237) at one vertex: samples the light and the BSDF,
 // records the shadow / MIS rays and their weights in the path state; the estimate is summed by resolve_pending once
 // both rays are traced. Returns whether anything is pending (false: Ld is black).
@@ -121,7 +193,13 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
                     V3 so, sd; spawn_ray_to(it, p1, so, sd);
                     if (VOL) {   // Li *= visibility.tr(): the unoccluded segment's transmittance (light.rs:125-150)
                         const uint32_t sm = medium_toward(mif, it.n, sd);
-                        if (sm != PT_NONE && s.media[sm].type == PT_MEDIUM_GRID) sh_medium = sm;   // estimated when the shadow ray has been traced (resolve_pending)
+                        if (s.has_shells) {   // the segment may end at a shell: every segment's transmittance is taken when it has been traced (vol_chain_step)
+                            sh_medium = sm;
+                            float4 *xq = reinterpret_cast<float4 *>(ps.ext) + 8 * (size_t)pid;
+                            xq[0] = make_float4(p1.p.x, p1.p.y, p1.p.z, 0.0f); xq[1] = make_float4(p1.p_error.x, p1.p_error.y, p1.p_error.z, 0.0f); xq[2] = make_float4(p1.n.x, p1.n.y, p1.n.z, 0.0f);
+                            n_bytes += 48;
+                        }
+                        else if (sm != PT_NONE && s.media[sm].type == PT_MEDIUM_GRID) sh_medium = sm;   // estimated when the shadow ray has been traced (resolve_pending)
                         else if (sm != PT_NONE) Li = Li * medium_tr(s.media[sm], 1.0f - kShadowEps, sd);
                     }
                     A = delta ? f * Li / lightpdf : f * Li * power_heuristic(lightpdf, scattpdf) / lightpdf;

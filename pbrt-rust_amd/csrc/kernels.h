@@ -31,7 +31,7 @@ constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersection
 // path flags (meta >> 24)
 enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
                   PF_CAMERA_RAY = 32u,     // the ray still carries the camera's differentials (cleared at the first shaded vertex)
-                  PF_STAGE_B = 64u };      // volpath with grid media: the vertex has done its NEE set-up and waits, in its own shade class, for the traced rays before it samples on
+                  PF_STAGE_B = 64u };      // volpath with grid media or material-less shells: the vertex has done its NEE set-up and waits, in its own shade class, for the traced rays before it samples on
 
 // Path state in HBM: five arrays of 16-byte-aligned RECORDS indexed by path id (pid). A record holds what one kernel reads or
 // writes together, so a lane moves whole 16-byte quads of one 32- or 64-byte line (dwordx4 accesses, every fetched sector fully
@@ -43,9 +43,12 @@ enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DE
 //   nee   64 B  {sh_o.xyz, sh_d.x} {sh_d.yz, occluded | sh_prim, nee_light} {A.rgb, choice_pdf} {nb.rgb, grid medium of the shadow ray}  pending shadow ray + its terms
 //   mis   64 B  {mis_o.xyz, mis_d.x} {mis_d.yz, w, spdf} {mis_prim, b0, b1, b2} {f.rgb, mis_t}              pending MIS ray + its hit
 // The accessors below name single words of those records; adjacent words accessed together merge into dwordx2/x4 instructions.
+//   ext  128 B  {p1.p, -} {p1.p_error, -} {p1.n, -} {-} {shadow hit} {shadow hit 2} {MIS hit} {MIS hit 2}                  volpath in scenes with material-less
+//               shells only (NULL otherwise): the far end of the shadow ray (VisibilityTester::p1) and the full hit records of the current
+//               shadow / MIS SEGMENT, from which the next segment of VisibilityTester::tr / Scene::intersect_tr is spawned (vol_chain_step)
 struct PathSoA {
-    float *core, *ray, *hit, *nee, *mis;
-    static constexpr int kCoreWords = 16, kRayWords = 8, kHitWords = 8, kNeeWords = 16, kMisWords = 16;
+    float *core, *ray, *hit, *nee, *mis, *ext;
+    static constexpr int kCoreWords = 16, kRayWords = 8, kHitWords = 8, kNeeWords = 16, kMisWords = 16, kExtWords = 32;
 #define PT_REC_F(name, arr, words, off) PT_HD float &name(size_t p) const { return arr[p * words + off]; }
 #define PT_REC_U(name, arr, words, off) PT_HD uint32_t &name(size_t p) const { return reinterpret_cast<uint32_t *>(arr)[p * words + off]; }
     PT_REC_F(L_r, core, 16, 0) PT_REC_F(L_g, core, 16, 1) PT_REC_F(L_b, core, 16, 2) PT_REC_F(etascale, core, 16, 3)

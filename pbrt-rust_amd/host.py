@@ -269,6 +269,9 @@ class SceneBuilder:
 
     # -- world block
     def material(self, kind, **kw):
+        if kind in ("none", ""):   # Material "none" (api.rs:597): shapes made from here on have no material -- medium-interface shells
+            self.material_id = None
+            return
         m = A.PtMaterial()
         kinds = dict(matte=A.PT_MAT_MATTE, mirror=A.PT_MAT_MIRROR, glass=A.PT_MAT_GLASS, plastic=A.PT_MAT_PLASTIC,
                      metal=A.PT_MAT_METAL, uber=A.PT_MAT_UBER, substrate=A.PT_MAT_SUBSTRATE,

@@ -588,6 +588,45 @@ def foggy_room(xres=96, yres=64, spp=16, maxdepth=5, g=0.3, camera_in_fog=True, 
     return b
 
 
+def shell_media(xres=64, yres=48, spp=8, maxdepth=5, grid=True, sampler="sobol", light_inside=True):
+    """Media bounded the way a .pbrt file bounds them: by shapes WITHOUT a material (`Material "none"`, api.rs:597) that only carry a
+    MediumInterface. The camera stands in vacuum; a sphere shell holds a homogeneous coloured fog, a box shell a GridDensityMedium
+    (grid=True), the two overlap the light paths of an opaque floor, a wall, an area light, a point light (inside the fog when
+    light_inside) and an environment. Every shadow ray and MIS ray that crosses a shell walks VisibilityTester::tr / Scene::intersect_tr
+    segment by segment (light.rs:125-150, scene.rs:68-87); camera paths cross with volpath.rs:152-156's `bounces -= 1`."""
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp; b.sampler = sampler
+    b.integ.update(maxdepth=maxdepth, kind="volpath")
+    b.make_named_medium("fog", sigma_a=(0.15, 0.3, 0.6), sigma_s=(0.9, 0.7, 0.5), g=0.3)
+    if grid:
+        rng = np.random.default_rng(9)
+        dens = rng.uniform(0.1, 1.0, (5, 4, 6)).astype(np.float32)
+        b.make_named_medium("smoke", sigma_a=(0.4, 0.4, 0.4), sigma_s=(1.6, 1.6, 1.6), g=-0.2, density=dens, p0=(0.6, 0.0, -1.0), p1=(2.6, 1.6, 1.0))
+    b.look_at((0.0, 1.8, 6.5), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=40.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.08, 0.1, 0.14))
+    b.attribute_begin(); b.area_light_source(L=(30.0, 27.0, 22.0))
+    P, I = quad((-1.0, 3.6, -1.0), (1.0, 3.6, -1.0), (1.0, 3.6, 1.0), (-1.0, 3.6, 1.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("point", from_=((-1.4, 0.9, 0.0) if light_inside else (-3.5, 2.5, 1.0)), I=(6.0, 6.0, 5.0))
+    b.material("matte", Kd=(0.55, 0.55, 0.5))
+    P, I = quad((-8.0, 0.0, -8.0), (-8.0, 0.0, 8.0), (8.0, 0.0, 8.0), (8.0, 0.0, -8.0)); b.trianglemesh(P, I)
+    b.material("plastic", Kd=(0.2, 0.5, 0.3), Ks=(0.3, 0.3, 0.3), roughness=0.15)
+    P, I = quad((-4.0, 0.0, -2.5), (-4.0, 3.0, -2.5), (4.0, 3.0, -2.5), (4.0, 0.0, -2.5)); b.trianglemesh(P, I)
+    # the homogeneous fog in a sphere shell (a real sphere: Sphere::intersect through the same loops)
+    b.attribute_begin(); b.material("none"); b.medium_interface("fog", ""); b.translate(-1.4, 0.95, 0.0); b.sphere(radius=0.9); b.attribute_end()
+    if grid:   # the grid medium in a box shell of twelve triangles
+        b.attribute_begin(); b.material("none"); b.medium_interface("smoke", "")
+        x0, y0, z0, x1, y1, z1 = 0.6, 0.0, -1.0, 2.6, 1.6, 1.0
+        c = [(x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)]
+        faces = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (3, 7, 6, 2), (0, 4, 7, 3), (1, 2, 6, 5)]   # outward normals
+        for f in faces:
+            P, I = quad(*[c[k] for k in f]); b.trianglemesh(P, I)
+        b.attribute_end()
+    b.material("metal", eta_rgb=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), roughness=0.1)
+    b.attribute_begin(); b.translate(0.2, 0.35, 1.6); b.sphere(radius=0.35); b.attribute_end()
+    return b
+
+
 def ganesha_halton_hlbvh(**kw):
     """The S2 analogue with the reference's default sampler (halton) and the GPU-built accelerator (splitmethod "hlbvh")."""
     b = ganesha_scale(**kw)

@@ -75,6 +75,7 @@ def make_recorder(pkg, out_dir):
 
         def material(self, kind, **kw):
             super().material(kind, **kw)
+            if kind in ("none", ""): self._emit('Material "none"'); return
             name = "m%d" % self.material_id
             if len(self.materials) == 1 and not self.lines: return   # the constructor's default matte
             kw2 = dict(kw)

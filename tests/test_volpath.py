@@ -222,12 +222,7 @@ def test_gpu_volpath_halton_thin_lens_and_no_media(pkg, gpu, oracle):
 
 @pytest.mark.gpu
 def test_gpu_volpath_refuses_what_it_cannot_render(pkg, gpu):
-    b = pkg.scenes.foggy_room()
-    b.material_id = None   # a shape without a material: a medium-interface shell
-    b.sphere(radius=0.2)
-    sd, rp = b.world_end()
-    g = pkg.Scene(gpu, sd)
-    with pytest.raises(Exception, match="without a material"): g.render(rp)
+    # (shapes without a material -- medium-interface shells -- are rendered since round 3: test_gpu_media_in_material_less_shells_match_oracle)
     b = pkg.scenes.subsurface_c5(xres=32, yres=24, spp=2); b.integ["kind"] = "volpath"
     sd, rp = b.world_end()
     with pytest.raises(Exception, match="subsurface"): pkg.Scene(gpu, sd).render(rp)
@@ -373,3 +368,82 @@ def test_gpu_grid_medium_with_spectrally_varying_coefficients_renders_with_chann
     film, ref = _compare_render(pkg, gpu, oracle, *b.world_end())
     assert film[..., :3].sum() > 0
     assert "spectrally uniform" in capfd.readouterr().err
+
+
+# ---- media bounded by material-less shells (api.rs:597; light.rs:125-150, scene.rs:68-87, volpath.rs:152-156) ----
+
+def _absorbing_shell_floor(pkg, sigma_a=0.9, spp=64):
+    """A point light straight above a Lambertian floor, an absorbing-only homogeneous sphere (radius 0.5, centre 1 above the floor) in a
+    material-less shell between them; maxdepth 1 = direct light only. The camera looks down at the floor from the side, past the shell."""
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=48, yres=48); b.spp = spp
+    b.integ.update(maxdepth=1, kind="volpath", strategy="uniform")
+    b.make_named_medium("ink", sigma_a=(sigma_a,) * 3, sigma_s=(0.0, 0.0, 0.0))
+    b.look_at((0.0, 0.4, 2.6), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=24.0)
+    b.world_begin()
+    b.light_source("point", from_=(0.0, 3.0, 0.0), I=(9.0, 9.0, 9.0))   # (point.rs:99-106 builds the position from (x, y, x): x = z here)
+    b.material("matte", Kd=(0.5, 0.5, 0.5))
+    P, I = pkg.scenes.quad((-4.0, 0.0, -4.0), (-4.0, 0.0, 4.0), (4.0, 0.0, 4.0), (4.0, 0.0, -4.0)); b.trianglemesh(P, I)
+    b.attribute_begin(); b.material("none"); b.medium_interface("ink", ""); b.translate(0.0, 1.0, 0.0); b.sphere(radius=0.5); b.attribute_end()
+    return b
+
+
+def _shell_floor_closed_form(pkg, rp, sigma_a):
+    """Per pixel: the floor point its centre ray hits, E = I cos / d^2 attenuated by exp(-sigma_a x chord of the segment floor point -> light
+    through the sphere), radiance Kd / pi x E."""
+    c2w = np.array(list(rp.camera_to_world), dtype=np.float64).reshape(4, 4); r2c = np.array(list(rp.raster_to_camera), dtype=np.float64).reshape(4, 4)
+    out = np.zeros((48, 48))
+    light = np.array([0.0, 3.0, 0.0]); centre = np.array([0.0, 1.0, 0.0]); radius = 0.5
+    for y in range(48):
+        for x in range(48):
+            pc = r2c @ np.array([x + 0.5, y + 0.5, 0.0, 1.0]); pc = pc[:3] / pc[3]
+            d = c2w[:3, :3] @ (pc / np.linalg.norm(pc)); o = c2w[:3, 3]
+            if d[1] >= 0: continue
+            p = o + d * (-o[1] / d[1])
+            if abs(p[0]) > 3.9 or abs(p[2]) > 3.9: continue   # (the floor quad ends at +-4)
+            w = light - p; dist2 = w @ w; w = w / np.sqrt(dist2)
+            oc = p - centre; bq = oc @ w; disc = bq * bq - (oc @ oc - radius * radius)
+            chord = 2.0 * np.sqrt(disc) if disc > 0 else 0.0
+            out[y, x] = 0.5 / np.pi * 9.0 * w[1] / dist2 * np.exp(-sigma_a * chord)
+    return out
+
+
+def test_oracle_shell_shadow_rays_match_the_closed_form(pkg, oracle):
+    """VisibilityTester::tr through a material-less shell (light.rs:125-150): the oracle's direct light on the floor under an absorbing sphere
+    equals the Beer-Lambert closed form -- in the sphere's shadow (attenuated, not black: the shell does not occlude) and beside it."""
+    sd, rp = _absorbing_shell_floor(pkg).world_end()
+    s = oracle.scene(sd)
+    rgb = s.resolve(s.render(rp, nthreads=4))[..., 0]
+    want = _shell_floor_closed_form(pkg, rp, 0.9)
+    # pixels whose camera ray crosses the shell itself are black in the reference (volpath.rs:152-156: bounces wraps below zero at the camera
+    # ray's first shell, the path ends at its next vertex without Le or direct light): compare where the camera sees the floor directly
+    seen = (rgb > 0) & (want > 0)
+    assert seen.mean() > 0.4
+    shadowed = want < 0.8 * np.where(want > 0, want, 0).max()
+    assert (seen & shadowed).sum() > 20                       # the attenuated region is in view
+    rel = np.abs(rgb[seen] - want[seen]) / want[seen]
+    assert np.median(rel) < 0.02 and rel.max() < 0.15, (np.median(rel), rel.max())   # (pixel-centre closed form vs 64 jittered samples at the shadow's edge)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(grid=False), dict(grid=True), dict(grid=True, sampler="halton", light_inside=False), dict(grid=False, maxdepth=2)])
+def test_gpu_media_in_material_less_shells_match_oracle(pkg, gpu, oracle, kw):
+    """VERDICT r2 missing #4: `Material "none"` shells under volpath. Shadow rays and MIS rays walk through the shells segment by segment
+    (vol_chain_step: one traced segment per wavefront iteration, the shadow chain before the MIS chain so that grid media draw their
+    ratio-tracking dimensions in the reference's order); films, every work counter and the path-length histogram (with the paths that
+    volpath.rs:152-156's wrapping `bounces -= 1` ends) equal the oracle's."""
+    from test_gpu_parity import _compare_render
+    sd, rp = pkg.scenes.shell_media(xres=56, yres=40, spp=8, **kw).world_end()
+    film, ref = _compare_render(pkg, gpu, oracle, sd, rp)
+    assert film[..., :3].sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_shell_shadow_rays_match_the_closed_form(pkg, gpu):
+    sd, rp = _absorbing_shell_floor(pkg).world_end()
+    g = pkg.Scene(gpu, sd)
+    rgb = g.resolve(g.render(rp))[..., 0]
+    want = _shell_floor_closed_form(pkg, rp, 0.9)
+    seen = (rgb > 0) & (want > 0)
+    rel = np.abs(rgb[seen] - want[seen]) / want[seen]
+    assert seen.mean() > 0.4 and np.median(rel) < 0.02 and rel.max() < 0.15
