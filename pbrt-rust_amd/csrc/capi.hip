@@ -602,13 +602,18 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     sc->end();
     int cur = 0;
     static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
-    const int kMaxIterations = 65536;   // a path needs <= max_depth + null-surface skips + probe segments iterations
+    const int kMaxIterations = 1 << 20;   // a path needs <= max_depth + null-surface skips + probe segments iterations
     for (int iter = 0; iter <= kMaxIterations; ++iter) {
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
         if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 2^32 - 1 intersections" : "Sobol dimension overflow (>= 1024)");
-        if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 65536 wavefront iterations");
+        if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 2^20 wavefront iterations");
+        if (iter > 0 && iter % 2048 == 0 && getenv("PT_DEBUG_ITER")) {
+            fprintf(stderr, "[iter %d] ext %u shadow %u mis %u probe %u shade:", iter, h.ext[cur], h.shadow, h.mis, h.probe[cur]);
+            for (int c = 0; c < kNumClasses; ++c) fprintf(stderr, " %u", h.shade[cur][c]);
+            fprintf(stderr, "\n");
+        }
         const uint32_t n_ext = h.ext[cur], n_resolve = h.shade[cur][kMissClass], n_shadow = h.shadow, n_mis = h.mis, n_probe = h.probe[cur];
         // volpath with grid media: vertices that did their NEE set-up last iteration wait in their own shade class for stage B
         uint32_t n_stage_b = 0;
