@@ -179,6 +179,7 @@ def test_oracle_renders_random_scenes(pkg, oracle, seed):
 def test_gpu_matches_oracle_on_random_scenes(pkg, gpu, oracle, seed):
     b = random_scene(pkg, seed)
     sd, rp = b.world_end()
+    if seed >= 90000 and seed % 3 == 0 and rp.light_strategy == pkg._abi.PT_LS_SPATIAL: rp.light_strategy = pkg._abi.PT_LS_SPATIAL_LAZY   # the first-touch form of the light grid (the same distribution: the oracle does not care)
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=8)
     gc, oc = g.counters(), orc.counters()
