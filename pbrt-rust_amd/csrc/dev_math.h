@@ -16,6 +16,16 @@
 #define PT_HDX PT_HD
 #define PT_DEVX PT_DEV
 #endif
+// The scalar f64 transcendentals (sin/cos, atan2, ln, exp: numbers in, numbers out, no memory arguments) are REAL functions since round 3:
+// inlined at each of their ~10 call sites they made up 20 % of the matte shade kernel's code and, more to the point, 16 of its 202 VGPRs
+// (k_shade<1, 0, 1>: 84 -> 67 KB, 202 -> 186 VGPRs; the specular-only kernel 145 -> 127 = four waves per SIMD). By itself that changes
+// nothing (the kernel's instruction cache hit rate was 99.98 % already: SQC_ICACHE counters, profiles/r3); it is what lets the matte kernel
+// run THREE waves per SIMD with 32 bytes of scratch instead of 76 (kern_shade.h): 93.4 -> 83.7 ms per C2 step. -DPT_INLINE_MATH restores the old form.
+#ifdef PT_INLINE_MATH
+#define PT_HDM PT_HDX
+#else
+#define PT_HDM __host__ __device__ __noinline__ inline
+#endif
 
 namespace ptd {
 
@@ -102,7 +112,7 @@ PT_HD double dm_cos_k(double r) {
 // sin and cos of one argument share the reduction.
 struct DmSC { float s, c; };
 PT_HD void dm_sincosf_impl(float xf, float &s, float &c);
-PT_HDX DmSC dm_sincosf2(float xf) { DmSC r; dm_sincosf_impl(xf, r.s, r.c); return r; }
+PT_HDM DmSC dm_sincosf2(float xf) { DmSC r; dm_sincosf_impl(xf, r.s, r.c); return r; }
 PT_HD void dm_sincosf(float xf, float &s, float &c) { DmSC r = dm_sincosf2(xf); s = r.s; c = r.c; }
 PT_HD void dm_sincosf_impl(float xf, float &s, float &c) {
 #if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
@@ -150,7 +160,7 @@ PT_HD double dm_atan01(double z) {
     return dm_atan_tab(k) + (t + t * (t2 * p));
 }
 PT_HD double dm_atan_pos(double z) { return (z > 1.0) ? kDmPio2Hi - dm_atan01(1.0 / z) : dm_atan01(z); }
-PT_HDX double dm_atan2d(double y, double x) {
+PT_HDM double dm_atan2d(double y, double x) {
     if (x != x || y != y) return __builtin_nan("");
     double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     double a;
@@ -176,7 +186,7 @@ PT_HD float dm_acosf(float xf) {
     return (float)dm_atan2d(s, x);
 }
 // ln of a positive finite double (the core of dm_logf, also used by dm_powf)
-PT_HD double dm_logd_pos(double x) {
+PT_HDM double dm_logd_pos(double x) {
     uint64_t bits = __builtin_bit_cast(uint64_t, x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
@@ -205,7 +215,7 @@ PT_HD float dm_logf(float xf) {
 }
 // e^y for |y| <= 700 in f64: y = k ln2 + r, Taylor series of e^r (|r| <= 0.35, degree 14), scaled by 2^k. Shared with the
 // oracle (ref_math.h) so that f32::powf / f32::exp call sites (materials/disney.rs) are bit-identical on both sides.
-PT_HD double dm_expd(double y) {
+PT_HDM double dm_expd(double y) {
     if (y > 700.0) y = 700.0;
     if (y < -700.0) y = -700.0;
     const double kf = __builtin_floor(y * (1.0 / kDmLn2) + 0.5);

@@ -11,7 +11,10 @@ template <int MAXL, int MODE, int DIFF>
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 1   // experiment hook (tools/build_variant.sh -DPT_SHADE_WAVES=N): minimum waves per SIMD the one-lobe kernels are compiled for
 #endif
-__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+// Waves per SIMD the kernel is compiled for. The matte kernel of triangle-only scenes (MAXL 1, MODE 0, DIFF 1: the headline's) takes three:
+// 168 VGPRs + 32 bytes of scratch, VALU-bound at two waves (57 % busy, 9 % of the wave cycles waiting on memory: SQ counters in profiles/r3).
+// The others lose more to spills than they gain (one-lobe general kernel at three waves: 160 bytes of scratch, 112.8 -> 114.8 ms on C3).
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SHADE_WAVES > 3 ? PT_SHADE_WAVES : 3) : (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
