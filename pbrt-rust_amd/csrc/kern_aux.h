@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
 // NEE resolved, the environment's Le where path.rs:106-117 adds it, and the path-length histogram entry -- none of the
 // BSDF / light-sampling code. Keeping them out of k_shade leaves its waves full of real surface hits.
 template <bool SPH, bool VOL>
-__global__ __launch_bounds__(256) void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job) {
+#ifndef PT_MISS_WAVES
+#define PT_MISS_WAVES 1   // experiment hook
+#endif
+__global__ __launch_bounds__(256, PT_MISS_WAVES) void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job) {
     __shared__ uint32_t s_hist[16];
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
 #ifdef PT_REGION_PROFILE

@@ -7,7 +7,11 @@
 // When the exit point pi is reached the lane finishes the vertex: resolve po's next-event estimation, beta *= S / pdf,
 // NEE at pi through the adapter BSDF, sample the adapter BSDF, Russian roulette, bounces += 1.
 template <bool SPH>
-__global__ __launch_bounds__(256) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
+#ifndef PT_BSSRDF_WAVES
+#define PT_BSSRDF_WAVES (SPH ? 1 : 3)   // waves per SIMD the kernel is compiled for. Triangle-only scenes: three (168 VGPRs + 64 bytes of scratch instead of 197: C5 41.1 -> 35.7 ms
+                                        // per 216-sample pass; like the matte shade kernel it is VALU-bound at two waves); with spheres / instances three waves spill 192 bytes: left alone
+#endif
+__global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
     __shared__ uint32_t s_sobol[kSobolLdsWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ uint32_t s_hist[16];

@@ -42,7 +42,10 @@
 // launch: one tail of straggling rays per iteration instead of three; measured with the PT_TRACE_UTIL build on S2: the wave slots of the three
 // separate launches were busy 73 / 53 / 62 % of launch span x resident waves, ~0.8 ms of tail each).
 template <int ANY, int MODE, bool PROBE>
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? PT_TRACE_WAVES_INST : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+#ifndef PT_TRACE_WAVES_PROBE
+#define PT_TRACE_WAVES_PROBE 1   // experiment hook: waves per SIMD of the triangle-only probe-chain kernel (125 VGPRs = four by itself)
+#endif
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? PT_TRACE_WAVES_INST : (MODE == 0 && PROBE) ? PT_TRACE_WAVES_PROBE : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
     constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;

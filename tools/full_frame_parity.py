@@ -18,7 +18,7 @@ build()
 lib = pkg.load_library(); lib.init(0)
 orc = Oracle(pkg._abi, pkg.runtime.TABLES_PATH)
 COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats",
-            "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite")
+            "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts")
 for spec in sys.argv[1:]:
     cfg, spp = spec.split(":"); spp = int(spp)
     builder, _, desc = pkg.scenes.CONFIG_SCENES[cfg]
