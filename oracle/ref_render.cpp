@@ -760,11 +760,12 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
             if (!found || bounces >= pp.max_depth) break;
             const MedIface mif = surface_iface(S, isect.prim, ray.medium);
             BSDF bsdf;
+            TabulatedBSSRDF bssrdf; bool has_bssrdf = false;
             TexCtx tctx;
             const bool textured = (bool)S.textures;
             if (textured) tctx = compute_differentials(isect, rdiff);
             rdiff.has = false;
-            if (!compute_scattering_functions(S, isect, bsdf, nullptr, nullptr, textured ? &tctx : nullptr)) {
+            if (!compute_scattering_functions(S, isect, bsdf, &bssrdf, &has_bssrdf, textured ? &tctx : nullptr)) {
                 // a material that leaves no BSDF (App. A #14): volpath.rs:127-131 then does `bounces -= 1; continue`, which skips the
                 // increment at the end of the loop -- the count drops by one (and wraps below zero, ending the path at its next vertex)
                 IData it; it.p = isect.p; it.p_error = isect.p_error; it.n = isect.n;
@@ -788,6 +789,50 @@ static RGB volpath_li(const RenderCtx &ctx, const PathParams &pp, Ray ray, Sobol
                 etascale *= (dot(wo, isect.n) > 0.0f) ? eta * eta : 1.0f / (eta * eta);
             }
             ray = spawn_ray(it, wi); ray.medium = medium_toward(mif, isect.n, wi);
+            if (has_bssrdf && (flags & BSDF_TRANSMISSION)) {   // volpath.rs:186-214: as path.rs:177-204, with the probe's samples drawn in the OTHER order
+                const Float s1 = sampler.get_1d();                 // (`sample_s(scene, sampler.get_1d(), &sampler.get_2d(), ..)`: arguments left to right)
+                const P2 s2 = sampler.get_2d();
+                if (std::isinf(beta.y())) ctx.c->ref_asserts++;    // volpath.rs:194
+                V3 start, target; Float u1n = 0.0f;
+                if (!bssrdf.probe_segment(s1, s2, start, target, u1n)) break;
+                // TabulatedBSSRDF::sample_sp's chain (bssrdf.rs:367-395). Every hit's MediumInterface is the primitive's own when it is a transition and
+                // the probe RAY's medium on both sides otherwise (primitive.rs:139-145); the next probe ray takes its medium from that interface
+                // (`base = si.get_data()`, interaction.rs:38-43,54-66); the first one starts from an interaction without any (InteractionData::default)
+                IData base; base.p = start; base.p_error = V3(0, 0, 0); base.n = V3(0, 0, 0);
+                MedIface base_if; bool base_has_if = false;
+                std::vector<SurfaceInteraction> chain; std::vector<MedIface> chain_if;
+                for (;;) {
+                    V3 d = target - base.p;
+                    Ray r(offset_ray_origin(base.p, base.p_error, base.n, d), d, 1.0f - SHADOW_EPSILON, 0.0f);
+                    r.medium = base_has_if ? medium_toward(base_if, base.n, d) : PT_NONE;
+                    SurfaceInteraction si2;
+                    if ((d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) || !S.intersect(r, si2, *ctx.c)) break;
+                    base.p = si2.p; base.p_error = si2.p_error; base.n = si2.n;
+                    base_if = surface_iface(S, si2.prim, r.medium); base_has_if = true;
+                    if (S.prim_material[si2.prim] == bssrdf.material) { chain.push_back(si2); chain_if.push_back(base_if); }
+                }
+                const size_t nfound = chain.size();
+                if (nfound == 0) break;
+                const size_t selected = (size_t)clampv((int64_t)(u1n * (Float)nfound), (int64_t)0, (int64_t)nfound - 1);
+                SurfaceInteraction pi = chain[selected];
+                const MedIface pif = chain_if[selected];
+                pdf = bssrdf.pdf_sp(pi.p, pi.n) / (Float)nfound;
+                const RGB Sp = bssrdf.sr(length(bssrdf.po_p - pi.p));
+                if (Sp.is_black() || pdf == 0.0f) break;
+                BSDF pibsdf; pibsdf.init(pi, 1.0f);
+                { Bxdf b; b.kind = BX_BSSRDF; b.type = BSDF_REFLECTION | BSDF_DIFFUSE; b.etab = bssrdf.eta; pibsdf.add(b); }
+                pi.wo = pi.sh_n;
+                beta *= Sp / pdf;
+                const Distribution1D *d2 = ctx.lights->lookup(pi.p);
+                IData pit; pit.p = pi.p; pit.p_error = pi.p_error; pit.n = pi.n; pit.wo = pi.wo;
+                L += beta * vol_uniform_sample_onelight(ctx, pit, pif, &pi, &pibsdf, 0.0f, sampler, d2);
+                const RGB ff = pibsdf.sample_f(pi.wo, wi, sampler.get_2d(), pdf, BSDF_ALL, flags);
+                if (ff.is_black() || pdf == 0.0f) break;
+                beta *= ff * abs_dot(wi, pi.sh_n) / pdf;
+                if (std::isinf(beta.y())) ctx.c->ref_asserts++;    // volpath.rs:210
+                specular_bounce = (flags & BSDF_SPECULAR) != 0;
+                ray = spawn_ray(pit, wi); ray.medium = medium_toward(pif, pi.n, wi);
+            }
         }
         RGB rrbeta = beta * etascale;
         if (rrbeta.max_component_value() < pp.rr_threshold && bounces > 3) {

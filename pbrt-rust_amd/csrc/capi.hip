@@ -340,8 +340,8 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
             float **ba[] = {&bs.start_x, &bs.start_y, &bs.start_z, &bs.target_x, &bs.target_y, &bs.target_z, &bs.po_x, &bs.po_y, &bs.po_z,
                             &bs.ns_x, &bs.ns_y, &bs.ns_z, &bs.ss_x, &bs.ss_y, &bs.ss_z, &bs.u1n, &bs.sa_r, &bs.sa_g, &bs.sa_b, &bs.sc_r, &bs.sc_g, &bs.sc_b};
             for (float **f : ba) { *f = bp; bp += capacity; }
-            bs.mat = (uint32_t *)bp; bp += capacity; bs.cnt = (uint32_t *)bp;
-            static_assert(sizeof(ba) / sizeof(ba[0]) + 2 == kBssSoAArrays, "BssSoA layout");
+            bs.mat = (uint32_t *)bp; bp += capacity; bs.cnt = (uint32_t *)bp; bp += capacity; bs.iface = (uint32_t *)bp;
+            static_assert(sizeof(ba) / sizeof(ba[0]) + 3 == kBssSoAArrays, "BssSoA layout");
         }
         // queues: ext[2] + shade[2][classes] + shadow + mis (+ probe[2])
         size_t nq = 2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0);
@@ -721,9 +721,11 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
             const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * 8u);
             sc->begin("bssrdf", n_probe);
-            sc->set_kernel((sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) ? "k_bssrdf<true>" : "k_bssrdf<false>");
-            if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0) hipLaunchKernelGGL((k_bssrdf<true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
-            else hipLaunchKernelGGL((k_bssrdf<false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+            const bool bsph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;
+            sc->set_kernel(rc.volpath ? "k_bssrdf<true, true>" : bsph ? "k_bssrdf<true, false>" : "k_bssrdf<false, false>");
+            if (rc.volpath) hipLaunchKernelGGL((k_bssrdf<true, true>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+            else if (bsph) hipLaunchKernelGGL((k_bssrdf<true, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+            else hipLaunchKernelGGL((k_bssrdf<false, false>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
             sc->end();
         }
         uint32_t class_n[kNumClasses];
@@ -1250,7 +1252,9 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
     if (rp->max_depth > 254) return fail(PT_ERR_INVALID_ARG, "maxdepth must be <= 254 (the bounce count of a path is kept in 8 bits)");
     if (rc.volpath) {   // VolPathIntegrator (volpath.rs): what this back end takes
-        if (sc->has_bssrdf) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials are not supported by the volumetric integrator here");
+        // subsurface materials under volpath (volpath.rs:186-214): the exit-point vertex is k_bssrdf's, which has no stage B -- not together with grid media or shells
+        if (sc->has_bssrdf && (sc->ds.has_grid || sc->has_null_material)) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials together with grid media or material-less shells are not supported");
+        if (sc->has_bssrdf && sc->ds.n_media >= 0xffffu) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials with more than 65534 media");
         if (rp->camera_medium != PT_NONE && rp->camera_medium >= sc->ds.n_media) return fail(PT_ERR_INVALID_ARG, "camera_medium out of range");
     }
     const uint32_t ntiles = rc.ntx * rc.nty;

@@ -6,9 +6,11 @@
 // k_trace<.., PROBE> in the launch before (kern_trace.h); this kernel finishes the vertex at the selected exit point.
 // When the exit point pi is reached the lane finishes the vertex: resolve po's next-event estimation, beta *= S / pdf,
 // NEE at pi through the adapter BSDF, sample the adapter BSDF, Russian roulette, bounces += 1.
-template <bool SPH>
+// VOL: under the volumetric integrator (volpath.rs:186-214) -- the estimate at pi handles media (shadow / MIS rays start in the medium pi's
+// MediumInterface names for their side; the interface is the one the probe chain handed on: BssSoA::iface), and the new ray carries its medium.
+template <bool SPH, bool VOL>
 #ifndef PT_BSSRDF_WAVES
-#define PT_BSSRDF_WAVES (SPH ? 1 : 3)   // waves per SIMD the kernel is compiled for. Triangle-only scenes: three (168 VGPRs + 64 bytes of scratch instead of 197: C5 41.1 -> 35.7 ms
+#define PT_BSSRDF_WAVES ((SPH || VOL) ? 1 : 3)   // waves per SIMD the kernel is compiled for. Triangle-only scenes: three (168 VGPRs + 64 bytes of scratch instead of 197: C5 41.1 -> 35.7 ms
                                         // per 216-sample pass; like the matte shade kernel it is VALU-bound at two waves); with spheres / instances three waves spill 192 bytes: left alone
 #endif
 __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
             // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
-            resolve_pending<SPH>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
+            resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                     si.wo = si.sh_n;
                     IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
-                    if (nee_vertex<SPH>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS)) flags |= PF_NEE_UNCOUNTED;
+                    MedIface mif{PT_NONE, PT_NONE};
+                    if (VOL) { const uint32_t pk = bs.iface[pid]; mif.inside = (pk & 0xffffu) == 0xffffu ? PT_NONE : (pk & 0xffffu); mif.outside = (pk >> 16) == 0xffffu ? PT_NONE : (pk >> 16); }
+                    if (nee_vertex<SPH, BssrdfAdapterBsdf, VOL, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) flags |= PF_NEE_UNCOUNTED;
                     else L = L + beta * RGB(0.0f);   // path.rs:190-192 `L += beta * uniform_sample_one_light(..)` with a black estimate: 0, or NaN when pdf_sp was (an exit point a few ulps from po: inf x 0)
                     // path.rs:194-201: indirect component
                     V3 wi; int sflags = 0;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                     if (ff.is_black() || pdf == 0.0f) terminated = true;
                     else {
                         beta = beta * (ff * abs_dot(wi, si.sh_n) / pdf);
-                        if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:201
+                        if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:201 / volpath.rs:210
                         if (sflags & BSDF_SPECULAR) flags |= PF_SPECULAR; else flags &= ~PF_SPECULAR;
                         V3 o; spawn_ray(it, wi, o);
                         // path.rs:206-214 Russian roulette
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                             bounces += 1;
                             ps.ox(pid) = o.x; ps.oy(pid) = o.y; ps.oz(pid) = o.z;
                             ps.dx(pid) = wi.x; ps.dy(pid) = wi.y; ps.dz(pid) = wi.z;
+                            if (VOL) ps.medium(pid) = medium_toward(mif, si.n, wi);   // pi.spawn_ray(wi) (interaction.rs:32-36,54-66)
                             push_ext = true; n_bytes += 24 + 4 + 4;
                         }
                     }

@@ -6,7 +6,7 @@
 template <int ANY, int MODE, bool PROBE = false> __global__ void k_trace(DeviceScene s, TraceJob job);   // ANY: 0 closest hit, 1 any hit, 2 mixed (per-lane kind)
 template <int MAXL, int MODE, int DIFF> __global__ void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);
 template <bool SPH, bool VOL> __global__ void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job);
-template <bool SPH> __global__ void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job);
+template <bool SPH, bool VOL> __global__ void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job);
 __global__ void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
                                uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c5, uint32_t *error);
 __global__ void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);

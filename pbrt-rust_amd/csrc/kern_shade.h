@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SH
                             // path.rs:177-183: importance sample the BSSRDF; the probe chain of sample_sp (bssrdf.rs:367-395)
                             // is walked by k_bssrdf over the following wavefront iterations
                             if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
-                                const P2 s2 = smp.get_2d();
-                                const float s1 = smp.get_1d();
-                                if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:184: evaluated after sample_s whatever it returned
+                                // path.rs:181-183 draws s2 then s1; volpath.rs:191 `sample_s(scene, sampler.get_1d(), &sampler.get_2d(), ..)` the other way round
+                                P2 s2; float s1;
+                                if (VOL) { s1 = smp.get_1d(); s2 = smp.get_2d(); } else { s2 = smp.get_2d(); s1 = smp.get_1d(); }
+                                if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:184 / volpath.rs:194: evaluated after sample_s whatever it returned
                                 DevBssrdf bss;
                                 if (is_sss) bss.init_medium(s.materials[mi], s.bss_tables, bss_sa, bss_ss); else bss.init_disney(s.materials[mi]);
                                 bss.init_frame(si);

@@ -111,6 +111,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     // PROBE: chain state of the lane. A chain with more than kProbeRing matches after the selected one is walked a second time
     // ("rewalk") up to match number `selected`; the rewalk's work is not counted (the reference indexes its Vec instead).
     uint32_t nfound = 0, seen = 0; bool rewalk = false;
+    // the medium the chain's current probe ray travels in (volpath only reads it): every hit's MediumInterface is the primitive's own when it is a
+    // transition, else this medium on both sides (primitive.rs:139-145); the next probe ray takes its medium from that interface (interaction.rs:38-43);
+    // the first ray starts from an interaction without one (bssrdf.rs:362-366). Packed as inside | outside << 16, 0xffff = none.
+    uint32_t cur_med = PT_NONE;
     uint32_t sv_nodes = 0, sv_tris = 0, sv_rays = 0, sv_sph = 0;
     uint4 *ring = PROBE ? job.ring + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * (kProbeRing * 3 * 64) + lane : nullptr;
 
@@ -158,23 +162,26 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     if (hit_pkt != PT_NONE) {
                         SurfaceInteraction si;
                         const uint32_t pfl = fill_hit_pkt<INST>(s, hit_pkt, INST ? hit_inst : PT_NONE, ro, rd, hb0, hb1, hb2, si);
-                        if (packet_material(s, pfl, s.leaf[hit_pkt].prim) == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
+                        const uint32_t hprim = s.leaf[hit_pkt].prim;
+                        const MedIface hif = surface_iface(s, hprim, cur_med);
+                        const uint32_t hif_packed = (hif.inside & 0xffffu) | (hif.outside << 16);
+                        if (packet_material(s, pfl, hprim) == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
                             if (!rewalk) {
                                 const uint32_t k = nfound % (uint32_t)kProbeRing;
                                 ring[(3 * k + 0) * 64] = make_uint4(hit_pkt, hit_inst, __float_as_uint(hb0), __float_as_uint(hb1));
                                 ring[(3 * k + 1) * 64] = make_uint4(__float_as_uint(hb2), __float_as_uint(ro.x), __float_as_uint(ro.y), __float_as_uint(ro.z));
-                                ring[(3 * k + 2) * 64] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), 0u);
+                                ring[(3 * k + 2) * 64] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), hif_packed);
                                 if (nfound == 0xffffffffu) atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); else nfound++;
                             } else {
                                 const uint32_t selected = min(f2u32_sat(job.bs.u1n[pid] * (float)nfound), nfound - 1u);
-                                if (seen == selected) finish = true;
+                                if (seen == selected) { finish = true; job.bs.iface[pid] = hif_packed; }
                                 seen++;
                             }
                         }
                         if (!finish) {   // base = si.get_data(); the next segment runs base -> target (interaction.rs:38-43)
                             const V3 d = target - si.p;
                             if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) chain_end = true;
-                            else { ro = offset_ray_origin(si.p, si.p_error, si.n, d); rd = d; next_seg = true; }
+                            else { ro = offset_ray_origin(si.p, si.p_error, si.n, d); rd = d; next_seg = true; cur_med = medium_toward(hif, si.n, d); }
                         }
                     } else chain_end = true;
                     if (chain_end) {
@@ -187,9 +194,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                                 hit_pkt = e0.x; hit_inst = e0.y; hb0 = __uint_as_float(e0.z); hb1 = __uint_as_float(e0.w); hb2 = __uint_as_float(e1.x);
                                 ro = V3(__uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w));
                                 rd = V3(__uint_as_float(e2.x), __uint_as_float(e2.y), __uint_as_float(e2.z));
+                                job.bs.iface[pid] = e2.w;
                                 finish = true;
                             } else {   // the selected intersection has left the ring: walk again from the start, uncounted
-                                rewalk = true; seen = 0u;
+                                rewalk = true; seen = 0u; cur_med = PT_NONE;
                                 sv_nodes = n_nodes; sv_tris = n_tris; sv_rays = n_rays; sv_sph = n_sph;
                                 ro = V3(job.bs.start_x[pid], job.bs.start_y[pid], job.bs.start_z[pid]); rd = target - ro;
                                 next_seg = true;
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     sp = 0; pending = 0;
                     hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                     in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
-                    if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; }
+                    if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; cur_med = PT_NONE; }
                     n_rays++;
                     state = ST_DONE;
                     if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)

@@ -90,8 +90,9 @@ struct BssSoA {
     float *sa_r, *sa_g, *sa_b, *sc_r, *sc_g, *sc_b;   // sigma_a / sigma_s as evaluated at the entry point (subsurface.rs:100-101: textures of the outgoing interaction)
     uint32_t *mat;   // material id of the BSSRDF (Arc::ptr_eq test of the chain, bssrdf.rs:385-391)
     uint32_t *cnt;   // nfound of the finished chain (written by k_trace<.., PROBE>, read by k_bssrdf)
+    uint32_t *iface; // volpath: the selected intersection's MediumInterface, inside | outside << 16 (0xffff = none), as the chain of probe rays handed it on
 };
-constexpr int kBssSoAArrays = 24;
+constexpr int kBssSoAArrays = 25;
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)

@@ -259,6 +259,38 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textu
     return b
 
 
+def subsurface_in_fog(n=16, xres=64, yres=48, spp=8, maxdepth=5, fog=True, sampler="sobol"):
+    """Subsurface materials under the VOLUMETRIC integrator (volpath.rs:186-214). With fog=True the camera and the world sit in a homogeneous
+    fog, one subsurface object is an ordinary primitive (its hits hand the probe ray's medium on: none for the first probe ray, so the path
+    leaves the object in VACUUM -- bssrdf.rs:362-366 starts the chain from an interaction without a MediumInterface) and the other carries a
+    MediumInterface of its own (its hits name "juice" inside / "fog" outside, whichever the chain reaches first)."""
+    from .host import SceneBuilder
+    b = SceneBuilder()
+    b.film.update(xres=xres, yres=yres); b.spp = spp; b.sampler = sampler
+    b.integ.update(maxdepth=maxdepth, kind="volpath")
+    if fog:
+        b.make_named_medium("fog", sigma_a=(0.03, 0.03, 0.03), sigma_s=(0.1, 0.1, 0.12), g=0.2)
+        b.make_named_medium("juice", sigma_a=(0.2, 0.6, 0.9), sigma_s=(0.8, 0.6, 0.4), g=-0.1)
+        b.medium_interface("", "fog")
+    b.look_at((0.0, 1.6, 6.0), (0.0, 0.2, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.25, 0.3, 0.35))
+    b.attribute_begin(); b.area_light_source(L=(30.0, 27.0, 22.0))
+    P, I = quad((-1.5, 4.0, -0.5), (1.5, 4.0, -0.5), (1.5, 4.0, 1.5), (-1.5, 4.0, 1.5)); b.trianglemesh(P, I); b.attribute_end()
+    b.light_source("point", from_=(2.5, 2.0, 2.5), I=(8.0, 8.0, 7.0))
+    b.material("matte", Kd=(0.45, 0.45, 0.5))
+    P, I = quad((-8.0, -1.0, -8.0), (-8.0, -1.0, 8.0), (8.0, -1.0, 8.0), (8.0, -1.0, -8.0)); b.trianglemesh(P, I)
+    b.attribute_begin()
+    b.material("subsurface", name="Skin1", scale=8.0, eta=1.33)
+    b.translate(-1.1, 0.0, 0.0)
+    P, I, N = displaced_sphere(n, with_normals=True); b.trianglemesh(P, I, N=N); b.attribute_end()
+    b.attribute_begin()
+    if fog: b.medium_interface("juice", "fog")
+    b.material("kdsubsurface", Kd=(0.7, 0.35, 0.2), mfp=(0.25, 0.15, 0.08), eta=1.4)
+    b.translate(1.2, 0.0, 0.3); b.sphere(radius=0.9); b.attribute_end()
+    return b
+
+
 def subsurface_sheets(xres=64, yres=48, spp=8, maxdepth=5, n_sheets=40):
     """A stack of thin parallel sheets (plus one sphere) sharing ONE subsurface material, spaced far below the mean free path:
     probe chains (bssrdf.rs:373-395) along the sheets' normal collect tens of matching intersections."""
