@@ -6,7 +6,7 @@
 //        no +0.5 as in Ward's original); new-style RLE, old-style repeat pixels and flat scanlines.
 //   PNG / TGA (imageio.rs:338-357): to_rgb8 then v / 255 per channel (grey replicated, alpha dropped, palette expanded,
 //        16-bit samples reduced to their high byte's rounding v * 255 / 65535).
-//   EXR  (imageio.rs:68-114, `exr` crate 1.0.0): scan-line files, uncompressed / ZIPS / ZIP, HALF / FLOAT / UINT channels are
+//   EXR  (imageio.rs:68-114, `exr` crate 1.0.0): scan-line and tiled files, single- and multi-part, uncompressed / RLE / ZIPS / ZIP, HALF / FLOAT / UINT channels are
 //        read; three uncompressed FLOAT channels are written.
 // zlib (system library, -lz) inflates PNG IDAT streams.
 #pragma once
@@ -176,70 +176,147 @@ inline float half_to_float(uint16_t h) {
     else bits = sign | ((e + 112u) << 23) | (m << 13);
     float f; std::memcpy(&f, &bits, 4); return f;
 }
-// read_image_exr (imageio.rs:68-97): R, G, B channels (HALF / FLOAT / UINT) of a single-part scan-line file with NO, ZIPS or
-// ZIP compression -- what `envmap.exr` of the reference's scenes uses; tiled, deep, PIZ/PXR24/B44/DWA files are refused by name.
+// read_image_exr (imageio.rs:68-97; the `exr` crate reads every flat image): R, G, B (or Y) channels -- HALF / FLOAT / UINT -- of the first flat
+// part of a scan-line or TILED file (level 0 of a mip / rip map), single- or multi-part, with NO, RLE, ZIPS or ZIP compression. Deep data and the
+// PIZ / PXR24 / B44 / DWA codecs are refused by name.
 inline Image read_exr(const std::string &path) {
     const std::vector<unsigned char> d = read_file(path);
-    auto need = [&](size_t p, size_t n) { if (p + n > d.size()) throw std::runtime_error("EXR \"" + path + "\" is truncated"); };
+    auto need = [&](size_t p, size_t n) { if (p + n > d.size() || p + n < p) throw std::runtime_error("EXR \"" + path + "\" is truncated"); };
     auto i32 = [&](size_t p) { need(p, 4); int32_t v; std::memcpy(&v, d.data() + p, 4); return v; };
     need(0, 8);
     if (i32(0) != 20000630) throw std::runtime_error("\"" + path + "\": not an OpenEXR file");
     const int32_t version = i32(4);
-    if (version & 0x1a00) throw std::runtime_error("EXR \"" + path + "\": tiled, deep and multi-part files are not supported");
+    const bool multipart = (version & 0x1000) != 0;
+    if (version & 0x800) throw std::runtime_error("EXR \"" + path + "\": deep data is not supported");
     struct Chan { std::string name; int type; };
-    std::vector<Chan> chans; int compression = -1, line_order = 0; int32_t win[4] = {0, 0, -1, -1};
+    struct Part { std::vector<Chan> chans; int compression = -1; int32_t win[4] = {0, 0, -1, -1}; bool tiled = false, deep = false; uint32_t tile_w = 0, tile_h = 0; int level_mode = 0, round_up = 0; int32_t chunk_count = -1; };
+    std::vector<Part> parts;
     size_t p = 8;
-    for (;;) {
-        need(p, 1);
-        if (d[p] == 0) { p++; break; }
-        auto cstr = [&]() { std::string t; while (true) { need(p, 1); if (!d[p]) { p++; break; } t.push_back((char)d[p++]); } return t; };
-        const std::string name = cstr(), type = cstr(); const int32_t size = i32(p); p += 4; need(p, (size_t)size);
-        if (name == "channels") { size_t q = p; while (d[q]) { Chan c; while (d[q]) c.name.push_back((char)d[q++]); q++; c.type = i32(q); if (i32(q + 8) != 1 || i32(q + 12) != 1) throw std::runtime_error("EXR \"" + path + "\": subsampled channels are not supported"); q += 16; chans.push_back(c); } }
-        else if (name == "compression") compression = d[p];
-        else if (name == "dataWindow") for (int k = 0; k < 4; ++k) win[k] = i32(p + 4 * k);
-        else if (name == "lineOrder") line_order = d[p];
-        (void)type; p += (size_t)size;
+    for (;;) {   // one header per part; a multi-part file ends the list with an empty header
+        Part pt; pt.tiled = !multipart && (version & 0x200) != 0;
+        bool any = false;
+        for (;;) {
+            need(p, 1);
+            if (d[p] == 0) { p++; break; }
+            any = true;
+            auto cstr = [&]() { std::string t; while (true) { need(p, 1); if (!d[p]) { p++; break; } t.push_back((char)d[p++]); } return t; };
+            const std::string name = cstr(), type = cstr(); const int32_t size = i32(p); p += 4;
+            if (size < 0) throw std::runtime_error("EXR \"" + path + "\": bad attribute size");
+            need(p, (size_t)size);
+            if (name == "channels") { size_t q = p; while (d[q]) { Chan c; while (d[q]) c.name.push_back((char)d[q++]); q++; c.type = i32(q); if (i32(q + 8) != 1 || i32(q + 12) != 1) throw std::runtime_error("EXR \"" + path + "\": subsampled channels are not supported"); q += 16; pt.chans.push_back(c); } }
+            else if (name == "compression") pt.compression = d[p];
+            else if (name == "dataWindow") for (int k = 0; k < 4; ++k) pt.win[k] = i32(p + 4 * k);
+            else if (name == "tiles" && size >= 9) { std::memcpy(&pt.tile_w, d.data() + p, 4); std::memcpy(&pt.tile_h, d.data() + p + 4, 4); pt.level_mode = d[p + 8] & 15; pt.round_up = d[p + 8] >> 4; }
+            else if (name == "type" && size > 0) { const std::string t((const char *)d.data() + p, (size_t)size); pt.tiled = t == "tiledimage"; pt.deep = t.compare(0, 4, "deep") == 0; }
+            else if (name == "chunkCount" && size == 4) pt.chunk_count = i32(p);
+            p += (size_t)size;
+        }
+        if (!any) break;             // the empty header that ends a multi-part list
+        parts.push_back(pt);
+        if (!multipart) break;
     }
-    (void)line_order;
+    if (parts.empty()) throw std::runtime_error("EXR \"" + path + "\": no header");
+    // chunk counts of all parts (the offset tables follow the headers back to back)
+    auto levels = [](int n, int round_up) { int l = 0; while (n > 1) { n = round_up ? (n + 1) / 2 : n / 2; ++l; } return l + 1; };
+    auto level_size = [](int n, int l, int round_up) { for (int i = 0; i < l; ++i) n = std::max(1, round_up ? (n + 1) / 2 : n / 2); return n; };
+    std::vector<size_t> n_chunks(parts.size());
+    for (size_t k = 0; k < parts.size(); ++k) {
+        const Part &pt = parts[k];
+        const int w = pt.win[2] - pt.win[0] + 1, h = pt.win[3] - pt.win[1] + 1;
+        if (w <= 0 || h <= 0 || pt.chans.empty()) throw std::runtime_error("EXR \"" + path + "\": missing dataWindow / channels");
+        if (pt.chunk_count >= 0) { n_chunks[k] = (size_t)pt.chunk_count; continue; }
+        if (!pt.tiled) { const int lpb = pt.compression == 3 ? 16 : (pt.compression == 4 || pt.compression == 6 ) ? 32 : (pt.compression == 5 || pt.compression == 7) ? 16 : 1; n_chunks[k] = (size_t)((h + lpb - 1) / lpb); continue; }
+        if (pt.tile_w == 0 || pt.tile_h == 0) throw std::runtime_error("EXR \"" + path + "\": tiled part without a tile description");
+        auto tiles = [&](int lw, int lh) { return (size_t)((lw + (int)pt.tile_w - 1) / (int)pt.tile_w) * (size_t)((lh + (int)pt.tile_h - 1) / (int)pt.tile_h); };
+        size_t n = 0;
+        if (pt.level_mode == 0) n = tiles(w, h);
+        else if (pt.level_mode == 1) { const int nl = levels(std::max(w, h), pt.round_up); for (int l = 0; l < nl; ++l) n += tiles(level_size(w, l, pt.round_up), level_size(h, l, pt.round_up)); }
+        else { const int nx = levels(w, pt.round_up), ny = levels(h, pt.round_up); for (int ly = 0; ly < ny; ++ly) for (int lx = 0; lx < nx; ++lx) n += tiles(level_size(w, lx, pt.round_up), level_size(h, ly, pt.round_up)); }
+        n_chunks[k] = n;
+    }
+    size_t use = parts.size();
+    for (size_t k = 0; k < parts.size() && use == parts.size(); ++k) if (!parts[k].deep) use = k;
+    if (use == parts.size()) throw std::runtime_error("EXR \"" + path + "\": deep data is not supported");
+    size_t table = p;
+    for (size_t k = 0; k < use; ++k) table += 8 * n_chunks[k];
+    const Part &pt = parts[use];
+    const std::vector<Chan> &chans = pt.chans; const int compression = pt.compression; const int32_t *win = pt.win;
     const int w = win[2] - win[0] + 1, h = win[3] - win[1] + 1;
-    if (w <= 0 || h <= 0 || chans.empty()) throw std::runtime_error("EXR \"" + path + "\": missing dataWindow / channels");
-    if (compression != 0 && compression != 2 && compression != 3) throw std::runtime_error("EXR \"" + path + "\": only uncompressed, ZIPS and ZIP files are supported (compression " + std::to_string(compression) + ")");
-    const int lines_per_block = compression == 3 ? 16 : 1, n_blocks = (h + lines_per_block - 1) / lines_per_block;
-    size_t line_bytes = 0; std::vector<size_t> chan_off;
-    for (auto &c : chans) { chan_off.push_back(line_bytes); line_bytes += (size_t)w * (c.type == 1 ? 2 : 4); }
+    if (compression < 0 || compression > 3) {
+        static const char *names[] = {"none", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
+        throw std::runtime_error("EXR \"" + path + "\": only uncompressed, RLE, ZIPS and ZIP data are supported (this file: " + (compression >= 0 && compression < 10 ? std::string(names[compression]) : std::to_string(compression)) + ")");
+    }
+    size_t px_bytes = 0; std::vector<size_t> chan_bytes;
+    for (auto &c : chans) { chan_bytes.push_back(c.type == 1 ? 2 : 4); px_bytes += chan_bytes.back(); }
     int idx[3] = {-1, -1, -1};
     for (size_t c = 0; c < chans.size(); ++c) { if (chans[c].name == "R") idx[0] = (int)c; else if (chans[c].name == "G") idx[1] = (int)c; else if (chans[c].name == "B") idx[2] = (int)c; else if (chans[c].name == "Y" && idx[0] < 0) idx[0] = idx[1] = idx[2] = (int)c; }
     if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) throw std::runtime_error("EXR \"" + path + "\": no R, G, B (or Y) channels");
     Image im; im.w = w; im.h = h; im.rgb.assign((size_t)w * h * 3, 0.0f);
-    const size_t table = p;
     std::vector<unsigned char> raw, tmp;
-    for (int b = 0; b < n_blocks; ++b) {
-        need(table + 8 * (size_t)b, 8);
-        uint64_t off; std::memcpy(&off, d.data() + table + 8 * (size_t)b, 8);
-        const int y0 = i32((size_t)off) - win[1]; const int32_t packed = i32((size_t)off + 4);
-        if (y0 < 0 || y0 >= h || packed < 0) throw std::runtime_error("EXR \"" + path + "\": bad scan-line block");
-        need((size_t)off + 8, (size_t)packed);
-        const int nl = std::min(lines_per_block, h - y0); const size_t want = line_bytes * (size_t)nl;
+    // one chunk's pixel data (bw x bh pixels, line by line, channel by channel) -> raw
+    auto unpack = [&](size_t src, size_t packed, size_t want) {
+        need(src, packed);
         raw.resize(want);
-        if (compression == 0 || (size_t)packed == want) std::memcpy(raw.data(), d.data() + off + 8, std::min<size_t>(want, (size_t)packed));
-        else {
-            tmp.resize(want); uLongf n = (uLongf)want;
-            if (uncompress(tmp.data(), &n, d.data() + off + 8, (uLong)packed) != Z_OK || n != want) throw std::runtime_error("EXR \"" + path + "\": corrupt ZIP block");
-            for (size_t i = 1; i < want; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);     // undo the byte predictor
-            const size_t half = (want + 1) / 2;                                                           // undo the even/odd split
-            for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+        if (compression == 0 || packed == want) { std::memcpy(raw.data(), d.data() + src, std::min(want, packed)); return; }
+        tmp.resize(want);
+        if (compression == 1) {   // RLE: a count n < 0 is followed by -n literal bytes, n >= 0 by one byte to repeat n + 1 times
+            size_t i = src, o = 0; const size_t end = src + packed;
+            while (i < end) {
+                const int n = (signed char)d[i++];
+                if (n < 0) { const size_t c = (size_t)(-n); if (i + c > end || o + c > want) throw std::runtime_error("EXR \"" + path + "\": corrupt RLE block"); std::memcpy(tmp.data() + o, d.data() + i, c); i += c; o += c; }
+                else { const size_t c = (size_t)n + 1; if (i >= end || o + c > want) throw std::runtime_error("EXR \"" + path + "\": corrupt RLE block"); std::memset(tmp.data() + o, d[i++], c); o += c; }
+            }
+            if (o != want) throw std::runtime_error("EXR \"" + path + "\": corrupt RLE block");
+        } else {
+            uLongf n = (uLongf)want;
+            if (uncompress(tmp.data(), &n, d.data() + src, (uLong)packed) != Z_OK || n != want) throw std::runtime_error("EXR \"" + path + "\": corrupt ZIP block");
         }
-        for (int l = 0; l < nl; ++l)
+        for (size_t i = 1; i < want; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);     // undo the byte predictor
+        const size_t half = (want + 1) / 2;                                                           // undo the even/odd split
+        for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+    };
+    auto store = [&](int x0, int y0, int bw, int bh) {
+        const size_t line_bytes = px_bytes * (size_t)bw;
+        for (int l = 0; l < bh; ++l)
             for (int c = 0; c < 3; ++c) {
-                const Chan &ch = chans[idx[c]]; const unsigned char *src = raw.data() + line_bytes * (size_t)l + chan_off[idx[c]];
-                for (int x = 0; x < w; ++x) {
+                size_t off = 0; for (int k = 0; k < idx[c]; ++k) off += chan_bytes[k] * (size_t)bw;
+                const Chan &ch = chans[idx[c]]; const unsigned char *src = raw.data() + line_bytes * (size_t)l + off;
+                for (int x = 0; x < bw; ++x) {
                     float v;
                     if (ch.type == 1) { uint16_t hv; std::memcpy(&hv, src + 2 * x, 2); v = half_to_float(hv); }
                     else if (ch.type == 2) std::memcpy(&v, src + 4 * x, 4);
                     else { uint32_t u; std::memcpy(&u, src + 4 * x, 4); v = (float)u; }
-                    im.rgb[((size_t)(y0 + l) * w + x) * 3 + c] = v;
+                    im.rgb[((size_t)(y0 + l) * w + (x0 + x)) * 3 + c] = v;
                 }
             }
+    };
+    const size_t part_field = multipart ? 4 : 0;
+    if (!pt.tiled) {
+        const int lines_per_block = compression == 3 ? 16 : 1, n_blocks = (h + lines_per_block - 1) / lines_per_block;
+        for (int b = 0; b < n_blocks; ++b) {
+            need(table + 8 * (size_t)b, 8);
+            uint64_t off; std::memcpy(&off, d.data() + table + 8 * (size_t)b, 8);
+            if (multipart && i32((size_t)off) != (int32_t)use) throw std::runtime_error("EXR \"" + path + "\": chunk of another part in this part's table");
+            const size_t q = (size_t)off + part_field;
+            const int y0 = i32(q) - win[1]; const int32_t packed = i32(q + 4);
+            if (y0 < 0 || y0 >= h || packed < 0) throw std::runtime_error("EXR \"" + path + "\": bad scan-line block");
+            const int nl = std::min(lines_per_block, h - y0);
+            unpack(q + 8, (size_t)packed, px_bytes * (size_t)w * (size_t)nl);
+            store(0, y0, w, nl);
+        }
+    } else {   // level (0, 0) comes first in the table of every level mode
+        const int tw = (int)pt.tile_w, th = (int)pt.tile_h, nx = (w + tw - 1) / tw, ny = (h + th - 1) / th;
+        for (int t = 0; t < nx * ny; ++t) {
+            need(table + 8 * (size_t)t, 8);
+            uint64_t off; std::memcpy(&off, d.data() + table + 8 * (size_t)t, 8);
+            if (multipart && i32((size_t)off) != (int32_t)use) throw std::runtime_error("EXR \"" + path + "\": chunk of another part in this part's table");
+            const size_t q = (size_t)off + part_field;
+            const int tx = i32(q), ty = i32(q + 4), lx = i32(q + 8), ly = i32(q + 12); const int32_t packed = i32(q + 16);
+            if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || tx >= nx || ty >= ny || packed < 0) throw std::runtime_error("EXR \"" + path + "\": bad tile");
+            const int x0 = tx * tw, y0 = ty * th, bw = std::min(tw, w - x0), bh = std::min(th, h - y0);
+            unpack(q + 20, (size_t)packed, px_bytes * (size_t)bw * (size_t)bh);
+            store(x0, y0, bw, bh);
+        }
     }
     return im;
 }

