@@ -27,7 +27,7 @@ int ptf_write_pfm(const char *path, int width, int height, const float *rgb);
 /* write_image (core/imageio.rs:42-60): by extension -- exr (three FLOAT channels, uncompressed), png / tga (8-bit, gamma
  * encoded, imageio.rs:359-381), pfm. */
 int ptf_write_image(const char *path, int width, int height, const float *rgb);
-/* read_image (core/imageio.rs:18-40): pfm, hdr, png, tga, exr (scan-line, NO/ZIPS/ZIP). Call with rgb == NULL to get the
+/* read_image (core/imageio.rs:18-40): pfm, hdr, png, tga, exr (scan-line / tiled / multi-part, NO/RLE/ZIPS/ZIP). Call with rgb == NULL to get the
  * size, then with a buffer of width*height*3 floats (top row first). */
 int ptf_read_image(const char *path, int *width, int *height, float *rgb, size_t capacity_floats);
 #ifdef __cplusplus
