@@ -12,6 +12,11 @@ enum LobeKind : uint8_t { LB_LAMBERT_R, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, 
                           LB_DISNEY_DIFFUSE, LB_DISNEY_FAKESS, LB_DISNEY_RETRO, LB_DISNEY_SHEEN, LB_DISNEY_CLEARCOAT };   // materials/disney.rs
 enum FresnelKind : uint8_t { FR_NOOP, FR_DIELECTRIC, FR_CONDUCTOR, FR_DISNEY };
 
+#ifdef PT_OUTLINE_BSDF   // experiment: the scalar microfacet / Fresnel helpers as real functions (like the f64 transcendentals, dev_math.h)
+#define PT_DEVO __device__ __noinline__ inline
+#else
+#define PT_DEVO PT_DEV
+#endif
 PT_DEV V3 cosine_sample_hemisphere(P2 u) {  // sampling.rs:188-193
     P2 d = concentric_sample_disk(u);
     float z = sqrtf(maxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
@@ -44,7 +49,7 @@ PT_DEV bool refract(V3 wi, V3 n, float eta, V3 &wt) {  // reflection.rs:160-174
     wt = n * (eta * cos_i - cos_t) + (-wi) * eta;
     return true;
 }
-PT_DEV float fr_dielectric(float cos_i, float etai, float etat) {  // reflection.rs:29-52
+PT_DEVO float fr_dielectric(float cos_i, float etai, float etat) {  // reflection.rs:29-52
     cos_i = clampf(cos_i, -1.0f, 1.0f);
     if (!(cos_i > 0.0f)) { float t = etai; etai = etat; etat = t; cos_i = fabsf(cos_i); }
     float sin_i = sqrtf(maxf(0.0f, 1.0f - cos_i * cos_i));
@@ -55,7 +60,7 @@ PT_DEV float fr_dielectric(float cos_i, float etai, float etat) {  // reflection
     float rperp = ((etai * cos_i) - (etat * cos_t)) / ((etai * cos_i) + (etat * cos_t));
     return (rparl * rparl + rperp * rperp) / 2.0f;
 }
-PT_DEV RGB fr_conductor(float cos_i, RGB etai, RGB etat, RGB k) {  // reflection.rs:54-76
+PT_DEVO RGB fr_conductor(float cos_i, RGB etai, RGB etat, RGB k) {  // reflection.rs:54-76
     cos_i = clampf(cos_i, -1.0f, 1.0f);
     RGB eta = etat / etai, etak = k / etai;
     float cos2 = cos_i * cos_i, sin2 = 1.0f - cos2;
@@ -111,14 +116,14 @@ PT_DEV float roughness_to_alpha(float roughness) {  // microfacet.rs:334-340
     float x = dm_logf(roughness);
     return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
 }
-PT_DEV float tr_d(float ax, float ay, V3 wh) {
+PT_DEVO float tr_d(float ax, float ay, V3 wh) {
     float t2 = tan2_theta(wh);
     if (__builtin_isinf(t2)) return 0.0f;
     float c4 = cos2_theta(wh) * cos2_theta(wh);
     float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * t2;
     return 1.0f / (kPi * ax * ay * c4 * (1.0f + e) * (1.0f + e));
 }
-PT_DEV float tr_lambda(float ax, float ay, V3 w) {
+PT_DEVO float tr_lambda(float ax, float ay, V3 w) {
     float abs_tan = fabsf(tan_theta(w));
     if (__builtin_isinf(abs_tan)) return 0.0f;
     float alpha = sqrtf(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
@@ -153,7 +158,7 @@ PT_DEV void tr_sample11(float cos_t, float u1, float u2, float &sx, float &sy) {
     float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) / (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
     sy = S * z * sqrtf(1.0f + sx * sx);
 }
-PT_DEV V3 tr_sample_wh(float ax, float ay, V3 wo, P2 u) {  // microfacet.rs:293-316,394-401
+PT_DEVO V3 tr_sample_wh(float ax, float ay, V3 wo, P2 u) {  // microfacet.rs:293-316,394-401
     bool flip = wo.z < 0.0f;
     V3 wi = flip ? -wo : wo;
     V3 wis = normalize(V3(ax * wi.x, ay * wi.y, wi.z));
