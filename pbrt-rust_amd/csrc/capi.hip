@@ -1279,6 +1279,10 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
         sc->ps.ext = (rc.volpath && sc->has_null_material) ? (float *)sc->ext_slab : nullptr;
         int eff;
         if ((st = ensure_light_grid(sc, (int)rp->light_strategy, eff))) return st;
+        if (sc->grid[eff].cell_ptr) {   // first-touch voxels: a render that failed half way may have named voxels it never computed -- start from a clean request list
+            HIP_TRY(hipMemsetAsync(sc->lazy.req_flag, 0, sc->lazy.ncell * 4, sc->stream));
+            HIP_TRY(hipMemsetAsync(sc->lazy.req_count, 0, 8, sc->stream));
+        }
         HIP_TRY(hipMemcpyAsync(sc->d_filter, rp->filter_table, 256 * 4, hipMemcpyHostToDevice, sc->stream));
         HIP_TRY(hipMemsetAsync(sc->film_rgbw, 0, film_px * 16, sc->stream));
         HIP_TRY(hipMemsetAsync(sc->dc, 0, sizeof(DevCounters), sc->stream));
