@@ -111,3 +111,16 @@ def test_distinct_devices_equal_the_plain_render(pkg, gpu):
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
     tm = multi.timing()
     assert all(c > 0 for c in tm["copy_ms"][1:])
+
+
+def test_bench_takes_the_one_process_form_for_gpus_n_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE must drive N devices itself (pt_multi_render) instead of silently rendering
+    on one. Without that many devices it says so and stops -- on this CPU box: before anything is built or rendered."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 3:
+        pytest.skip("a multi-GPU box: the command would really run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "asks for device ordinals [0, 1, 2]" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])
