@@ -40,7 +40,7 @@ bool g_refill_from_env = false;
 bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one traversal launch per ray kind (extend / extend_mis / shadow) instead of the mixed launch
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU = 7 per SIMD: k_trace<*, 0> needs 71 VGPRs and 5 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %, 24 -> 28: +3 %)
-thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 constexpr int kMaxDevices = kMaxReplicas;
 struct DevCtx { bool ready = false; int num_cus = 256; SobolTables tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
 DevCtx g_ctx[kMaxDevices];
@@ -81,6 +81,19 @@ int upload_tables(SobolTables &g_tabs) {   // (fills the per-device context pass
     g_tabs.m32 = (const uint32_t *)d;
     g_tabs.vdc = (const uint64_t *)((const char *)d + 1024 * 52 * 4);
     g_tabs.vdc_inv = g_tabs.vdc + 25 * 52;
+    {   // the generator matrices folded by index nibble (dev_sampler.h: SobolTables::nib)
+        std::vector<uint32_t> m32(1024 * 52), nib((size_t)1024 * kSobolNibWords);
+        std::memcpy(m32.data(), p, m32.size() * 4);
+        for (uint32_t d = 0; d < 1024; ++d) for (uint32_t j = 0; j < kSobolNibbles; ++j) for (uint32_t n = 0; n < 16; ++n) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 4; ++b) if (n >> b & 1u) v ^= m32[d * 52 + 4 * j + b];
+            nib[((size_t)j * 1024 + d) * 16 + n] = v;
+        }
+        void *dn = nullptr;
+        HIP_TRY(hipMalloc(&dn, nib.size() * 4));
+        HIP_TRY(hipMemcpy(dn, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
+        g_tabs.nib = (const uint32_t *)dn;
+    }
     // Halton: the first 1000 primes (PRIMES / PRIME_SUMS, lowdiscrepancy.rs:9-192: here sieved, not tabulated) and the digit
     // permutations of compute_radical_inverse_permutations(&mut RNG::default()) (lowdiscrepancy.rs:359-378): per base the
     // identity permutation shuffled by `shuffle` (sampling.rs:178-186) with PCG32 (rng.rs:17-58), one RNG for all bases.
@@ -519,7 +532,7 @@ __global__ void k_reset(QCounters *qc, uint32_t mask, int cur) {
 
 template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderConst &rc, const LightGrid &grid, const ShadeJob &job, uint32_t upper) {
 #ifndef PT_SHADE_BLOCKS_PER_CU
-#define PT_SHADE_BLOCKS_PER_CU 8u   // (experiment hook)
+#define PT_SHADE_BLOCKS_PER_CU 24u   // experiment hook. Each block walks a fixed stride of the queue: 24 a CU (2, 3 or 4 resident at a time) even out the per-vertex cost differences; 8 left the matte kernel's third round two-thirds full (80.1 -> 76.3 ms on C2)
 #endif
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);  // persistent blocks: the LDS Sobol' table is staged once per block
     const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
@@ -719,7 +732,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
             bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
-            const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * 8u);
+            const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);
             sc->begin("bssrdf", n_probe);
             const bool bsph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;
             sc->set_kernel(rc.volpath ? "k_bssrdf<true, true>" : bsph ? "k_bssrdf<true, false>" : "k_bssrdf<false, false>");

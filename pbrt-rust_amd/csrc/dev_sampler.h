@@ -18,7 +18,12 @@ struct SobolTables {
     const uint32_t *prime;     // [1000]
     const uint32_t *prime_sum; // [1000]
     const uint16_t *perm;      // [sum of the first 1000 primes]
+    // m32 folded by index nibble (built by capi.hip from m32): nib[j][d][n] = XOR of m32[d][4 j + b] over the set bits b of n, j < kSobolNibbles.
+    // A Sobol' value is then one 16-entry table look-up per index nibble instead of one step per set index bit -- the same XORs, regrouped.
+    const uint32_t *nib;       // [kSobolNibbles][1024][16]
 };
+constexpr uint32_t kSobolNibbles = 10;                       // index bits 0..39 through the nibble tables, the rest bit by bit from m32
+constexpr uint32_t kSobolNibWords = kSobolNibbles * 16;      // per dimension (LDS budget: 640 B a dimension)
 
 struct HaltonParams {          // HaltonSampler::new (halton.rs:62-110)
     uint32_t enabled;          // PtRenderParams.sampler_type == PT_SAMPLER_HALTON
@@ -60,11 +65,29 @@ PT_DEV uint32_t sobol_bits(const uint32_t *row, uint64_t a) {
 PT_DEV float sobol_to_float(uint32_t v) { return minf((float)v * 0x1.0p-32f, kOneMinusEps); }
 PT_DEV float sobol_sample_float(const uint32_t *m32, uint64_t a, uint32_t dim) { return sobol_to_float(sobol_bits(m32 + dim * 52, a)); }
 
-constexpr uint32_t kSobolLdsDims = 64;                   // generator matrices of dimensions 0..63 staged in LDS (13 KB)
-constexpr uint32_t kSobolLdsWords = kSobolLdsDims * 52;
-// Cooperative copy of the first kSobolLdsDims rows into LDS; caller __syncthreads() afterwards.
-PT_DEV void sobol_stage_lds(uint32_t *lds, const uint32_t *m32, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid; i < kSobolLdsWords; i += nthreads) lds[i] = m32[i];
+// One dimension through the nibble tables: `t` = the dimension's first table (LDS or HBM), the next nibble's `jstride` words on;
+// `row` = the dimension's m32 row for index bits >= 40.
+PT_DEV uint32_t sobol_bits_nib(const uint32_t *t, uint32_t jstride, const uint32_t *row, uint64_t a) {
+    const uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+    uint32_t v = t[lo & 15u] ^ t[jstride + ((lo >> 4) & 15u)] ^ t[2 * jstride + ((lo >> 8) & 15u)] ^ t[3 * jstride + ((lo >> 12) & 15u)]
+               ^ t[4 * jstride + ((lo >> 16) & 15u)] ^ t[5 * jstride + ((lo >> 20) & 15u)] ^ t[6 * jstride + ((lo >> 24) & 15u)] ^ t[7 * jstride + (lo >> 28)];
+    if (hi != 0) {
+        v ^= t[8 * jstride + (hi & 15u)] ^ t[9 * jstride + ((hi >> 4) & 15u)];
+        for (uint32_t r = hi >> 8; r != 0; r &= r - 1) v ^= row[40 + __builtin_ctz(r)];
+    }
+    return v;
+}
+// The same from the HBM tables as a real function: the one-dimension-at-a-time path of Sampler::sample_dimension (dimensions outside the
+// vertex's window: ratio / delta tracking in grid media, the tail of very deep paths) is rare, and inlined at every get_1d / get_2d it
+// only spreads the hot code of the large shade kernels over more instruction-cache lines.
+__device__ __noinline__ inline uint32_t sobol_bits_far(const uint32_t *nib, const uint32_t *m32, uint32_t d, uint64_t a) {
+    return sobol_bits_nib(nib + d * 16u, 1024u * 16u, m32 + d * 52u, a);
+}
+// Cooperative copy of the first `dims` dimensions' nibble tables into LDS, [nibble][dimension][16] (a 16-entry table spans 16
+// banks, so the per-lane look-ups never conflict); caller __syncthreads() afterwards.
+PT_DEV void sobol_stage_lds(uint32_t *lds, const uint32_t *nib, uint32_t dims, uint32_t tid, uint32_t nthreads) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(nib); uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = tid; i < kSobolNibbles * dims * 4u; i += nthreads) { const uint32_t j = i / (dims * 4u), r = i - j * (dims * 4u); dst[i] = src[j * (1024u * 4u) + r]; }
 }
 
 constexpr uint32_t kHaltonMaxDims = 1000;  // PRIME_TABLE_SIZE: permutation_for_dimension panics beyond (halton.rs:113-119)
@@ -116,17 +139,20 @@ PT_DEV float halton_sample_dimension(const SobolTables &T, const HaltonParams &h
 struct Sampler {
     uint64_t index;
     uint32_t dim;
-    const uint32_t *m32;      // full table in HBM
-    const uint32_t *lds;      // first kSobolLdsDims rows in LDS
+    const uint32_t *m32;      // full table in HBM (index bits >= 40)
+    const uint32_t *nib;      // nibble tables of every dimension in HBM
+    const uint32_t *lds;      // nibble tables of the first lds_dims dimensions in LDS
+    uint32_t lds_dims;
     bool overflow;
     bool halton;              // wave-uniform: Halton instead of Sobol' (the window then holds float bits)
     const uint32_t *prime, *prime_sum; const uint16_t *perm;
-    uint32_t base;            // window of 8 consecutive dimensions evaluated in one pass over the index bits
+    uint32_t base;            // window of 8 (or 3) consecutive dimensions evaluated together
+    uint32_t wn;              // how many of them
     uint32_t w0, w1, w2, w3, w4, w5, w6, w7;
     // A path vertex consumes at most 8 dimensions (1 light choice + 2 + 2 + 2 BSDF + 1 roulette, path.rs /
-    // integrator.rs:91-101); evaluating them together shares the bit loop and issues 8 independent LDS reads per bit.
+    // integrator.rs:91-101); evaluating them together shares the nibble addresses: 8 independent LDS reads per index nibble.
     PT_DEV void load_window() {
-        base = dim;
+        base = dim; wn = 8;
         w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0;
         if (halton) {
             if (base + 8 > kHaltonMaxDims) { base = 0xffffffffu; return; }
@@ -139,25 +165,60 @@ struct Sampler {
         { uint32_t h = (uint32_t)index * 0x9E3779B9u ^ (uint32_t)(index >> 32) ^ (base * 0x85EBCA6Bu);
           w0 = h; w1 = h * 3u; w2 = h * 5u; w3 = h * 7u; w4 = h * 11u; w5 = h * 13u; w6 = h * 17u; w7 = h * 19u; return; }
 #endif
-        if (base + 8 <= kSobolLdsDims) {
-            const uint32_t *row = lds + base * 52;
-            uint64_t a = index;
-            while (a != 0) {
-                const int i = __builtin_ctzll(a); a &= a - 1;
-                w0 ^= row[i]; w1 ^= row[52 + i]; w2 ^= row[104 + i]; w3 ^= row[156 + i];
-                w4 ^= row[208 + i]; w5 ^= row[260 + i]; w6 ^= row[312 + i]; w7 ^= row[364 + i];
+        if (base + 8 <= lds_dims) nib_window(lds + base * 16u, lds_dims * 16u);
+        else if (base + 8 <= 1024u) nib_window(nib + base * 16u, 1024u * 16u);
+        else base = 0xffffffffu;  // the last dimensions: one at a time
+    }
+    // the eight dimensions' tables of one nibble are 16 words apart: one address per index nibble, eight reads at constant offsets from it
+    PT_DEV void nib_window(const uint32_t *t, uint32_t jstride) {
+        const uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+#define PT_NIB2(j, xa, xb) { const uint32_t *qa = t + (j) * jstride + ((xa) & 15u), *qb = t + ((j) + 1) * jstride + ((xb) & 15u); \
+                             const uint32_t a0 = qa[0], a1 = qa[16], a2 = qa[32], a3 = qa[48], a4 = qa[64], a5 = qa[80], a6 = qa[96], a7 = qa[112]; \
+                             const uint32_t b0 = qb[0], b1 = qb[16], b2 = qb[32], b3 = qb[48], b4 = qb[64], b5 = qb[80], b6 = qb[96], b7 = qb[112]; \
+                             w0 ^= a0 ^ b0; w1 ^= a1 ^ b1; w2 ^= a2 ^ b2; w3 ^= a3 ^ b3; w4 ^= a4 ^ b4; w5 ^= a5 ^ b5; w6 ^= a6 ^ b6; w7 ^= a7 ^ b7; }
+#ifdef PT_NIB_SPLIT   // experiment hook: the look-ups in two bursts of 16 reads instead of one of 32
+        PT_NIB2(0, lo, lo >> 4) PT_NIB2(2, lo >> 8, lo >> 12)
+        __builtin_amdgcn_sched_barrier(0);
+        PT_NIB2(4, lo >> 16, lo >> 20) PT_NIB2(6, lo >> 24, lo >> 28)
+#else
+        PT_NIB2(0, lo, lo >> 4) PT_NIB2(2, lo >> 8, lo >> 12) PT_NIB2(4, lo >> 16, lo >> 20) PT_NIB2(6, lo >> 24, lo >> 28)
+#endif
+        if (hi != 0) {
+            PT_NIB2(8, hi, hi >> 4)
+            for (uint32_t r = hi >> 8; r != 0; r &= r - 1) {
+                const uint32_t *row = m32 + base * 52 + 40 + __builtin_ctz(r);
+                w0 ^= row[0]; w1 ^= row[52]; w2 ^= row[104]; w3 ^= row[156]; w4 ^= row[208]; w5 ^= row[260]; w6 ^= row[312]; w7 ^= row[364];
             }
-        } else base = 0xffffffffu;  // beyond the staged rows: evaluate on demand from HBM
+        }
+#undef PT_NIB2
+    }
+    // A vertex with a specular-only BSDF draws three dimensions (BSDF sample + roulette; no light sampling: path.rs:131) -- Sobol' only
+    PT_DEV void load_window3() {
+        base = dim; wn = 3;
+        w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = 0;
+        if (halton || base + 3 > lds_dims) { base = 0xffffffffu; return; }
+        const uint32_t *t = lds + base * 16u; const uint32_t js = lds_dims * 16u;
+        const uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+#define PT_NIB3(j, x) { const uint32_t *q = t + (j) * js + ((x) & 15u); w0 ^= q[0]; w1 ^= q[16]; w2 ^= q[32]; }
+        PT_NIB3(0, lo) PT_NIB3(1, lo >> 4) PT_NIB3(2, lo >> 8) PT_NIB3(3, lo >> 12) PT_NIB3(4, lo >> 16) PT_NIB3(5, lo >> 20) PT_NIB3(6, lo >> 24) PT_NIB3(7, lo >> 28)
+        if (hi != 0) {
+            PT_NIB3(8, hi) PT_NIB3(9, hi >> 4)
+            for (uint32_t r = hi >> 8; r != 0; r &= r - 1) { const uint32_t *row = m32 + base * 52 + 40 + __builtin_ctz(r); w0 ^= row[0]; w1 ^= row[52]; w2 ^= row[104]; }
+        }
+#undef PT_NIB3
     }
     PT_DEV float sample_dimension(uint32_t d) {  // sobol.rs:68-86 / halton.rs:157-165 for dim >= 2
         if (d >= (halton ? kHaltonMaxDims : 1024u)) { overflow = true; return 0.0f; }  // the reference panics here
         const uint32_t k = d - base;
-        if (base != 0xffffffffu && k < 8u) {
+        if (base != 0xffffffffu && k < wn) {
             const uint32_t v = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : k == 3 ? w3 : k == 4 ? w4 : k == 5 ? w5 : k == 6 ? w6 : w7;
             return halton ? __uint_as_float(v) : sobol_to_float(v);
         }
         if (halton) return halton_scrambled_radical_inverse(prime[d], perm + prime_sum[d], index);
-        return sobol_sample_float(d < kSobolLdsDims ? lds : m32, index, d);
+        return sobol_to_float(sobol_bits_far(nib, m32, d, index));
+    }
+    PT_DEV float peek_sobol(uint32_t d) const {   // one Sobol' dimension of the staged ones (d < lds_dims), window or not
+        return sobol_to_float(sobol_bits_nib(lds + d * 16u, lds_dims * 16u, m32 + d * 52, index));
     }
     PT_DEV float get_1d() { float r = sample_dimension(dim); dim += 1; return r; }  // sampler.rs:322-333 (array_end_dim == 5)
     PT_DEV P2 get_2d() {                                                             // sampler.rs:336-354

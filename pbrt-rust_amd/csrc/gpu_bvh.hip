@@ -351,6 +351,7 @@ int build_hlbvh_gpu(const std::vector<PrimBound> &prims, uint32_t max_node_prims
     HCHK(hipMemcpy(d_cb, cb_init, sizeof cb_init, hipMemcpyHostToDevice));
     HCHK(hipMemset(d_root_of_bin, 0xFF, kBins * 4));
     HCHK(hipMemset(t.visits, 0, std::max<size_t>(n_int, 1) * 4));
+    HCHK(hipMemset(t.parent, 0xFF, 4));   // the root has no parent: k_karras writes it too, but does not run for a single primitive (k_emit reads it)
     hipLaunchKernelGGL(k_centroid_bounds, dim3(std::min<uint32_t>(1024, (n + 255) / 256)), dim3(256), 0, 0, d_pb, n, d_cb);
     uint32_t cb_ord[6]; float cbf[6];
     HCHK(hipMemcpy(cb_ord, d_cb, sizeof cb_ord, hipMemcpyDeviceToHost));

@@ -7,9 +7,8 @@
 __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
                                                      uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c5, uint32_t *error) {
     __shared__ LdsQueue<1024> q0, q1, q2, q3, q4, q5;
-    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    // (the two medium-sampling dimensions, or a grid medium's delta-tracking run, come one at a time from the HBM nibble tables: no LDS copy)
     lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q5);
-    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t count = *count_ptr;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -24,7 +23,7 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
             const uint32_t med = ps.medium(pid);
             if (med != PT_NONE) {
                 uint32_t meta = ps.meta(pid);
-                Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+                Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.nib = tabs.nib; smp.lds = nullptr; smp.lds_dims = 0u; smp.overflow = false;
                 smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
                 const V3 rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
                 bool sampled; float t;
@@ -68,7 +67,8 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
 // uniform_sample_onelight with the phase function in the BSDF's place (integrator.rs:142-147,186-190), then a new direction from
 // the phase function; beta is unchanged (phase value / its pdf = 1) and the ray stays in the same medium.
 __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
-    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    constexpr uint32_t LDS_DIMS = 56u;
+    __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis, s_qself;
     __shared__ uint32_t s_hist[16];
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qself);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
     if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
     Prof prof{s_pt, s_pr, s_pacc};
 #endif
-    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    sobol_stage_lds(s_sobol, tabs.nib, LDS_DIMS, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_shade_medium(DeviceScene s, RenderConst
             pid = job.queue[qi];
             const uint32_t meta = ps.meta(pid);
             uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false;
+            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.nib = tabs.nib; smp.lds = s_sobol; smp.lds_dims = LDS_DIMS; smp.overflow = false;
             smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm; smp.base = 0xffffffffu;
             RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));

@@ -14,12 +14,13 @@ template <bool SPH, bool VOL>
                                         // per 216-sample pass; like the matte shade kernel it is VALU-bound at two waves); with spheres / instances three waves spill 192 bytes: left alone
 #endif
 __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job) {
-    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    constexpr uint32_t LDS_DIMS = 56u;
+    __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ uint32_t s_hist[16];
     lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
-    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    sobol_stage_lds(s_sobol, tabs.nib, LDS_DIMS, threadIdx.x, blockDim.x);
     __syncthreads();
 #ifdef PT_REGION_PROFILE
     __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
         if (at_exit || dead) {
             uint32_t meta = ps.meta(pid);
             uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
-            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+            Sampler smp; smp.index = ps.sobol_index(pid); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.nib = tabs.nib; smp.lds = s_sobol; smp.lds_dims = LDS_DIMS; smp.overflow = false; smp.halton = rc.halton.enabled != 0; smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
             smp.base = 0xffffffffu;
             RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));

@@ -14,9 +14,12 @@ template <int MAXL, int MODE, int DIFF>
 // Waves per SIMD the kernel is compiled for. The matte kernel of triangle-only scenes (MAXL 1, MODE 0, DIFF 1: the headline's) takes three:
 // 168 VGPRs + 32 bytes of scratch, VALU-bound at two waves (57 % busy, 9 % of the wave cycles waiting on memory: SQ counters in profiles/r3).
 // The others lose more to spills than they gain (one-lobe general kernel at three waves: 160 bytes of scratch, 112.8 -> 114.8 ms on C3).
-__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SHADE_WAVES > 3 ? PT_SHADE_WAVES : 3) : (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SHADE_WAVES > 3 ? PT_SHADE_WAVES : 3) : (MAXL == 1 && MODE == 0 && DIFF == 2) ? 4 : (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
-    __shared__ uint32_t s_sobol[kSobolLdsWords];
+    // Sobol' nibble tables of the first dimensions (dev_sampler.h): 56 cover the vertices of bounces 0..5; the five-lobe class, whose lobe store
+    // fills the LDS, keeps 20 and reads the rest from HBM (one 64-byte line per look-up, the same for every lane of a bounce)
+    constexpr uint32_t LDS_DIMS = MAXL == 5 ? 20u : DIFF == 2 ? 32u : 56u;   // (the specular-only kernel runs four workgroups per CU: 37 KB each)
+    __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
     // (the five-lobe class flushes its queues every round -- 256-entry buffers: with the 60 KB lobe store, two of its workgroups fit a CU's
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SH
     if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
     Prof prof{s_pt, s_pr, s_pacc};
 #endif
-    sobol_stage_lds(s_sobol, tabs.m32, threadIdx.x, blockDim.x);
+    sobol_stage_lds(s_sobol, tabs.nib, LDS_DIMS, threadIdx.x, blockDim.x);
     __syncthreads();
     const uint32_t count = *job.count;
     const uint32_t rounded = (count + 255u) & ~255u;   // whole blocks iterate together
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SH
         uint32_t meta = __float_as_uint(c1.w);
         uint32_t flags = meta >> 24, bounces = (meta >> 16) & 0xffu;
         float etascale = c0.w;
-        Sampler smp; smp.index = (uint64_t)__float_as_uint(c2.x) | ((uint64_t)__float_as_uint(c2.y) << 32); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.lds = s_sobol; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+        Sampler smp; smp.index = (uint64_t)__float_as_uint(c2.x) | ((uint64_t)__float_as_uint(c2.y) << 32); smp.dim = meta & 0xffffu; smp.m32 = tabs.m32; smp.nib = tabs.nib; smp.lds = s_sobol; smp.lds_dims = LDS_DIMS; smp.overflow = false; smp.halton = MODE >= 1 && rc.halton.enabled != 0;   /* Halton scenes run the general kernels: the triangle-only ones stay Sobol'-only */ smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
         smp.base = 0xffffffffu;
         RGB L(c0.x, c0.y, c0.z);
         RGB beta(c1.x, c1.y, c1.z);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SH
             bool terminated = !found || bounces >= rc.max_depth;  // path.rs:120
             if (!terminated) {
                 PT_T(4);
-                if (!stage_b) smp.load_window();
+                if (DIFF == 2) smp.load_window3(); else if (!stage_b) smp.load_window();
                 PT_T(10);
                 Bsdf<MAXL, DIFF> bsdf; bsdf.bind(s_lobes);
                 const uint32_t mi = packet_material(s, pfl, hp);
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SH
                     if (flags & PF_CAMERA_RAY) {
                         P2 plens_u(0.0f, 0.0f);
                         if (rc.lens_radius > 0.0f) plens_u = rc.halton.enabled ? P2(halton_sample_dimension(tabs, rc.halton, smp.index, 3u), halton_sample_dimension(tabs, rc.halton, smp.index, 4u))
-                                                                              : P2(sobol_sample_float(s_sobol, smp.index, 3u), sobol_sample_float(s_sobol, smp.index, 4u));
+                                                                              : P2(smp.peek_sobol(3u), smp.peek_sobol(4u));
                         rdiff = camera_ray_differentials(rc, c2.z, c2.w, plens_u, ro, rd);
                     }
                     const TexCtx tctx = compute_differentials(si, rdiff);
