@@ -1207,10 +1207,11 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const uint32_t *d_ordered = nullptr;
         const uint32_t n_packets = (uint32_t)packet_refs.size();
         if ((st = sc->upload(&d_ordered, packet_refs.data(), packet_refs.size()))) return bail(st);
-        TriPacket *leaf = nullptr; float *area = nullptr;
+        TriPacket *leaf = nullptr; float *area = nullptr; float4 *lrec = nullptr;
         if ((st = sc->dalloc(&leaf, (size_t)n_packets + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
+        if ((st = sc->dalloc(&lrec, 4 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         hipLaunchKernelGGL(k_build_packets, dim3((n_packets + 255) / 256), dim3(256), 0, 0, ds, d_ordered, n_packets, leaf);
         ds.leaf = leaf;
         {
@@ -1218,8 +1219,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             if ((st = sc->upload(&d_last, leaf_last.data(), leaf_last.size()))) return bail(st);
             hipLaunchKernelGGL(k_mark_leaf_ends, dim3(((uint32_t)leaf_last.size() + 255) / 256), dim3(256), 0, 0, leaf, d_last, (uint32_t)leaf_last.size());
         }
-        if (d->n_lights) hipLaunchKernelGGL(k_light_area, dim3((d->n_lights + 255) / 256), dim3(256), 0, 0, ds, area);
-        ds.light_area = area;
+        if (d->n_lights) hipLaunchKernelGGL(k_light_area, dim3((d->n_lights + 255) / 256), dim3(256), 0, 0, ds, area, lrec);
+        ds.light_area = area; ds.light_rec = lrec;
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return bail(fail(PT_ERR_HIP, "scene preparation kernels failed"));
     }
     *out = sc;

@@ -25,6 +25,23 @@ PT_DEV int find_interval_cdf(const float *cdf, int size, float u) {
 struct Dist1D { const float *func; const float *cdf; float func_int; int n; };
 
 PT_DEV int dist_sample_discrete(const Dist1D &d, float u, float &pdf) {  // sampling.rs:66-85
+    if (d.n <= 3) {   // up to three lights: the whole cdf, func and func_int in one round trip to memory; the SAME bisection, over registers
+        const int n = d.n;
+        const float c0 = d.cdf[0], c1 = d.cdf[1], c2 = d.cdf[n < 2 ? n : 2], c3 = d.cdf[n < 3 ? n : 3];
+        const float f0 = d.func[0], f1 = d.func[n < 2 ? 0 : 1], f2 = d.func[n < 3 ? 0 : 2];
+        int first = 0, len = n + 1;
+        while (len > 0) {
+            const int half = len >> 1, middle = first + half;
+            const float cm = middle == 0 ? c0 : middle == 1 ? c1 : middle == 2 ? c2 : c3;
+            if (cm <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        const int r = first - 1;
+        const int off = r < 0 ? 0 : (r > n - 1 ? n - 1 : r);
+        const float fo = off == 0 ? f0 : off == 1 ? f1 : f2;
+        pdf = (d.func_int > 0.0f) ? fo / (d.func_int * (float)n) : 0.0f;
+        return off;
+    }
     int off = find_interval_cdf(d.cdf, d.n + 1, u);
     pdf = (d.func_int > 0.0f) ? d.func[off] / (d.func_int * (float)d.n) : 0.0f;
     return off;
@@ -78,6 +95,17 @@ PT_DEV RGB area_l(const PtLight &L, V3 n, V3 w) {  // diffuse.rs:71-79
     if (L.two_sided || dot(n, w) > 0.0f) return RGB(L.L[0], L.L[1], L.L[2]);
     return RGB(0.0f);
 }
+// A triangle area light from DeviceScene::light_rec
+struct LightTri { V3 p0, p1, p2; uint32_t fl, tri; float area; RGB Lemit; bool two_sided; };
+PT_DEV bool load_light_tri(const DeviceScene &s, uint32_t li, LightTri &t) {
+    const float4 *r = s.light_rec + 4 * (size_t)li;
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+    t.p0 = V3(q0.x, q0.y, q0.z); t.p1 = V3(q1.x, q1.y, q1.z); t.p2 = V3(q2.x, q2.y, q2.z);
+    t.fl = __float_as_uint(q0.w) & 0xffu; t.tri = __float_as_uint(q1.w); t.area = q2.w;
+    t.Lemit = RGB(q3.x, q3.y, q3.z); t.two_sided = __float_as_uint(q3.w) != 0u;
+    return (__float_as_uint(q0.w) & 0x100u) != 0u;
+}
+PT_DEV RGB area_l(const LightTri &t, V3 n, V3 w) { return (t.two_sided || dot(n, w) > 0.0f) ? t.Lemit : RGB(0.0f); }   // diffuse.rs:71-79
 PT_DEV M4 ldm4(const float *p) { M4 m; for (int i = 0; i < 16; ++i) m.m[i] = p[i]; return m; }
 
 PT_DEV RGB light_le(const DeviceScene &s, const PtLight &L, V3 ray_d) {  // infinite.rs:118-126 (others: 0)
@@ -154,8 +182,40 @@ PT_DEV IData sphere_sample_interaction(const PtSphere &S, const IData &ref, P2 u
 
 // Light::sample_li. Returns Li; fills wi, pdf and the far end of the visibility segment.
 template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li, const IData &ref, P2 u, V3 &wi, float &pdf, IData &p1) {
-    const PtLight &L = s.lights[li];
     p1.p = V3(); p1.p_error = V3(); p1.n = V3();
+    {   // a triangle area light (diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584), everything from its record
+        LightTri t;
+        if (load_light_tri(s, li, t)) {
+            const float su0 = sqrtf(u.x);
+            const float b0 = 1.0f - su0, b1 = u.y * su0;  // uniform_sample_triangle, sampling.rs:250-254
+            IData it;
+            const float b2 = 1.0f - b0 - b1;
+            it.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+            it.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+            if (t.fl & PT_TRI_HAS_N) {
+                const uint32_t i0 = s.indices[3 * t.tri], i1 = s.indices[3 * t.tri + 1], i2 = s.indices[3 * t.tri + 2];
+                const V3 ns = ld3(s.N, i0) * b0 + ld3(s.N, i1) * b1 + ld3(s.N, i2) * b2;
+                it.n = face_forward(it.n, ns);
+            } else if (((t.fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((t.fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) {
+                it.n = it.n * -1.0f;
+            }
+            const V3 pabs = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
+            it.p_error = pabs * gammaf(6);
+            pdf = 1.0f / t.area;
+            V3 w = it.p - ref.p;
+            if (length_squared(w) == 0.0f) pdf = 0.0f;
+            else {
+                w = normalize(w);
+                pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -w);
+                if (__builtin_isinf(pdf)) pdf = 0.0f;
+            }
+            if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
+            wi = normalize(it.p - ref.p);
+            p1 = it;
+            return area_l(t, it.n, -wi);
+        }
+    }
+    const PtLight &L = s.lights[li];
     switch (L.type) {
     case PT_LIGHT_DIFFUSE_AREA: {  // diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584
         if (SPH && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE && s.spheres[s.prim_shape[L.prim] & 0x3fffffffu].kind == PT_QUADRIC_DISK) {
@@ -187,36 +247,7 @@ template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li
             p1 = it;
             return area_l(L, it.n, -wi);
         }
-        uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
-        float su0 = sqrtf(u.x);
-        float b0 = 1.0f - su0, b1 = u.y * su0;  // uniform_sample_triangle, sampling.rs:250-254
-        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
-        V3 p0 = ld3(s.P, i0), p1v = ld3(s.P, i1), p2 = ld3(s.P, i2);
-        IData it;
-        float b2 = 1.0f - b0 - b1;
-        it.p = p0 * b0 + p1v * b1 + p2 * b2;
-        it.n = normalize(cross(p1v - p0, p2 - p0));
-        uint32_t fl = s.tri_flags[tri];
-        if (fl & PT_TRI_HAS_N) {
-            V3 ns = ld3(s.N, i0) * b0 + ld3(s.N, i1) * b1 + ld3(s.N, i2) * b2;
-            it.n = face_forward(it.n, ns);
-        } else if (((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) {
-            it.n = it.n * -1.0f;
-        }
-        V3 pabs = vabs(p0 * b0) + vabs(p1v * b1) + vabs(p2 * b2);
-        it.p_error = pabs * gammaf(6);
-        pdf = 1.0f / s.light_area[li];
-        V3 w = it.p - ref.p;
-        if (length_squared(w) == 0.0f) pdf = 0.0f;
-        else {
-            w = normalize(w);
-            pdf *= distance_squared(ref.p, it.p) / abs_dot(it.n, -w);
-            if (__builtin_isinf(pdf)) pdf = 0.0f;
-        }
-        if (pdf == 0.0f || length_squared(it.p - ref.p) == 0.0f) { pdf = 0.0f; return RGB(0.0f); }
-        wi = normalize(it.p - ref.p);
-        p1 = it;
-        return area_l(L, it.n, -wi);
+        pdf = 0.0f; return RGB(0.0f);   // (triangle lights were served from their record above)
     }
     case PT_LIGHT_DISTANT: {  // distant.rs:64-84
         V3 wl(L.dir[0], L.dir[1], L.dir[2]);
@@ -262,6 +293,26 @@ template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li
 
 // Light::pdf_li (area: Shape::pdf_wi re-intersects the light's own triangle, shape.rs:63-82)
 template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li, const IData &ref, V3 wi) {
+    {   // Shape::pdf_wi of a triangle light (shape.rs:63-82): intersect the light's own triangle, without a shape (no orientation from
+        // shading normals: interaction.n is the geometric normal, flipped by the triangle's flags -- triangle.rs:266-392 with `s` = None)
+        LightTri t;
+        if (load_light_tri(s, li, t)) {
+            V3 o; spawn_ray(ref, wi, o);
+            float th, b0, b1, b2;
+            if (!tri_hit_params(t.p0, t.p1, t.p2, o, wi, PT_INF, th, b0, b1, b2)) return 0.0f;
+            P2 uv[3];
+            if (t.fl & PT_TRI_HAS_UV) { const uint32_t i0 = s.indices[3 * t.tri], i1 = s.indices[3 * t.tri + 1], i2 = s.indices[3 * t.tri + 2]; tri_uvs(s, t.tri, i0, i1, i2, uv); }
+            else { uv[0] = P2(0.0f, 0.0f); uv[1] = P2(1.0f, 0.0f); uv[2] = P2(1.0f, 1.0f); }
+            V3 dpdu, dpdv;
+            if (!tri_partials(t.p0, t.p1, t.p2, uv, dpdu, dpdv)) return 0.0f;
+            const V3 ip = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
+            V3 in = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
+            if (((t.fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((t.fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) in = -in;
+            float pdf = distance_squared(ref.p, ip) / (dot(in, -wi) * t.area);
+            if (__builtin_isinf(pdf)) pdf = 0.0f;
+            return pdf;
+        }
+    }
     const PtLight &L = s.lights[li];
 #ifdef PT_ABL_LIGHTPDF   // timing ablation only
     return 0.5f + 0.0f * L.L[0];
@@ -292,22 +343,7 @@ template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li,
         const float cos_thetamax = sqrtf(maxf(1.0f - sin_thetamax2, 0.0f));
         return 1.0f / (2.0f * kPi * (1.0f - cos_thetamax));
     }
-    if (L.type == PT_LIGHT_DIFFUSE_AREA) {
-        uint32_t tri = s.prim_shape[L.prim] & 0x3fffffffu;
-        V3 o; spawn_ray(ref, wi, o);
-        uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
-        V3 p0 = ld3(s.P, i0), p1 = ld3(s.P, i1), p2 = ld3(s.P, i2);
-        float t, b0, b1, b2;
-        if (!tri_hit_params(p0, p1, p2, o, wi, PT_INF, t, b0, b1, b2)) return 0.0f;
-        P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
-        V3 dpdu, dpdv;
-        if (!tri_partials(p0, p1, p2, uv, dpdu, dpdv)) return 0.0f;
-        SurfaceInteraction il;
-        tri_fill_interaction(s, tri, wi, b0, b1, b2, false, il);
-        float pdf = distance_squared(ref.p, il.p) / (dot(il.n, -wi) * s.light_area[li]);
-        if (__builtin_isinf(pdf)) pdf = 0.0f;
-        return pdf;
-    }
+    if (L.type == PT_LIGHT_DIFFUSE_AREA) return 0.0f;   // (triangle lights were served from their record above)
     if (L.type == PT_LIGHT_INFINITE) {  // infinite.rs:128-138
         V3 w = xf_vector(ldm4(L.world_to_light), wi);
         float theta = spherical_theta(w), phi = spherical_phi(w);

@@ -68,6 +68,10 @@ struct DeviceScene {
     const PtMaterial *materials; uint32_t n_materials;
     const PtLight *lights; uint32_t n_lights;
     const float *light_area;            // per light: Shape::area() of its primitive
+    // per light, four quads {p0, flags} {p1, triangle} {p2, area} {Lemit, two_sided}: what sampling a TRIANGLE area light and evaluating its
+    // pdf read, in one place (flags: the triangle's PT_TRI_* byte | 0x100 = the record is valid) instead of behind the chain
+    // lights -> prim_shape -> indices -> P (k_light_area)
+    const float4 *light_rec;
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class
     const DevBssTable *bss_tables; uint32_t n_bss_tables;   // subsurface materials (row a23)

@@ -44,16 +44,20 @@ __global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, ui
     if (i < n) leaf[last_index[i]].flags |= TP_LAST;
 }
 
-__global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight::new -> shape.area()
+__global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // DiffuseAreaLight::new -> shape.area(); DeviceScene::light_rec
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n_lights) return;
     float a = 0.0f;
     const PtLight &L = s.lights[i];
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     if (L.type == PT_LIGHT_DIFFUSE_AREA) {
         uint32_t shape = s.prim_shape[L.prim];
         if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
             uint32_t tri = shape & 0x3fffffffu;
-            a = tri_area(ld3(s.P, s.indices[3 * tri]), ld3(s.P, s.indices[3 * tri + 1]), ld3(s.P, s.indices[3 * tri + 2]));
+            const V3 p0 = ld3(s.P, s.indices[3 * tri]), p1 = ld3(s.P, s.indices[3 * tri + 1]), p2 = ld3(s.P, s.indices[3 * tri + 2]);
+            a = tri_area(p0, p1, p2);
+            r0 = make_float4(p0.x, p0.y, p0.z, __uint_as_float((uint32_t)s.tri_flags[tri] | 0x100u));
+            r1 = make_float4(p1.x, p1.y, p1.z, __uint_as_float(tri)); r2 = make_float4(p2.x, p2.y, p2.z, a);
         } else {  // Sphere::area (sphere.rs:291-293)
             const PtSphere &S = s.spheres[shape & 0x3fffffffu];
             a = S.kind == PT_QUADRIC_DISK ? S.phi_max * 0.5f * (S.radius * S.radius - S.inner_radius * S.inner_radius)   // Disk::area (disk.rs:120-122)
@@ -61,6 +65,8 @@ __global__ void k_light_area(DeviceScene s, float *area) {  // DiffuseAreaLight:
         }
     }
     area[i] = a;
+    rec[4 * (size_t)i] = r0; rec[4 * (size_t)i + 1] = r1; rec[4 * (size_t)i + 2] = r2;
+    rec[4 * (size_t)i + 3] = make_float4(L.L[0], L.L[1], L.L[2], __uint_as_float(L.two_sided));
 }
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
