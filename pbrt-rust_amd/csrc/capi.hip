@@ -1211,7 +1211,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if ((st = sc->dalloc(&leaf, (size_t)n_packets + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
-        if ((st = sc->dalloc(&lrec, 4 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);
+        if ((st = sc->dalloc(&lrec, 6 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         hipLaunchKernelGGL(k_build_packets, dim3((n_packets + 255) / 256), dim3(256), 0, 0, ds, d_ordered, n_packets, leaf);
         ds.leaf = leaf;
         {

@@ -96,14 +96,20 @@ PT_DEV RGB area_l(const PtLight &L, V3 n, V3 w) {  // diffuse.rs:71-79
     return RGB(0.0f);
 }
 // A triangle area light from DeviceScene::light_rec
-struct LightTri { V3 p0, p1, p2; uint32_t fl, tri; float area; RGB Lemit; bool two_sided; };
-PT_DEV bool load_light_tri(const DeviceScene &s, uint32_t li, LightTri &t) {
-    const float4 *r = s.light_rec + 4 * (size_t)li;
-    const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+struct LightTri { V3 p0, p1, p2, n_sample, n_pdf; uint32_t fl, tri; float area, inv_area; RGB Lemit; bool two_sided, degenerate; };
+PT_DEV bool load_light_tri(const DeviceScene &s, uint32_t li, LightTri &t, bool for_pdf) {
+    const float4 *r = s.light_rec + 6 * (size_t)li;
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
     t.p0 = V3(q0.x, q0.y, q0.z); t.p1 = V3(q1.x, q1.y, q1.z); t.p2 = V3(q2.x, q2.y, q2.z);
-    t.fl = __float_as_uint(q0.w) & 0xffu; t.tri = __float_as_uint(q1.w); t.area = q2.w;
-    t.Lemit = RGB(q3.x, q3.y, q3.z); t.two_sided = __float_as_uint(q3.w) != 0u;
-    return (__float_as_uint(q0.w) & 0x100u) != 0u;
+    const uint32_t bits = __float_as_uint(q0.w);
+    t.fl = bits & 0xffu; t.degenerate = (bits & 0x200u) != 0u; t.tri = __float_as_uint(q1.w); t.area = q2.w;
+    if (for_pdf) { const float4 q5 = r[5]; t.n_pdf = V3(q5.x, q5.y, q5.z); }
+    else {
+        const float4 q3 = r[3], q4 = r[4];
+        t.Lemit = RGB(q3.x, q3.y, q3.z); t.two_sided = __float_as_uint(q3.w) != 0u;
+        t.n_sample = V3(q4.x, q4.y, q4.z); t.inv_area = q4.w;
+    }
+    return (bits & 0x100u) != 0u;
 }
 PT_DEV RGB area_l(const LightTri &t, V3 n, V3 w) { return (t.two_sided || dot(n, w) > 0.0f) ? t.Lemit : RGB(0.0f); }   // diffuse.rs:71-79
 PT_DEV M4 ldm4(const float *p) { M4 m; for (int i = 0; i < 16; ++i) m.m[i] = p[i]; return m; }
@@ -185,23 +191,21 @@ template <bool SPH> PT_DEV RGB light_sample_li(const DeviceScene &s, uint32_t li
     p1.p = V3(); p1.p_error = V3(); p1.n = V3();
     {   // a triangle area light (diffuse.rs:95-112 + shape.rs:40-58 + triangle.rs:556-584), everything from its record
         LightTri t;
-        if (load_light_tri(s, li, t)) {
+        if (load_light_tri(s, li, t, false)) {
             const float su0 = sqrtf(u.x);
             const float b0 = 1.0f - su0, b1 = u.y * su0;  // uniform_sample_triangle, sampling.rs:250-254
             IData it;
             const float b2 = 1.0f - b0 - b1;
             it.p = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
-            it.n = normalize(cross(t.p1 - t.p0, t.p2 - t.p0));
+            it.n = t.n_sample;   // normalize(cross(p1 - p0, p2 - p0)), flipped by the orientation flags when the mesh has no normals
             if (t.fl & PT_TRI_HAS_N) {
                 const uint32_t i0 = s.indices[3 * t.tri], i1 = s.indices[3 * t.tri + 1], i2 = s.indices[3 * t.tri + 2];
                 const V3 ns = ld3(s.N, i0) * b0 + ld3(s.N, i1) * b1 + ld3(s.N, i2) * b2;
                 it.n = face_forward(it.n, ns);
-            } else if (((t.fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((t.fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) {
-                it.n = it.n * -1.0f;
             }
             const V3 pabs = vabs(t.p0 * b0) + vabs(t.p1 * b1) + vabs(t.p2 * b2);
             it.p_error = pabs * gammaf(6);
-            pdf = 1.0f / t.area;
+            pdf = t.inv_area;   // 1 / area
             V3 w = it.p - ref.p;
             if (length_squared(w) == 0.0f) pdf = 0.0f;
             else {
@@ -296,18 +300,13 @@ template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li,
     {   // Shape::pdf_wi of a triangle light (shape.rs:63-82): intersect the light's own triangle, without a shape (no orientation from
         // shading normals: interaction.n is the geometric normal, flipped by the triangle's flags -- triangle.rs:266-392 with `s` = None)
         LightTri t;
-        if (load_light_tri(s, li, t)) {
+        if (load_light_tri(s, li, t, true)) {
             V3 o; spawn_ray(ref, wi, o);
             float th, b0, b1, b2;
             if (!tri_hit_params(t.p0, t.p1, t.p2, o, wi, PT_INF, th, b0, b1, b2)) return 0.0f;
-            P2 uv[3];
-            if (t.fl & PT_TRI_HAS_UV) { const uint32_t i0 = s.indices[3 * t.tri], i1 = s.indices[3 * t.tri + 1], i2 = s.indices[3 * t.tri + 2]; tri_uvs(s, t.tri, i0, i1, i2, uv); }
-            else { uv[0] = P2(0.0f, 0.0f); uv[1] = P2(1.0f, 0.0f); uv[2] = P2(1.0f, 1.0f); }
-            V3 dpdu, dpdv;
-            if (!tri_partials(t.p0, t.p1, t.p2, uv, dpdu, dpdv)) return 0.0f;
+            if (t.degenerate) return 0.0f;   // tri_partials fails for this triangle (a property of its vertices and uvs)
             const V3 ip = t.p0 * b0 + t.p1 * b1 + t.p2 * b2;
-            V3 in = normalize(cross(t.p0 - t.p2, t.p1 - t.p2));
-            if (((t.fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((t.fl & PT_TRI_SWAPS_HANDEDNESS) != 0)) in = -in;
+            const V3 in = t.n_pdf;          // normalize(cross(p0 - p2, p1 - p2)), flipped by the orientation flags
             float pdf = distance_squared(ref.p, ip) / (dot(in, -wi) * t.area);
             if (__builtin_isinf(pdf)) pdf = 0.0f;
             return pdf;
@@ -375,9 +374,11 @@ PT_DEV size_t light_grid_cell(const LightGrid &g, const DeviceScene &s, V3 p) { 
     uint32_t pi[3];
     for (int i = 0; i < 3; ++i) {
         if (s.wb_max[i] > s.wb_min[i]) o[i] /= s.wb_max[i] - s.wb_min[i];
-        int64_t v = f2i_sat(o[i] * (float)g.nvox[i]);
-        int64_t hi = (int64_t)g.nvox[i] - 1;
-        pi[i] = (uint32_t)(v < 0 ? 0 : (v > hi ? hi : v));
+        // clamp(`as i64`, 0, nvox - 1): the saturating cast (NaN -> 0) followed by the clamp, without the 64-bit conversion
+        const float x = o[i] * (float)g.nvox[i];
+        const uint32_t hi = g.nvox[i] - 1u;
+        const uint32_t v = (x > 0.0f) ? (uint32_t)(int32_t)fminf(x, 2147483520.0f) : 0u;
+        pi[i] = v > hi ? hi : v;
     }
     return ((size_t)pi[2] * g.nvox[1] + pi[1]) * g.nvox[0] + pi[0];
 }

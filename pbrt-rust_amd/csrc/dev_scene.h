@@ -68,9 +68,12 @@ struct DeviceScene {
     const PtMaterial *materials; uint32_t n_materials;
     const PtLight *lights; uint32_t n_lights;
     const float *light_area;            // per light: Shape::area() of its primitive
-    // per light, four quads {p0, flags} {p1, triangle} {p2, area} {Lemit, two_sided}: what sampling a TRIANGLE area light and evaluating its
-    // pdf read, in one place (flags: the triangle's PT_TRI_* byte | 0x100 = the record is valid) instead of behind the chain
-    // lights -> prim_shape -> indices -> P (k_light_area)
+    // per light, six quads {p0, flags} {p1, triangle} {p2, area} {Lemit, two_sided} {n_sample, 1 / area} {n_pdf, -}: what sampling a TRIANGLE
+    // area light and evaluating its pdf read, in one place instead of behind the chain lights -> prim_shape -> indices -> P, with the
+    // per-light constants of both computed once by k_light_area (the same instruction sequences the shade kernels ran per vertex).
+    // flags: the triangle's PT_TRI_* byte | 0x100 = the record is valid | 0x200 = Triangle::intersect rejects every hit (degenerate
+    // partials, triangle.rs:236-264); n_sample = Triangle::sample's normal before the face-forward to interpolated normals
+    // (triangle.rs:566-577), n_pdf = the interaction normal Triangle::intersect leaves without a shape (triangle.rs:283-300)
     const float4 *light_rec;
     const uint32_t *infinite_lights; uint32_t n_infinite;
     const uint8_t *mat_class;           // per material: shade-queue class

@@ -49,14 +49,24 @@ __global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // Diff
     if (i >= s.n_lights) return;
     float a = 0.0f;
     const PtLight &L = s.lights[i];
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r4 = r0, r5 = r0;
     if (L.type == PT_LIGHT_DIFFUSE_AREA) {
         uint32_t shape = s.prim_shape[L.prim];
         if ((shape >> 30) == PT_SHAPE_TRIANGLE) {
             uint32_t tri = shape & 0x3fffffffu;
             const V3 p0 = ld3(s.P, s.indices[3 * tri]), p1 = ld3(s.P, s.indices[3 * tri + 1]), p2 = ld3(s.P, s.indices[3 * tri + 2]);
             a = tri_area(p0, p1, p2);
-            r0 = make_float4(p0.x, p0.y, p0.z, __uint_as_float((uint32_t)s.tri_flags[tri] | 0x100u));
+            const uint32_t fl = s.tri_flags[tri];
+            const bool flip = ((fl & PT_TRI_REVERSE_ORIENTATION) != 0) != ((fl & PT_TRI_SWAPS_HANDEDNESS) != 0);
+            V3 ns = normalize(cross(p1 - p0, p2 - p0));                      // Triangle::sample (triangle.rs:566-577)
+            if (!(fl & PT_TRI_HAS_N) && flip) ns = ns * -1.0f;
+            V3 np = normalize(cross(p0 - p2, p1 - p2));                      // Triangle::intersect (triangle.rs:283-300), no shape
+            if (flip) np = -np;
+            P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
+            V3 dpdu, dpdv;
+            const bool degenerate = !tri_partials(p0, p1, p2, uv, dpdu, dpdv);
+            r4 = make_float4(ns.x, ns.y, ns.z, 1.0f / a); r5 = make_float4(np.x, np.y, np.z, 0.0f);
+            r0 = make_float4(p0.x, p0.y, p0.z, __uint_as_float(fl | 0x100u | (degenerate ? 0x200u : 0u)));
             r1 = make_float4(p1.x, p1.y, p1.z, __uint_as_float(tri)); r2 = make_float4(p2.x, p2.y, p2.z, a);
         } else {  // Sphere::area (sphere.rs:291-293)
             const PtSphere &S = s.spheres[shape & 0x3fffffffu];
@@ -65,8 +75,8 @@ __global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // Diff
         }
     }
     area[i] = a;
-    rec[4 * (size_t)i] = r0; rec[4 * (size_t)i + 1] = r1; rec[4 * (size_t)i + 2] = r2;
-    rec[4 * (size_t)i + 3] = make_float4(L.L[0], L.L[1], L.L[2], __uint_as_float(L.two_sided));
+    float4 *r = rec + 6 * (size_t)i;
+    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = make_float4(L.L[0], L.L[1], L.L[2], __uint_as_float(L.two_sided)); r[4] = r4; r[5] = r5;
 }
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
