@@ -395,15 +395,27 @@ __global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, 
     for (uint32_t d = 0; d < n_dims; ++d) out[(size_t)i * n_dims + d] = halton_sample_dimension(tabs, hp, index, d);
 }
 
-__global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
-                                uint32_t n_dims, float *out, uint64_t *out_index) {
+// Dimensions >= 2 go through the shade kernels' own Sampler (dev_sampler.h): windows of eight dimensions from the LDS nibble tables, then from
+// their HBM copy, the last dimensions one at a time -- so this parity entry checks the product's sampling code, index bits >= 32 and >= 40 included.
+__global__ __launch_bounds__(256) void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
+                                                       uint32_t n_dims, float *out, uint64_t *out_index) {
+    constexpr uint32_t LDS_DIMS = 56u;
+    __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
+    sobol_stage_lds(s_sobol, tabs.nib, LDS_DIMS, threadIdx.x, blockDim.x);
+    __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
     uint64_t index = sobol_interval_to_index(tabs, (uint32_t)sp.log2_resolution, sample_num[i], (uint32_t)(px - sp.sb_min[0]), (uint32_t)(py - sp.sb_min[1]));
     if (out_index) out_index[i] = index;
-    for (uint32_t d = 0; d < n_dims; ++d)
-        out[(size_t)i * n_dims + d] = (d < 2) ? sobol_pixel_dim(tabs.m32, sp, index, (int)d, d == 0 ? px : py) : sobol_sample_float(tabs.m32, index, d);
+    for (uint32_t d = 0; d < 2 && d < n_dims; ++d) out[(size_t)i * n_dims + d] = sobol_pixel_dim(tabs.m32, sp, index, (int)d, d == 0 ? px : py);
+    Sampler smp; smp.index = index; smp.m32 = tabs.m32; smp.nib = tabs.nib; smp.lds = s_sobol; smp.lds_dims = LDS_DIMS; smp.overflow = false; smp.halton = false;
+    smp.prime = tabs.prime; smp.prime_sum = tabs.prime_sum; smp.perm = tabs.perm;
+    for (uint32_t d = 2; d < n_dims;) {
+        smp.dim = d;
+        smp.load_window();
+        for (uint32_t k = 0; k < 8 && d < n_dims; ++k, ++d) out[(size_t)i * n_dims + d] = smp.get_1d();
+    }
 }
 __global__ void k_camera_rays(RenderConst rc, uint32_t n, const float *cs, float *out_o, float *out_d) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,13 +13,17 @@ def _small_scene(pkg, **kw):
     return pkg.scenes.ganesha_scale(**args).world_end()
 
 
-def test_sobol_samples_bit_exact(pkg, gpu, oracle):
+@pytest.mark.parametrize("nd,max_sample", [(48, 4096), (70, 1 << 12), (1024, 1 << 30), (19, 1 << 30)])
+def test_sobol_samples_bit_exact(pkg, gpu, oracle, nd, max_sample):
+    """pt_sobol_samples runs the shade kernels' Sampler: eight-dimension windows from the LDS nibble tables (dimensions < 56), from their HBM
+    copy, the last dimensions one by one; sample numbers up to 2^30 put index bits above 32 and above 40 (the bit-by-bit tail) to work."""
     A = pkg._abi
     rng = np.random.default_rng(1)
-    n, nd = 4096, 48
+    n = 4096 if nd <= 70 else 512
     sb = (C.c_int32 * 4)(0, 0, 1920, 1080)
     xy = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n)], axis=1).astype(np.int32)
-    sn = rng.integers(0, 4096, n).astype(np.uint32)
+    sn = rng.integers(0, max_sample, n).astype(np.uint32)
+    sn[:4] = [0, max_sample - 1, max_sample >> 1, 1]
     outs = []
     for fn in (gpu.lib.pt_sobol_samples, oracle.lib.orc_sobol_samples):
         out = np.zeros((n, nd), np.float32); idx = np.zeros(n, np.uint64)
