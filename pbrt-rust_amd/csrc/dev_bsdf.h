@@ -502,6 +502,35 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
         for (int i = 0; i < n; ++i) if (matches(i, flags)) { ++matching; p += lobe_pdf<DIFF, FULL>(get(i), wo, wi); }
         return matching > 0 ? p / (float)matching : 0.0f;
     }
+    // f(wow, wiw, flags) and pdf(wow, wiw, flags) of the same pair of directions (estimate_direct's light sample, integrator.rs:142-147) in ONE
+    // pass over the lobes: each lobe is fetched from the LDS store and decoded once, and what its value and its density share (the half
+    // vector, the microfacet distribution's D) is computed once -- the two functions are inlined side by side on the same operands.
+#ifndef PT_FUSE_FPDF
+#define PT_FUSE_FPDF 1   // experiment hooks: 0 = the two passes as they were
+#endif
+#ifndef PT_FUSE_TAIL
+#define PT_FUSE_TAIL 1
+#endif
+    PT_DEV RGB f_pdf(V3 wow, V3 wiw, int flags, float &pdf_out) const {
+        // (one lobe in registers: nothing to share; the five-lobe class, already spilling, loses more to the longer live ranges than it gains:
+        //  C3 two-lobe kernel 130.6 -> 124.7 ms with both fusions, five-lobe kernel 157.8 -> 150.4 ms with only sample_f's)
+        if (MAXL != 2 || !PT_FUSE_FPDF) { const RGB r = f(wow, wiw, flags); pdf_out = pdf(wow, wiw, flags); return r; }
+        pdf_out = 0.0f;
+        V3 wi = to_local(wiw), wo = to_local(wow);
+        if (wo.z == 0.0f) return RGB(0.0f);
+        bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
+        RGB res(0.0f);
+        float p = 0.0f; int matching = 0;
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) {
+            if (!matches(i, flags)) continue;
+            const Lobe b = get(i);
+            ++matching; p += lobe_pdf<DIFF, FULL>(b, wo, wi);
+            if ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))) res = res + scaled(i, lobe_f<DIFF, FULL>(b, wo, wi));
+        }
+        pdf_out = matching > 0 ? p / (float)matching : 0.0f;
+        return res;
+    }
     // `pdf` must hold the caller's previous value on entry (it is left untouched on the wo.z == 0 exit,
     // reflection.rs:1603-1604).
     PT_DEV RGB sample_f(V3 wow, V3 &wiw, P2 u, float &pdf, int ty, int &sampled) const {
@@ -525,19 +554,34 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
         fv = scaled(idx, lobe_sample_f<DIFF, FULL>(get(idx), wo, wi, ur, pdf, sampled));
         if (pdf == 0.0f) { sampled = 0; return RGB(0.0f); }
         wiw = to_world(wi);
-        if (!(btype & BSDF_SPECULAR) && matching > 1) {
+        if (!LDS || !PT_FUSE_TAIL) {
+            if (!(btype & BSDF_SPECULAR) && matching > 1) {
 #pragma unroll 1
-            for (int i = 0; i < n; ++i) if (i != idx && matches(i, ty)) pdf += lobe_pdf<DIFF, FULL>(get(i), wo, wi);
+                for (int i = 0; i < n; ++i) if (i != idx && matches(i, ty)) pdf += lobe_pdf<DIFF, FULL>(get(i), wo, wi);
+            }
+            if (matching > 1) pdf /= (float)matching;
+            if (!(btype & BSDF_SPECULAR)) {
+                bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
+                fv = RGB(0.0f);
+#pragma unroll 1
+                for (int i = 0; i < n; ++i)
+                    if (matches(i, ty) && ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))))
+                        fv = fv + scaled(i, lobe_f<DIFF, FULL>(get(i), wo, wi));
+            }
+            return fv;
         }
-        if (matching > 1) pdf /= (float)matching;
-        if (!(btype & BSDF_SPECULAR)) {
-            bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
+        if (!(btype & BSDF_SPECULAR)) {   // the other lobes' densities (reflection.rs:1627-1633) and every matching lobe's value (:1639-1650), one pass
+            const bool refl = dot(wiw, ng) * dot(wow, ng) > 0.0f;
             fv = RGB(0.0f);
 #pragma unroll 1
-            for (int i = 0; i < n; ++i)
-                if (matches(i, ty) && ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))))
-                    fv = fv + scaled(i, lobe_f<DIFF, FULL>(get(i), wo, wi));
+            for (int i = 0; i < n; ++i) {
+                if (!matches(i, ty)) continue;
+                const Lobe b = get(i);
+                if (i != idx && matching > 1) pdf += lobe_pdf<DIFF, FULL>(b, wo, wi);
+                if ((refl && (type_of(i) & BSDF_REFLECTION)) || (!refl && (type_of(i) & BSDF_TRANSMISSION))) fv = fv + scaled(i, lobe_f<DIFF, FULL>(b, wo, wi));
+            }
         }
+        if (matching > 1) pdf /= (float)matching;
         return fv;
     }
 };

@@ -274,6 +274,7 @@ struct BssrdfAdapterBsdf {
         if (wo.z == 0.0f) return 0.0f;
         return matches(flags) ? lobe_pdf(wo, wi) : 0.0f;
     }
+    PT_DEV RGB f_pdf(V3 wow, V3 wiw, int flags, float &p) const { p = pdf(wow, wiw, flags); return f(wow, wiw, flags); }
     PT_DEV RGB sample_f(V3 wow, V3 &wiw, P2 u, float &pdf, int ty, int &sampled) const {
         if (!matches(ty)) { pdf = 0.0f; sampled = 0; return RGB(0.0f); }
         P2 ur(minf(u.x, kOneMinusEps), u.y);

@@ -133,6 +133,7 @@ struct PhaseBsdf {
     float g; V3 wo_;
     PT_DEV RGB f(V3 wo, V3 wi, int) const { return RGB(phase_hg(dot(wo, wi), g)); }
     PT_DEV float pdf(V3 wo, V3 wi, int) const { return phase_hg(dot(wo, wi), g); }
+    PT_DEV RGB f_pdf(V3 wo, V3 wi, int fl, float &p) const { p = pdf(wo, wi, fl); return f(wo, wi, fl); }
     PT_DEV RGB sample_f(V3 wo, V3 &wi, P2 u, float &pdf, int, int &sampled) const { const float p = hg_sample_p(g, wo, wi, u); pdf = p; sampled = 0; return RGB(p); }
 };
 

@@ -187,8 +187,8 @@ PT_DEV bool nee_vertex(const DeviceScene &s, const LightGrid &grid, const PathSo
             PT_T(7);
             const bool delta = light_is_delta(s.lights[li]);
             if (lightpdf > 0.0f && !Li.is_black()) {
-                RGB f = MEDIUM ? bsdf.f(si.wo, wi, bf) : bsdf.f(si.wo, wi, bf) * abs_dot(wi, si.sh_n);
-                scattpdf = bsdf.pdf(si.wo, wi, bf);
+                RGB f = bsdf.f_pdf(si.wo, wi, bf, scattpdf);
+                if (!MEDIUM) f = f * abs_dot(wi, si.sh_n);
                 if (!f.is_black()) {
                     V3 so, sd; spawn_ray_to(it, p1, so, sd);
                     if (VOL) {   // Li *= visibility.tr(): the unoccluded segment's transmittance (light.rs:125-150)
