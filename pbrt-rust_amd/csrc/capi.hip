@@ -728,6 +728,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             }
             BssrdfJob bj{};
             bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
+            bj.self_next = sc->q.shade[1 - cur][kSpecClass]; bj.self_next_count = &qc->shade[1 - cur][kSpecClass];   // (volpath has no specular-only class: its queue serves the waiting exit-point vertices)
             bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
             bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
             bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
@@ -751,7 +752,22 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         } else for (int c = 0; c < kNumClasses; ++c) class_n[c] = upper;
         for (int c = 0; c < kNumClasses; ++c) {
             const bool used = sc->class_used[c] || (c == 1 && rc.volpath && sc->class_used[kSpecClass]);   // (the volumetric router folds class 6 into class 1)
-            if (!used || class_n[c] == 0 || (c == kSpecClass && rc.volpath)) continue;
+            if (c == kSpecClass && rc.volpath) {   // exit-point vertices of subsurface chains in stage B (k_bssrdf put them here an iteration ago)
+                if (!sc->has_bssrdf || !(sc->ds.has_grid || sc->ds.has_shells) || class_n[c] == 0) continue;
+                BssrdfJob bj{};
+                bj.queue = sc->q.shade[cur][c]; bj.count = &qc->shade[cur][c];
+                bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
+                bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
+                bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
+                bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
+                bj.self_next = sc->q.shade[1 - cur][c]; bj.self_next_count = &qc->shade[1 - cur][c]; bj.stage_b = 1u;
+                sc->begin("bssrdf_stage_b", rp_profile_exact ? class_n[c] : 0);
+                sc->set_kernel("k_bssrdf<true, true>");
+                hipLaunchKernelGGL((k_bssrdf<true, true>), dim3(std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU)), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, bj);
+                sc->end();
+                continue;
+            }
+            if (!used || class_n[c] == 0) continue;
             ShadeJob sj{};
             sj.queue = sc->q.shade[cur][c]; sj.count = &qc->shade[cur][c];
             sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
@@ -1266,8 +1282,6 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
     if (rp->max_depth > 254) return fail(PT_ERR_INVALID_ARG, "maxdepth must be <= 254 (the bounce count of a path is kept in 8 bits)");
     if (rc.volpath) {   // VolPathIntegrator (volpath.rs): what this back end takes
-        // subsurface materials under volpath (volpath.rs:186-214): the exit-point vertex is k_bssrdf's, which has no stage B -- not together with grid media or shells
-        if (sc->has_bssrdf && (sc->ds.has_grid || sc->has_null_material)) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials together with grid media or material-less shells are not supported");
         if (sc->has_bssrdf && sc->ds.n_media >= 0xffffu) return fail(PT_ERR_UNSUPPORTED, "volpath: subsurface materials with more than 65534 media");
         if (rp->camera_medium != PT_NONE && rp->camera_medium >= sc->ds.n_media) return fail(PT_ERR_INVALID_ARG, "camera_medium out of range");
     }

@@ -17,8 +17,9 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
     constexpr uint32_t LDS_DIMS = 56u;
     __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
     __shared__ LdsQueue<1024> s_qext, s_qres, s_qsh, s_qmis;
+    __shared__ LdsQueue<VOL ? 1024 : 1> s_qself;   // volpath, grid media / shells: exit-point vertices waiting for stage B
     __shared__ uint32_t s_hist[16];
-    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis);
+    lq_init(s_qext); lq_init(s_qres); lq_init(s_qsh); lq_init(s_qmis); lq_init(s_qself);
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     sobol_stage_lds(s_sobol, tabs.nib, LDS_DIMS, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -34,9 +35,10 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
     uint32_t n_assert = 0;   // PtCounters::reference_asserts
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < rounded; qi += gridDim.x * blockDim.x) {
     const bool valid = qi < count;
-    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false;
+    bool push_ext = false, push_resolve = false, push_shadow = false, push_mis = false, push_self = false;
     int finished_bounces = -1;
     uint32_t pid = 0;
+    const bool stage_b = VOL && job.stage_b != 0u;   // the queue holds exit-point vertices whose shadow / MIS rays (or their next segments) have just been traced
     if (valid) {
         n_valid++;
         pid = job.queue[qi];
@@ -59,8 +61,14 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
             RGB L(ps.L_r(pid), ps.L_g(pid), ps.L_b(pid));
             RGB beta(ps.beta_r(pid), ps.beta_g(pid), ps.beta_b(pid));
             n_bytes += 4 + 8 + 12 + 12 + 12 + 12 + 4;
+            if (stage_b) {   // this vertex's own estimate: ratio-tracking transmittances draw the dimensions that follow its light and scattering samples (kern_shade.h, stage B)
+                smp.load_window();
+                if (!(s.has_shells && vol_chain_step<SPH>(s, ps, pid, flags, smp, push_shadow, push_mis, n_bytes)))
+                    resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS, s.has_shells ? nullptr : &smp);
+                flags &= ~PF_STAGE_B;
+            }
             // the outgoing vertex's NEE rays were traced at the start of the iteration after its shade
-            resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
+            else resolve_pending<SPH, VOL>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
             bool terminated = dead;
             if (at_exit) {
                 const PtMaterial &m = s.materials[mat];
@@ -71,12 +79,15 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                 bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
                 n_bytes += 36 + 24;
                 // bssrdf.rs:403-405: pdf = pdf_sp(pi) / nfound ; Sp = sr(|po - pi|)
-                float pdf = bss.pdf_sp(si.p, si.n) / (float)nfound;
-                const RGB S = bss.sr(length(bss.po_p - si.p));
-                if (S.is_black() || pdf == 0.0f) terminated = true;   // path.rs:185
-                else {
-                    smp.load_window();
-                    beta = beta * (S / pdf);
+                float pdf = 0.0f;
+                bool go = true;
+                if (!stage_b) {
+                    pdf = bss.pdf_sp(si.p, si.n) / (float)nfound;
+                    const RGB S = bss.sr(length(bss.po_p - si.p));
+                    if (S.is_black() || pdf == 0.0f) { terminated = true; go = false; }   // path.rs:185
+                    else { smp.load_window(); beta = beta * (S / pdf); }
+                }
+                if (go) {
                     // sample_s (bssrdf.rs:563-571): BSDF::new(pi, 1.0) + adapter lobe; pi.wo = shading.n
                     BssrdfAdapterBsdf bsdf; bsdf.init(si, bss.eta);
                     si.wo = si.sh_n;
@@ -84,12 +95,19 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
                     MedIface mif{PT_NONE, PT_NONE};
                     if (VOL) { const uint32_t pk = bs.iface[pid]; mif.inside = (pk & 0xffffu) == 0xffffu ? PT_NONE : (pk & 0xffffu); mif.outside = (pk >> 16) == 0xffffu ? PT_NONE : (pk >> 16); }
-                    if (nee_vertex<SPH, BssrdfAdapterBsdf, VOL, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) flags |= PF_NEE_UNCOUNTED;
-                    else L = L + beta * RGB(0.0f);   // path.rs:190-192 `L += beta * uniform_sample_one_light(..)` with a black estimate: 0, or NaN when pdf_sp was (an exit point a few ulps from po: inf x 0)
+                    if (!stage_b) {
+                        if (nee_vertex<SPH, BssrdfAdapterBsdf, VOL, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) flags |= PF_NEE_UNCOUNTED;
+                        else L = L + beta * RGB(0.0f);   // path.rs:190-192 `L += beta * uniform_sample_one_light(..)` with a black estimate: 0, or NaN when pdf_sp was (an exit point a few ulps from po: inf x 0)
+                    }
+                    // wait for the traced rays before drawing any further dimension (the vertex's shadow / MIS rays; with shells: the next segment of one of them)
+                    const bool defer = VOL && (s.has_grid != 0u || s.has_shells != 0u) && (push_shadow || push_mis);
                     // path.rs:194-201: indirect component
                     V3 wi; int sflags = 0;
-                    const RGB ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
-                    if (ff.is_black() || pdf == 0.0f) terminated = true;
+                    RGB ff(0.0f);
+                    if (defer) { flags |= PF_STAGE_B; push_self = true; }
+                    else ff = bsdf.sample_f(si.wo, wi, smp.get_2d(), pdf, BSDF_ALL, sflags);
+                    if (defer) { /* stage B samples on */ }
+                    else if (ff.is_black() || pdf == 0.0f) terminated = true;
                     else {
                         beta = beta * (ff * abs_dot(wi, si.sh_n) / pdf);
                         if (__builtin_isinf(beta.y())) n_assert++;   // path.rs:201 / volpath.rs:210
@@ -128,18 +146,21 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
     lq_push(s_qres, pid, push_resolve);
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
+    if (VOL) lq_push(s_qself, pid, push_self);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);
     __syncthreads();
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
+    if (VOL) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 256u, false);
     __syncthreads();
     }
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 0u, true);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
+    if (VOL) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 0u, true);
     __syncthreads();
     if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&job.counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
     counter_add(&job.counters->zero_num, zero_num);

@@ -202,6 +202,10 @@ struct BssrdfJob {           // k_bssrdf: the vertex at the exit point of every 
     uint32_t *error;
     DevCounters *counters;
     BssSoA bs;
+    // volpath in scenes with grid media or material-less shells: the exit-point vertex waits for its traced shadow / MIS rays (stage B, as the
+    // surface vertices of kern_shade.h do) in a queue of its own and comes back to k_bssrdf with stage_b set
+    uint32_t *self_next, *self_next_count;
+    uint32_t stage_b;
 };
 
 }  // namespace ptd

@@ -259,7 +259,7 @@ def subsurface_c5(n=24, xres=96, yres=64, spp=16, maxdepth=5, rough=False, textu
     return b
 
 
-def subsurface_in_fog(n=16, xres=64, yres=48, spp=8, maxdepth=5, fog=True, sampler="sobol"):
+def subsurface_in_fog(n=16, xres=64, yres=48, spp=8, maxdepth=5, fog=True, sampler="sobol", fog_density=None):
     """Subsurface materials under the VOLUMETRIC integrator (volpath.rs:186-214). With fog=True the camera and the world sit in a homogeneous
     fog, one subsurface object is an ordinary primitive (its hits hand the probe ray's medium on: none for the first probe ray, so the path
     leaves the object in VACUUM -- bssrdf.rs:362-366 starts the chain from an interaction without a MediumInterface) and the other carries a
@@ -269,7 +269,8 @@ def subsurface_in_fog(n=16, xres=64, yres=48, spp=8, maxdepth=5, fog=True, sampl
     b.film.update(xres=xres, yres=yres); b.spp = spp; b.sampler = sampler
     b.integ.update(maxdepth=maxdepth, kind="volpath")
     if fog:
-        b.make_named_medium("fog", sigma_a=(0.03, 0.03, 0.03), sigma_s=(0.1, 0.1, 0.12), g=0.2)
+        if fog_density is not None: b.make_named_medium("fog", sigma_a=(0.03, 0.03, 0.03), sigma_s=(0.1, 0.1, 0.1), g=0.2, density=fog_density, p0=(-8.0, -1.5, -8.0), p1=(8.0, 5.0, 8.0))   # a GridDensityMedium
+        else: b.make_named_medium("fog", sigma_a=(0.03, 0.03, 0.03), sigma_s=(0.1, 0.1, 0.12), g=0.2)
         b.make_named_medium("juice", sigma_a=(0.2, 0.6, 0.9), sigma_s=(0.8, 0.6, 0.4), g=-0.1)
         b.medium_interface("", "fog")
     b.look_at((0.0, 1.6, 6.0), (0.0, 0.2, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=38.0)

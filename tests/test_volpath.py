@@ -220,14 +220,22 @@ def test_gpu_volpath_halton_thin_lens_and_no_media(pkg, gpu, oracle):
     assert np.all(np.abs(rgb - want) < 0.03 * want)
 
 
+def _sss_with_shell(pkg, grid=False, **kw):
+    """subsurface_in_fog + a material-less shell of "juice" hanging in the fog (and, grid=True, the fog as a GridDensityMedium): the exit-point vertex of
+    a BSSRDF then waits for its traced shadow / MIS segments like every other vertex (k_bssrdf's stage B, round 3)."""
+    b = pkg.scenes.subsurface_in_fog(fog_density=np.random.default_rng(11).uniform(0.1, 1.0, (4, 3, 5)).astype(np.float32) if grid else None, **kw)
+    b.attribute_begin(); b.material("none"); b.medium_interface("juice", "fog"); b.translate(0.0, 2.0, 0.0); b.sphere(radius=0.6); b.attribute_end()
+    return b
+
+
 @pytest.mark.gpu
-def test_gpu_volpath_refuses_what_it_cannot_render(pkg, gpu):
-    # (shapes without a material -- medium-interface shells -- and subsurface materials are rendered since round 3; not the two together, nor
-    #  subsurface materials next to a grid medium: the exit-point vertex of a BSSRDF has no stage B)
-    b = pkg.scenes.subsurface_in_fog(xres=32, yres=24, spp=2)
-    b.attribute_begin(); b.material("none"); b.medium_interface("juice", "fog"); b.translate(0.0, 2.0, 0.0); b.sphere(radius=0.3); b.attribute_end()
-    sd, rp = b.world_end()
-    with pytest.raises(Exception, match="subsurface materials together"): pkg.Scene(gpu, sd).render(rp)
+@pytest.mark.parametrize("grid", [False, True])
+def test_gpu_subsurface_next_to_shells_and_grid_media_matches_oracle(pkg, gpu, oracle, grid):
+    from test_gpu_parity import _compare_render
+    b = _sss_with_shell(pkg, grid=grid, xres=48, yres=36, spp=8)
+    _compare_render(pkg, gpu, oracle, *b.world_end())
+    b = _sss_with_shell(pkg, grid=grid, xres=32, yres=24, spp=4, sampler="halton")
+    _compare_render(pkg, gpu, oracle, *b.world_end())
 
 
 # ---- GridDensityMedium (media/grid.rs; VERDICT r1 item 10) ----------------------------------------------------------------
