@@ -523,6 +523,41 @@ def _negative_light_scene(pkg, spp=4):
     return b.world_end()
 
 
+def _odd_triangle_lights_scene(pkg, strategy, reverse=False):
+    """Every branch of the per-light record of DeviceScene::light_rec (k_light_area): an emissive mesh with interpolated normals (Triangle::sample face-forwards
+    to them), one with uvs whose partials are degenerate (uv of all three vertices equal: coordinate_system fallback, still a valid hit), one with
+    three collinear vertices (area 0, 1 / area = inf, degenerate partials: Shape::pdf_wi finds no intersection), a two-sided one and a reversed one."""
+    b = pkg.host.SceneBuilder()
+    b.film.update(xres=48, yres=32); b.spp = 8
+    b.integ.update(maxdepth=4, strategy=strategy)
+    b.look_at((0.0, 2.2, 6.0), (0.0, 0.6, 0.0), (0.0, 1.0, 0.0)); b.camera(fov=42.0)
+    b.world_begin()
+    b.light_source("infinite", L=(0.05, 0.06, 0.08))
+    tri = np.array([[0, 1, 2]])
+    b.attribute_begin(); b.area_light_source(L=(9.0, 8.0, 6.0))   # interpolated normals, pointing down and outwards
+    P = np.array([(-1.5, 3.0, -0.5), (-0.5, 3.0, 0.8), (-0.3, 3.0, -0.7)], np.float32)
+    b.trianglemesh(P, tri, N=np.array([(0.2, -1.0, 0.0), (0.0, -1.0, 0.3), (-0.3, -1.0, -0.1)], np.float32)); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(4.0, 7.0, 9.0), twosided=True)   # all uvs equal: degenerate uv determinant
+    P = np.array([(0.4, 2.6, -0.6), (1.6, 2.9, -0.2), (0.9, 2.7, 0.9)], np.float32)
+    b.trianglemesh(P, tri, UV=np.array([(0.3, 0.3)] * 3, np.float32)); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(20.0, 20.0, 20.0))   # three collinear vertices
+    b.trianglemesh(np.array([(-1.0, 2.0, 1.0), (0.0, 2.0, 1.0), (1.0, 2.0, 1.0)], np.float32), tri); b.attribute_end()
+    b.attribute_begin(); b.area_light_source(L=(6.0, 3.0, 3.0))
+    if reverse: b.toggle_reverse_orientation()
+    P, I = pkg.scenes.quad((2.0, 0.2, -1.0), (2.0, 0.2, 1.0), (2.0, 1.8, 1.0), (2.0, 1.8, -1.0)); b.trianglemesh(P, I); b.attribute_end()
+    b.material("matte", Kd=(0.6, 0.55, 0.5))
+    P, I = pkg.scenes.quad((-5.0, 0.0, -5.0), (-5.0, 0.0, 5.0), (5.0, 0.0, 5.0), (5.0, 0.0, -5.0)); b.trianglemesh(P, I)
+    b.material("plastic", Kd=(0.3, 0.4, 0.5), Ks=(0.4, 0.4, 0.4), roughness=0.15)
+    b.attribute_begin(); b.translate(-0.6, 0.7, 0.3); b.sphere(radius=0.7); b.attribute_end()
+    return b.world_end()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy,reverse", [("spatial", False), ("uniform", True), ("power", False)])
+def test_triangle_light_records_match_oracle(pkg, gpu, oracle, strategy, reverse):
+    _compare_render(pkg, gpu, oracle, *_odd_triangle_lights_scene(pkg, strategy, reverse))
+
+
 @pytest.mark.gpu
 def test_reference_asserts_counter_matches_oracle(pkg, gpu, oracle):
     sd, rp = _negative_light_scene(pkg, spp=8)
