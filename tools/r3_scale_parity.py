@@ -15,10 +15,20 @@ lib = pkg.load_library(); lib.init(0)
 orc = Oracle(pkg._abi, pkg.runtime.TABLES_PATH)
 COUNTERS = ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats",
             "zero_radiance_paths_num", "zero_radiance_paths_den", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts")
+def _sss_shell(grid, sampler="sobol"):
+    import numpy as np
+    b = pkg.scenes.subsurface_in_fog(n=48, xres=960, yres=540, spp=16, sampler=sampler,
+                                     fog_density=np.random.default_rng(11).uniform(0.1, 1.0, (4, 3, 5)).astype(np.float32) if grid else None)
+    b.attribute_begin(); b.material("none"); b.medium_interface("juice", "fog"); b.translate(0.0, 2.0, 0.0); b.sphere(radius=0.6); b.attribute_end()
+    return b
+
+
 CASES = [
     ("shell_media grid", lambda: pkg.scenes.shell_media(xres=960, yres=540, spp=32, grid=True)),
     ("shell_media homogeneous halton", lambda: pkg.scenes.shell_media(xres=960, yres=540, spp=32, grid=False, sampler="halton")),
     ("subsurface_in_fog", lambda: pkg.scenes.subsurface_in_fog(n=48, xres=960, yres=540, spp=32)),
+    ("subsurface next to a shell, fog = grid medium (k_bssrdf stage B)", lambda: _sss_shell(True)),
+    ("subsurface next to a shell, homogeneous fog, halton (k_bssrdf stage B)", lambda: _sss_shell(False, "halton")),
     ("emissive_field 20000 lights (first-touch light grid)", lambda: pkg.scenes.emissive_field(n_lights=20000, xres=96, yres=64, spp=4, maxdepth=3)),
 ]
 for name, make in CASES:
