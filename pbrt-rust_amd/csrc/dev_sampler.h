@@ -176,13 +176,7 @@ struct Sampler {
                              const uint32_t a0 = qa[0], a1 = qa[16], a2 = qa[32], a3 = qa[48], a4 = qa[64], a5 = qa[80], a6 = qa[96], a7 = qa[112]; \
                              const uint32_t b0 = qb[0], b1 = qb[16], b2 = qb[32], b3 = qb[48], b4 = qb[64], b5 = qb[80], b6 = qb[96], b7 = qb[112]; \
                              w0 ^= a0 ^ b0; w1 ^= a1 ^ b1; w2 ^= a2 ^ b2; w3 ^= a3 ^ b3; w4 ^= a4 ^ b4; w5 ^= a5 ^ b5; w6 ^= a6 ^ b6; w7 ^= a7 ^ b7; }
-#ifdef PT_NIB_SPLIT   // experiment hook: the look-ups in two bursts of 16 reads instead of one of 32
-        PT_NIB2(0, lo, lo >> 4) PT_NIB2(2, lo >> 8, lo >> 12)
-        __builtin_amdgcn_sched_barrier(0);
-        PT_NIB2(4, lo >> 16, lo >> 20) PT_NIB2(6, lo >> 24, lo >> 28)
-#else
-        PT_NIB2(0, lo, lo >> 4) PT_NIB2(2, lo >> 8, lo >> 12) PT_NIB2(4, lo >> 16, lo >> 20) PT_NIB2(6, lo >> 24, lo >> 28)
-#endif
+        PT_NIB2(0, lo, lo >> 4) PT_NIB2(2, lo >> 8, lo >> 12) PT_NIB2(4, lo >> 16, lo >> 20) PT_NIB2(6, lo >> 24, lo >> 28)   // (two bursts of 16 reads instead of one of 32: no difference)
         if (hi != 0) {
             PT_NIB2(8, hi, hi >> 4)
             for (uint32_t r = hi >> 8; r != 0; r &= r - 1) {
