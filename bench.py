@@ -6,7 +6,7 @@ synthetic scene (4,298,312-triangle displaced sphere, matte, quad area light + c
 1920x1080 x 256 spp, PathIntegrator maxdepth 5, Sobol sampler, box filter, spatial light sampling.
 `--config C3|C4|C5` selects the other BASELINE configs built to SURVEY 8(d)'s S3 / S4 / S5 specification
 (pbrt-rust_amd/scenes.py: country_kitchen_s3, ecosystem_s4, dragon_s5) at their named spp (override: --spp).
-The default C2 run on one GPU also renders C3 / C4 / C5 once each at a reduced spp AFTER the headline's timed region and reports
+The default C2 run on one GPU also renders C3 / C4 / C5 once each (one pass of the pass size) AFTER the headline's timed region and reports
 them under "other_configs" of the same JSON line, so every BASELINE config has a number on the driver's record.
 Scene generation, BVH build and upload are outside the timed region. The film stays on the device
 (pt_render's film_is_device path): the 33 MB read-back of SURVEY 8(d)'s definition (0.6 ms over PCIe) is not in `value`;
@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 GATHER_CEILING_GREQ_S = 54.0  # profiles/r2_gather_calibration.json: dependent random 64-byte gathers, 128-byte fabric requests per ns, whole chip
 TRACE_KINDS = ("trace", "extend", "extend_mis", "shadow", "extend_camera", "extend_probe")   # "trace" = the mixed launch: continuation + MIS + shadow rays of one wavefront iteration
-OTHER_CONFIG_SPP = {"C3": 64, "C4": 32, "C5": 128}   # one step each after the headline (C4: 0.7 s, C3 0.4 s, C5 0.3 s of render)
+OTHER_CONFIG_SPP = {"C3": 256, "C4": 256, "C5": 216}   # one step each after the headline, ONE pass of the size the library picks for the config at its named spp
+                                                     # (so the rate is the named-spp rate and the committed PMC profile applies): C3 1.4 s, C4 5.6 s, C5 0.4 s of render per step
 
 
 def algo_bytes(name, s):
@@ -295,7 +296,7 @@ def main():
     ap.add_argument("--sim-world", type=int, default=0, help="single-GPU study: render rank 0's shard of an N-rank job (value is then this rank's share only)")
     ap.add_argument("--in-process", action="store_true", help="force the one-process pt_multi_render form (it is the default for --gpus N > 1 without a launcher)")
     ap.add_argument("--devices", default="", help="one-process form: explicit device ordinals, e.g. 0,1,2,3 (an ordinal may repeat: replicas share the device; default 0..gpus-1)")
-    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"], help="after the headline, one step each of C3 / C4 / C5 at reduced spp under 'other_configs' (auto: default C2 run on one GPU)")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"], help="after the headline, one step (one wavefront pass) each of C3 / C4 / C5 under 'other_configs' (auto: default C2 run on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -346,7 +347,7 @@ def main():
             except Exception as e:   # the headline line must not be lost to a side measurement
                 oc[cfg] = dict(error=f"{type(e).__name__}: {e}")
         out["other_configs"] = oc
-        out["other_configs_note"] = "one timed step after one warm-up, at a reduced spp (the per-sample cost does not depend on the spp beyond the pass size); the value is Msamples/s of that step"
+        out["other_configs_note"] = "one timed step after one warm-up, each step = one wavefront pass of the size the library picks at the config's named spp (the per-sample cost does not depend on the spp beyond the pass size); the value is Msamples/s of that step"
     if out is not None:
         print(json.dumps(out))
     if dist is not None:
