@@ -29,7 +29,7 @@ thread_local int g_device = -1;
 thread_local int g_num_cus = 256;
 std::atomic<int> g_default_device{-1};
 // traversal scheduling knobs (env PT_TRACE_REFILL_MIN / PT_TRACE_LEAF_QUORUM override)
-uint32_t g_refill_min[4] = {24, 24, 24, 32};     // per launch kind: extend, extend_mis, shadow, extend_camera
+uint32_t g_refill_min[4] = {16, 16, 16, 48};     // per launch kind: extend, extend_mis, shadow, extend_camera (round 3, 256-spp passes: {24, 24, 24, 32} -> these: camera launch 42.7 -> 41.1 ms on C2, 95.9 -> 85.4 on C3)
 uint32_t g_leaf_quorum[4] = {8, 8, 8, 8};         // lanes at a leaf wait until this many of them do, then all of them run until none is left (sticky). History: round 1
                                                   // shipped {24, 24, 24, 32}, but its ballot ran under the leaf lanes' exec mask and never held a lane back; with the ballot
                                                   // fixed, a quorum that has to form again for every packet of a leaf lost (C2 at 64 spp: 1 -> 1132, 8 -> 1084, 24 -> 1038);
@@ -295,7 +295,7 @@ __global__ void k_trace_util_fold(DevCounters *dc, uint32_t kind, uint32_t waves
 int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe = false) {
     if (n_upper == 0) return PT_OK;
     const uint32_t knob = job.sub[0].kind == 4 ? 0 : (job.sub[0].kind & 3);
-    job.refill_min = g_refill_min[knob]; job.leaf_quorum = g_leaf_quorum[knob];
+    job.refill_min = (probe && !g_refill_from_env) ? 24u : g_refill_min[knob]; job.leaf_quorum = g_leaf_quorum[knob];   // (probe chains: 24 measured best on C5, 16: +1.6 %)
     if (sc->ds.n_instances > 0 && !g_refill_from_env) job.refill_min = 8;   // rays through instanced scenes are long (S4: 200 node visits): idle lanes are refilled early (measured 24 -> 8: +9 %)
     uint32_t waves = (n_upper + 63) / 64;
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
