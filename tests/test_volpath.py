@@ -228,6 +228,19 @@ def _sss_with_shell(pkg, grid=False, **kw):
     return b
 
 
+@pytest.mark.parametrize("grid", [False, True])
+def test_oracle_subsurface_next_to_shells_and_grid_media(pkg, oracle, grid):
+    """CPU side of the test below: the oracle's volpath BSSRDF branch (volpath.rs:186-214) with VisibilityTester::tr / intersect_tr chains through a
+    shell and ratio tracking in a grid fog at the exit point -- finite film, every camera ray accounted for, and the shell changes the picture."""
+    sd, rp = _sss_with_shell(pkg, grid=grid, xres=24, yres=18, spp=4).world_end()
+    o = oracle.scene(sd); film = o.render(rp, nthreads=4); c = o.counters()
+    assert np.isfinite(film).all() and sum(c["path_length_hist"]) == c["camera_rays"] == 24 * 18 * 4
+    b = pkg.scenes.subsurface_in_fog(xres=24, yres=18, spp=4, fog_density=np.random.default_rng(11).uniform(0.1, 1.0, (4, 3, 5)).astype(np.float32) if grid else None)
+    sd0, rp0 = b.world_end()
+    o0 = oracle.scene(sd0); film0 = o0.render(rp0, nthreads=4)
+    assert not np.array_equal(film0, film)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid", [False, True])
 def test_gpu_subsurface_next_to_shells_and_grid_media_matches_oracle(pkg, gpu, oracle, grid):
