@@ -405,7 +405,8 @@ typedef struct PtCounters {
     uint64_t camera_rays;
     uint64_t intersect_tests;        /* Scene::intersect calls            */
     uint64_t shadow_tests;           /* Scene::intersect_p calls          */
-    uint64_t bvh_nodes_visited;      /* Bounds3f::intersect_p2 executed   */
+    uint64_t bvh_nodes_visited;      /* pt_set_trace_exact(1): Bounds3f::intersect_p2 executed, the reference's count (bvh.rs:705-814);
+                                        default (production traversal): four-wide traversal records fetched (128 B each)   */
     uint64_t triangle_tests;         /* Triangle::intersect(_p) entered via the BVH */
     uint64_t sphere_tests;
     uint64_t zero_radiance_paths_num, zero_radiance_paths_den;
@@ -441,6 +442,12 @@ typedef struct pt_multi_scene pt_multi_scene;
 int pt_init(int device_ordinal);
 int pt_device_count(int *n_devices);
 const char *pt_last_error(void);
+/* Which BVH walk the traversal kernels of this process run (all scenes, from the next launch on; also env PT_TRACE_EXACT=1 at pt_init).
+ * 0 (default, production): four-wide records built from the same tree -- children visited in the order of BVHAccel::intersect / intersect_p
+ * (accelerators/bvh.rs:705-814), so every hit (primitive, t, barycentrics), every film and every other counter is what the two-wide walk gives;
+ * PtCounters.bvh_nodes_visited then counts the records fetched. 1: the two-wide walk that tests the reference's nodes one for one, for comparing
+ * bvh_nodes_visited with the reference's counter. Returns the previous setting. */
+int pt_set_trace_exact(int exact);
 
 /* Limits: at most 2^25 - 1 interior BVH nodes and 2^25 - 1 leaf packets (primitives + instance references) per scene, all
  * accelerators of the scene together (traversal stack entries keep 25-bit references); more returns PT_ERR_UNSUPPORTED. */

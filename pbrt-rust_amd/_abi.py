@@ -158,6 +158,7 @@ ENTRY_POINTS = {
     "pt_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),
     "pt_film_resolve": (C.c_int, [fp, u32, f32, fp]),
     "pt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pt_set_trace_exact": (C.c_int, [C.c_int]),
     "pt_multi_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(C.c_int), u32, C.POINTER(VP)]),
     "pt_multi_scene_destroy": (None, [VP]),
     "pt_multi_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),

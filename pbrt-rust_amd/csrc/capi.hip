@@ -38,6 +38,7 @@ uint32_t g_leaf_quorum[4] = {8, 8, 8, 8};         // lanes at a leaf wait until 
                                                   // of its dependent gathers (~2 us under load, six waves per SIMD), not by instruction issue.
 bool g_refill_from_env = false;
 bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one traversal launch per ray kind (extend / extend_mis / shadow) instead of the mixed launch
+bool g_trace_exact = false;                        // pt_set_trace_exact / env PT_TRACE_EXACT=1: walk the two-wide records, PtCounters.bvh_nodes_visited is then the reference's count
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU = 7 per SIMD: k_trace<*, 0> needs 71 VGPRs and 5 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %, 24 -> 28: +3 %)
 thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -304,7 +305,9 @@ int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool pro
 #ifdef PT_TRACE_UTIL
     hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, 0u, 1);
 #endif
-    #define PT_LAUNCH_TRACE(A, M, P) hipLaunchKernelGGL((k_trace<A, M, P>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job)
+    const bool quad = !g_trace_exact;   // production: the four-wide records; pt_set_trace_exact(1): the two-wide walk with the reference's node-visit counter
+    #define PT_LAUNCH_TRACE(A, M, P) do { if (quad) hipLaunchKernelGGL((k_trace<A, M, P, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); \
+                                          else hipLaunchKernelGGL((k_trace<A, M, P, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); } while (0)
     #define PT_LAUNCH_TRACE_MODE(A, P) do { if (mode == 3) PT_LAUNCH_TRACE(A, 3, P); else if (mode == 2) PT_LAUNCH_TRACE(A, 2, P); else if (mode == 1) PT_LAUNCH_TRACE(A, 1, P); else PT_LAUNCH_TRACE(A, 0, P); } while (0)
     if (probe) PT_LAUNCH_TRACE_MODE(0, true);
     else if (any == 2) PT_LAUNCH_TRACE_MODE(2, false);
@@ -315,7 +318,7 @@ int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool pro
 #ifdef PT_TRACE_UTIL
     hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, blocks * (kTraceBlock / 64), 0);
 #endif
-    sc->set_kernel(std::string("k_trace<") + std::to_string(any) + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ">");
+    sc->set_kernel(std::string("k_trace<") + std::to_string(any) + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ", " + (quad ? "true" : "false") + ">");
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -327,7 +330,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         if ((st = sc->dalloc(&sc->qc, 1))) return st;
         if ((st = sc->dalloc(&sc->dc, 1))) return st;
         sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 5 KB per wave)
-        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * (kMaxStack - kLdsStack)))) return st;
+        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * kSpillEntries))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
         if (sc->has_bssrdf && (st = sc->dalloc(&sc->probe_ring, (size_t)sc->spill_waves * 64 * kProbeRing * 3))) return st;
     }
@@ -866,12 +869,15 @@ int pt_init(int device_ordinal) {
     if (device_ordinal < 0 || device_ordinal >= n) return fail(PT_ERR_INVALID_ARG, "device ordinal out of range");
     if (const char *e = getenv("PT_TRACE_REFILL_MIN")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_refill_min[0] = a; g_refill_min[1] = b; g_refill_min[2] = c; g_refill_min[3] = d; g_refill_from_env = true; } }
     if (const char *e = getenv("PT_TRACE_SPLIT")) g_trace_split = atoi(e) != 0;
+    if (const char *e = getenv("PT_TRACE_EXACT")) g_trace_exact = atoi(e) != 0;
     if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }
     if (const char *e = getenv("PT_TRACE_LEAF_QUORUM")) { int a = 0, b = 0, c = 0, d = 0; int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d); if (n == 1) b = c = d = a; if (n == 3) d = a; if (n >= 1) { g_leaf_quorum[0] = a; g_leaf_quorum[1] = b; g_leaf_quorum[2] = c; g_leaf_quorum[3] = d; } }
     g_default_device.store(device_ordinal);
     return bind_device(device_ordinal);
 }
+
+int pt_set_trace_exact(int exact) { const int prev = g_trace_exact ? 1 : 0; g_trace_exact = exact != 0; return prev; }
 
 int pt_device_count(int *n_devices) {
     if (!n_devices) return fail(PT_ERR_INVALID_ARG, "null argument");
@@ -1046,7 +1052,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     std::vector<uint32_t> leaf_last, packet_refs;
     std::vector<WideNode> wide;
     std::vector<DevInstance> dinst(instanced ? d->n_instances : 0);
-    auto append_accel = [&](const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &refs, uint32_t &root_ref) {
+    std::vector<QuadNode> quad;
+    auto append_accel = [&](const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &refs, uint32_t &root_ref, uint32_t &root_ref4) {
         const uint32_t wbase = (uint32_t)wide.size(), pbase = (uint32_t)packet_refs.size();
         std::vector<uint32_t> wide_id(nn.size(), 0);
         uint32_t n_int = 0;
@@ -1063,27 +1070,70 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             w.left_ref = ref_of((uint32_t)i + 1); w.right_ref = ref_of(nn[i].offset);
             w.meta = nn[i].axis; w.pad = 0;
         }
+        // four-wide records of the same tree (dev_scene.h: QuadNode): two binary levels per record, emitted depth first
+        {
+            const float inf = std::numeric_limits<float>::infinity();
+            std::vector<uint32_t> todo;   // binary interior nodes that root a record, in emission order (their record = quad[qbase + position])
+            std::vector<uint32_t> quad_id(nn.size(), PT_NONE);
+            auto qref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | (pbase + nn[i].offset)) : quad_id[i]; };
+            const uint32_t qbase = (uint32_t)quad.size();
+            if (!nn.empty() && nn[0].n_prims == 0) {
+                // pre-order numbering: a record's interior grandchildren root the next records, left to right
+                std::vector<uint32_t> stack{0};
+                while (!stack.empty()) {
+                    const uint32_t i = stack.back(); stack.pop_back();
+                    quad_id[i] = qbase + (uint32_t)todo.size(); todo.push_back(i);
+                    uint32_t kids[4]; int nk = 0;
+                    for (uint32_t c : {(uint32_t)i + 1u, (uint32_t)nn[i].offset}) {
+                        if (nn[c].n_prims) continue;
+                        kids[nk++] = c + 1u; kids[nk++] = nn[c].offset;
+                    }
+                    for (int k = nk - 1; k >= 0; --k) if (nn[kids[k]].n_prims == 0) stack.push_back(kids[k]);
+                }
+            }
+            quad.resize(qbase + todo.size());
+            for (size_t t = 0; t < todo.size(); ++t) {
+                const uint32_t i = todo[t];
+                QuadNode &q = quad[qbase + t];
+                for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { q.lo[a][k] = inf; q.hi[a][k] = -inf; }
+                for (int k = 0; k < 4; ++k) q.ref[k] = PT_NONE;
+                q.pad[0] = q.pad[1] = q.pad[2] = 0;
+                const uint32_t c2[2] = {i + 1u, (uint32_t)nn[i].offset};
+                uint32_t axes[3] = {nn[i].axis, 0u, 0u};
+                auto put = [&](int slot, uint32_t n) {
+                    for (int a = 0; a < 3; ++a) { q.lo[a][slot] = nn[n].bmin[a]; q.hi[a][slot] = nn[n].bmax[a]; }
+                    q.ref[slot] = qref_of(n);
+                };
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t c = c2[side];
+                    if (nn[c].n_prims) put(2 * side, c);
+                    else { axes[1 + side] = nn[c].axis; put(2 * side, c + 1u); put(2 * side + 1, nn[c].offset); }
+                }
+                q.meta = axes[0] | (axes[1] << 2) | (axes[2] << 4);
+            }
+            root_ref4 = nn.empty() ? 0u : qref_of(0);
+        }
         packet_refs.insert(packet_refs.end(), refs.begin(), refs.end());
         root_ref = ref_of(0);
     };
     {
         std::vector<uint32_t> top_order(n_top);
         for (uint32_t i = 0; i < n_top; ++i) top_order[i] = top_ref(sc->ordered[i]);
-        append_accel(sc->nodes, top_order, ds.root_ref);
+        append_accel(sc->nodes, top_order, ds.root_ref, ds.root_ref4);
         ds.n_nodes = (uint32_t)sc->nodes.size();
         for (int k = 0; k < 3; ++k) { ds.root_min[k] = sc->nodes[0].bmin[k]; ds.root_max[k] = sc->nodes[0].bmax[k]; }
-        std::vector<uint32_t> obj_root(obj.size(), 0);
+        std::vector<uint32_t> obj_root(obj.size(), 0), obj_root4(obj.size(), 0);
         for (size_t o = 0; o < obj.size(); ++o) {
             if (d->objects[o].n_prims == 1) {  // single primitive: a one-packet "leaf" without a BVH
-                obj_root[o] = kLeafBit | (uint32_t)packet_refs.size();
+                obj_root[o] = obj_root4[o] = kLeafBit | (uint32_t)packet_refs.size();
                 leaf_last.push_back((uint32_t)packet_refs.size());
                 packet_refs.push_back(d->objects[o].first_prim);
-            } else append_accel(obj[o].nodes, obj[o].ordered, obj_root[o]);
+            } else append_accel(obj[o].nodes, obj[o].ordered, obj_root[o], obj_root4[o]);
         }
         for (size_t i = 0; i < dinst.size(); ++i) {
             const PtInstance &I = d->instances[i]; DevInstance &D = dinst[i];
             std::memcpy(D.world_to_instance, I.world_to_instance, 64); std::memcpy(D.instance_to_world, I.instance_to_world, 64);
-            D.single = d->objects[I.object].n_prims == 1; D.root_ref = obj_root[I.object]; D.pad = 0;
+            D.single = d->objects[I.object].n_prims == 1; D.root_ref = obj_root[I.object]; D.root_ref4 = obj_root4[I.object];
             for (int k = 0; k < 3; ++k) { D.root_min[k] = D.single ? 0.0f : obj[I.object].nodes[0].bmin[k]; D.root_max[k] = D.single ? 0.0f : obj[I.object].nodes[0].bmax[k]; }
             bool ident = true;
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ident = ident && I.instance_to_world[4 * r + c] == ((r == c) ? 1.0f : 0.0f);
@@ -1230,7 +1280,16 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const uint32_t n_packets = (uint32_t)packet_refs.size();
         if ((st = sc->upload(&d_ordered, packet_refs.data(), packet_refs.size()))) return bail(st);
         TriPacket *leaf = nullptr; float *area = nullptr; float4 *lrec = nullptr;
-        if ((st = sc->dalloc(&leaf, (size_t)n_packets + 2))) return bail(st);  // +2: the leaf loop loads packets in pairs
+        // the four-wide records and the packets share ONE allocation, so that the production traversal addresses both with 32-bit byte offsets from
+        // one base (at most 2^24 records x 128 B + 2^25 packets x 48 B < 4 GB): [records][packets + 2] (+2: a packet's fourth quad is loaded with it)
+        if (quad.empty()) quad.resize(1);
+        const size_t quad_bytes = quad.size() * sizeof(QuadNode), pool_bytes = quad_bytes + ((size_t)n_packets + 2) * sizeof(TriPacket);
+        if (pool_bytes >= ((size_t)1 << 32)) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 4 GB of traversal records + packets"));
+        uint8_t *pool = nullptr;
+        if ((st = sc->dalloc(&pool, pool_bytes))) return bail(st);
+        if (hipMemcpy(pool, quad.data(), quad_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PT_ERR_HIP, "upload of the four-wide records"));
+        leaf = reinterpret_cast<TriPacket *>(pool + quad_bytes);
+        ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)quad_bytes;
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         if ((st = sc->dalloc(&lrec, 6 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);

@@ -34,6 +34,22 @@ struct WideNode {
     uint32_t meta;   // bits 0-7: split axis (bvh.rs:671,686)
     uint32_t pad;
 };
+// Four-wide traversal record of the PRODUCTION traversal (128 B = one L2 line, eight dwordx4 loads): one per interior node N of the reference tree at
+// an even interior level -- the boxes of N's grandchildren, structure of arrays, in tree order: slots 0, 1 = the children of N's left child L,
+// slots 2, 3 = the children of its right child R; a child of N that is a leaf fills the first slot of its pair with its own box and leaves the second
+// empty (bounds +inf / -inf, reference PT_NONE). The ray visits the slots in the order the reference's binary walk reaches them -- near side of N
+// first, inside a pair the near side of L (R) first -- so leaves are met in the reference's order and every hit is the reference's hit; only the
+// number of boxes tested differs (boxes of L and R themselves are never tested: a child that passes its own test lies inside its parent's box and
+// the parent would have passed too). meta: bits 0-1 split axis of N, 2-3 of L, 4-5 of R (bvh.rs:671,686).
+// A lane reads the bound planes of an axis through two dwordx4 loads whose offsets depend on the ray's sign along that axis, so "near" and "far"
+// planes arrive sorted and the selects of Bounds3f::intersect_p2's `bounds[dir_is_neg]` indexing cost nothing.
+struct QuadNode {
+    float lo[3][4];          // [axis][slot]
+    float hi[3][4];
+    uint32_t ref[4];         // bit 31 set => leaf, low bits = first packet; else index of the child's QuadNode; PT_NONE = empty slot
+    uint32_t meta; uint32_t pad[3];
+};
+static_assert(sizeof(QuadNode) == 128, "QuadNode is one 128-byte line");
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kRefMask = 0x01ffffffu;   // 25 bits: 33 M records / packets (stack entries pack 6 more bits above)
 
@@ -44,7 +60,7 @@ struct DevInstance {
     uint32_t root_ref;                // wide-record index or kLeafBit | first packet
     uint32_t single;                  // object holds one primitive: no BVH, no root test (api.rs:1692)
     uint32_t identity;                // Transform::is_identity(instance_to_world) (primitive.rs:73)
-    uint32_t pad;
+    uint32_t root_ref4;               // the same root in the four-wide records (QuadNode index or kLeafBit | first packet)
 };
 
 // media/grid.rs GridDensityMedium: what the device needs besides the PtMedium record
@@ -59,6 +75,8 @@ struct DevImage { uint32_t width, height, n_levels, channels; const float *texel
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
+    const QuadNode *quad; uint32_t root_ref4; uint32_t leaf_off;   // (leaf_off: byte offset of `leaf` from `quad` -- one allocation)
+    //         // four-wide records of the same trees (production traversal) and the root's reference among them
     const TriPacket *leaf; uint32_t n_prims;
     const float *P; const float *N; const float *S; const float *UV;
     const uint32_t *indices; const uint8_t *tri_flags; uint32_t n_triangles;

@@ -41,25 +41,36 @@
 // back to back and every lane carries the kind of its own ray (the continuation, MIS and shadow rays of one wavefront iteration in one
 // launch: one tail of straggling rays per iteration instead of three; measured with the PT_TRACE_UTIL build on S2: the wave slots of the three
 // separate launches were busy 73 / 53 / 62 % of launch span x resident waves, ~0.8 ms of tail each).
-template <int ANY, int MODE, bool PROBE>
+// QUAD: the production traversal -- four-wide records (dev_scene.h: QuadNode), one dependent fetch per two levels of the reference tree, children
+// visited in the reference's order, so every hit (primitive, t, barycentrics) and the triangle / sphere test counters are the reference's; the node
+// counter then counts RECORDS fetched (128 B each). QUAD = false walks the two-wide records and reproduces the reference's node-visit counter
+// (pt_set_trace_exact / PT_TRACE_EXACT=1: the counter tests and the oracle comparisons of bvh_nodes_visited).
+template <int ANY, int MODE, bool PROBE, bool QUAD>
 #ifndef PT_TRACE_WAVES_PROBE
 #define PT_TRACE_WAVES_PROBE 1   // experiment hook: waves per SIMD of the triangle-only probe-chain kernel (125 VGPRs = four by itself)
 #endif
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES : (MODE == 3 && !PROBE) ? PT_TRACE_WAVES_INST : (MODE == 0 && PROBE) ? PT_TRACE_WAVES_PROBE : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+#ifndef PT_TRACE_WAVES_QUAD
+#define PT_TRACE_WAVES_QUAD 5        // waves per SIMD of the four-wide triangle-only kernels (eight quads of a record in flight per lane)
+#endif
+#ifndef PT_TRACE_WAVES_QUAD_INST
+#define PT_TRACE_WAVES_QUAD_INST 4
+#endif
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRACE_WAVES_QUAD : PT_TRACE_WAVES) : (MODE == 3 && !PROBE) ? (QUAD ? PT_TRACE_WAVES_QUAD_INST : PT_TRACE_WAVES_INST) : (MODE == 0 && PROBE) ? PT_TRACE_WAVES_PROBE : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
     constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
-    constexpr int kLds = MODE == 0 ? kLdsStack : kLdsStackGeneral;   // LDS stack entries per lane
-    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLds * 2 * 64];
+    constexpr int kLds = QUAD ? kLdsStackQuad : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
+    constexpr int kMaxS = QUAD ? kMaxStackQuad : kMaxStack;   // deepest stack (the four-wide walk pushes up to three entries per record)
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * (kLds + 1) * 2 * 64];   // (+1: the scratch slot of `push`)
     __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    uint32_t *stack = lds_stack + wave_in_block * (kLds * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    uint32_t *stack = lds_stack + wave_in_block * ((kLds + 1) * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
     float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
-    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * (kMaxStack - kLds)) + lane;
+    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * kSpillEntries) + lane;   // (the slab is sized for the deeper of the two walks: both index it the same way)
     // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
     // (measured and dropped, round 2: one work head per XCD group, each group draining "its" contiguous eighth of the queues first -- no
     //  change on any config with the segments on or off, and the dozen wave-uniform words of segment state overflowed the SGPR file into
@@ -72,6 +83,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     if (MIX && lane_id() < 16u) kcnt[lane_id()] = 0u;
 #define PT_SUB(f) (MIX ? (ksel == 0u ? job.sub[0].f : (ksel == 1u ? job.sub[1].f : job.sub[2].f)) : job.sub[0].f)
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
+    const char *const pool = reinterpret_cast<const char *>(s.quad);   // QUAD: records and packets live in ONE allocation, addressed by 32-bit byte offsets from its start
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
@@ -121,18 +133,20 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
     // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
     auto pop_next = [&]() {
         for (;;) {
-            n_nodes += pending; pending = 0;          // skipped far children above the top entry: popped + failed
+            if (!QUAD) { n_nodes += pending; pending = 0; }   // skipped far children above the top entry: popped + failed
             if (sp == 0) { state = ST_DONE; return; }
             sp--;
-            uint32_t w0, w1;
-            if (sp < (uint32_t)kLds) { w0 = stack[(2 * sp) * 64]; w1 = stack[(2 * sp + 1) * 64]; }
-            else { w0 = spill[(2 * (sp - kLds)) * 64]; w1 = spill[(2 * (sp - kLds) + 1) * 64]; }
+            // (the LDS entry is read unconditionally and the rare spilled entry replaces it: written as `sp < kLds ? LDS : HBM` the two became ONE pair
+            //  of flat loads through a selected address -- every pop went down the vector-memory path and waited on both counters)
+            const uint32_t se = min(sp, (uint32_t)(kLds - 1));
+            uint32_t w0 = stack[(2 * se) * 64], w1 = stack[(2 * se + 1) * 64];
+            asm volatile("" : "+v"(w0), "+v"(w1));   // keeps the two loads apart
+            if (sp >= (uint32_t)kLds) { w0 = spill[(2 * (sp - kLds)) * 64]; w1 = spill[(2 * (sp - kLds) + 1) * 64]; }
             if (INST && w1 == kMarker) {               // the object's BVH is exhausted: back to world space (primitive.rs:70-77), in the transform step
                 xf_arg = w0; state = ST_RET;
                 return;
             }
-            n_nodes++;                                 // the reference tests the popped node now
-            pending = (w0 >> 25) & 63u;
+            if (!QUAD) { n_nodes++; pending = (w0 >> 25) & 63u; }   // the reference tests the popped node now
             if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
                 cur = w0 & kRefMask;
                 state = (w0 & kLeafBit) ? ST_LEAF : ST_ENTER;
@@ -140,6 +154,17 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
             }
         }
     };
+
+    // (an entry is written to LDS unconditionally -- beyond the LDS entries into a scratch slot behind them -- and the rare deep entry goes to the HBM slab
+    //  as well: written as `sp < kLds ? LDS : HBM` the two stores of an entry became flat stores through a selected address, ~27 instructions per push)
+    auto push = [&](uint32_t w0, uint32_t w1) {
+        const uint32_t se = min(sp, (uint32_t)kLds);
+        stack[(2 * se) * 64] = w0; stack[(2 * se + 1) * 64] = w1;
+        asm volatile("" ::: "memory");
+        if (sp >= (uint32_t)kLds) { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
+        sp++;
+    };
+    const uint32_t root_ref = QUAD ? s.root_ref4 : s.root_ref;
 
     for (;;) {
         // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
@@ -222,8 +247,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                         if (s.n_nodes > 0) {
                             n_nodes++;
                             if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
-                                cur = s.root_ref & kRefMask;
-                                state = (s.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                                cur = root_ref & kRefMask;
+                                state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                             }
                         }
                     } else {
@@ -295,8 +320,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
                         n_nodes++;
                         if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
-                            cur = s.root_ref & kRefMask;
-                            state = (s.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                            cur = root_ref & kRefMask;
+                            state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                         }
                     }
                 }
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
 #endif
                 if (state == ST_RET) {
                     const uint32_t w0 = xf_arg;
-                    pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
+                    if (!QUAD) pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
                     ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
@@ -355,19 +380,18 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                     const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
                     bool enter = true;
                     if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
-                    if (enter && (pending > 63u || sp >= (uint32_t)kMaxStack)) { atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW); enter = false; }
+                    if (enter && ((!QUAD && pending > 63u) || sp >= (uint32_t)kMaxS)) { atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW); enter = false; }
                     if (enter) {
                         // remember where to resume: the rest of this leaf (if any) and the outer skip count
-                        const uint32_t w0 = (more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (pending << 25);
-                        if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = kMarker; }
-                        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = kMarker; }
-                        sp++; pending = 0;
+                        push((more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (QUAD ? 0u : (pending << 25)), kMarker);
+                        pending = 0;
                         wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
                         ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
                         tray = tri_ray_setup(rd);
-                        cur = I.root_ref & kRefMask;
-                        state = (I.root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                        const uint32_t iroot = QUAD ? I.root_ref4 : I.root_ref;
+                        cur = iroot & kRefMask;
+                        state = (iroot & kLeafBit) ? ST_LEAF : ST_ENTER;
                     } else if (more) { cur = li + 1u; state = ST_LEAF; }
                     else need_pop = true;
                 }
@@ -384,14 +408,88 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
         const long long u_c1 = clock64();
 #endif
         if (at_node || at_leaf) {
-            const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
-            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
-            // Pin the whole record in front of the node / leaf branch: left alone, the compiler sinks the fields only the node path
-            // reads (q2.z, q3.z) below the branch as two more dword loads, i.e. a second dependent L1 round trip in every node step
-            // (measured: extend 143 -> 126 ms per step).
-            asm volatile("" :: "v"(q2.z), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+            uint4 q0, q1, q2, q3, f0, f1, f2;
+            uint32_t qbase = 0, onx = 0, ony = 0, onz = 0, qmeta = 0;
+            if constexpr (QUAD) {
+                // three loads serve both kinds of lane: a packet's three quads, or the NEAR planes of a record's four boxes along x, y, z -- the ray's
+                // sign along an axis picks which of the record's lo / hi quads that is, so the planes arrive as Bounds3f::intersect_p2 indexes them
+                // (`bounds[dir_is_neg[k]]`, bounds.rs:561-566) without a select per plane
+                onx = nx ? 48u : 0u; ony = ny ? 64u : 16u; onz = nz ? 80u : 32u;
+                qbase = at_leaf ? s.leaf_off + cur * 48u : cur * 128u;
+                q0 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 0u : onx)));
+                q1 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 16u : ony)));
+                q2 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 32u : onz)));
+                // a node lane's other five loads of the same 128-byte line -- the far planes, the four references, the axis word -- are issued before anybody
+                // waits (left to itself the compiler issued them inside the node branch, behind the leaf branch and its wait: three dependent round trips per step)
+                if (at_node) {
+                    f0 = *reinterpret_cast<const uint4 *>(pool + (qbase + 48u - onx));
+                    f1 = *reinterpret_cast<const uint4 *>(pool + (qbase + 80u - ony));
+                    f2 = *reinterpret_cast<const uint4 *>(pool + (qbase + 112u - onz));
+                    q3 = *reinterpret_cast<const uint4 *>(pool + (qbase + 96u));
+                    qmeta = *reinterpret_cast<const uint32_t *>(pool + (qbase + 112u));
+                } else {   // (a leaf lane's copies are never read: "any value", so that no register is cleared for them)
+                    uint32_t u_ = 0u; u_ = __builtin_nondeterministic_value(u_);
+                    f0 = f1 = f2 = q3 = make_uint4(u_, u_, u_, u_); qmeta = u_;
+                }
+                asm volatile("" :: "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q2.w), "v"(f0.x), "v"(f1.x), "v"(f2.x), "v"(q3.x), "v"(qmeta));
+            } else {
+                const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
+                q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
+                // Pin the whole record in front of the node / leaf branch: left alone, the compiler sinks the fields only the node path
+                // reads (q2.z, q3.z) below the branch as two more dword loads, i.e. a second dependent L1 round trip in every node step
+                // (measured: extend 143 -> 126 ms per step).
+                asm volatile("" :: "v"(q2.z), "v"(q3.x), "v"(q3.y), "v"(q3.z));
+            }
             bool need_pop = false;
-            if (at_node) {
+            if (QUAD && at_node) {
+                const uint4 rf = q3; const uint32_t meta = qmeta;
+                n_nodes++;   // records fetched
+                const float kk = 1.0f + 2.0f * gammaf(3);
+                const uint32_t nxp[4] = {q0.x, q0.y, q0.z, q0.w}, nyp[4] = {q1.x, q1.y, q1.z, q1.w}, nzp[4] = {q2.x, q2.y, q2.z, q2.w};
+                const uint32_t fxp[4] = {f0.x, f0.y, f0.z, f0.w}, fyp[4] = {f1.x, f1.y, f1.z, f1.w}, fzp[4] = {f2.x, f2.y, f2.z, f2.w};
+                const uint32_t rfs[4] = {rf.x, rf.y, rf.z, rf.w};
+                float T[4]; uint32_t R[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // Bounds3f::intersect_p2 (bounds.rs:559-580) for slot k, the arithmetic of slab_geo; a slot that fails (or is empty) gets entry distance +inf
+                    float tmin = (__uint_as_float(nxp[k]) - ro.x) * inv_dir.x;
+                    float tmax = (__uint_as_float(fxp[k]) - ro.x) * inv_dir.x;
+                    const float tymin = (__uint_as_float(nyp[k]) - ro.y) * inv_dir.y;
+                    float tymax = (__uint_as_float(fyp[k]) - ro.y) * inv_dir.y;
+                    const float tzmin = (__uint_as_float(nzp[k]) - ro.z) * inv_dir.z;
+                    float tzmax = (__uint_as_float(fzp[k]) - ro.z) * inv_dir.z;
+                    tmax *= kk; tymax *= kk; tzmax *= kk;
+                    const bool miss_xy = (tmin > tymax) | (tymin > tmax);
+                    tmin = (tymin > tmin) ? tymin : tmin;
+                    tmax = (tymax < tmax) ? tymax : tmax;
+                    const bool miss_z = (tmin > tzmax) | (tzmin > tmax);
+                    tmin = (tzmin > tmin) ? tzmin : tmin;
+                    tmax = (tzmax < tmax) ? tzmax : tmax;
+                    const bool ok = !(miss_xy | miss_z) & (tmax > 0.0f) & (rfs[k] != PT_NONE);
+                    T[k] = ok ? tmin : __builtin_inff(); R[k] = rfs[k];
+                }
+                // the reference's order of the four slots (bvh.rs:728-751: the near child of a node first, near = the second child when the ray is
+                // negative along the node's split axis): inside each pair by the axis of L / R, between the pairs by the axis of N
+                const uint32_t sgn = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+                const bool n0 = ((sgn >> (meta & 3u)) & 1u) != 0u, n1 = ((sgn >> ((meta >> 2) & 3u)) & 1u) != 0u, n2 = ((sgn >> ((meta >> 4) & 3u)) & 1u) != 0u;
+                const float ta = n1 ? T[1] : T[0], tb = n1 ? T[0] : T[1], tc = n2 ? T[3] : T[2], td = n2 ? T[2] : T[3];
+                const uint32_t ra = n1 ? R[1] : R[0], rb = n1 ? R[0] : R[1], rc = n2 ? R[3] : R[2], rd4 = n2 ? R[2] : R[3];
+                const float t0 = n0 ? tc : ta, t1 = n0 ? td : tb, t2 = n0 ? ta : tc, t3 = n0 ? tb : td;
+                const uint32_t r0 = n0 ? rc : ra, r1 = n0 ? rd4 : rb, r2 = n0 ? ra : rc, r3 = n0 ? rb : rd4;
+                // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max); later ones are pushed with
+                // their entry distance and pass or fail the same comparison when popped, against the t_max of then; one that fails now fails then too
+                const bool m0 = t0 < t_max, m1 = t1 < t_max, m2 = t2 < t_max, m3 = t3 < t_max;
+                if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                else {
+                    if (m3 & (m0 | m1 | m2)) push(r3, __float_as_uint(t3));
+                    if (m2 & (m0 | m1)) push(r2, __float_as_uint(t2));
+                    if (m1 & m0) push(r1, __float_as_uint(t1));
+                }
+                if (m0 | m1 | m2 | m3) {
+                    const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
+                    cur = nr & kRefMask;
+                    state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
+                } else need_pop = true;
+            } else if (at_node) {
                 const float lmin[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
                 const float lmax[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
                 const float rmin[3] = {__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
@@ -406,13 +504,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? PT_TRACE_WAVES
                 const uint32_t near_ref = neg ? q3.y : q3.x, far_ref = neg ? q3.x : q3.y;
                 // reference: push far, cur = near, test near
                 if (geo_far) {
-                    if (pending > 63u || sp >= (uint32_t)kMaxStack) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
-                    else {
-                        const uint32_t w0 = far_ref | (pending << 25), w1 = __float_as_uint(tmin_far);
-                        if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
-                        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
-                        sp++; pending = 0;
-                    }
+                    if (pending > 63u || sp >= (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    else { push(far_ref | (pending << 25), __float_as_uint(tmin_far)); pending = 0; }
                 } else pending++;
                 n_nodes++;  // the near child's test
                 if (geo_near && tmin_near < t_max) {

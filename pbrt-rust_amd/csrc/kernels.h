@@ -15,16 +15,22 @@ constexpr int kNumClasses = 7;      // material-sorted shade queues: 0 matte, 1 
 //       //     the volumetric integrator estimates direct light at every vertex, so its router folds this class into class 1
 constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6;
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 10
+#define PT_LDS_STACK 9
 #endif
 constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM. Triangle-only scenes: 10, so
                                               // that seven workgroups fit a CU's LDS; scenes with instances push a marker entry per instance entered and run five
                                               // waves per SIMD: 12 (C4 with 10: trace +2.3 %)
 #ifndef PT_LDS_STACK_GENERAL
-#define PT_LDS_STACK_GENERAL 12
+#define PT_LDS_STACK_GENERAL 11
 #endif
 constexpr int kLdsStackGeneral = PT_LDS_STACK_GENERAL;
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
+#ifndef PT_LDS_STACK_QUAD
+#define PT_LDS_STACK_QUAD 13
+#endif
+constexpr int kLdsStackQuad = PT_LDS_STACK_QUAD;   // the four-wide walk (kern_trace.h, QUAD): up to three pushes per record; five waves per SIMD x 7 KB per wave of LDS
+constexpr int kMaxStackQuad = 96;   // a reference tree of depth 64 collapses to 32 four-wide levels x 3 pushes
+constexpr int kSpillEntries = (kMaxStackQuad - kLdsStackQuad) > (kMaxStack - (kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral)) ? (kMaxStackQuad - kLdsStackQuad) : (kMaxStack - (kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral));   // per-lane HBM stack entries behind the LDS ones
 constexpr int kTraceBlock = 256;
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
 

@@ -38,6 +38,11 @@ class Library:
     def init(self, device=0):
         self.check(self.lib.pt_init(device), "pt_init")
 
+    def set_trace_exact(self, exact):
+        """True: the two-wide BVH walk whose `bvh_nodes_visited` is the reference's counter; False (default): the four-wide production walk
+        (same hits, films and other counters). Returns the previous setting."""
+        return bool(self.lib.pt_set_trace_exact(1 if exact else 0))
+
 
 _lib = None
 

@@ -1,0 +1,49 @@
+#!/bin/bash
+# round-4 traversal experiments on the GPU box: tools/r4_exp.sh <tag> <what...>
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
+tag=$1; shift
+OUT=gpurun_out/$tag; mkdir -p $OUT
+one() {   # one <label> <bench args...>   (env of the caller applies)
+  local label=$1; shift
+  python bench.py "$@" --cpu-seconds 0 --other-configs off 2>$OUT/err_$label.log | tail -1 > $OUT/bench_$label.json || { tail -5 $OUT/err_$label.log; return 1; }
+  python3 - $OUT/bench_$label.json "$label" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); k=d['kernels_ms_per_step']
+print('%-22s %9.2f Msamples/s  %8.2f ms/step  ' % (sys.argv[2], d['value'], d['ms_per_step']) + ' '.join('%s=%.1f' % (n, x['ms']) for n, x in k.items() if x['ms'] >= 1.0), flush=True)
+PY
+}
+for what in "$@"; do
+case $what in
+exact_tests) PT_TRACE_EXACT=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
+parity) timeout -k 10 900 python tools/full_frame_parity.py C2:16 C5:8 C3:8 C4:4 > $OUT/full_frame_parity.jsonl 2>$OUT/parity_err.log; python3 -c "
+import json
+for l in open('$OUT/full_frame_parity.jsonl'):
+    d=json.loads(l); print(d['config'], d['spp'], 'differing', d['counters_differing'], 'weights', d['weights_identical'], 'rel', d['max_rel_diff_film'], 'linf', d['linf_normalised'])
+" ;;
+c2sweep)
+  PT_TRACE_EXACT=1 one c2_exact --config C2 --steps 2 --warmup 1
+  for q in 8 16 24 32 48; do PT_TRACE_LEAF_QUORUM=$q one c2_spec_q$q --config C2 --steps 2 --warmup 1; done ;;
+c4sweep)
+  PT_TRACE_EXACT=1 one c4_exact --config C4 --spp 64 --steps 1 --warmup 1
+  for q in 8 16 32; do PT_TRACE_LEAF_QUORUM=$q one c4_spec_q$q --config C4 --spp 64 --steps 1 --warmup 1; done ;;
+c35)
+  PT_TRACE_EXACT=1 one c3_exact --config C3 --spp 256 --steps 1 --warmup 1
+  for q in 8 24; do PT_TRACE_LEAF_QUORUM=$q one c3_spec_q$q --config C3 --spp 256 --steps 1 --warmup 1; done
+  PT_TRACE_EXACT=1 one c5_exact --config C5 --spp 216 --steps 1 --warmup 1
+  for q in 8 24; do PT_TRACE_LEAF_QUORUM=$q one c5_spec_q$q --config C5 --spp 216 --steps 1 --warmup 1; done ;;
+base)
+  one c2 --config C2 --steps 3 --warmup 1
+  one c4 --config C4 --spp 64 --steps 1 --warmup 1 ;;
+base35)
+  one c3 --config C3 --spp 256 --steps 1 --warmup 1
+  one c5 --config C5 --spp 216 --steps 2 --warmup 1 ;;
+both)
+  one c2_quad --config C2 --steps 3 --warmup 1
+  PT_TRACE_EXACT=1 one c2_exact --config C2 --steps 2 --warmup 1
+  one c4_quad --config C4 --spp 64 --steps 1 --warmup 1
+  PT_TRACE_EXACT=1 one c4_exact --config C4 --spp 64 --steps 1 --warmup 1 ;;
+exact_quick) PT_TRACE_EXACT=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 ;;
+quick_tests) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 ;;
+esac
+done
