@@ -38,10 +38,14 @@ OTHER_CONFIG_SPP = {"C3": 256, "C4": 256, "C5": 216}   # one step each after the
 
 
 def algo_bytes(name, s):
-    """ALGORITHMIC bytes of a launch kind: trace kernels 32 B per reference BVH node visited + 48 B per shape
-    packet tested + 44 B per ray (pid 4, ray 24, hit record 16); shade kernels count their path-state / mesh / queue quads in-kernel."""
+    """ALGORITHMIC bytes of a launch kind: trace kernels 128 B per four-wide BVH record fetched (32 B per reference node
+    visited in the exact walk) + 48 B per shape packet tested + 44 B per ray (pid 4, ray 24, hit record 16); shade kernels count their
+    path-state / mesh / queue quads in-kernel."""
     if name in TRACE_KINDS:
-        return 32 * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
+        # production traversal (kernel symbol k_trace<.., true>): the node counter counts four-wide records fetched, 128 B each; the exact walk
+        # (pt_set_trace_exact, k_trace<.., false>) counts the reference's node visits, 32 B each
+        node_bytes = 128 if str(s.get("kernel", "")).rstrip().endswith("true>") else 32
+        return node_bytes * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
     if name.startswith("shade_") or name == "bssrdf":
         return s["bvh_nodes"]
     return None

@@ -1109,7 +1109,10 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
                     if (nn[c].n_prims) put(2 * side, c);
                     else { axes[1 + side] = nn[c].axis; put(2 * side, c + 1u); put(2 * side + 1, nn[c].offset); }
                 }
-                q.meta = axes[0] | (axes[1] << 2) | (axes[2] << 4);
+                // order word: for each of the eight sign octants o = nx | ny << 1 | nz << 2, three bits at 3 o: bit 0 = the ray is negative along N's
+                // axis (the right pair comes first), bit 1 = along L's (slot 1 before slot 0), bit 2 = along R's (slot 3 before slot 2)
+                q.meta = 0;
+                for (uint32_t o = 0; o < 8; ++o) q.meta |= (((o >> axes[0]) & 1u) | (((o >> axes[1]) & 1u) << 1) | (((o >> axes[2]) & 1u) << 2)) << (3u * o);
             }
             root_ref4 = nn.empty() ? 0u : qref_of(0);
         }
@@ -1284,12 +1287,12 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         // one base (at most 2^24 records x 128 B + 2^25 packets x 48 B < 4 GB): [records][packets + 2] (+2: a packet's fourth quad is loaded with it)
         if (quad.empty()) quad.resize(1);
         const size_t quad_bytes = quad.size() * sizeof(QuadNode), pool_bytes = quad_bytes + ((size_t)n_packets + 2) * sizeof(TriPacket);
-        if (pool_bytes >= ((size_t)1 << 32)) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 4 GB of traversal records + packets"));
+        if (pool_bytes >= (size_t)0xE0000000u) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 4 GB of traversal records + packets"));
         uint8_t *pool = nullptr;
         if ((st = sc->dalloc(&pool, pool_bytes))) return bail(st);
         if (hipMemcpy(pool, quad.data(), quad_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PT_ERR_HIP, "upload of the four-wide records"));
         leaf = reinterpret_cast<TriPacket *>(pool + quad_bytes);
-        ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)quad_bytes;
+        ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)quad_bytes; ds.pool_bytes = (uint32_t)pool_bytes;
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         if ((st = sc->dalloc(&lrec, 6 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);

@@ -40,7 +40,8 @@ struct WideNode {
 // empty (bounds +inf / -inf, reference PT_NONE). The ray visits the slots in the order the reference's binary walk reaches them -- near side of N
 // first, inside a pair the near side of L (R) first -- so leaves are met in the reference's order and every hit is the reference's hit; only the
 // number of boxes tested differs (boxes of L and R themselves are never tested: a child that passes its own test lies inside its parent's box and
-// the parent would have passed too). meta: bits 0-1 split axis of N, 2-3 of L, 4-5 of R (bvh.rs:671,686).
+// the parent would have passed too). meta: the slot order for each of the eight sign octants of a ray, three bits per octant (capi.hip), from the split
+// axes of N, L and R (bvh.rs:671,686).
 // A lane reads the bound planes of an axis through two dwordx4 loads whose offsets depend on the ray's sign along that axis, so "near" and "far"
 // planes arrive sorted and the selects of Bounds3f::intersect_p2's `bounds[dir_is_neg]` indexing cost nothing.
 struct QuadNode {
@@ -75,7 +76,7 @@ struct DevImage { uint32_t width, height, n_levels, channels; const float *texel
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
-    const QuadNode *quad; uint32_t root_ref4; uint32_t leaf_off;   // (leaf_off: byte offset of `leaf` from `quad` -- one allocation)
+    const QuadNode *quad; uint32_t root_ref4; uint32_t leaf_off, pool_bytes;   // (leaf_off: byte offset of `leaf` from `quad` -- one allocation of pool_bytes < 3.5 GB)
     //         // four-wide records of the same trees (production traversal) and the root's reference among them
     const TriPacket *leaf; uint32_t n_prims;
     const float *P; const float *N; const float *S; const float *UV;

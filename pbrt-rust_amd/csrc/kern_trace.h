@@ -83,7 +83,10 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     if (MIX && lane_id() < 16u) kcnt[lane_id()] = 0u;
 #define PT_SUB(f) (MIX ? (ksel == 0u ? job.sub[0].f : (ksel == 1u ? job.sub[1].f : job.sub[2].f)) : job.sub[0].f)
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
-    const char *const pool = reinterpret_cast<const char *>(s.quad);   // QUAD: records and packets live in ONE allocation, addressed by 32-bit byte offsets from its start
+    // QUAD: records and packets live in ONE allocation, addressed by 32-bit byte offsets from its start through a buffer resource
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<QuadNode *>(s.quad), 0, (int)s.pool_bytes, 0x00020000);
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     V3 ro, rd, inv_dir;
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
     bool nx = false, ny = false, nz = false;
+    uint32_t sgn3 = 0;   // QUAD: 3 x the ray's sign octant (nx | ny << 1 | nz << 2): the shift that finds the octant's slot order in a record's order word
+#define PT_SGN3() do { if (QUAD) sgn3 = 3u * ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u)); } while (0)
     float t_max = 0.0f;
     // closest hit so far: its packet (index in DeviceScene::leaf, PT_NONE = no hit yet) -- the primitive id and the flag word are
     // read back from that packet when the ray retires instead of being carried through the loop
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         retire = false;
                         t_max = job.sub[0].scalar_tmax;
                         inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                        nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                        nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
                         tray = tri_ray_setup(rd);
                         sp = 0; pending = 0;
                         hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     rd = V3(r0.w, r1.x, r1.y);
                     t_max = PT_SUB(per_ray_tmax) ? r1.z : PT_SUB(scalar_tmax);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
                     tray = tri_ray_setup(rd);
                     sp = 0; pending = 0;
                     hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     if (!QUAD) pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
                     ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f;
+                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
                     tray = tri_ray_setup(rd);
                     t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
                     in_inst = PT_NONE; inst_hit = false;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         pending = 0;
                         wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
-                        ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; t_max = tm2;
+                        ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; PT_SGN3(); t_max = tm2;
                         tray = tri_ray_setup(rd);
                         const uint32_t iroot = QUAD ? I.root_ref4 : I.root_ref;
                         cur = iroot & kRefMask;
@@ -408,30 +413,78 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
         const long long u_c1 = clock64();
 #endif
         if (at_node || at_leaf) {
-            uint4 q0, q1, q2, q3, f0, f1, f2;
-            uint32_t qbase = 0, onx = 0, ony = 0, onz = 0, qmeta = 0;
+            uint4 q0, q1, q2, q3;
+            bool need_pop = false;
             if constexpr (QUAD) {
-                // three loads serve both kinds of lane: a packet's three quads, or the NEAR planes of a record's four boxes along x, y, z -- the ray's
-                // sign along an axis picks which of the record's lo / hi quads that is, so the planes arrive as Bounds3f::intersect_p2 indexes them
-                // (`bounds[dir_is_neg[k]]`, bounds.rs:561-566) without a select per plane
-                onx = nx ? 48u : 0u; ony = ny ? 64u : 16u; onz = nz ? 80u : 32u;
-                qbase = at_leaf ? s.leaf_off + cur * 48u : cur * 128u;
-                q0 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 0u : onx)));
-                q1 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 16u : ony)));
-                q2 = *reinterpret_cast<const uint4 *>(pool + (qbase + (at_leaf ? 32u : onz)));
-                // a node lane's other five loads of the same 128-byte line -- the far planes, the four references, the axis word -- are issued before anybody
-                // waits (left to itself the compiler issued them inside the node branch, behind the leaf branch and its wait: three dependent round trips per step)
+                // Buffer loads off ONE resource (records and packets in one allocation, 32-bit byte offsets; an offset beyond the allocation reads zeros
+                // without touching memory). Three loads serve both kinds of lane: a packet's three quads, or the NEAR planes of a record's four boxes along
+                // x, y, z -- the ray's sign along an axis picks which of the record's lo / hi quads that is, so the planes arrive as
+                // Bounds3f::intersect_p2 indexes them (`bounds[dir_is_neg[k]]`, bounds.rs:561-566) without a select per plane. A node lane's other five
+                // loads of the same 128-byte line (far planes, references, order word) go out with them -- a leaf lane aims them past the end --, so a step is
+                // one round trip and nobody waits inside a branch.
+                const uint32_t onx = nx ? 48u : 0u, ony = ny ? 64u : 16u, onz = nz ? 80u : 32u;
+                const uint32_t qb = at_leaf ? ((cur * 3u) << 4) + s.leaf_off : (cur << 7);
+                const uint32_t nb = at_node ? qb : 0xffffff00u;
+                const v4u a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 0u : onx), 0, 0);
+                const v4u a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 16u : ony), 0, 0);
+                const v4u a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 32u : onz), 0, 0);
+                const v4u b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (48u - onx), 0, 0);
+                const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (80u - ony), 0, 0);
+                const v4u b2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (112u - onz), 0, 0);
+                const v4u rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + 96u, 0, 0);
+                const uint32_t meta = __builtin_amdgcn_raw_buffer_load_b32(rsrc, nb + 112u, 0, 0);
+                asm volatile("" :: "v"(a0.x), "v"(a1.x), "v"(a2.x), "v"(a2.w), "v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(rf.x), "v"(meta));   // all eight before the node / leaf branch
+                q0 = make_uint4(a0.x, a0.y, a0.z, a0.w); q1 = make_uint4(a1.x, a1.y, a1.z, a1.w); q2 = make_uint4(a2.x, a2.y, a2.z, a2.w); q3 = make_uint4(0u, 0u, 0u, 0u);
                 if (at_node) {
-                    f0 = *reinterpret_cast<const uint4 *>(pool + (qbase + 48u - onx));
-                    f1 = *reinterpret_cast<const uint4 *>(pool + (qbase + 80u - ony));
-                    f2 = *reinterpret_cast<const uint4 *>(pool + (qbase + 112u - onz));
-                    q3 = *reinterpret_cast<const uint4 *>(pool + (qbase + 96u));
-                    qmeta = *reinterpret_cast<const uint32_t *>(pool + (qbase + 112u));
-                } else {   // (a leaf lane's copies are never read: "any value", so that no register is cleared for them)
-                    uint32_t u_ = 0u; u_ = __builtin_nondeterministic_value(u_);
-                    f0 = f1 = f2 = q3 = make_uint4(u_, u_, u_, u_); qmeta = u_;
+                    n_nodes++;   // records fetched
+                    // Bounds3f::intersect_p2 (bounds.rs:559-580) for the four slots, the arithmetic of slab_geo, two slots per packed instruction:
+                    // t = (plane - o) * inv_dir, far planes times 1 + 2 gamma(3)
+                    const f2 kk2 = {1.0f + 2.0f * gammaf(3), 1.0f + 2.0f * gammaf(3)};
+                    const f2 ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z}, ix = {inv_dir.x, inv_dir.x}, iy = {inv_dir.y, inv_dir.y}, iz = {inv_dir.z, inv_dir.z};
+#define PT_F2(v, lo, hi) f2{__uint_as_float(v.lo), __uint_as_float(v.hi)}
+                    const f2 tnx[2] = {(PT_F2(a0, x, y) - ox) * ix, (PT_F2(a0, z, w) - ox) * ix}, tfx[2] = {((PT_F2(b0, x, y) - ox) * ix) * kk2, ((PT_F2(b0, z, w) - ox) * ix) * kk2};
+                    const f2 tny[2] = {(PT_F2(a1, x, y) - oy) * iy, (PT_F2(a1, z, w) - oy) * iy}, tfy[2] = {((PT_F2(b1, x, y) - oy) * iy) * kk2, ((PT_F2(b1, z, w) - oy) * iy) * kk2};
+                    const f2 tnz[2] = {(PT_F2(a2, x, y) - oz) * iz, (PT_F2(a2, z, w) - oz) * iz}, tfz[2] = {((PT_F2(b2, x, y) - oz) * iz) * kk2, ((PT_F2(b2, z, w) - oz) * iz) * kk2};
+#undef PT_F2
+                    float T[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // the reference's conditional updates `if tymin > tmin { tmin = tymin }` are max / min except when the x-axis value is a NaN (a ray
+                        // with d.x == 0 starting on a plane of the box): the reference then keeps the NaN and rejects the box -- `ord` below; a NaN along y or
+                        // z is ignored by both forms
+                        const float tminx = tnx[k >> 1][k & 1], tmaxx = tfx[k >> 1][k & 1], tymin = tny[k >> 1][k & 1], tymax = tfy[k >> 1][k & 1], tzmin = tnz[k >> 1][k & 1], tzmax = tfz[k >> 1][k & 1];
+                        const bool miss_xy = (tminx > tymax) | (tymin > tmaxx);
+                        const float tmin1 = __builtin_fmaxf(tminx, tymin), tmax1 = __builtin_fminf(tmaxx, tymax);
+                        const bool miss_z = (tmin1 > tzmax) | (tzmin > tmax1);
+                        const float tmin = __builtin_fmaxf(tmin1, tzmin), tmax = __builtin_fminf(tmax1, tzmax);
+                        const bool ord = !__builtin_isunordered(tminx, tmaxx);
+                        const bool ok = !(miss_xy | miss_z) & (tmax > 0.0f) & ord;   // (an empty slot's planes are +inf / -inf: it misses)
+                        T[k] = ok ? tmin : __builtin_inff();   // a slot that fails gets entry distance +inf: it fails every `tmin < t_max` below
+                    }
+                    // the reference's order of the four slots (bvh.rs:728-751: the near child of a node first, near = the second child when the ray is
+                    // negative along the node's split axis): inside each pair by the axis of L / R, between the pairs by the axis of N -- the record
+                    // holds the three decisions for each of the eight sign octants
+                    const uint32_t ord3 = meta >> sgn3;
+                    const bool n0 = (ord3 & 1u) != 0u, n1 = (ord3 & 2u) != 0u, n2 = (ord3 & 4u) != 0u;
+                    const float ta = n1 ? T[1] : T[0], tb = n1 ? T[0] : T[1], tc = n2 ? T[3] : T[2], td = n2 ? T[2] : T[3];
+                    const uint32_t ra = n1 ? rf.y : rf.x, rb = n1 ? rf.x : rf.y, rc = n2 ? rf.w : rf.z, rd4 = n2 ? rf.z : rf.w;
+                    const float t0 = n0 ? tc : ta, t1 = n0 ? td : tb, t2 = n0 ? ta : tc, t3 = n0 ? tb : td;
+                    const uint32_t r0 = n0 ? rc : ra, r1 = n0 ? rd4 : rb, r2 = n0 ? ra : rc, r3 = n0 ? rb : rd4;
+                    // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max); later ones are pushed with
+                    // their entry distance and pass or fail the same comparison when popped, against the t_max of then; one that fails now fails then too
+                    const bool m0 = t0 < t_max, m1 = t1 < t_max, m2 = t2 < t_max, m3 = t3 < t_max;
+                    if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    else {
+                        if (m3 & (m0 | m1 | m2)) push(r3, __float_as_uint(t3));
+                        if (m2 & (m0 | m1)) push(r2, __float_as_uint(t2));
+                        if (m1 & m0) push(r1, __float_as_uint(t1));
+                    }
+                    if (m0 | m1 | m2 | m3) {
+                        const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
+                        cur = nr & kRefMask;
+                        state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
+                    } else need_pop = true;
                 }
-                asm volatile("" :: "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q2.w), "v"(f0.x), "v"(f1.x), "v"(f2.x), "v"(q3.x), "v"(qmeta));
             } else {
                 const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
                 q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
@@ -440,55 +493,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 // (measured: extend 143 -> 126 ms per step).
                 asm volatile("" :: "v"(q2.z), "v"(q3.x), "v"(q3.y), "v"(q3.z));
             }
-            bool need_pop = false;
             if (QUAD && at_node) {
-                const uint4 rf = q3; const uint32_t meta = qmeta;
-                n_nodes++;   // records fetched
-                const float kk = 1.0f + 2.0f * gammaf(3);
-                const uint32_t nxp[4] = {q0.x, q0.y, q0.z, q0.w}, nyp[4] = {q1.x, q1.y, q1.z, q1.w}, nzp[4] = {q2.x, q2.y, q2.z, q2.w};
-                const uint32_t fxp[4] = {f0.x, f0.y, f0.z, f0.w}, fyp[4] = {f1.x, f1.y, f1.z, f1.w}, fzp[4] = {f2.x, f2.y, f2.z, f2.w};
-                const uint32_t rfs[4] = {rf.x, rf.y, rf.z, rf.w};
-                float T[4]; uint32_t R[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {   // Bounds3f::intersect_p2 (bounds.rs:559-580) for slot k, the arithmetic of slab_geo; a slot that fails (or is empty) gets entry distance +inf
-                    float tmin = (__uint_as_float(nxp[k]) - ro.x) * inv_dir.x;
-                    float tmax = (__uint_as_float(fxp[k]) - ro.x) * inv_dir.x;
-                    const float tymin = (__uint_as_float(nyp[k]) - ro.y) * inv_dir.y;
-                    float tymax = (__uint_as_float(fyp[k]) - ro.y) * inv_dir.y;
-                    const float tzmin = (__uint_as_float(nzp[k]) - ro.z) * inv_dir.z;
-                    float tzmax = (__uint_as_float(fzp[k]) - ro.z) * inv_dir.z;
-                    tmax *= kk; tymax *= kk; tzmax *= kk;
-                    const bool miss_xy = (tmin > tymax) | (tymin > tmax);
-                    tmin = (tymin > tmin) ? tymin : tmin;
-                    tmax = (tymax < tmax) ? tymax : tmax;
-                    const bool miss_z = (tmin > tzmax) | (tzmin > tmax);
-                    tmin = (tzmin > tmin) ? tzmin : tmin;
-                    tmax = (tzmax < tmax) ? tzmax : tmax;
-                    const bool ok = !(miss_xy | miss_z) & (tmax > 0.0f) & (rfs[k] != PT_NONE);
-                    T[k] = ok ? tmin : __builtin_inff(); R[k] = rfs[k];
-                }
-                // the reference's order of the four slots (bvh.rs:728-751: the near child of a node first, near = the second child when the ray is
-                // negative along the node's split axis): inside each pair by the axis of L / R, between the pairs by the axis of N
-                const uint32_t sgn = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-                const bool n0 = ((sgn >> (meta & 3u)) & 1u) != 0u, n1 = ((sgn >> ((meta >> 2) & 3u)) & 1u) != 0u, n2 = ((sgn >> ((meta >> 4) & 3u)) & 1u) != 0u;
-                const float ta = n1 ? T[1] : T[0], tb = n1 ? T[0] : T[1], tc = n2 ? T[3] : T[2], td = n2 ? T[2] : T[3];
-                const uint32_t ra = n1 ? R[1] : R[0], rb = n1 ? R[0] : R[1], rc = n2 ? R[3] : R[2], rd4 = n2 ? R[2] : R[3];
-                const float t0 = n0 ? tc : ta, t1 = n0 ? td : tb, t2 = n0 ? ta : tc, t3 = n0 ? tb : td;
-                const uint32_t r0 = n0 ? rc : ra, r1 = n0 ? rd4 : rb, r2 = n0 ? ra : rc, r3 = n0 ? rb : rd4;
-                // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max); later ones are pushed with
-                // their entry distance and pass or fail the same comparison when popped, against the t_max of then; one that fails now fails then too
-                const bool m0 = t0 < t_max, m1 = t1 < t_max, m2 = t2 < t_max, m3 = t3 < t_max;
-                if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
-                else {
-                    if (m3 & (m0 | m1 | m2)) push(r3, __float_as_uint(t3));
-                    if (m2 & (m0 | m1)) push(r2, __float_as_uint(t2));
-                    if (m1 & m0) push(r1, __float_as_uint(t1));
-                }
-                if (m0 | m1 | m2 | m3) {
-                    const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
-                    cur = nr & kRefMask;
-                    state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
-                } else need_pop = true;
+                // (the four-wide step above)
             } else if (at_node) {
                 const float lmin[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
                 const float lmax[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
@@ -608,3 +614,4 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 }
 #undef PT_SUB
 #undef PT_UTIL
+#undef PT_SGN3

@@ -8,6 +8,7 @@ import subprocess
 
 import numpy as np
 import pytest
+from conftest import ckeys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -264,7 +265,7 @@ def test_front_end_scene_renders_on_gpu_like_the_oracle(pkg, gpu, oracle, tmp_pa
     g = pkg.Scene(gpu, fs); orc = oracle.scene(fs)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     # gaussian filter: overlapping splats are summed by float atomics in a different order
     np.testing.assert_allclose(film, ref, rtol=2e-4, atol=2e-6)

@@ -3,6 +3,7 @@ by the oracle. Exact work counters and 2e-6 relative radiance, as in the hand-wr
 nobody wrote a scene for (odd parameter combinations, partial spheres under non-uniform transforms, lights inside media, ...)."""
 import numpy as np
 import pytest
+from conftest import ckeys
 
 
 def random_scene(pkg, seed, builder=None):
@@ -190,7 +191,7 @@ def test_gpu_matches_oracle_on_random_scenes(pkg, gpu, oracle, seed):
     sss = any(m.type == pkg._abi.PT_MAT_SUBSURFACE or (m.type == pkg._abi.PT_MAT_DISNEY and any(m.disney_scatter)) for m in b.materials)
     exact = ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "sanitized_nan", "sanitized_negative", "sanitized_infinite",
              "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "reference_asserts")   # reference_asserts: the assert!()s of path.rs:143,162-163,184,201,213 / volpath.rs:176,194,210,223 that would have fired; BSSRDF probe chains included: walked once, inside k_trace<.., PROBE>
-    for k in exact: assert gc[k] == oc[k], (k, gc[k], oc[k])
+    for k in ckeys(exact): assert gc[k] == oc[k], (k, gc[k], oc[k])
     # filter-weight sums: exact for the box filter, float summation order otherwise
     if b.filter["kind"] == "box" and max(b.filter["radius"]) <= 0.5: assert np.array_equal(film[..., 3], ref[..., 3])
     else: np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=2e-6)
@@ -310,9 +311,9 @@ def test_gpu_traversal_of_edge_case_rays(pkg, gpu, oracle, seed):
     gp, gt, gb = g.trace_closest(o, d, t); gc = g.counters()
     op, ot, ob = orc.trace_closest(o, d, t); oc = orc.counters()
     assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
-    for k in ("bvh_nodes_visited", "triangle_tests", "intersect_tests"): assert gc[k] == oc[k], k
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "intersect_tests")): assert gc[k] == oc[k], k
     tf = np.where(np.isinf(t), np.float32(50.0), t)
     gh = g.trace_any(o, d, tf); gc = g.counters()
     oh = orc.trace_any(o, d, tf); oc = orc.counters()
     assert np.array_equal(gh, oh)
-    for k in ("bvh_nodes_visited", "triangle_tests", "shadow_tests"): assert gc[k] == oc[k], k
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "shadow_tests")): assert gc[k] == oc[k], k

@@ -3,6 +3,7 @@ Integer/index work must be bit-exact; radiance is compared with the tolerance st
 import ctypes as C
 import numpy as np
 import pytest
+from conftest import ckeys
 
 pytestmark = pytest.mark.gpu
 
@@ -79,13 +80,13 @@ def test_trace_closest_and_any_bit_exact(pkg, gpu, oracle):
     assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
     assert np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
     assert (gp != 0xFFFFFFFF).mean() > 0.2
-    for k in ("bvh_nodes_visited", "triangle_tests", "intersect_tests"):
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "intersect_tests")):
         assert gc[k] == oc[k], k
     tm2 = np.full(len(o), 3.0, np.float32)
     gh = g.trace_any(o, d, tm2); gc = g.counters()
     oh = orc.trace_any(o, d, tm2); oc = orc.counters()
     assert np.array_equal(gh, oh)
-    for k in ("bvh_nodes_visited", "triangle_tests", "shadow_tests"):
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "shadow_tests")):
         assert gc[k] == oc[k], k
 
 
@@ -96,8 +97,8 @@ def test_film_matches_oracle(pkg, gpu, oracle, kw):
     film = g.render(rp)
     ref = orc.render(rp, nthreads=1)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "zero_radiance_paths_num",
-              "zero_radiance_paths_den", "path_length_hist", "film_splats"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "zero_radiance_paths_num",
+              "zero_radiance_paths_den", "path_length_hist", "film_splats")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     # identical sample radiances; the only difference allowed is float summation order of filter splats
     assert np.array_equal(film[..., 3], ref[..., 3])
@@ -111,8 +112,8 @@ def _compare_render(pkg, gpu, oracle, sd, rp, rtol=2e-6, atol=1e-7):
     film = g.render(rp)
     ref = orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "zero_radiance_paths_num",
-              "zero_radiance_paths_den", "path_length_hist", "film_splats", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "zero_radiance_paths_num",
+              "zero_radiance_paths_den", "path_length_hist", "film_splats", "sanitized_nan", "sanitized_negative", "sanitized_infinite", "reference_asserts")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=rtol, atol=atol)
@@ -137,7 +138,7 @@ def test_thin_lens_gaussian_filter_and_crop(pkg, gpu, oracle):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=1)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "bvh_nodes_visited", "triangle_tests", "film_splats", "path_length_hist"):
+    for k in ckeys(("camera_rays", "bvh_nodes_visited", "triangle_tests", "film_splats", "path_length_hist")):
         assert gc[k] == oc[k], k
     np.testing.assert_allclose(film, ref, rtol=2e-5, atol=1e-6)
 
@@ -237,7 +238,7 @@ def test_full_size_parity_gate_on_a_crop(pkg, gpu, oracle):
     orc = oracle.scene(sd)
     ref = orc.render(rp, nthreads=32)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     assert np.abs(g.resolve(film) - orc.resolve(ref)).max() < 1e-3   # the gate; in practice the films agree to 2e-6 relative
@@ -252,7 +253,7 @@ def test_spheres_c1_matches_oracle(pkg, gpu, oracle):
     assert bytes(gn) == bytes(on) and np.array_equal(go, oo)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist", "film_splats")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
 
@@ -292,8 +293,8 @@ def test_subsurface_matches_oracle(pkg, gpu, oracle, rough):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
-              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+    for k in ckeys(("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
+              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
@@ -309,8 +310,8 @@ def test_subsurface_with_sigma_textures_matches_oracle(pkg, gpu, oracle, rough):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
-              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+    for k in ckeys(("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
+              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
@@ -326,8 +327,8 @@ def test_kdsubsurface_with_textures_matches_oracle(pkg, gpu, oracle):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
-              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+    for k in ckeys(("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den",
+              "sanitized_nan", "sanitized_negative", "sanitized_infinite", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
@@ -342,7 +343,7 @@ def test_long_probe_chains_fall_back_to_an_uncounted_rewalk(pkg, gpu, oracle):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"):
+    for k in ckeys(("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     assert oc["intersect_tests"] > 5 * oc["camera_rays"]       # the chains really are long (40 matches where a probe crosses the stack)
     assert np.array_equal(film[..., 3], ref[..., 3])
@@ -368,8 +369,8 @@ def test_sphere_area_lights_match_oracle(pkg, gpu, oracle):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
-              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
+              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
 
@@ -386,8 +387,8 @@ def test_textures_match_oracle(pkg, gpu, oracle, trilinear, bump, noise):
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     gc, oc = g.counters(), orc.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
-              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests", "path_length_hist",
+              "film_splats", "zero_radiance_paths_num", "zero_radiance_paths_den")):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
     np.testing.assert_allclose(film, ref, rtol=2e-6, atol=1e-7)
 
@@ -464,7 +465,7 @@ def test_disk_shapes_and_lights_match_oracle(pkg, gpu, oracle):
     gp, gt, gb = g.trace_closest(o, d, tmax); op, ot, ob = orc.trace_closest(o, d, tmax)
     assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
     assert np.array_equal(g.trace_any(o, d, tmax), orc.trace_any(o, d, tmax))
-    for k in ("bvh_nodes_visited", "intersect_tests", "shadow_tests"): assert g.counters()[k] == orc.counters()[k], k
+    for k in ckeys(("bvh_nodes_visited", "intersect_tests", "shadow_tests")): assert g.counters()[k] == orc.counters()[k], k
 
 
 def test_disney_limits_are_reported(pkg, gpu):
@@ -490,7 +491,7 @@ def test_disney_bssrdf_matches_oracle(pkg, gpu, oracle, g):
     gsc = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = gsc.render(rp), orc.render(rp, nthreads=4)
     gc, oc = gsc.counters(), orc.counters()
-    for k in ("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests"): assert gc[k] == oc[k], k
+    for k in ckeys(("camera_rays", "shadow_tests", "path_length_hist", "film_splats", "intersect_tests", "bvh_nodes_visited", "triangle_tests", "sphere_tests")): assert gc[k] == oc[k], k
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
 

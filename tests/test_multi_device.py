@@ -8,6 +8,7 @@ summing to the same totals."""
 import ctypes as C
 import numpy as np
 import pytest
+from conftest import ckeys
 
 
 def test_replica_tile_shards_partition_the_callers_shard(pkg):
@@ -50,7 +51,7 @@ def test_three_replicas_on_one_device_equal_the_plain_render(pkg, gpu, scene):
     multi = pkg.MultiScene(gpu, sd, [0, 0, 0])
     film = multi.render(rp)
     mc = multi.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats")):
         assert mc[k] == rc[k], (k, mc[k], rc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
@@ -85,7 +86,7 @@ def test_eight_replicas_and_two_film_sizes_on_one_multiscene(pkg, gpu):
     for rp in (rp_small, rp_big, rp_small):
         ref = single.render(rp); rc = single.counters()
         film = multi.render(rp); mc = multi.counters()
-        for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+        for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats")):
             assert mc[k] == rc[k], (k, mc[k], rc[k])
         assert film.shape == ref.shape and np.array_equal(film[..., 3], ref[..., 3])
         np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
@@ -105,7 +106,7 @@ def test_distinct_devices_equal_the_plain_render(pkg, gpu):
     ref = single.render(rp); rc = single.counters()
     multi = pkg.MultiScene(gpu, sd, devs)
     film = multi.render(rp); mc = multi.counters()
-    for k in ("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats"):
+    for k in ckeys(("camera_rays", "intersect_tests", "shadow_tests", "bvh_nodes_visited", "triangle_tests", "path_length_hist", "film_splats")):
         assert mc[k] == rc[k], (k, mc[k], rc[k])
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)

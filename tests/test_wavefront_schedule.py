@@ -23,6 +23,7 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
 from _pkg import import_pkg
 pkg = import_pkg()
 import torch   # before the library touches HIP (tests/conftest.py)
+from conftest import ckeys, trace_env
 torch.cuda.init()
 lib = pkg.load_library(); lib.init(0)
 out = {{}}
@@ -47,7 +48,7 @@ def _scenes(pkg):
 def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_path):
     """PT_TRACE_SPLIT=1 (read by pt_init, so in a process of its own) traces the three ray kinds of an iteration in three launches, as
     round 1 did; the default traces them in one. Same counters, same weights bit for bit, same radiance up to the order of the film's float atomics; the launch kinds differ."""
-    env = dict(os.environ, PT_TRACE_SPLIT="1")
+    env = trace_env(dict(os.environ, PT_TRACE_SPLIT="1"))
     code = _CHILD.format(root=ROOT, out=str(tmp_path), counters=COUNTERS)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -58,7 +59,7 @@ def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_pat
         film = g.render(rp)
         c = g.counters()
         stats = sorted(s["name"] for s in g.kernel_stats() if s["launches"])
-        for k in COUNTERS:
+        for k in ckeys(COUNTERS):
             assert c[k] == split[name]["counters"][k], (name, k)
         other = np.load(tmp_path / (name + ".npy"))
         assert np.array_equal(film[..., 3], other[..., 3]), name
@@ -80,7 +81,7 @@ def test_pass_size_does_not_change_the_image(pkg, gpu, per_pass):
     b = g.render(rp); cb = g.counters()
     n_pass = [s["launches"] for s in g.kernel_stats() if s["name"] == "generate"][0]
     assert n_pass_auto == 1 and n_pass == -(-8 // per_pass)
-    for k in COUNTERS:
+    for k in ckeys(COUNTERS):
         assert ca[k] == cb[k], k
     assert np.array_equal(a[..., 3], b[..., 3])
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=1e-6, atol=1e-7)
@@ -95,7 +96,7 @@ def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
     st = {s["name"]: s for s in g.kernel_stats() if s["launches"]}
     assert "shade_specular" in st and st["shade_specular"]["kernel"] == "k_shade<1, 1, 2>" and "shade_1lobe" not in st
     gc, oc = g.counters(), orc.counters()
-    for k in COUNTERS:
+    for k in ckeys(COUNTERS):
         assert gc[k] == oc[k], k
     np.testing.assert_allclose(film, ref, rtol=3e-6, atol=1e-6)
     # the zoo has metal + substrate (one lobe, with NEE), mirror + glass (specular), plastic + rough glass (two lobes) and an uber with a specular term (class 3)
@@ -134,7 +135,7 @@ def test_uber_without_specular_terms_is_a_two_lobe_material(pkg, gpu, oracle, ub
     names = {s["name"] for s in g.kernel_stats() if s["launches"]}
     assert expect_class in names and ({"shade_2lobe", "shade_uber"} - {expect_class}).isdisjoint(names), names
     gc, oc = g.counters(), orc.counters()
-    for k in COUNTERS:
+    for k in ckeys(COUNTERS):
         assert gc[k] == oc[k], k
     np.testing.assert_allclose(film, ref, rtol=3e-6, atol=1e-6)
 

@@ -44,6 +44,17 @@ both)
   one c4_quad --config C4 --spp 64 --steps 1 --warmup 1
   PT_TRACE_EXACT=1 one c4_exact --config C4 --spp 64 --steps 1 --warmup 1 ;;
 exact_quick) PT_TRACE_EXACT=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 ;;
+knobs)
+  for q in 4 12 16 24; do PT_TRACE_LEAF_QUORUM=$q one c2_lq$q --config C2 --steps 2 --warmup 1; done
+  for r in 8 24 32; do PT_TRACE_REFILL_MIN=$r one c2_rf$r --config C2 --steps 2 --warmup 1; done
+  for w in 20 24; do PT_TRACE_WAVES_PER_CU=$w one c2_w$w --config C2 --steps 2 --warmup 1; done ;;
+variants)
+  for v in q4w q6w; do PT_LIB_PATH=pbrt-rust_amd/csrc/variants/$v one c2_$v --config C2 --steps 2 --warmup 1; done
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q4w PT_TRACE_WAVES_PER_CU=16 one c2_q4w_w16 --config C2 --steps 2 --warmup 1
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q6w PT_TRACE_WAVES_PER_CU=24 one c2_q6w_w24 --config C2 --steps 2 --warmup 1 ;;
+util)
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/qutil python bench.py --config C2 --spp 128 --steps 1 --warmup 0 --cpu-seconds 0 --other-configs off 2>&1 >/dev/null | grep trace-util | tee $OUT/c2_util.txt
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/qutil python bench.py --config C4 --spp 32 --steps 1 --warmup 0 --cpu-seconds 0 --other-configs off 2>&1 >/dev/null | grep trace-util | tee $OUT/c4_util.txt ;;
 quick_tests) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 ;;
 esac
 done
