@@ -92,10 +92,14 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
     uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0, u_it3 = 0, u_act3 = 0;
     unsigned long long u_cxf = 0, u_cmain = 0;   // wave cycles inside the transform step / the record step
+    unsigned long long u_cfetch = 0, u_cnode = 0, u_cleaf = 0, u_cpop = 0;   // of the record step: issue + wait of the loads, the node branch, the leaf branch, the pops
+    long long u_cm = 0;
+#define PT_UTIL_MARK(acc) do { const long long n_ = clock64(); acc += (unsigned long long)(n_ - u_cm); u_cm = n_; } while (0)
     const unsigned long long u_t0 = wall_clock64(); const long long u_t0c = clock64();
 #define PT_UTIL(it, act, pred) do { const unsigned long long m_ = __ballot(pred); if (pred) { act++; it += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } } while (0)
 #else
 #define PT_UTIL(it, act, pred) do { } while (0)
+#define PT_UTIL_MARK(acc) do { } while (0)
 #endif
 
     // lane state: ST_IDLE (no ray), ST_ENTER (fetch record `cur`), ST_LEAF (test packets from `cur`), ST_DONE
@@ -309,6 +313,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     const uint32_t *const qp = PT_SUB(queue);
                     pid = qp ? qp[qk] : qk;
                     const float4 *const rp = PT_SUB(ray) + (size_t)pid * PT_SUB(ray_stride);
+                    // (measured round 4 and dropped: requesting the record here and unpacking it after this iteration's record step, so that the wave's busy
+                    //  lanes do not stand still for the round trip -- every refilled lane then starts one iteration later: node-step occupancy 80 -> 75 %,
+                    //  C2 trace 134 -> 147 ms)
                     const float4 r0 = rp[0], r1 = rp[1];   // one 32-byte record
                     ro = V3(r0.x, r0.y, r0.z);
                     rd = V3(r0.w, r1.x, r1.y);
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
         PT_UTIL(u_it1, u_act1, at_node || at_leaf);
         PT_UTIL(u_it2, u_act2, at_leaf);
 #ifdef PT_TRACE_UTIL
-        const long long u_c1 = clock64();
+        const long long u_c1 = clock64(); u_cm = u_c1;
 #endif
         if (at_node || at_leaf) {
             uint4 q0, q1, q2, q3;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 // loads of the same 128-byte line (far planes, references, order word) go out with them -- a leaf lane aims them past the end --, so a step is
                 // one round trip and nobody waits inside a branch.
                 const uint32_t onx = nx ? 48u : 0u, ony = ny ? 64u : 16u, onz = nz ? 80u : 32u;
-                const uint32_t qb = at_leaf ? ((cur * 3u) << 4) + s.leaf_off : (cur << 7);
+                const uint32_t c3x = (cur << 1) + cur, qb = at_leaf ? (c3x << 4) + s.leaf_off : (cur << 7);
                 const uint32_t nb = at_node ? qb : 0xffffff00u;
                 const v4u a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 0u : onx), 0, 0);
                 const v4u a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 16u : ony), 0, 0);
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 const v4u rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + 96u, 0, 0);
                 const uint32_t meta = __builtin_amdgcn_raw_buffer_load_b32(rsrc, nb + 112u, 0, 0);
                 asm volatile("" :: "v"(a0.x), "v"(a1.x), "v"(a2.x), "v"(a2.w), "v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(rf.x), "v"(meta));   // all eight before the node / leaf branch
+                PT_UTIL_MARK(u_cfetch);
                 q0 = make_uint4(a0.x, a0.y, a0.z, a0.w); q1 = make_uint4(a1.x, a1.y, a1.z, a1.w); q2 = make_uint4(a2.x, a2.y, a2.z, a2.w); q3 = make_uint4(0u, 0u, 0u, 0u);
                 if (at_node) {
                     n_nodes++;   // records fetched
@@ -473,11 +481,18 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max); later ones are pushed with
                     // their entry distance and pass or fail the same comparison when popped, against the t_max of then; one that fails now fails then too
                     const bool m0 = t0 < t_max, m1 = t1 < t_max, m2 = t2 < t_max, m3 = t3 < t_max;
-                    if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    const bool c3 = m3 & (m0 | m1 | m2), c2 = m2 & (m0 | m1), c1 = m1 & m0;
+                    if (sp + 3u <= (uint32_t)kLds) {   // the usual case: all three land in LDS, at slots known without a chain of sp updates
+                        const uint32_t p2 = sp + (c3 ? 1u : 0u), p1 = p2 + (c2 ? 1u : 0u);
+                        if (c3) { stack[(2 * sp) * 64] = r3; stack[(2 * sp + 1) * 64] = __float_as_uint(t3); }
+                        if (c2) { stack[(2 * p2) * 64] = r2; stack[(2 * p2 + 1) * 64] = __float_as_uint(t2); }
+                        if (c1) { stack[(2 * p1) * 64] = r1; stack[(2 * p1 + 1) * 64] = __float_as_uint(t1); }
+                        sp = p1 + (c1 ? 1u : 0u);
+                    } else if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
                     else {
-                        if (m3 & (m0 | m1 | m2)) push(r3, __float_as_uint(t3));
-                        if (m2 & (m0 | m1)) push(r2, __float_as_uint(t2));
-                        if (m1 & m0) push(r1, __float_as_uint(t1));
+                        if (c3) push(r3, __float_as_uint(t3));
+                        if (c2) push(r2, __float_as_uint(t2));
+                        if (c1) push(r1, __float_as_uint(t1));
                     }
                     if (m0 | m1 | m2 | m3) {
                         const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
                     } else need_pop = true;
                 }
+                PT_UTIL_MARK(u_cnode);
             } else {
                 const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
                 q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
@@ -569,7 +585,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 }
                 if (advance) { if (fl & TP_LAST) need_pop = true; else cur = li + 1u; }
             }
+            PT_UTIL_MARK(u_cleaf);
             if (need_pop) pop_next();
+            PT_UTIL_MARK(u_cpop);
         }
 #ifdef PT_TRACE_UTIL
         u_cmain += (unsigned long long)(clock64() - u_c1);
@@ -603,7 +621,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); }
     if (lane == 0) {
         atomicAdd(&job.counters->tail[12], (unsigned long long)u_it3); atomicAdd(&job.counters->tail[13], (unsigned long long)u_act3);
-        atomicAdd(&job.counters->tail[14], u_cxf); atomicAdd(&job.counters->tail[15], u_cmain); atomicAdd(&job.counters->tail[2], (unsigned long long)(clock64() - (long long)u_t0c));
+        atomicAdd(&job.counters->tail[14], u_cxf); atomicAdd(&job.counters->tail[15], u_cmain);
+        atomicAdd(&job.counters->util2[0], u_cfetch); atomicAdd(&job.counters->util2[1], u_cnode); atomicAdd(&job.counters->util2[2], u_cleaf); atomicAdd(&job.counters->util2[3], u_cpop); atomicAdd(&job.counters->tail[2], (unsigned long long)(clock64() - (long long)u_t0c));
     }
     for (int o = 32; o > 0; o >>= 1) { u_it1 += __shfl_xor(u_it1, o); u_act1 += __shfl_xor(u_act1, o); u_it2 += __shfl_xor(u_it2, o); u_act2 += __shfl_xor(u_act2, o); }
     if (lane == 0) {
@@ -614,4 +633,5 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 }
 #undef PT_SUB
 #undef PT_UTIL
+#undef PT_UTIL_MARK
 #undef PT_SGN3

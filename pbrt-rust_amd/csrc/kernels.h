@@ -128,6 +128,7 @@ struct DevCounters {  // PtCounters mirror, atomically updated once per wave
     unsigned long long shade_items[kNumClasses], shade_bytes[kNumClasses];  // path vertices shaded / path-state + queue bytes moved
     unsigned long long regions[16];            // PT_REGION_PROFILE builds: wave cycles per k_shade region
     unsigned long long tail[16];               // PT_TRACE_UTIL builds: [0] first wave start, [1] last wave exit of the launch in flight; per kind k: [4+2k] sum of wave busy time, [5+2k] sum of launch span x waves (wall_clock64 ticks)
+    unsigned long long util2[8];               // PT_TRACE_UTIL builds: wave cycles of the record step's parts: [0] loads issued + waited for, [1] node branch, [2] leaf branch, [3] pops
     unsigned long long dbg[4];                 // PT_TRACE_UTIL builds: scheduling knobs as the kernel saw them
     unsigned long long bss_items, bss_bytes;   // k_bssrdf: probe steps processed / state bytes moved
     unsigned long long k_nodes[5], k_tris[5], k_rays[5];  // per trace launch kind: 0 extend, 1 extend_mis, 2 shadow, 3 extend_camera, 4 extend_probe (segments)

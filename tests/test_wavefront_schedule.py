@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 import pytest
+from conftest import ckeys, trace_env
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,6 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
 from _pkg import import_pkg
 pkg = import_pkg()
 import torch   # before the library touches HIP (tests/conftest.py)
-from conftest import ckeys, trace_env
 torch.cuda.init()
 lib = pkg.load_library(); lib.init(0)
 out = {{}}

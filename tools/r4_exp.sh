@@ -48,6 +48,8 @@ knobs)
   for q in 4 12 16 24; do PT_TRACE_LEAF_QUORUM=$q one c2_lq$q --config C2 --steps 2 --warmup 1; done
   for r in 8 24 32; do PT_TRACE_REFILL_MIN=$r one c2_rf$r --config C2 --steps 2 --warmup 1; done
   for w in 20 24; do PT_TRACE_WAVES_PER_CU=$w one c2_w$w --config C2 --steps 2 --warmup 1; done ;;
+v5w)
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
   for v in q4w q6w; do PT_LIB_PATH=pbrt-rust_amd/csrc/variants/$v one c2_$v --config C2 --steps 2 --warmup 1; done
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q4w PT_TRACE_WAVES_PER_CU=16 one c2_q4w_w16 --config C2 --steps 2 --warmup 1
