@@ -5,7 +5,7 @@
 // HBM layout (all read-only during render):
 //   nodes      : PtBVHNode[n_nodes]     32 B, reference order (left child = i+1, right = offset)
 //   leaf_tris  : TriPacket[n_prims]     48 B, in ordered_prims order -> a leaf is a contiguous run
-//                p0.xyz p1.xyz p2.xyz (9 f32) | prim id | shape ref | flags
+//                one quad per axis: p0 p1 p2 along x | prim id, along y | shape ref, along z | flags
 //   P/N/S/UV, indices, tri_flags, prim_* tables: shading-time data only (never touched by traversal)
 #pragma once
 #include "dev_math.h"
@@ -13,10 +13,10 @@
 
 namespace ptd {
 
-struct TriPacket {           // 48 bytes, 16-byte aligned: three dwordx4 loads per test
-    float p0[3]; float p1x;
-    float p1yz[2]; float p2xy[2];
-    float p2z; uint32_t prim; uint32_t shape; uint32_t flags;
+struct TriPacket {           // 48 bytes, 16-byte aligned, one quad per AXIS: {p0.x p1.x p2.x | prim} {p0.y p1.y p2.y | shape} {p0.z p1.z p2.z | flags}.
+    float x[3]; uint32_t prim;   // A traversal lane loads the three quads in the order (kx, ky, kz) of its ray's watertight permutation (triangle.rs:147-160), so the
+    float y[3]; uint32_t shape;  // vertices arrive permuted and the test's 18 selects per packet are gone; the three id words arrive permuted with them (tp_aux).
+    float z[3]; uint32_t flags;
 };
 enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11, TP_ALPHA = 1u << 12 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
 // flags bits 13-15: shade-queue class of the primitive's material (what k_route needs), bits 16-31: its material index, 0xffff =
@@ -134,16 +134,17 @@ PT_DEV TriRay tri_ray_setup(V3 rd) {
     r.Sx = -dx / dz; r.Sy = -dy / dz; r.Sz = 1.0f / dz;
     return r;
 }
-PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t_max, float &t, float &b0, float &b1, float &b2) {
-    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    // permute(kx, ky, kz) as per-component selects (two v_cndmask each) instead of a three-way branch: lanes of a wave differ in kz, so
-    // the branch form executed every arm with its register shuffles under exec masks
-    {
-        const bool k0 = tr.kz == 0, k1 = tr.kz == 1;
-#define PT_PERM(v) v = V3(k0 ? v.y : (k1 ? v.z : v.x), k0 ? v.z : (k1 ? v.x : v.y), k0 ? v.x : (k1 ? v.y : v.z))
-        PT_PERM(p0t); PT_PERM(p1t); PT_PERM(p2t);
-#undef PT_PERM
-    }
+// permute(v, kx, ky, kz) of triangle.rs:152-160 for the ray's kz
+PT_DEV V3 tri_permute(V3 v, int kz) { const bool k0 = kz == 0, k1 = kz == 1; return V3(k0 ? v.y : (k1 ? v.z : v.x), k0 ? v.z : (k1 ? v.x : v.y), k0 ? v.x : (k1 ? v.y : v.z)); }
+// word `axis` (0 prim, 1 shape, 2 flags) of a packet whose quads were loaded in the order (kx, ky, kz)
+PT_DEV uint32_t tp_aux(uint32_t w0, uint32_t w1, uint32_t w2, int kz, int axis) {   // quad 0 holds axis kx = kz + 1, quad 1 axis ky = kz + 2 (mod 3), quad 2 axis kz
+    const bool k0 = kz == 0, k1 = kz == 1;
+    if (axis == 2) return k0 ? w1 : (k1 ? w0 : w2);
+    if (axis == 1) return k0 ? w0 : (k1 ? w2 : w1);
+    return k0 ? w2 : (k1 ? w1 : w0);
+}
+// The test proper on vertices already translated to the ray origin and permuted (triangle.rs:161-233 == :424-495).
+PT_DEV bool tri_hit_core(V3 p0t, V3 p1t, V3 p2t, const TriRay &tr, float t_max, float &t, float &b0, float &b1, float &b2) {
     const float Sx = tr.Sx, Sy = tr.Sy, Sz = tr.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
@@ -183,6 +184,10 @@ PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t
     float deltat = 3.0f * (gammaf(3) * maxe * maxzt + deltae * maxzt + deltaz * maxe) * fabsf(invdet);
     if (t <= deltat) return false;
     return true;
+}
+// Watertight ray-triangle test shared by intersect / intersect_p (triangle.rs:136-233 == :400-495): translate, permute, tri_hit_core.
+PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, const TriRay &tr, float t_max, float &t, float &b0, float &b1, float &b2) {
+    return tri_hit_core(tri_permute(p0 - ro, tr.kz), tri_permute(p1 - ro, tr.kz), tri_permute(p2 - ro, tr.kz), tr, t_max, t, b0, b1, b2);
 }
 
 PT_DEV bool tri_hit_params(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float t_max, float &t, float &b0, float &b1, float &b2) {

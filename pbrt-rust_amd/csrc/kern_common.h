@@ -140,10 +140,10 @@ template <bool SPH> PT_DEV void fill_hit(const DeviceScene &s, uint32_t prim, ui
 template <bool SPH> PT_DEV uint32_t fill_hit_pkt(const DeviceScene &s, uint32_t pkt, uint32_t inst, V3 ro, V3 rd, float b0, float b1, float b2, SurfaceInteraction &si) {
     const uint4 *q = reinterpret_cast<const uint4 *>(s.leaf) + 3 * (size_t)pkt;
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
-    const uint32_t sh = q2.z, fl = q2.w;
-    const V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-    const V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-    const V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+    const uint32_t sh = q1.w, fl = q2.w;   // one quad per axis (dev_scene.h: TriPacket)
+    const V3 p0(__uint_as_float(q0.x), __uint_as_float(q1.x), __uint_as_float(q2.x));
+    const V3 p1(__uint_as_float(q0.y), __uint_as_float(q1.y), __uint_as_float(q2.y));
+    const V3 p2(__uint_as_float(q0.z), __uint_as_float(q1.z), __uint_as_float(q2.z));
     if (SPH && inst != PT_NONE) {  // TransformedPrimitive::intersect (primitive.rs:58-80): object-space interaction, then to world
         const DevInstance &I = s.instances[inst];
         const M4 w2i = ldm4g(I.world_to_instance), i2w = ldm4g(I.instance_to_world);

@@ -10,7 +10,7 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
     uint32_t prim = ordered[i];      // primitive index, or PT_TOP_INSTANCE | instance index
     TriPacket p;
     if (prim & PT_TOP_INSTANCE) {
-        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.x[0] = p.x[1] = p.x[2] = p.y[0] = p.y[1] = p.y[2] = p.z[0] = p.z[1] = p.z[2] = 0.0f;
         p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
         out[i] = p;
         return;
@@ -27,12 +27,11 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
         P2 uv[3]; tri_uvs(s, tri, i0, i1, i2, uv);
         V3 dpdu, dpdv;
         bool ok = tri_partials(p0, p1, p2, uv, dpdu, dpdv);
-        p.p0[0] = p0.x; p.p0[1] = p0.y; p.p0[2] = p0.z; p.p1x = p1.x;
-        p.p1yz[0] = p1.y; p.p1yz[1] = p1.z; p.p2xy[0] = p2.x; p.p2xy[1] = p2.y; p.p2z = p2.z;
+        p.x[0] = p0.x; p.x[1] = p1.x; p.x[2] = p2.x; p.y[0] = p0.y; p.y[1] = p1.y; p.y[2] = p2.y; p.z[0] = p0.z; p.z[1] = p1.z; p.z[2] = p2.z;
         p.flags = (uint32_t)s.tri_flags[tri] | (ok ? 0u : (uint32_t)TP_BOGUS) | hi;
         if ((s.tri_alpha && s.tri_alpha[tri] >= 0) || (s.tri_shadow_alpha && s.tri_shadow_alpha[tri] >= 0)) p.flags |= TP_ALPHA;
     } else {
-        p.p0[0] = p.p0[1] = p.p0[2] = p.p1x = p.p1yz[0] = p.p1yz[1] = p.p2xy[0] = p.p2xy[1] = p.p2z = 0.0f;
+        p.x[0] = p.x[1] = p.x[2] = p.y[0] = p.y[1] = p.y[2] = p.z[0] = p.z[1] = p.z[2] = 0.0f;
         p.flags = TP_SPHERE | hi;
     }
     out[i] = p;

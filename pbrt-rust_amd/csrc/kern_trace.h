@@ -118,6 +118,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
     V3 ro, rd, inv_dir;
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
+    V3 rop;              // the ray origin permuted like the packet quads the lane loads (dev_scene.h: TriPacket)
+    uint32_t lofs = 0;   // byte offsets of a packet's quads in the ray's order (kx, ky, kz): 16 kx | 16 ky << 8 | 16 kz << 16
+#define PT_TRI_RAY() do { tray = tri_ray_setup(rd); rop = tri_permute(ro, tray.kz); const uint32_t kz_ = (uint32_t)tray.kz, kx_ = kz_ == 2u ? 0u : kz_ + 1u, ky_ = kx_ == 2u ? 0u : kx_ + 1u; lofs = (kx_ << 4) | (ky_ << 12) | (kz_ << 20); } while (0)
     bool nx = false, ny = false, nz = false;
     uint32_t sgn3 = 0;   // QUAD: 3 x the ray's sign octant (nx | ny << 1 | nz << 2): the shift that finds the octant's slot order in a record's order word
 #define PT_SGN3() do { if (QUAD) sgn3 = 3u * ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u)); } while (0)
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         t_max = job.sub[0].scalar_tmax;
                         inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
-                        tray = tri_ray_setup(rd);
+                        PT_TRI_RAY();
                         sp = 0; pending = 0;
                         hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                         in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 if (lane_any) o_word[(size_t)pid * o_word_stride] = hit_pkt != PT_NONE ? 1u : 0u;   // (an any-hit ray records the packet that stopped it)
                 else {
                     uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
-                    if (hit_pkt != PT_NONE) { const uint4 hq = leaf4[3 * (size_t)hit_pkt + 2]; hit_prim = hq.y; hit_fl = hq.w; }   // {p2.z, prim, shape, flags}
+                    if (hit_pkt != PT_NONE) { hit_prim = s.leaf[hit_pkt].prim; hit_fl = s.leaf[hit_pkt].flags; }
                     if (o_hit) o_hit[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
                     else o_word[(size_t)pid * o_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
                     // (triangle-only scenes: the closest hit's t IS the ray's t_max -- one register less in the loop; inside instances t_max is an object-space value)
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     t_max = PT_SUB(per_ray_tmax) ? r1.z : PT_SUB(scalar_tmax);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
-                    tray = tri_ray_setup(rd);
+                    PT_TRI_RAY();
                     sp = 0; pending = 0;
                     hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                     in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
-                    tray = tri_ray_setup(rd);
+                    PT_TRI_RAY();
                     t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
                     in_inst = PT_NONE; inst_hit = false;
                     if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; }  // remaining packets of the outer leaf
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
                         ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; PT_SGN3(); t_max = tm2;
-                        tray = tri_ray_setup(rd);
+                        PT_TRI_RAY();
                         const uint32_t iroot = QUAD ? I.root_ref4 : I.root_ref;
                         cur = iroot & kRefMask;
                         state = (iroot & kLeafBit) ? ST_LEAF : ST_ENTER;
@@ -432,9 +435,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 const uint32_t onx = nx ? 48u : 0u, ony = ny ? 64u : 16u, onz = nz ? 80u : 32u;
                 const uint32_t c3x = (cur << 1) + cur, qb = at_leaf ? (c3x << 4) + s.leaf_off : (cur << 7);
                 const uint32_t nb = at_node ? qb : 0xffffff00u;
-                const v4u a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 0u : onx), 0, 0);
-                const v4u a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 16u : ony), 0, 0);
-                const v4u a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? 32u : onz), 0, 0);
+                const v4u a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs & 0xffu) : onx), 0, 0);
+                const v4u a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? ((lofs >> 8) & 0xffu) : ony), 0, 0);
+                const v4u a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs >> 16) : onz), 0, 0);
                 const v4u b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (48u - onx), 0, 0);
                 const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (80u - ony), 0, 0);
                 const v4u b2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (112u - onz), 0, 0);
@@ -503,7 +506,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 PT_UTIL_MARK(u_cnode);
             } else {
                 const uint4 *rec = at_leaf ? leaf4 + 3 * (size_t)cur : wide4 + 4 * (size_t)cur;
-                q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];   // q3 of a packet = start of the next one (array is padded)
+                // (a packet's three quads in the ray's order kx, ky, kz; q3 of a packet = start of the next one, the array is padded)
+                q0 = rec[at_leaf ? (lofs >> 4) & 3u : 0u]; q1 = rec[at_leaf ? (lofs >> 12) & 3u : 1u]; q2 = rec[at_leaf ? lofs >> 20 : 2u]; q3 = rec[3];
                 // Pin the whole record in front of the node / leaf branch: left alone, the compiler sinks the fields only the node path
                 // reads (q2.z, q3.z) below the branch as two more dword loads, i.e. a second dependent L1 round trip in every node step
                 // (measured: extend 143 -> 126 ms per step).
@@ -536,15 +540,16 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 } else need_pop = true;
             } else {
                 // leaf packets in ordered_prims order
-                const uint32_t fl = q2.w, li = cur;
+                const uint32_t fl = tp_aux(q0.w, q1.w, q2.w, tray.kz, 2), li = cur;   // the packet's quads came in the ray's axis order
+                const uint32_t shw = tp_aux(q0.w, q1.w, q2.w, tray.kz, 1);
                 bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
                 if (fl & TP_INSTANCE) {
-                    if constexpr (INST) { xf_arg = q2.z | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
+                    if constexpr (INST) { xf_arg = shw | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
                 } else if (fl & TP_SPHERE) {
                     if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
                         n_sph++;
                         float t, phi; V3 ph, dobj;
-                        if (sphere_hit(s.spheres[q2.z & 0x3fffffffu], ro, rd, t_max, lane_any, t, ph, phi, dobj)) {
+                        if (sphere_hit(s.spheres[shw & 0x3fffffffu], ro, rd, t_max, lane_any, t, ph, phi, dobj)) {
                             if (lane_any) { hit_pkt = li; state = ST_DONE; advance = false; }
                             else {
                                 t_max = t;
@@ -555,16 +560,18 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     }
                 } else {
                     n_tris++;
-                    V3 p0(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-                    V3 p1(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
-                    V3 p2(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+                    // vertices arrive permuted: quad j = the three vertices' coordinate along the ray's j-th permuted axis
+                    const V3 p0t(__uint_as_float(q0.x) - rop.x, __uint_as_float(q1.x) - rop.y, __uint_as_float(q2.x) - rop.z);
+                    const V3 p1t(__uint_as_float(q0.y) - rop.x, __uint_as_float(q1.y) - rop.y, __uint_as_float(q2.y) - rop.z);
+                    const V3 p2t(__uint_as_float(q0.z) - rop.x, __uint_as_float(q1.z) - rop.y, __uint_as_float(q2.z) - rop.z);
                     float t, b0, b1, b2;
-                    bool hit = tri_hit_params(p0, p1, p2, ro, tray, t_max, t, b0, b1, b2);
+                    bool hit = tri_hit_core(p0t, p1t, p2t, tray, t_max, t, b0, b1, b2);
                     if constexpr (ALPHA) {
                         // Triangle::intersect (triangle.rs:275-285) / intersect_p (:497-545) with an alpha mask: the hit is
                         // discarded where the mask evaluates to 0; intersect_p then also rejects degenerate triangles
                         if (hit && (fl & TP_ALPHA) && !(fl & TP_BOGUS)) {
-                            const uint32_t tri = q2.z & 0x3fffffffu;
+                            const uint32_t tri = shw & 0x3fffffffu;
+                            const V3 p0 = ld3(s.P, s.indices[3 * tri]), p1 = ld3(s.P, s.indices[3 * tri + 1]), p2 = ld3(s.P, s.indices[3 * tri + 2]);   // (world-space vertices for the mask lookup)
                             P2 uv[3]; tri_uvs(s, tri, s.indices[3 * tri], s.indices[3 * tri + 1], s.indices[3 * tri + 2], uv);
                             TexCtx c; c.dpdx = V3(0.0f, 0.0f, 0.0f); c.dpdy = V3(0.0f, 0.0f, 0.0f); c.dudx = c.dvdx = c.dudy = c.dvdy = 0.0f;
                             c.p = p0 * b0 + p1 * b1 + p2 * b2;
@@ -635,3 +642,4 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #undef PT_UTIL
 #undef PT_UTIL_MARK
 #undef PT_SGN3
+#undef PT_TRI_RAY

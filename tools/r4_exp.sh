@@ -48,6 +48,11 @@ knobs)
   for q in 4 12 16 24; do PT_TRACE_LEAF_QUORUM=$q one c2_lq$q --config C2 --steps 2 --warmup 1; done
   for r in 8 24 32; do PT_TRACE_REFILL_MIN=$r one c2_rf$r --config C2 --steps 2 --warmup 1; done
   for w in 20 24; do PT_TRACE_WAVES_PER_CU=$w one c2_w$w --config C2 --steps 2 --warmup 1; done ;;
+stage)
+  for r in 4 8 16; do PT_TRACE_REFILL_MIN=$r one c2_stage_rf$r --config C2 --steps 2 --warmup 1; done
+  PT_TRACE_STAGE=0 one c2_nostage --config C2 --steps 2 --warmup 1
+  for r in 4 8; do PT_TRACE_REFILL_MIN=$r one c4_stage_rf$r --config C4 --spp 64 --steps 1 --warmup 1; done
+  PT_TRACE_STAGE=0 one c4_nostage --config C4 --spp 64 --steps 1 --warmup 1 ;;
 v5w)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
