@@ -489,6 +489,11 @@ int pt_multi_get_kernel_stats(const pt_multi_scene *scene, uint32_t replica, PtK
  * copy, and `merge_ms` = from the moment the LAST replica finished rendering to the summed film (copy tail + the sum kernel).
  * render_ms / copy_ms hold max_replicas entries (either may be NULL). */
 int pt_multi_get_timing(const pt_multi_scene *scene, double *merge_ms, double *render_ms, double *copy_ms, uint32_t max_replicas);
+/* How replica i's film reaches the first device (decided once, at pt_multi_scene_create): PT_PEER_SAME_DEVICE (it lives there: no copy),
+ * PT_PEER_ENABLED (hipDeviceEnablePeerAccess succeeded in both directions: hipMemcpyPeerAsync goes device to device over xGMI) or
+ * PT_PEER_STAGED (no peer access: the runtime stages the copy through host memory -- correct, slower). `peer` holds max_replicas entries. */
+enum { PT_PEER_SAME_DEVICE = 0, PT_PEER_ENABLED = 1, PT_PEER_STAGED = 2 };
+int pt_multi_get_peer_access(const pt_multi_scene *scene, int *peer, uint32_t max_replicas);
 /* The tile shard of replica `replica` of `n_replicas` inside the caller's shard (tile_rank of tile_world). Pure host arithmetic. */
 void pt_multi_tile_shard(uint32_t tile_rank, uint32_t tile_world, uint32_t replica, uint32_t n_replicas, uint32_t *rank_out, uint32_t *world_out);
 

@@ -165,6 +165,7 @@ ENTRY_POINTS = {
     "pt_multi_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
     "pt_multi_get_kernel_stats": (C.c_int, [VP, u32, C.POINTER(PtKernelStat), u32, u32p]),
     "pt_multi_get_timing": (C.c_int, [VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), u32]),
+    "pt_multi_get_peer_access": (C.c_int, [VP, C.POINTER(C.c_int), u32]),
     "pt_multi_tile_shard": (None, [u32, u32, u32, u32, u32p, u32p]),
     "pt_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
     "pt_get_kernel_stats": (C.c_int, [VP, C.POINTER(PtKernelStat), u32, u32p]),

@@ -247,6 +247,7 @@ struct pt_multi_scene {
     std::vector<float *> stage;       // on dev[0], one landing buffer per replica that lives on ANOTHER device: the peer copies of all
     std::vector<size_t> stage_cap;    // sources are in flight together (one xGMI link each), issued by the replicas' own host threads
     std::vector<double> render_ms, copy_ms;   // last pt_multi_render, per replica: wall time of its pt_render / of its peer copy
+    std::vector<int> peer;            // per replica: PT_PEER_* -- how its film reaches the first device
     double merge_ms = 0;              // last pt_multi_render: from the last replica's render end to the summed film (copy tails + the sum kernel)
     PtCounters counters{};
 };
@@ -556,8 +557,11 @@ template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderCo
 #endif
 constexpr size_t kPassMaxPaths = (size_t)1 << PT_PASS_MAX_PATHS_LOG2;
 constexpr double kPassMemFraction = 0.65;   // of the device's free memory
-uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share) {
-    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u);
+uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share, bool volpath) {
+    // per path: the five state records, the queues, the probe state of scenes with subsurface materials and -- volpath through material-less shells -- the
+    // 128-byte chain record (PathSoA::ext, allocated after the main slab: left out of this sum, a shell scene asked for ~1.4x its budget)
+    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u)
+                            + ((volpath && sc->has_null_material) ? 4u * (size_t)PathSoA::kExtWords : 0u);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     // (the present workspace is freed before a larger one is allocated)
@@ -1365,7 +1369,7 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
         uint32_t S = rp->spp_per_pass;
-        if (S == 0) S = choose_pass_size(sc, rc.n_pix_slots, rp->spp, 1);
+        if (S == 0) S = choose_pass_size(sc, rc.n_pix_slots, rp->spp, 1, rc.volpath != 0);
         S = std::min(S, rp->spp);
         if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
@@ -1597,13 +1601,20 @@ int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, u
             d.nodes = sc->nodes.data(); d.n_nodes = (uint32_t)sc->nodes.size(); d.ordered_prims = sc->ordered.data();
         }
     }
-    // peer access first device <-> the others (the film merge copies device to device; without access the runtime stages through the host)
+    // peer access first device <-> the others (the film merge copies device to device; without access the runtime stages the copies through the
+    // host): the outcome per replica is kept and reported (pt_multi_get_peer_access), so that a run which fell back says so instead of just being slow
+    ms->peer.assign(n_devices, PT_PEER_SAME_DEVICE);
     for (uint32_t i = 1; i < n_devices; ++i) {
         if (ms->dev[i] == ms->dev[0]) continue;
-        int can = 0;
-        if (bind_device(ms->dev[0]) == PT_OK && hipDeviceCanAccessPeer(&can, ms->dev[0], ms->dev[i]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[i], 0); (void)hipGetLastError(); }
-        can = 0;
-        if (bind_device(ms->dev[i]) == PT_OK && hipDeviceCanAccessPeer(&can, ms->dev[i], ms->dev[0]) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(ms->dev[0], 0); (void)hipGetLastError(); }
+        auto enable = [&](int from, int to) {   // `from` may address memory of `to`
+            int can = 0;
+            if (bind_device(from) != PT_OK || hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            (void)hipGetLastError();
+            return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        };
+        const bool a = enable(ms->dev[0], ms->dev[i]), b = enable(ms->dev[i], ms->dev[0]);
+        ms->peer[i] = (a && b) ? PT_PEER_ENABLED : PT_PEER_STAGED;
     }
     if ((st = bind_device(home))) return bail(st);
     *out = ms;
@@ -1651,7 +1662,7 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
             pt_multi_tile_shard(rp->tile_rank, rp->tile_world, i, n, &p.tile_rank, &p.tile_world);
             fill_render_const(&p, rc);
             const uint32_t ntiles = rc.ntx * rc.nty, slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world * 256u : 0u;
-            if (slots) pass_size[i] = choose_pass_size(ms->sc[i], slots, rp->spp, share);
+            if (slots) pass_size[i] = choose_pass_size(ms->sc[i], slots, rp->spp, share, rc.volpath != 0);
         }
     }
     std::vector<clk::time_point> t_rendered(n);
@@ -1717,6 +1728,12 @@ int pt_multi_render(pt_multi_scene *ms, const PtRenderParams *rp, float *film_xy
         for (size_t k = 0; k < sizeof(PtCounters) / 8; ++k) dst[k] += src[k];
     }
     if (home >= 0 && home != ms->dev[0]) bind_device(home);
+    return PT_OK;
+}
+
+int pt_multi_get_peer_access(const pt_multi_scene *ms, int *peer, uint32_t max_replicas) {
+    if (!ms || !peer) return fail(PT_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < max_replicas && i < ms->sc.size(); ++i) peer[i] = ms->peer[i];
     return PT_OK;
 }
 

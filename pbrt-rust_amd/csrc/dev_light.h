@@ -25,7 +25,7 @@ PT_DEV int find_interval_cdf(const float *cdf, int size, float u) {
 struct Dist1D { const float *func; const float *cdf; float func_int; int n; };
 
 PT_DEV int dist_sample_discrete(const Dist1D &d, float u, float &pdf) {  // sampling.rs:66-85
-    if (d.n <= 3) {   // up to three lights: the whole cdf, func and func_int in one round trip to memory; the SAME bisection, over registers
+    if (d.n >= 1 && d.n <= 3) {   // one to three lights (an empty distribution takes the general path, which reads nothing): the whole cdf, func and func_int in one round trip to memory; the SAME bisection, over registers
         const int n = d.n;
         const float c0 = d.cdf[0], c1 = d.cdf[1], c2 = d.cdf[n < 2 ? n : 2], c3 = d.cdf[n < 3 ? n : 3];
         const float f0 = d.func[0], f1 = d.func[n < 2 ? 0 : 1], f2 = d.func[n < 3 ? 0 : 2];

@@ -187,7 +187,7 @@ inline Image read_exr(const std::string &path) {
     if (i32(0) != 20000630) throw std::runtime_error("\"" + path + "\": not an OpenEXR file");
     const int32_t version = i32(4);
     const bool multipart = (version & 0x1000) != 0;
-    if (version & 0x800) throw std::runtime_error("EXR \"" + path + "\": deep data is not supported");
+    if (version & 0x800) throw std::runtime_error("EXR \"" + path + "\": deep data is not supported");   // (any file with a deep part sets this bit: none gets past here)
     struct Chan { std::string name; int type; };
     struct Part { std::vector<Chan> chans; int compression = -1; int32_t win[4] = {0, 0, -1, -1}; bool tiled = false, deep = false; uint32_t tile_w = 0, tile_h = 0; int level_mode = 0, round_up = 0; int32_t chunk_count = -1; };
     std::vector<Part> parts;
@@ -203,9 +203,23 @@ inline Image read_exr(const std::string &path) {
             const std::string name = cstr(), type = cstr(); const int32_t size = i32(p); p += 4;
             if (size < 0) throw std::runtime_error("EXR \"" + path + "\": bad attribute size");
             need(p, (size_t)size);
-            if (name == "channels") { size_t q = p; while (d[q]) { Chan c; while (d[q]) c.name.push_back((char)d[q++]); q++; c.type = i32(q); if (i32(q + 8) != 1 || i32(q + 12) != 1) throw std::runtime_error("EXR \"" + path + "\": subsampled channels are not supported"); q += 16; pt.chans.push_back(c); } }
-            else if (name == "compression") pt.compression = d[p];
-            else if (name == "dataWindow") for (int k = 0; k < 4; ++k) pt.win[k] = i32(p + 4 * k);
+            if (name == "channels") {   // (name NUL, type, pLinear + 3 reserved bytes, xSampling, ySampling) ..., NUL -- every read stays inside the attribute
+                const size_t end = p + (size_t)size; size_t q = p;
+                auto in_attr = [&](size_t at, size_t n) { if (at + n > end || at + n < at) throw std::runtime_error("EXR \"" + path + "\": channel list runs past its attribute"); };
+                for (;;) {
+                    in_attr(q, 1);
+                    if (!d[q]) break;
+                    Chan c;
+                    for (;;) { in_attr(q, 1); if (!d[q]) break; c.name.push_back((char)d[q++]); }
+                    q++;
+                    in_attr(q, 16);
+                    c.type = i32(q);
+                    if (i32(q + 8) != 1 || i32(q + 12) != 1) throw std::runtime_error("EXR \"" + path + "\": subsampled channels are not supported");
+                    q += 16; pt.chans.push_back(c);
+                }
+            }
+            else if (name == "compression") { if (size < 1) throw std::runtime_error("EXR \"" + path + "\": empty compression attribute"); pt.compression = d[p]; }
+            else if (name == "dataWindow") { if (size < 16) throw std::runtime_error("EXR \"" + path + "\": short dataWindow attribute"); for (int k = 0; k < 4; ++k) pt.win[k] = i32(p + 4 * k); }
             else if (name == "tiles" && size >= 9) { std::memcpy(&pt.tile_w, d.data() + p, 4); std::memcpy(&pt.tile_h, d.data() + p + 4, 4); pt.level_mode = d[p + 8] & 15; pt.round_up = d[p + 8] >> 4; }
             else if (name == "type" && size > 0) { const std::string t((const char *)d.data() + p, (size_t)size); pt.tiled = t == "tiledimage"; pt.deep = t.compare(0, 4, "deep") == 0; }
             else if (name == "chunkCount" && size == 4) pt.chunk_count = i32(p);
@@ -222,11 +236,13 @@ inline Image read_exr(const std::string &path) {
     std::vector<size_t> n_chunks(parts.size());
     for (size_t k = 0; k < parts.size(); ++k) {
         const Part &pt = parts[k];
-        const int w = pt.win[2] - pt.win[0] + 1, h = pt.win[3] - pt.win[1] + 1;
-        if (w <= 0 || h <= 0 || pt.chans.empty()) throw std::runtime_error("EXR \"" + path + "\": missing dataWindow / channels");
+        const int64_t w64 = (int64_t)pt.win[2] - pt.win[0] + 1, h64 = (int64_t)pt.win[3] - pt.win[1] + 1;
+        if (w64 <= 0 || h64 <= 0 || w64 > (1 << 26) || h64 > (1 << 26) || pt.chans.empty()) throw std::runtime_error("EXR \"" + path + "\": missing or absurd dataWindow / no channels");
+        const int w = (int)w64, h = (int)h64;
+        // a tiled part needs its tile description whether or not a chunkCount spares us the arithmetic (every part of a multi-part file carries one)
+        if (pt.tiled && (pt.tile_w == 0 || pt.tile_h == 0 || pt.tile_w > (uint32_t)INT32_MAX || pt.tile_h > (uint32_t)INT32_MAX)) throw std::runtime_error("EXR \"" + path + "\": tiled part without a (sane) tile description");
         if (pt.chunk_count >= 0) { n_chunks[k] = (size_t)pt.chunk_count; continue; }
         if (!pt.tiled) { const int lpb = pt.compression == 3 ? 16 : (pt.compression == 4 || pt.compression == 6 ) ? 32 : (pt.compression == 5 || pt.compression == 7) ? 16 : 1; n_chunks[k] = (size_t)((h + lpb - 1) / lpb); continue; }
-        if (pt.tile_w == 0 || pt.tile_h == 0) throw std::runtime_error("EXR \"" + path + "\": tiled part without a tile description");
         auto tiles = [&](int lw, int lh) { return (size_t)((lw + (int)pt.tile_w - 1) / (int)pt.tile_w) * (size_t)((lh + (int)pt.tile_h - 1) / (int)pt.tile_h); };
         size_t n = 0;
         if (pt.level_mode == 0) n = tiles(w, h);
@@ -234,14 +250,13 @@ inline Image read_exr(const std::string &path) {
         else { const int nx = levels(w, pt.round_up), ny = levels(h, pt.round_up); for (int ly = 0; ly < ny; ++ly) for (int lx = 0; lx < nx; ++lx) n += tiles(level_size(w, lx, pt.round_up), level_size(h, ly, pt.round_up)); }
         n_chunks[k] = n;
     }
-    size_t use = parts.size();
-    for (size_t k = 0; k < parts.size() && use == parts.size(); ++k) if (!parts[k].deep) use = k;
-    if (use == parts.size()) throw std::runtime_error("EXR \"" + path + "\": deep data is not supported");
+    for (const Part &q : parts) if (q.deep) throw std::runtime_error("EXR \"" + path + "\": a part says it is deep although the version field does not: refused");
+    const size_t use = 0;   // the first part (all parts are flat here)
     size_t table = p;
     for (size_t k = 0; k < use; ++k) table += 8 * n_chunks[k];
     const Part &pt = parts[use];
     const std::vector<Chan> &chans = pt.chans; const int compression = pt.compression; const int32_t *win = pt.win;
-    const int w = win[2] - win[0] + 1, h = win[3] - win[1] + 1;
+    const int w = (int)((int64_t)win[2] - win[0] + 1), h = (int)((int64_t)win[3] - win[1] + 1);   // (checked above)
     if (compression < 0 || compression > 3) {
         static const char *names[] = {"none", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
         throw std::runtime_error("EXR \"" + path + "\": only uncompressed, RLE, ZIPS and ZIP data are supported (this file: " + (compression >= 0 && compression < 10 ? std::string(names[compression]) : std::to_string(compression)) + ")");

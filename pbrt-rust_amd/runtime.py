@@ -171,6 +171,13 @@ class MultiScene:
         self.L.check(self.L.lib.pt_multi_get_timing(self.h, C.byref(merge), r, c, n))
         return dict(merge_ms=merge.value, render_ms=list(r), copy_ms=list(c))
 
+    def peer_access(self):
+        """Per replica: "same device", "peer access" (device-to-device copies) or "staged through the host" -- how its film reaches the first device."""
+        n = len(self.devices)
+        p = (C.c_int * n)()
+        self.L.check(self.L.lib.pt_multi_get_peer_access(self.h, p, n))
+        return [("same device", "peer access", "staged through the host")[v] for v in p]
+
     def kernel_stats(self, replica=0):
         arr = (A.PtKernelStat * 32)(); n = C.c_uint32()
         self.L.check(self.L.lib.pt_multi_get_kernel_stats(self.h, replica, arr, 32, C.byref(n)))

@@ -876,3 +876,39 @@ def test_exr_codecs_that_are_not_read_are_named(pkg, tmp_path):
     rw, rh = C.c_int(), C.c_int(); back = np.zeros((4, 4, 3), np.float32)
     assert F.ptf_read_image(str(path).encode(), C.byref(rw), C.byref(rh), back.ctypes.data_as(pkg._abi.fp), back.size) != 0
     assert b"PIZ" in F.ptf_last_error()
+
+
+def test_malformed_exr_headers_are_refused_not_crashed_on(pkg, tmp_path):
+    """a tiled part of a multi-part file without (or with a zero) tile description used to reach `(w + tw - 1) / tw` with tw = 0 -- SIGFPE in the
+    host process -- because its chunkCount attribute skipped the check; a channel list without its terminating NUL was read past the attribute. Both are
+    errors with a message now, like every other malformed input of the reader (imageio.rs:68-97 surfaces the exr crate's Err the same way)."""
+    F = pkg.frontend.lib()
+    px = {c: np.zeros((7, 9), np.float32) for c in "RGB"}
+    good = _exr_bytes([dict(w=9, h=7, pixels=px, chans=[("R", 2), ("G", 2), ("B", 2)], compression=3, tile=(4, 4)),
+                       dict(w=9, h=7, pixels=px, chans=[("R", 2), ("G", 2), ("B", 2)], compression=0)], multipart=True)
+    rw, rh = C.c_int(), C.c_int(); back = np.zeros((7, 9, 3), np.float32)
+
+    def read(data, name):
+        path = tmp_path / name; path.write_bytes(bytes(data))
+        st = F.ptf_read_image(str(path).encode(), C.byref(rw), C.byref(rh), back.ctypes.data_as(pkg._abi.fp), back.size)
+        return st, F.ptf_last_error()
+    assert read(good, "good.exr")[0] == 0
+    # tile width 0 in the tile description of the first (tiled) part
+    b = bytearray(good)
+    i = bytes(b).index(b"tiles\0tiledesc\0") + len(b"tiles\0tiledesc\0") + 4
+    b[i:i + 4] = (0).to_bytes(4, "little")
+    st, err = read(b, "tile0.exr")
+    assert st != 0 and b"tile description" in err, err
+    # tile width 2^31: would become a negative int
+    b = bytearray(good); b[i:i + 4] = (1 << 31).to_bytes(4, "little")
+    st, err = read(b, "tilebig.exr")
+    assert st != 0 and b"tile description" in err, err
+    # the attribute renamed: the part is tiled ("type" = tiledimage) and has no description at all
+    b = bytearray(good); j = bytes(b).index(b"tiles\0tiledesc\0"); b[j:j + 5] = b"tilez"
+    st, err = read(b, "notiles.exr")
+    assert st != 0 and b"tile description" in err, err
+    # channel list whose terminating NUL was overwritten: reading on would leave the attribute
+    b = bytearray(good); j = bytes(b).index(b"channels\0chlist\0") + len(b"channels\0chlist\0")
+    size = int.from_bytes(b[j:j + 4], "little"); b[j + 4 + size - 1] = ord("X")
+    st, err = read(b, "chlist.exr")
+    assert st != 0 and (b"channel list" in err or b"truncated" in err or b"subsampled" in err), err

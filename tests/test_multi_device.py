@@ -6,6 +6,7 @@ device of the test box (ordinals may repeat) render through one host thread + st
 the result must equal the plain single-scene render (weights bit for bit, radiance to float summation order) with the counters
 summing to the same totals."""
 import ctypes as C
+import json
 import numpy as np
 import pytest
 from conftest import ckeys
@@ -72,6 +73,7 @@ def test_three_replicas_on_one_device_equal_the_plain_render(pkg, gpu, scene):
     assert len(multi.kernel_stats(2)) > 0
     tm = multi.timing()
     assert len(tm["render_ms"]) == 3 and all(x > 0 for x in tm["render_ms"]) and tm["merge_ms"] > 0 and tm["copy_ms"] == [0.0, 0.0, 0.0]   # replicas on the first device are summed in place
+    assert multi.peer_access() == ["same device"] * 3   # how each replica's film reaches the first device is reported, not guessed from the timing
 
 
 @pytest.mark.gpu
@@ -112,6 +114,7 @@ def test_distinct_devices_equal_the_plain_render(pkg, gpu):
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)
     tm = multi.timing()
     assert all(c > 0 for c in tm["copy_ms"][1:])
+    assert multi.peer_access()[0] == "same device" and all(p in ("peer access", "staged through the host") for p in multi.peer_access()[1:])
 
 
 def test_bench_takes_the_one_process_form_for_gpus_n_without_a_launcher():
@@ -125,3 +128,32 @@ def test_bench_takes_the_one_process_form_for_gpus_n_without_a_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "asks for device ordinals [0, 1, 2]" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_launcher_form_of_bench_runs_with_two_ranks_on_one_gpu(pkg, gpu, tmp_path):
+    """the launcher form of bench.py (one process per rank under `python -m torch.distributed.run`, WORLD_SIZE set, tiles
+    sharded `tile % world == rank`, films reduced onto rank 0 -- what the driver's SCALE run starts with nccl on eight GPUs) executed once before a
+    multi-GPU node sees it: two fresh child processes (started before anything in them touches the GPU), both on device 0, backend gloo with the film
+    staged through the host. The reduced film must equal the single render: weights bit for bit, radiance to float summation order.
+    Shape matched: core/integrator.rs:294-296 (tiles fanned out), :392-396 (merge_film_tile)."""
+    import os, socket, subprocess, sys
+    from conftest import trace_env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    env = trace_env({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+    out = tmp_path / "film.npy"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--devices", "0,0", "--dist-backend", "gloo", "--xres", "256", "--yres", "144", "--spp", "8", "--mesh-n", "64",
+           "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--other-configs", "off", "--projection", "off", "--dump-film", str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["form"].startswith("one process per GPU") and len(line["multi_gpu"]["per_rank_kernel_busy_ms"]) == 2
+    merged = np.load(out)
+    sd, rp = pkg.scenes.ganesha_scale(n=64, xres=256, yres=144, spp=8).world_end()
+    ref = pkg.Scene(gpu, sd).render(rp)
+    assert merged.shape == ref.shape
+    assert np.array_equal(merged[..., 3], ref[..., 3])
+    np.testing.assert_allclose(merged[..., :3], ref[..., :3], rtol=2e-6, atol=1e-7)

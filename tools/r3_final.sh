@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3 record: GPU tests, the driver's bench command, sim-world lines, the other configs at their named spp, rocprofv3 stats of the bench command
-cd ${GRAFT_REPO_ROOT:-/root/repo}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
 O=gpurun_out/r3_final; mkdir -p $O
 echo "== GPU tests"; timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -n 2 $O/gpu_tests.log
 echo "== bench (driver form)"; timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
@@ -23,8 +24,8 @@ for C in C3 C4 C5; do
 import json;d=json.loads(open('$O/bench_$C.json').read().strip().split('\n')[-1]);r=d['roofline'];print('$C', d['value'], d['ms_per_step'], d['config']['spp_per_pass'], r['kernel'], 'frac', r['frac'], 'algo/peak', r['algorithmic_over_hbm_peak'], 'cpu', d['cpu_baseline']['value'] if d['cpu_baseline'] else None)"
 done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --other-configs off > $GRAFT_REPO_ROOT/$O/stats_bench.json 2> $GRAFT_REPO_ROOT/$O/stats.err
-cd $GRAFT_REPO_ROOT; find $O -name '*kernel_trace.csv' -size +4M -delete
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/stats -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --other-configs off > $REPO/$O/stats_bench.json 2> $REPO/$O/stats.err
+cd $REPO; find $O -name '*kernel_trace.csv' -size +4M -delete
 python3 - <<'PY'
 import csv,glob
 for f in glob.glob('gpurun_out/r3_final/stats/**/*kernel_stats.csv', recursive=True):
