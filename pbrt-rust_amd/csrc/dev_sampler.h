@@ -14,11 +14,11 @@ struct SobolTables {
     const uint64_t *vdc;      // [25][52]
     const uint64_t *vdc_inv;  // [26][52]
     // Halton: the first 1000 primes, their running sums and the digit permutations (compute_radical_inverse_permutations
-    // with the default RNG, lowdiscrepancy.rs:359-378), built once on the host by capi.hip
+    // with the default RNG, lowdiscrepancy.rs:359-378), built once on the host by host_device.hip
     const uint32_t *prime;     // [1000]
     const uint32_t *prime_sum; // [1000]
     const uint16_t *perm;      // [sum of the first 1000 primes]
-    // m32 folded by index nibble (built by capi.hip from m32): nib[j][d][n] = XOR of m32[d][4 j + b] over the set bits b of n, j < kSobolNibbles.
+    // m32 folded by index nibble (built by host_device.hip from m32): nib[j][d][n] = XOR of m32[d][4 j + b] over the set bits b of n, j < kSobolNibbles.
     // A Sobol' value is then one 16-entry table look-up per index nibble instead of one step per set index bit -- the same XORs, regrouped.
     const uint32_t *nib;       // [kSobolNibbles][1024][16]
 };

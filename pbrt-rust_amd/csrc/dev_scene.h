@@ -40,7 +40,7 @@ struct WideNode {
 // empty (bounds +inf / -inf, reference PT_NONE). The ray visits the slots in the order the reference's binary walk reaches them -- near side of N
 // first, inside a pair the near side of L (R) first -- so leaves are met in the reference's order and every hit is the reference's hit; only the
 // number of boxes tested differs (boxes of L and R themselves are never tested: a child that passes its own test lies inside its parent's box and
-// the parent would have passed too). meta: the slot order for each of the eight sign octants of a ray, three bits per octant (capi.hip), from the split
+// the parent would have passed too). meta: the slot order for each of the eight sign octants of a ray, three bits per octant (scene_create.hip), from the split
 // axes of N, L and R (bvh.rs:671,686).
 // A lane reads the bound planes of an axis through two dwordx4 loads whose offsets depend on the ray's sign along that axis, so "near" and "far"
 // planes arrive sorted and the selects of Bounds3f::intersect_p2's `bounds[dir_is_neg]` indexing cost nothing.

@@ -1,4 +1,4 @@
-// kern_decl.h -- declarations of every kernel for the host driver (capi.hip). The definitions live in kern_*.h and are
+// kern_decl.h -- declarations of every kernel for the host driver (host_common.h and the .hip files it names). The definitions live in kern_*.h and are
 // instantiated by the tu_*.hip translation units (one code object each, compiled in parallel).
 #pragma once
 #include "kern_common.h"

@@ -1,4 +1,4 @@
-// kernels.h -- shared declarations between the HIP kernels (kernels.hip) and the host driver (capi.hip).
+// kernels.h -- shared declarations between the HIP kernels (kernels.hip) and the host driver (host_common.h: scene_create.hip, render_loop.hip, ...).
 #pragma once
 #include <cstddef>
 #include "dev_scene.h"
@@ -117,7 +117,7 @@ struct QCounters {
     uint32_t pad;
 };
 
-// pt_multi_render's film merge: at most one film per replica (capi.hip: kMaxDevices)
+// pt_multi_render's film merge: at most one film per replica (host_common.h: kMaxDevices)
 constexpr int kMaxReplicas = 64;
 struct FilmSumArgs { const float4 *src[kMaxReplicas]; uint32_t n; };
 
@@ -173,7 +173,7 @@ struct TraceSub {
 
 // A traversal launch. k_trace<0 | 1, ..> walks the rays of sub[0] (closest hit | any hit); k_trace<2, ..> walks the queues of
 // sub[0..2] back to back -- the continuation, MIS and shadow rays of one wavefront iteration in ONE launch, so that the iteration
-// has one tail of straggling rays instead of three (run_pass in capi.hip).
+// has one tail of straggling rays instead of three (run_pass in render_loop.hip).
 struct TraceJob {
     TraceSub sub[3];
     uint32_t *head;          // persistent-wave work head (zeroed before launch)

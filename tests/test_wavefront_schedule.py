@@ -1,6 +1,6 @@
 """How the wavefront is scheduled must not change what is computed: one traversal launch per iteration (k_trace<2, ..>: continuation, MIS
 and shadow rays together) against one launch per ray kind, any pass size, and the material classes a scene's vertices are shaded by
-(capi.hip: material_class). The reference has no counterpart of these choices (core/integrator.rs:263-403 is one loop per sample), so
+(scene_create.hip: material_class). The reference has no counterpart of these choices (core/integrator.rs:263-403 is one loop per sample), so
 the checks are: identical films and counters between the schedules, and GPU == oracle for the scenes that exercise each class."""
 import json
 import os
