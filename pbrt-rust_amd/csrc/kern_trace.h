@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     uint32_t state = ST_IDLE;
     bool exhausted = false;
 #ifndef PT_TRACE_CHUNK
-#define PT_TRACE_CHUNK 256   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
+#define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
                              // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
 #endif
     constexpr int kChunk = PT_TRACE_CHUNK;

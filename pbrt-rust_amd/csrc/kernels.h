@@ -26,7 +26,7 @@ constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 word
 constexpr int kLdsStackGeneral = PT_LDS_STACK_GENERAL;
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 #ifndef PT_LDS_STACK_QUAD
-#define PT_LDS_STACK_QUAD 13
+#define PT_LDS_STACK_QUAD 14
 #endif
 constexpr int kLdsStackQuad = PT_LDS_STACK_QUAD;   // the four-wide walk (kern_trace.h, QUAD): up to three pushes per record; five waves per SIMD x 7 KB per wave of LDS
 constexpr int kMaxStackQuad = 96;   // a reference tree of depth 64 collapses to 32 four-wide levels x 3 pushes

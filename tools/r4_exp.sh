@@ -53,6 +53,16 @@ stage)
   PT_TRACE_STAGE=0 one c2_nostage --config C2 --steps 2 --warmup 1
   for r in 4 8; do PT_TRACE_REFILL_MIN=$r one c4_stage_rf$r --config C4 --spp 64 --steps 1 --warmup 1; done
   PT_TRACE_STAGE=0 one c4_nostage --config C4 --spp 64 --steps 1 --warmup 1 ;;
+streams)
+  for v in 1 0; do PT_SHADE_STREAMS=$v one c2_streams$v --config C2 --steps 3 --warmup 1; PT_SHADE_STREAMS=$v one c3_streams$v --config C3 --spp 256 --steps 1 --warmup 1; PT_SHADE_STREAMS=$v one c5_streams$v --config C5 --spp 216 --steps 2 --warmup 1; done ;;
+knobs2)
+  for r in 16,16,16,32 16,16,16,64 16,16,16,24 12,12,12,48 20,20,20,48; do PT_TRACE_REFILL_MIN=$r one c2_rf_$r --config C2 --steps 2 --warmup 1; done
+  for q in 8,8,8,16 8,8,8,4 2,2,2,8; do PT_TRACE_LEAF_QUORUM=$q one c2_lq_$q --config C2 --steps 2 --warmup 1; done
+  for v in qlds14 qchunk512 qchunk128; do PT_LIB_PATH=pbrt-rust_amd/csrc/variants/$v one c2_$v --config C2 --steps 2 --warmup 1; done ;;
+knobs4)
+  for q in 8 12 24; do PT_TRACE_INST_QUORUM=$q one c4_iq$q --config C4 --spp 64 --steps 1 --warmup 1; done
+  for q in 4 12 16; do PT_TRACE_LEAF_QUORUM=$q one c4_lq$q --config C4 --spp 64 --steps 1 --warmup 1; done
+  for r in 4 12 16; do PT_TRACE_REFILL_MIN=$r one c4_rf$r --config C4 --spp 64 --steps 1 --warmup 1; done ;;
 v5w)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
