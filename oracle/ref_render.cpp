@@ -1426,6 +1426,42 @@ int orc_light_pdf_li(orc_scene *h, uint32_t li, const float *p, const float *per
 }
 }
 
+// ---- BSDF of a material at a canonical interaction, for the analytic lobe checks of tests/test_oracle_bsdf.py ---------------------------------
+// The material `mi` is evaluated as Material::compute_scattering_functions would at a point with geometric and shading normal +z, dpdu = +x,
+// dpdv = +y, no textures; then for each of n queries: f(wo, wi) and pdf(wo, wi) over all lobes (reflection.rs:1541-1600), and sample_f(wo, u)
+// (reflection.rs:1602-1689) -> sampled wi, its f, pdf and lobe type. Directions are world = local here.
+extern "C" {
+using namespace ref;
+int orc_bsdf_eval(orc_scene *h, uint32_t mi, uint32_t n, const float *wo, const float *wi, const float *u,
+                  float *f_out, float *pdf_out, float *s_wi_out, float *s_f_out, float *s_pdf_out, int32_t *s_type_out, int32_t *n_lobes_out) {
+    if (mi >= h->scene.materials.size()) return 1;
+    SurfaceInteraction si{};
+    si.p = V3(0, 0, 0); si.p_error = V3(0, 0, 0); si.n = V3(0, 0, 1); si.sh_n = V3(0, 0, 1); si.wo = V3(0, 0, 1);
+    si.dpdu = V3(1, 0, 0); si.dpdv = V3(0, 1, 0); si.sh_dpdu = V3(1, 0, 0); si.sh_dpdv = V3(0, 1, 0);
+    si.uv = P2(0.5f, 0.5f); si.has_shape = false; si.shape_flip = false; si.prim = 0;
+    BSDF bsdf;
+    if (!material_scattering_functions(h->scene, mi, si, bsdf, nullptr, nullptr, nullptr)) return 2;
+    if (n_lobes_out) *n_lobes_out = bsdf.n;
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3 o(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+        if (wi && f_out && pdf_out) {
+            const V3 w(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+            const RGB f = bsdf.f(o, w, BSDF_ALL);
+            for (int c = 0; c < 3; ++c) f_out[3 * i + c] = f.c[c];
+            pdf_out[i] = bsdf.pdf(o, w, BSDF_ALL);
+        }
+        if (u && s_wi_out && s_f_out && s_pdf_out) {
+            V3 w(0, 0, 0); Float pdf = 0.0f; int sampled = 0;
+            const RGB f = bsdf.sample_f(o, w, P2(u[2 * i], u[2 * i + 1]), pdf, BSDF_ALL, sampled);
+            s_wi_out[3 * i] = w.x; s_wi_out[3 * i + 1] = w.y; s_wi_out[3 * i + 2] = w.z; s_pdf_out[i] = pdf;
+            for (int c = 0; c < 3; ++c) s_f_out[3 * i + c] = f.c[c];
+            if (s_type_out) s_type_out[i] = sampled;
+        }
+    }
+    return 0;
+}
+}
+
 // ---- tests/hg.rs restated (the reference's assertions on HenyeyGreenstein::p / sample_p, medium.rs:149-193), run inside the oracle ----
 extern "C" {
 using namespace ref;
