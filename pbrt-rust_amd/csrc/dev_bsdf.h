@@ -184,6 +184,9 @@ template <bool FULL = true> PT_DEV float lobe_g(const Lobe &b, V3 wo, V3 wi) { r
 template <int DIFF, bool FULL> PT_DEV uint8_t lobe_kind(const Lobe &b) {
     if (DIFF == 1) return b.kind == LB_OREN_NAYAR ? (uint8_t)LB_OREN_NAYAR : (uint8_t)LB_LAMBERT_R;
     if (DIFF == 2) return b.kind == LB_FRESNEL_SPEC ? (uint8_t)LB_FRESNEL_SPEC : (uint8_t)LB_SPEC_R;
+    if (DIFF == 3) return (uint8_t)LB_MICRO_R;   // class 1 of a scene whose one-lobe materials are all metals: the conductor microfacet lobe only
+    if (DIFF == 4) return b.kind == LB_LAMBERT_R ? (uint8_t)LB_LAMBERT_R : (uint8_t)LB_MICRO_R;
+    if (DIFF == 5) return b.kind == LB_LAMBERT_R ? (uint8_t)LB_LAMBERT_R : b.kind == LB_MICRO_R ? (uint8_t)LB_MICRO_R : b.kind == LB_SPEC_R ? (uint8_t)LB_SPEC_R : (uint8_t)LB_SPEC_T;   // class 3 of a scene whose many-lobe materials are all ubers   // class 2 of a scene without rough glass: plastic / opaque uber = Lambert + dielectric microfacet reflection
     return FULL ? b.kind : (b.kind > LB_FRESNEL_BLEND ? (uint8_t)LB_FRESNEL_BLEND : b.kind);
 }
 
@@ -434,7 +437,7 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
     uint64_t types;        // BxDFType byte of lobe i in bits 8i .. 8i+7 (what `matches` and the reflect / transmit split read)
     // MixMaterial (mix.rs:25-50): lobes [0, n1) are ScaledBxDFs with scale s1, lobes [n1, n) with scale s2 (reflection.rs:466-517);
     // only the five-lobe class carries this. `frozen`: the second material's init() must not reset the frame / eta / lobes.
-    static constexpr bool MIX = MAXL == 5, FULL = MAXL == 5;
+    static constexpr bool MIX = MAXL == 5 && DIFF != 5, FULL = MAXL == 5 && DIFF != 5;   // (DIFF 5: the uber-only form of the five-lobe class carries no mix / Disney code)
     int n1; RGB s1, s2; bool frozen;
 
     PT_DEV void bind(float *block_store) { store = LDS ? block_store + threadIdx.x : nullptr; }
@@ -451,6 +454,7 @@ template <int MAXL, int DIFF = 0> struct Bsdf {
         Lobe b;
         const uint32_t w0 = __float_as_uint(p[0]);
         b.kind = (uint8_t)(w0 & 0xffu); b.type = (uint8_t)((w0 >> 8) & 0xffu); b.fresnel = (uint8_t)((w0 >> 16) & 0xffu); b.sepg = (uint8_t)(w0 >> 24);
+        if (DIFF == 4 || DIFF == 5) { b.fresnel = (uint8_t)FR_DIELECTRIC; b.sepg = 0; }   // (the only Fresnel term a plastic-like lobe set evaluates; the Lambert lobe reads none)
         b.r = RGB(p[1 * kLobeStride], p[2 * kLobeStride], p[3 * kLobeStride]);
         const RGB x4(p[4 * kLobeStride], p[5 * kLobeStride], p[6 * kLobeStride]);
         const float y7 = p[7 * kLobeStride], y8 = p[8 * kLobeStride], y9 = p[9 * kLobeStride], z10 = p[10 * kLobeStride];
@@ -607,7 +611,7 @@ struct ConstMatEval {
 // (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
 template <int MAXL, class ME, int DIFF> PT_DEV bool build_bsdf_leaf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
     // class 0 holds matte materials only, class 6 mirrors and smooth glass: the other cases drop out of those kernels
-    switch (DIFF == 1 ? (uint32_t)PT_MAT_MATTE : DIFF == 2 ? (m.type == PT_MAT_MIRROR ? (uint32_t)PT_MAT_MIRROR : (uint32_t)PT_MAT_GLASS) : m.type) {
+    switch (DIFF == 1 ? (uint32_t)PT_MAT_MATTE : DIFF == 2 ? (m.type == PT_MAT_MIRROR ? (uint32_t)PT_MAT_MIRROR : (uint32_t)PT_MAT_GLASS) : DIFF == 3 ? (uint32_t)PT_MAT_METAL : DIFF == 4 ? (m.type == PT_MAT_PLASTIC ? (uint32_t)PT_MAT_PLASTIC : (uint32_t)PT_MAT_UBER) : DIFF == 5 ? (uint32_t)PT_MAT_UBER : m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
         RGB r = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);

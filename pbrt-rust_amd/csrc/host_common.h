@@ -37,6 +37,7 @@ extern bool g_refill_from_env;
 extern bool g_trace_split;
 extern bool g_trace_exact;
 extern uint32_t g_inst_quorum;
+extern bool g_metal_kernel;
 extern uint32_t g_trace_waves_per_cu;
 extern thread_local SobolTables g_tabs;
 constexpr int kMaxDevices = kMaxReplicas;
@@ -74,6 +75,9 @@ struct pt_scene {
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
     bool class_used[kNumClasses] = {true, false, false, false, true, false, false};
+    bool class3_uber_only = false;    // every many-lobe material is an uber (Lambert + microfacet + specular reflection / transmission): k_shade<5, MODE, 5>
+    bool class2_plastic_like = false; // every two-lobe material is plastic or an opaque uber without specular terms (no rough glass): k_shade<2, MODE, 4>
+    bool class1_metal_only = false;   // every one-lobe material of the scene is a metal: its vertices are shaded by the conductor-microfacet specialisation k_shade<1, MODE, 3>
     bool has_null_material = false;   // a primitive without a material: a medium-interface shell (api.rs:597). The path integrator steps over it (path.rs:124-129);
                                       // the volumetric one also walks its shadow / MIS rays through it, segment by segment (kern_shade_common.h: vol_chain_step)
     void *ext_slab = nullptr; size_t ext_capacity = 0;   // PathSoA::ext, allocated for volpath renders of scenes with shells

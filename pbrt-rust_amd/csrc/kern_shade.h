@@ -14,17 +14,25 @@ template <int MAXL, int MODE, int DIFF>
 // Waves per SIMD the kernel is compiled for. The matte kernel of triangle-only scenes (MAXL 1, MODE 0, DIFF 1: the headline's) takes three:
 // 168 VGPRs + 32 bytes of scratch, VALU-bound at two waves (57 % busy, 9 % of the wave cycles waiting on memory: SQ counters in profiles/r3).
 // The others lose more to spills than they gain (one-lobe general kernel at three waves: 160 bytes of scratch, 112.8 -> 114.8 ms on C3).
-__global__ __launch_bounds__(256, (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SHADE_WAVES > 3 ? PT_SHADE_WAVES : 3) : (MAXL == 1 && MODE == 0 && DIFF == 2) ? 4 : (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
+#ifndef PT_P2_WAVES
+#define PT_P2_WAVES 3     // the plastic-like two-lobe kernel (DIFF 4) of triangle-only scenes: three waves per SIMD (168 VGPRs + 80 B of scratch) with 28 Sobol' dimensions staged
+#define PT_P2_DIMS 28u    // in LDS and 512-entry queues (51 KB per workgroup: three fit a CU) -- C3 shade_2lobe 101.0 -> 86.9 ms against two waves with 56 dimensions / 1024 entries
+#define PT_P2_QCAP 512
+#endif
+#ifndef PT_METAL_WAVES
+#define PT_METAL_WAVES 3   // experiment hook: waves per SIMD of the metal-only one-lobe kernel (DIFF 3) of triangle-only scenes
+#endif
+__global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_WAVES : (MAXL == 1 && MODE == 0 && DIFF == 3) ? PT_METAL_WAVES : (MAXL == 1 && MODE == 0 && DIFF == 1) ? (PT_SHADE_WAVES > 3 ? PT_SHADE_WAVES : 3) : (MAXL == 1 && MODE == 0 && DIFF == 2) ? 4 : (MAXL == 1 && MODE == 1) ? (PT_SHADE_WAVES > 2 ? PT_SHADE_WAVES : 2) : (MAXL == 1 ? PT_SHADE_WAVES : (MAXL >= 2 && MODE < 2) ? 2 : 1)) PT_SHADE_ATTR void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job) {
     constexpr bool SPH = MODE >= 1, TEX = MODE >= 2, VOL = MODE == 3;   // MODE 3: general + textures + participating media (volpath.rs)
     // Sobol' nibble tables of the first dimensions (dev_sampler.h): 56 cover the vertices of bounces 0..5; the five-lobe class, whose lobe store
     // fills the LDS, keeps 20 and reads the rest from HBM (one 64-byte line per look-up, the same for every lane of a bounce)
-    constexpr uint32_t LDS_DIMS = MAXL == 5 ? 20u : DIFF == 2 ? 32u : 56u;   // (the specular-only kernel runs four workgroups per CU: 37 KB each)
+    constexpr uint32_t LDS_DIMS = MAXL == 5 ? 20u : DIFF == 2 ? 32u : (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_DIMS : 56u;   // (the specular-only kernel runs four workgroups per CU: 37 KB each)
     __shared__ uint32_t s_sobol[LDS_DIMS * kSobolNibWords];
     // Block-level queues on purpose: their barriers keep the four waves of a block in lockstep through this very large
     // kernel, which measured 10 % faster than barrier-free per-wave queues (WaveQueue) at the same occupancy.
     // (the five-lobe class flushes its queues every round -- 256-entry buffers: with the 60 KB lobe store, two of its workgroups fit a CU's
     //  LDS; its vertices cost ~0.8 ns each, so the extra global atomics, one per queue and 256 vertices, do not show)
-    constexpr int QCAP = MAXL == 5 ? 256 : 1024;
+    constexpr int QCAP = MAXL == 5 ? 256 : (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_QCAP : 1024;
     __shared__ LdsQueue<QCAP> s_qext, s_qres, s_qsh, s_qmis;
     __shared__ LdsQueue<(MAXL == 5) ? QCAP : 1> s_qprobe;
     __shared__ LdsQueue<(MODE == 3) ? QCAP : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue

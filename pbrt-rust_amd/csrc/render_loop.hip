@@ -256,9 +256,10 @@ template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderCo
 #endif
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);  // persistent blocks: the LDS Sobol' table is staged once per block
     const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
+    if (DIFF >= 3 && mode >= 2) { launch_shade<MAXL, 0>(sc, rc, grid, job, upper); return; }   // (the metal-only kernel exists for the untextured path integrator)
     sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + std::to_string(DIFF) + ">");
-    if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, DIFF == 2 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
-    else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, (DIFF >= 2) ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF >= 3 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }
@@ -520,8 +521,9 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             }
             else if (c == 0) launch_shade<1, 1>(sc, rc, grid, sj, class_n[c]);
             else if (c == kSpecClass) launch_shade<1, 2>(sc, rc, grid, sj, class_n[c]);
-            else if (c == 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
-            else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 1) { if (sc->class1_metal_only && g_metal_kernel) launch_shade<1, 3>(sc, rc, grid, sj, class_n[c]); else launch_shade<1>(sc, rc, grid, sj, class_n[c]); }
+            else if (c == 2) { if (sc->class2_plastic_like && g_metal_kernel) launch_shade<2, 4>(sc, rc, grid, sj, class_n[c]); else launch_shade<2>(sc, rc, grid, sj, class_n[c]); }
+            else if (sc->class3_uber_only && g_metal_kernel) launch_shade<5, 5>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
             sc->end();
         }

@@ -346,6 +346,12 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
         for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }
+        sc->class1_metal_only = sc->class_used[1];
+        sc->class2_plastic_like = sc->class_used[2];
+        sc->class3_uber_only = sc->class_used[3];
+        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 3 && d->materials[i].type != PT_MAT_UBER) sc->class3_uber_only = false;
+        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 2 && d->materials[i].type != PT_MAT_PLASTIC && d->materials[i].type != PT_MAT_UBER) sc->class2_plastic_like = false;
+        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 1 && d->materials[i].type != PT_MAT_METAL) sc->class1_metal_only = false;
         UP(mat_class, mc.data(), mc.size());
         std::vector<DevBssTable> bt(d->n_bssrdf_tables);
         for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {

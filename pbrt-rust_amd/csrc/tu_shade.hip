@@ -10,6 +10,15 @@ PT_INST_SHADE(1, PT_TU_MODE, 1) PT_INST_SHADE(1, PT_TU_MODE, 0)
 #if PT_TU_MODE != 3   // (the volumetric integrator has no specular-only class: it estimates direct light at every vertex)
 PT_INST_SHADE(1, PT_TU_MODE, 2)
 #endif
+#if PT_TU_MODE < 2     // class 1 of scenes whose one-lobe materials are all metals
+PT_INST_SHADE(1, PT_TU_MODE, 3)
+#endif
 #else
 PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, 0)
+#if PT_TU_MAXL == 5 && PT_TU_MODE < 2   // class 3 of scenes whose many-lobe materials are all ubers
+PT_INST_SHADE(5, PT_TU_MODE, 5)
+#endif
+#if PT_TU_MAXL == 2 && PT_TU_MODE < 2   // class 2 of scenes whose two-lobe materials are all plastic-like (no rough glass)
+PT_INST_SHADE(2, PT_TU_MODE, 4)
+#endif
 #endif

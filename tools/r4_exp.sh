@@ -63,6 +63,14 @@ knobs4)
   for q in 8 12 24; do PT_TRACE_INST_QUORUM=$q one c4_iq$q --config C4 --spp 64 --steps 1 --warmup 1; done
   for q in 4 12 16; do PT_TRACE_LEAF_QUORUM=$q one c4_lq$q --config C4 --spp 64 --steps 1 --warmup 1; done
   for r in 4 12 16; do PT_TRACE_REFILL_MIN=$r one c4_rf$r --config C4 --spp 64 --steps 1 --warmup 1; done ;;
+metal)
+  one c3_metal3 --config C3 --spp 256 --steps 1 --warmup 1
+  PT_METAL_KERNEL=0 one c3_general --config C3 --spp 256 --steps 1 --warmup 1
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/metal2 one c3_metal2 --config C3 --spp 256 --steps 1 --warmup 1
+  timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_configs.py tests/test_wavefront_schedule.py -m gpu -x -q -k 'zoo or c3 or specular' 2>&1 | tail -3 ;;
+p2)
+  one c3_default --config C3 --spp 256 --steps 1 --warmup 1
+  PT_LIB_PATH=pbrt-rust_amd/csrc/variants/p2w3 one c3_p2w3 --config C3 --spp 256 --steps 1 --warmup 1 ;;
 v5w)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
