@@ -509,9 +509,10 @@ def run_cpu_baseline(pkg, sd, rp_full, spp, args):
     n1, s1 = render(coprime_stride(max(1, ntiles // want)), 1)
     single = n1 / s1 / 1e6
     cands = sorted({t for t in (info["logical_cpus"], info["physical_cores"], int(info["cgroup_cpu_quota"] + 0.5) if info["cgroup_cpu_quota"] else None, 16) if t and 1 < t <= info["logical_cpus"]})
+    cap = max(2, int(info["cgroup_cpu_quota"] + 0.5) if info["cgroup_cpu_quota"] else (info["physical_cores"] or info["logical_cpus"]))
     tried, best = [], None
     for t in cands:
-        want = max(t, int(single * 1e6 * min(t, 32) * budget * 0.8 / max(1, len(cands)) / (256 * cpu_spp)))   # (sized as if it scaled to 32 threads: bounds the sample)
+        want = max(t, int(single * 1e6 * min(t, cap) * budget * 0.8 / max(1, len(cands)) / (256 * cpu_spp)))   # (sized as if it scaled up to the CPU share: bounds the oversubscribed runs)
         stride = coprime_stride(max(1, ntiles // want))
         nt, st = render(stride, t)
         r = dict(threads=t, msamples_s=round(nt / st / 1e6, 4), samples=int(nt), seconds=round(st, 2), tiles=-(-ntiles // stride), parallel_efficiency=round(nt / st / 1e6 / (single * t), 3))
