@@ -7,10 +7,12 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 dst = os.path.join(R, "profiles", "pmc_traffic.json")
 data = json.load(open(dst)) if os.path.exists(dst) else {}
+import glob
 for cfg in ("C2", "C3", "C4", "C5"):
-    f = os.path.join(tag, cfg, "pmc_traffic.json")
-    if os.path.exists(f):
-        data[cfg] = json.load(open(f))[cfg]
+    for f in sorted(glob.glob(os.path.join(tag, "**", "pmc_traffic.json"), recursive=True)):
+        rec = json.load(open(f))
+        if cfg in rec and rec[cfg]:
+            data[cfg] = rec[cfg]
 for spec in sys.argv[2:]:
     cfg, path = spec.split("=", 1)
     # lines of tools/sq_profile.sh: "<kernel> n=.. NAME=value ..."; VALU busy = 4 cycles x wave instructions / (SIMDs x active cycles of one XCD)
