@@ -106,6 +106,45 @@ def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
     assert {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_specular", "shade_miss"} <= names
 
 
+def test_lobe_set_specialised_kernels_are_chosen_per_scene_and_change_nothing(pkg, gpu, oracle, tmp_path):
+    """Round 4: a scene whose one-lobe materials are all metals, whose two-lobe materials are all plastic-like and whose many-lobe materials are all ubers
+    (the C3 palette) is shaded by k_shade<1, 0, 3> / <2, 0, 4> / <5, 0, 5>; one substrate, one rough glass or one translucent material in the scene brings
+    the general kernel of that class back (the zoo). Either way GPU == oracle, and PT_METAL_KERNEL=0 (general kernels everywhere, a process of its own:
+    pt_init reads it) renders the same film."""
+    sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    film, ref = g.render(rp), orc.render(rp, nthreads=4)
+    st = {s["name"]: s["kernel"] for s in g.kernel_stats() if s["launches"]}
+    assert st["shade_1lobe"] == "k_shade<1, 0, 3>" and st["shade_2lobe"] == "k_shade<2, 0, 4>" and st["shade_uber"] == "k_shade<5, 0, 5>", st
+    gc, oc = g.counters(), orc.counters()
+    for k in ckeys(COUNTERS):
+        assert gc[k] == oc[k], k
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)
+    sd2, rp2 = pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=4).world_end()
+    g2 = pkg.Scene(gpu, sd2); g2.render(rp2)
+    st2 = {s["name"]: s["kernel"] for s in g2.kernel_stats() if s["launches"]}
+    assert st2["shade_1lobe"] == "k_shade<1, 0, 0>" and st2["shade_2lobe"] == "k_shade<2, 0, 0>", st2   # substrate in class 1, rough glass in class 2
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from _pkg import import_pkg
+pkg = import_pkg()
+import torch
+torch.cuda.init()
+lib = pkg.load_library(); lib.init(0)
+sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
+g = pkg.Scene(lib, sd); film = g.render(rp)
+assert all("k_shade<1, 0, 0>" == s["kernel"] for s in g.kernel_stats() if s["launches"] and s["name"] == "shade_1lobe")
+np.save({out!r}, film)
+""".format(root=ROOT, out=str(tmp_path / "general.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=trace_env(dict(os.environ, PT_METAL_KERNEL="0")), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    other = np.load(tmp_path / "general.npy")
+    assert np.array_equal(film[..., 3], other[..., 3])
+    np.testing.assert_allclose(film[..., :3], other[..., :3], rtol=2e-6, atol=1e-7)
+
+
 def _uber_ball(pkg, uber):
     """A displaced ball of the given uber material over a matte floor, one area light and a dim constant environment."""
     S = pkg.scenes
