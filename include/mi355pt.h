@@ -450,7 +450,9 @@ const char *pt_last_error(void);
 int pt_set_trace_exact(int exact);
 
 /* Limits: at most 2^25 - 1 interior BVH nodes and 2^25 - 1 leaf packets (primitives + instance references) per scene, all
- * accelerators of the scene together (traversal stack entries keep 25-bit references); more returns PT_ERR_UNSUPPORTED. */
+ * accelerators of the scene together (traversal stack entries keep 25-bit references), and the four-wide traversal records (128 B per two
+ * interior levels) + the packets (48 B each) below 3.5 GB together (one allocation addressed with 32-bit offsets): 2^25 packets with their
+ * records fit; more returns PT_ERR_UNSUPPORTED. */
 int pt_scene_create(const PtSceneDesc *desc, pt_scene **out_scene);
 void pt_scene_destroy(pt_scene *scene);
 

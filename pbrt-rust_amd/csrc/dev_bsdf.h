@@ -186,6 +186,7 @@ template <int DIFF, bool FULL> PT_DEV uint8_t lobe_kind(const Lobe &b) {
     if (DIFF == 2) return b.kind == LB_FRESNEL_SPEC ? (uint8_t)LB_FRESNEL_SPEC : (uint8_t)LB_SPEC_R;
     if (DIFF == 3) return (uint8_t)LB_MICRO_R;   // class 1 of a scene whose one-lobe materials are all metals: the conductor microfacet lobe only
     if (DIFF == 4) return b.kind == LB_LAMBERT_R ? (uint8_t)LB_LAMBERT_R : (uint8_t)LB_MICRO_R;
+    if (DIFF == 6) return (uint8_t)LB_FRESNEL_SPEC;   // class 3 of a scene whose many-lobe materials are all subsurface materials with the smooth dielectric BSDF
     if (DIFF == 5) return b.kind == LB_LAMBERT_R ? (uint8_t)LB_LAMBERT_R : b.kind == LB_MICRO_R ? (uint8_t)LB_MICRO_R : b.kind == LB_SPEC_R ? (uint8_t)LB_SPEC_R : (uint8_t)LB_SPEC_T;   // class 3 of a scene whose many-lobe materials are all ubers   // class 2 of a scene without rough glass: plastic / opaque uber = Lambert + dielectric microfacet reflection
     return FULL ? b.kind : (b.kind > LB_FRESNEL_BLEND ? (uint8_t)LB_FRESNEL_BLEND : b.kind);
 }
@@ -611,7 +612,7 @@ struct ConstMatEval {
 // (possibly textured) parameters: ConstMatEval above, or the texture evaluator of kernels.hip.
 template <int MAXL, class ME, int DIFF> PT_DEV bool build_bsdf_leaf(const PtMaterial &m, const SurfaceInteraction &si, Bsdf<MAXL, DIFF> &bsdf, const ME &E) {
     // class 0 holds matte materials only, class 6 mirrors and smooth glass: the other cases drop out of those kernels
-    switch (DIFF == 1 ? (uint32_t)PT_MAT_MATTE : DIFF == 2 ? (m.type == PT_MAT_MIRROR ? (uint32_t)PT_MAT_MIRROR : (uint32_t)PT_MAT_GLASS) : DIFF == 3 ? (uint32_t)PT_MAT_METAL : DIFF == 4 ? (m.type == PT_MAT_PLASTIC ? (uint32_t)PT_MAT_PLASTIC : (uint32_t)PT_MAT_UBER) : DIFF == 5 ? (uint32_t)PT_MAT_UBER : m.type) {
+    switch (DIFF == 1 ? (uint32_t)PT_MAT_MATTE : DIFF == 2 ? (m.type == PT_MAT_MIRROR ? (uint32_t)PT_MAT_MIRROR : (uint32_t)PT_MAT_GLASS) : DIFF == 3 ? (uint32_t)PT_MAT_METAL : DIFF == 4 ? (m.type == PT_MAT_PLASTIC ? (uint32_t)PT_MAT_PLASTIC : (uint32_t)PT_MAT_UBER) : DIFF == 5 ? (uint32_t)PT_MAT_UBER : DIFF == 6 ? (uint32_t)PT_MAT_SUBSURFACE : m.type) {
     case PT_MAT_MATTE: {  // matte.rs:28-53
         bsdf.init(si, 1.0f);
         RGB r = E.spec(m, PT_MP_KD, m.kd).clamps(0.0f, PT_INF);

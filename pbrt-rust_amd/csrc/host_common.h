@@ -75,6 +75,7 @@ struct pt_scene {
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
     bool class_used[kNumClasses] = {true, false, false, false, true, false, false};
+    bool class3_sss_smooth = false;   // every many-lobe material is a subsurface material with constant zero roughness (one FresnelSpecular lobe + BSSRDF): k_shade<1, MODE, 6>
     bool class3_uber_only = false;    // every many-lobe material is an uber (Lambert + microfacet + specular reflection / transmission): k_shade<5, MODE, 5>
     bool class2_plastic_like = false; // every two-lobe material is plastic or an opaque uber without specular terms (no rough glass): k_shade<2, MODE, 4>
     bool class1_metal_only = false;   // every one-lobe material of the scene is a metal: its vertices are shaded by the conductor-microfacet specialisation k_shade<1, MODE, 3>

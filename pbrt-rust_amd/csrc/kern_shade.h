@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
     //  LDS; its vertices cost ~0.8 ns each, so the extra global atomics, one per queue and 256 vertices, do not show)
     constexpr int QCAP = MAXL == 5 ? 256 : (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_QCAP : 1024;
     __shared__ LdsQueue<QCAP> s_qext, s_qres, s_qsh, s_qmis;
-    __shared__ LdsQueue<(MAXL == 5) ? QCAP : 1> s_qprobe;
+    constexpr bool SSS = MAXL == 5 || DIFF == 6;   // the launch can hold subsurface materials: the five-lobe class, or its smooth-dielectric-only form (DIFF 6: one FresnelSpecular lobe + the BSSRDF)
+    __shared__ LdsQueue<SSS ? QCAP : 1> s_qprobe;
     __shared__ LdsQueue<(MODE == 3) ? QCAP : 1> s_qself;   // volpath with grid media: vertices waiting for stage B, back into this class's next queue
     __shared__ uint32_t s_hist[16];
     __shared__ uint32_t s_bins[16];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
                 const uint32_t mi = packet_material(s, pfl, hp);
                 bool has_bsdf = false;
                 RGB bss_sa(0.0f), bss_ss(0.0f);   // subsurface.rs:100-101: sigma_a / sigma_s textures, evaluated with the BSDF's parameters
-                const bool is_sss = MAXL == 5 && mi != PT_NONE && s.materials[mi].type == PT_MAT_SUBSURFACE;
+                const bool is_sss = SSS && mi != PT_NONE && s.materials[mi].type == PT_MAT_SUBSURFACE;
                 if (TEX) {
                     // compute_scattering_functions -> compute_differentials(ray) (interaction.rs:262-342): only the camera ray
                     // carries differentials; every spawned ray has none
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
                         }
                         V3 o; spawn_ray(it, wi, o);
                         bool rr_kill = false, to_probe = false;
-                        if constexpr (MAXL == 5) {
+                        if constexpr (SSS) {
                             // path.rs:177-183: importance sample the BSSRDF; the probe chain of sample_sp (bssrdf.rs:367-395)
                             // is walked by k_bssrdf over the following wavefront iterations
                             if ((s.materials[mi].type == PT_MAT_SUBSURFACE || disney_has_bssrdf(s.materials[mi])) && (sflags & BSDF_TRANSMISSION)) {
@@ -285,14 +286,14 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)
-    if constexpr (MAXL == 5) if (job.probe_next) lq_push(s_qprobe, pid, push_probe);
+    if constexpr (SSS) if (job.probe_next) lq_push(s_qprobe, pid, push_probe);
     if constexpr (MODE == 3) lq_push(s_qself, pid, push_self);
     __syncthreads();
     lq_flush_nosync(s_qext, job.ext_next_count, job.ext_next, 256u, false);
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 256u, false);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 256u, false);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 256u, false);
-    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
+    if constexpr (SSS) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 256u, false);
     if constexpr (MODE == 3) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 256u, false);
     __syncthreads();
     }  // persistent loop over the queue
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
     lq_flush_nosync(s_qres, job.shade_next0_count, job.shade_next0, 0u, true);
     lq_flush_nosync(s_qsh, job.shadow_count, job.shadow, 0u, true);
     lq_flush_nosync(s_qmis, job.mis_count, job.mis, 0u, true);
-    if constexpr (MAXL == 5) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
+    if constexpr (SSS) if (job.probe_next) lq_flush_nosync(s_qprobe, job.probe_next_count, job.probe_next, 0u, true);
     if constexpr (MODE == 3) lq_flush_nosync(s_qself, job.self_next_count, job.self_next, 0u, true);
     __syncthreads();
     __syncthreads();   // s_hist complete

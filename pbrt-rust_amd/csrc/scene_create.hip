@@ -349,6 +349,9 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         sc->class1_metal_only = sc->class_used[1];
         sc->class2_plastic_like = sc->class_used[2];
         sc->class3_uber_only = sc->class_used[3];
+        sc->class3_sss_smooth = sc->class_used[3];
+        for (uint32_t i = 0; i < d->n_materials; ++i) { const PtMaterial &m = d->materials[i];
+            if (mc[i] == 3 && !(m.type == PT_MAT_SUBSURFACE && m.u_roughness == 0.0f && m.v_roughness == 0.0f && m.tex[PT_MP_U_ROUGHNESS] < 0 && m.tex[PT_MP_V_ROUGHNESS] < 0)) sc->class3_sss_smooth = false; }
         for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 3 && d->materials[i].type != PT_MAT_UBER) sc->class3_uber_only = false;
         for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 2 && d->materials[i].type != PT_MAT_PLASTIC && d->materials[i].type != PT_MAT_UBER) sc->class2_plastic_like = false;
         for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 1 && d->materials[i].type != PT_MAT_METAL) sc->class1_metal_only = false;

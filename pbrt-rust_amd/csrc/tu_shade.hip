@@ -10,8 +10,8 @@ PT_INST_SHADE(1, PT_TU_MODE, 1) PT_INST_SHADE(1, PT_TU_MODE, 0)
 #if PT_TU_MODE != 3   // (the volumetric integrator has no specular-only class: it estimates direct light at every vertex)
 PT_INST_SHADE(1, PT_TU_MODE, 2)
 #endif
-#if PT_TU_MODE < 2     // class 1 of scenes whose one-lobe materials are all metals
-PT_INST_SHADE(1, PT_TU_MODE, 3)
+#if PT_TU_MODE < 2     // class 1 of scenes whose one-lobe materials are all metals; class 3 of scenes whose many-lobe materials are all smooth subsurface materials
+PT_INST_SHADE(1, PT_TU_MODE, 3) PT_INST_SHADE(1, PT_TU_MODE, 6)
 #endif
 #else
 PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, 0)

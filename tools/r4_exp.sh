@@ -71,6 +71,10 @@ metal)
 p2)
   one c3_default --config C3 --spp 256 --steps 1 --warmup 1
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/p2w3 one c3_p2w3 --config C3 --spp 256 --steps 1 --warmup 1 ;;
+sss)
+  one c5_spec --config C5 --spp 216 --steps 2 --warmup 1
+  PT_METAL_KERNEL=0 one c5_general --config C5 --spp 216 --steps 2 --warmup 1
+  timeout -k 10 800 python -m pytest tests/test_gpu_parity.py tests/test_configs.py tests/test_golden.py -m gpu -x -q -k 'subsurface or c5 or probe or golden' 2>&1 | tail -3 ;;
 v5w)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
