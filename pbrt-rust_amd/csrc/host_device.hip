@@ -21,7 +21,7 @@ bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one 
 bool g_trace_exact = false;                        // pt_set_trace_exact / env PT_TRACE_EXACT=1: walk the two-wide records, PtCounters.bvh_nodes_visited is then the reference's count
 bool g_metal_kernel = true;                        // env PT_METAL_KERNEL=0: class 1 always runs the general one-lobe kernel
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
-uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU = 7 per SIMD: k_trace<*, 0> needs 71 VGPRs and 5 KB of LDS per wave (env PT_TRACE_WAVES_PER_CU; 20 -> 24: +1 %, 24 -> 28: +3 %)
+uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU the grid (and the per-wave HBM stack slab) is sized for: 7 per SIMD, what the exact walk of triangle-only scenes fits; the production walk fits 5 (4 with instances) and its surplus blocks start as the first ones drain (env PT_TRACE_WAVES_PER_CU; 20 / 24 / 28: the same, profiles/r4/NOTES.md)
 thread_local SobolTables g_tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 DevCtx g_ctx[kMaxDevices];
 std::mutex g_ctx_mutex;

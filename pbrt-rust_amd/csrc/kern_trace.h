@@ -19,12 +19,13 @@
 // ("if-if"); lanes at a leaf join once a quorum of them waits. Instance entry / exit is a step of its own (ST_INST / ST_RET).
 
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 7   // waves per SIMD the triangle-only traversal kernels are compiled for (experiment hook: tools/build_variant.sh -DPT_TRACE_WAVES=N).
+#define PT_TRACE_WAVES 6   // waves per SIMD the triangle-only kernels of the EXACT walk are compiled for (round 4: six, 80 VGPRs without scratch -- the walk serves the counter
+                           // comparisons now, its seventh wave cost 12-20 B of scratch once the shared code grew). History of the knob (rounds 2-3, when this was the production kernel):
                            // Round 2: 71 VGPRs without scratch, and with a 10-entry LDS stack (kernels.h) seven workgroups share a CU's LDS: trace -3 %, camera
                            // rays -6 % against six waves; eight waves need 64 VGPRs = 24 bytes of scratch per lane and lose 9 %. The loop waits on its gathers.
 #endif
 #ifndef PT_TRACE_WAVES_INST
-#define PT_TRACE_WAVES_INST 5   // triangles + instances (MODE 3): 89 VGPRs. Six waves (-DPT_TRACE_WAVES_INST=6 -DPT_LDS_STACK_GENERAL=10: 80 VGPRs + 52 B of scratch per
+#define PT_TRACE_WAVES_INST 4   // exact walk, triangles + instances (MODE 3): four since round 4 (no scratch; it serves the counter comparisons). Rounds 2-3 ran five at 89 VGPRs. Six waves (-DPT_TRACE_WAVES_INST=6 -DPT_LDS_STACK_GENERAL=10: 80 VGPRs + 52 B of scratch per
                                 // lane, 161 KB of LDS per CU) measured on S4: mixed launches -2.4 %, camera rays +4 %, 94.0 -> 95.4 Msamples/s -- not worth the scratch
 #endif
 #ifndef PT_TRACE_ATTR
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     uint32_t state = ST_IDLE;
     bool exhausted = false;
 #ifndef PT_TRACE_CHUNK
-#define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
+#define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (round 4: 512 against 256: C2 trace 136.5 -> 135.1 ms, camera rays 36.1 -> 35.6; measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
                              // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
 #endif
     constexpr int kChunk = PT_TRACE_CHUNK;
