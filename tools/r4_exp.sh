@@ -75,6 +75,10 @@ sss)
   one c5_spec --config C5 --spp 216 --steps 2 --warmup 1
   PT_METAL_KERNEL=0 one c5_general --config C5 --spp 216 --steps 2 --warmup 1
   timeout -k 10 800 python -m pytest tests/test_gpu_parity.py tests/test_configs.py tests/test_golden.py -m gpu -x -q -k 'subsurface or c5 or probe or golden' 2>&1 | tail -3 ;;
+ab_old)
+  for i in 1 2; do one c2_new$i --config C2 --steps 3 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/oldblock one c2_old$i --config C2 --steps 3 --warmup 1; done
+  one c4_new --config C4 --spp 64 --steps 1 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/oldblock one c4_old --config C4 --spp 64 --steps 1 --warmup 1
+  one c3_new --config C3 --spp 256 --steps 1 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/oldblock one c3_old --config C3 --spp 256 --steps 1 --warmup 1 ;;
 v5w)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/q5w one c2_q5w --config C2 --steps 3 --warmup 1 ;;
 variants)
