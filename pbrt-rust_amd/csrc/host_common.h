@@ -37,7 +37,7 @@ extern bool g_refill_from_env;
 extern bool g_trace_split;
 extern bool g_trace_exact;
 extern uint32_t g_inst_quorum;
-extern bool g_metal_kernel;
+extern bool g_shade_specialise;
 extern uint32_t g_trace_waves_per_cu;
 extern thread_local SobolTables g_tabs;
 constexpr int kMaxDevices = kMaxReplicas;

@@ -521,10 +521,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             }
             else if (c == 0) launch_shade<1, 1>(sc, rc, grid, sj, class_n[c]);
             else if (c == kSpecClass) launch_shade<1, 2>(sc, rc, grid, sj, class_n[c]);
-            else if (c == 1) { if (sc->class1_metal_only && g_metal_kernel) launch_shade<1, 3>(sc, rc, grid, sj, class_n[c]); else launch_shade<1>(sc, rc, grid, sj, class_n[c]); }
-            else if (c == 2) { if (sc->class2_plastic_like && g_metal_kernel) launch_shade<2, 4>(sc, rc, grid, sj, class_n[c]); else launch_shade<2>(sc, rc, grid, sj, class_n[c]); }
-            else if (sc->class3_sss_smooth && g_metal_kernel && !rc.volpath && sc->ds.n_textures == 0) launch_shade<1, 6>(sc, rc, grid, sj, class_n[c]);   // (the form exists for the untextured path integrator)
-            else if (sc->class3_uber_only && g_metal_kernel) launch_shade<5, 5>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 1) { if (sc->class1_metal_only && g_shade_specialise) launch_shade<1, 3>(sc, rc, grid, sj, class_n[c]); else launch_shade<1>(sc, rc, grid, sj, class_n[c]); }
+            else if (c == 2) { if (sc->class2_plastic_like && g_shade_specialise) launch_shade<2, 4>(sc, rc, grid, sj, class_n[c]); else launch_shade<2>(sc, rc, grid, sj, class_n[c]); }
+            else if (sc->class3_sss_smooth && g_shade_specialise && !rc.volpath && sc->ds.n_textures == 0) launch_shade<1, 6>(sc, rc, grid, sj, class_n[c]);   // (the form exists for the untextured path integrator)
+            else if (sc->class3_uber_only && g_shade_specialise) launch_shade<5, 5>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
             sc->end();
         }

@@ -109,7 +109,7 @@ def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
 def test_lobe_set_specialised_kernels_are_chosen_per_scene_and_change_nothing(pkg, gpu, oracle, tmp_path):
     """Round 4: a scene whose one-lobe materials are all metals, whose two-lobe materials are all plastic-like and whose many-lobe materials are all ubers
     (the C3 palette) is shaded by k_shade<1, 0, 3> / <2, 0, 4> / <5, 0, 5>; one substrate, one rough glass or one translucent material in the scene brings
-    the general kernel of that class back (the zoo). Either way GPU == oracle, and PT_METAL_KERNEL=0 (general kernels everywhere, a process of its own:
+    the general kernel of that class back (the zoo). Either way GPU == oracle, and PT_SHADE_SPECIALISE=0 (general kernels everywhere, a process of its own:
     pt_init reads it) renders the same film."""
     sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
@@ -138,7 +138,7 @@ g = pkg.Scene(lib, sd); film = g.render(rp)
 assert all("k_shade<1, 0, 0>" == s["kernel"] for s in g.kernel_stats() if s["launches"] and s["name"] == "shade_1lobe")
 np.save({out!r}, film)
 """.format(root=ROOT, out=str(tmp_path / "general.npy"))
-    r = subprocess.run([sys.executable, "-c", code], env=trace_env(dict(os.environ, PT_METAL_KERNEL="0")), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=trace_env(dict(os.environ, PT_SHADE_SPECIALISE="0")), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     other = np.load(tmp_path / "general.npy")
     assert np.array_equal(film[..., 3], other[..., 3])

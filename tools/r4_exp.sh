@@ -65,7 +65,7 @@ knobs4)
   for r in 4 12 16; do PT_TRACE_REFILL_MIN=$r one c4_rf$r --config C4 --spp 64 --steps 1 --warmup 1; done ;;
 metal)
   one c3_metal3 --config C3 --spp 256 --steps 1 --warmup 1
-  PT_METAL_KERNEL=0 one c3_general --config C3 --spp 256 --steps 1 --warmup 1
+  PT_SHADE_SPECIALISE=0 one c3_general --config C3 --spp 256 --steps 1 --warmup 1
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/metal2 one c3_metal2 --config C3 --spp 256 --steps 1 --warmup 1
   timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_configs.py tests/test_wavefront_schedule.py -m gpu -x -q -k 'zoo or c3 or specular' 2>&1 | tail -3 ;;
 p2)
@@ -73,7 +73,7 @@ p2)
   PT_LIB_PATH=pbrt-rust_amd/csrc/variants/p2w3 one c3_p2w3 --config C3 --spp 256 --steps 1 --warmup 1 ;;
 sss)
   one c5_spec --config C5 --spp 216 --steps 2 --warmup 1
-  PT_METAL_KERNEL=0 one c5_general --config C5 --spp 216 --steps 2 --warmup 1
+  PT_SHADE_SPECIALISE=0 one c5_general --config C5 --spp 216 --steps 2 --warmup 1
   timeout -k 10 800 python -m pytest tests/test_gpu_parity.py tests/test_configs.py tests/test_golden.py -m gpu -x -q -k 'subsurface or c5 or probe or golden' 2>&1 | tail -3 ;;
 ab_old)
   for i in 1 2; do one c2_new$i --config C2 --steps 3 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/oldblock one c2_old$i --config C2 --steps 3 --warmup 1; done
