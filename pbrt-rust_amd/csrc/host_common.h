@@ -91,7 +91,8 @@ struct pt_scene {
     LightGrid grid[5]{}; bool grid_ready[5] = {false, false, false, false, false};   // by PtLightStrategy; PT_LS_SPATIAL itself resolves to _EAGER or _LAZY
     // PT_LS_SPATIAL_LAZY: voxels are filled when a vertex first needs them (lightdistrib.rs:233-337), once per wavefront iteration
     struct LazyGrid { unsigned long long *cell_ptr = nullptr; float *zero_block = nullptr; uint32_t *req_flag = nullptr, *req_list = nullptr, *req_count = nullptr, *missing = nullptr;
-                      size_t ncell = 0, stride = 0; uint64_t filled = 0; } lazy;
+                      size_t ncell = 0, stride = 0; uint64_t filled = 0;
+                      float *arena = nullptr; size_t arena_left = 0; } lazy;   // (arena: the blocks of newly touched voxels are carved from 64 MB slabs, not allocated one fill at a time)
     // render workspace
     hipStream_t stream = nullptr;
     void *slab = nullptr; size_t capacity = 0; PathSoA ps{};

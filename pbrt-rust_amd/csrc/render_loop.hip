@@ -315,8 +315,16 @@ int lazy_light_fill(pt_scene *sc, const LightGrid &grid) {
     const size_t per_batch = std::max<size_t>(1, std::min<size_t>(((size_t)1 << 31) / std::max(1u, nl), ((size_t)1 << 28) / z.stride));
     for (size_t first = 0; first < n_new; first += per_batch) {
         const size_t n = std::min<size_t>(per_batch, n_new - first);
-        float *blocks = nullptr; int st;
-        if ((st = sc->dalloc(&blocks, n * z.stride))) return st;
+        // blocks live as long as the scene (their addresses are published in cell_ptr): carved from slabs of >= 64 MB, so that a long render that keeps
+        // touching a few new voxels per iteration makes a handful of allocations instead of one per iteration
+        const size_t need = n * z.stride;
+        if (need > z.arena_left) {
+            const size_t slab = std::max<size_t>(need, (size_t)16 << 20);   // floats
+            int st;
+            if ((st = sc->dalloc(&z.arena, slab))) return st;
+            z.arena_left = slab;
+        }
+        float *blocks = z.arena; z.arena += need; z.arena_left -= need;
         const size_t total = n * nl;
         sc->begin("light_grid", total); sc->set_kernel("k_light_grid_contrib");
         hipLaunchKernelGGL(k_light_grid_contrib, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sc->stream, sc->ds, grid.nvox[0], grid.nvox[1], grid.nvox[2], blocks, (const uint32_t *)(z.req_list + first), n, z.stride);
