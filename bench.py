@@ -35,7 +35,7 @@ from code_hash import code_hash   # noqa: E402  (hash of the device library's so
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 GATHER_CEILING_GREQ_S = 54.0  # profiles/r2_gather_calibration.json: dependent random 64-byte gathers, 128-byte fabric requests per ns, whole chip
 TRACE_KINDS = ("trace", "extend", "extend_mis", "shadow", "extend_camera", "extend_probe")   # "trace" = the mixed launch: continuation + MIS + shadow rays of one wavefront iteration
-OTHER_CONFIG_SPP = {"C3": 256, "C4": 256, "C5": 216}   # one step each after the headline, ONE pass of the size the library picks for the config at its named spp
+OTHER_CONFIG_SPP = {"C3": 1024, "C4": 256, "C5": 216}   # one step each after the headline: C3 (a 1-GPU config in BASELINE.json) as its WHOLE job (1024 spp = four passes); C4 / C5 (8-GPU configs) ONE pass of the size the library picks at their named spp
                                                      # (so the rate is the named-spp rate and the committed PMC profile applies): C3 1.4 s, C4 5.6 s, C5 0.4 s of render per step
 
 
@@ -428,7 +428,7 @@ def main():
             except Exception as e:   # the headline line must not be lost to a side measurement
                 oc[cfg] = dict(error=f"{type(e).__name__}: {e}")
         out["other_configs"] = oc
-        out["other_configs_note"] = "one timed step after one warm-up, each step = one wavefront pass of the size the library picks at the config's named spp (the per-sample cost does not depend on the spp beyond the pass size); the value is Msamples/s of that step"
+        out["other_configs_note"] = "one timed step after one warm-up; C3: the whole job at its named 1024 spp; C4 / C5: one wavefront pass of the size the library picks at the config's named spp (the per-sample cost does not depend on the spp beyond the pass size), with scaling_projection = rank 0's shard of the whole 8-GPU job; the value is Msamples/s of that step"
     if out is not None:
         print(json.dumps(out))
     if dist is not None:
