@@ -82,7 +82,35 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     __shared__ uint32_t lds_kcnt[MIX ? (kTraceBlock / 64) * 16 : 1];   // MIX: per wave {nodes, tris, rays} x 3 subs
     uint32_t *kcnt = lds_kcnt + (MIX ? (threadIdx.x >> 6) * 16 : 0u);
     if (MIX && lane_id() < 16u) kcnt[lane_id()] = 0u;
-#define PT_SUB(f) (MIX ? (ksel == 0u ? job.sub[0].f : (ksel == 1u ? job.sub[1].f : job.sub[2].f)) : job.sub[0].f)
+    // MIX: what a lane needs of ITS ray kind when it retires / refills -- queue, ray records, output arrays, strides -- sits in an LDS table of three
+    // rows (five quads each, row stride 20 words: the three rows' quads fall into different banks) and is fetched with the lane's `ksel` as the row:
+    // two ds_read_b128 per refill, three per retire. Chosen per lane out of the kernel arguments it was 26 + 47 selects, and the 60 scalars of the
+    // three TraceSubs overflowed the SGPR file (123 v_readlane / 45 v_writelane in the kernel, 69 of them in this block).
+    //   quad 0: queue, ray   quad 1: ray_stride, per_ray_tmax | any << 1, scalar_tmax, first queue index of the kind
+    //   quad 2: out_hit, out_hit2   quad 3: out_word, out_t   quad 4: out_hit_stride, out_word_stride, out_t_stride, -
+    constexpr int kSubRow = 20;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_sub[MIX ? 3 * kSubRow : 4];
+    if constexpr (MIX) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const TraceSub &S = job.sub[k];
+                uint32_t *r = lds_sub + k * kSubRow;
+                const unsigned long long pq = (unsigned long long)S.queue, pr = (unsigned long long)S.ray, ph = (unsigned long long)S.out_hit, ph2 = (unsigned long long)S.out_hit2,
+                                         pw = (unsigned long long)S.out_word, pt = (unsigned long long)S.out_t;
+                r[0] = (uint32_t)pq; r[1] = (uint32_t)(pq >> 32); r[2] = (uint32_t)pr; r[3] = (uint32_t)(pr >> 32);
+                r[4] = S.ray_stride; r[5] = (S.per_ray_tmax ? 1u : 0u) | (S.any ? 2u : 0u); r[6] = __float_as_uint(S.scalar_tmax); r[7] = k == 0 ? 0u : (k == 1 ? c0 : c01);
+                r[8] = (uint32_t)ph; r[9] = (uint32_t)(ph >> 32); r[10] = (uint32_t)ph2; r[11] = (uint32_t)(ph2 >> 32);
+                r[12] = (uint32_t)pw; r[13] = (uint32_t)(pw >> 32); r[14] = (uint32_t)pt; r[15] = (uint32_t)(pt >> 32);
+                r[16] = S.out_hit_stride; r[17] = S.out_word_stride; r[18] = S.out_t_stride; r[19] = 0u;
+            }
+        }
+        __syncthreads();
+    }
+    const uint4 *const sub_rows = reinterpret_cast<const uint4 *>(lds_sub);
+    // (pointers rebuilt from table words are GLOBAL pointers: left generic they become flat loads / stores, which wait on both memory counters)
+#define PT_GPTR(T, lo, hi) ((__attribute__((address_space(1))) T *)(((unsigned long long)(hi) << 32) | (unsigned long long)(lo)))
+#define PT_SUB(f) (job.sub[0].f)   // the launches of ONE ray kind (the mixed launch reads its lane's row of lds_sub instead)
     const uint4 *wide4 = reinterpret_cast<const uint4 *>(s.wide);
     // QUAD: records and packets live in ONE allocation, addressed by 32-bit byte offsets from its start through a buffer resource
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -116,6 +144,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #endif
     constexpr int kChunk = PT_TRACE_CHUNK;
     uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
+    uint32_t qwin = 0u, win_base = 0xffffffffu;   // the prefetched queue window (per lane) and the queue index it starts at (wave-uniform); see the refill block
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
     V3 ro, rd, inv_dir;
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
@@ -270,25 +299,37 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     }
                 }
             }
-            if (retire) {
-                float4 *const o_hit = PT_SUB(out_hit), *const o_hit2 = PT_SUB(out_hit2); uint32_t *const o_word = PT_SUB(out_word); float *const o_t = PT_SUB(out_t);
-                const uint32_t o_hit_stride = PT_SUB(out_hit_stride), o_word_stride = PT_SUB(out_word_stride), o_t_stride = PT_SUB(out_t_stride);
-                if (lane_any) o_word[(size_t)pid * o_word_stride] = hit_pkt != PT_NONE ? 1u : 0u;   // (an any-hit ray records the packet that stopped it)
-                else {
-                    uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
-                    if (hit_pkt != PT_NONE) { hit_prim = s.leaf[hit_pkt].prim; hit_fl = s.leaf[hit_pkt].flags; }
-                    if (o_hit) o_hit[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(hit_prim), hb0, hb1, hb2);   // one quad
-                    else o_word[(size_t)pid * o_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
-                    // (triangle-only scenes: the closest hit's t IS the ray's t_max -- one register less in the loop; inside instances t_max is an object-space value)
-                    const float t_out = (INST || PROBE) ? hit_t : (hit_pkt != PT_NONE ? t_max : 0.0f);
-                    if (o_hit2) o_hit2[(size_t)pid * o_hit_stride] = make_float4(__uint_as_float(INST ? hit_inst : PT_NONE), t_out, __uint_as_float(hit_pkt), __uint_as_float(hit_fl));
-                    if (o_t) o_t[(size_t)pid * o_t_stride] = t_out;
-                }
-                if constexpr (MIX) {   // per-kind work counters (LDS atomics of the wave's own slots)
-                    atomicAdd(&kcnt[3u * ksel], n_nodes); atomicAdd(&kcnt[3u * ksel + 1u], n_tris); atomicAdd(&kcnt[3u * ksel + 2u], 1u);   // (MIX: n_nodes / n_tris count the lane's current ray only)
-                }
-            }
+            // The block is ordered for ONE memory round trip: (A) the retiring lanes request the two words of their hit's packet, (B) the lanes to be refilled take
+            // their path ids out of the wave's prefetched queue window and request their ray records, (C) the retiring lanes store their hit records, (D) the new rays
+            // are unpacked, (E) the window behind the entries just taken is requested for the next refill. Until round 4's second half the wave stood still for three
+            // dependent round trips here (packet words -> stores; queue entry -> ray record), once per ~4 record steps.
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) v4f_ gf4; typedef __attribute__((address_space(1))) uint32_t gu32; typedef __attribute__((address_space(1))) float gf32;
+            typedef __attribute__((address_space(1))) const uint32_t gcu32; typedef __attribute__((address_space(1))) const v4f_ gcf4;
+            // (A)
+            uint32_t hit_prim = PT_NONE, hit_fl = (uint32_t)kMissClass << kTpClassShift;
+            if (retire && !lane_any && hit_pkt != PT_NONE) { hit_prim = s.leaf[hit_pkt].prim; hit_fl = s.leaf[hit_pkt].flags; }
+            const uint32_t r_pid = pid, r_ksel = ksel, r_pkt = hit_pkt, r_inst = hit_inst, r_nn = n_nodes, r_nt = n_tris; const bool r_any = lane_any;
+            const float r_b0 = hb0, r_b1 = hb1, r_b2 = hb2;
+            // (triangle-only scenes: the closest hit's t IS the ray's t_max -- one register less in the loop; inside instances t_max is an object-space value)
+            const float r_t = (INST || PROBE) ? hit_t : (hit_pkt != PT_NONE ? t_max : 0.0f);
             if (retire) state = ST_IDLE;
+            // (B)
+            bool get = false; v4f_ rr0 = {0.0f, 0.0f, 0.0f, 0.0f}, rr1 = rr0; bool per_ray_tmax = PT_SUB(per_ray_tmax) != 0u; float scalar_tmax = PT_SUB(scalar_tmax);
+            // the wave's queue window: lane l holds the path id of queue entry win_base + l
+            auto load_window = [&](uint32_t base, uint32_t left) {
+                const uint32_t qi = base + lane; uint32_t w = 0u;
+                if (lane < left) {
+                    uint32_t qk = qi; gcu32 *qp = (gcu32 *)PT_SUB(queue);
+                    if constexpr (MIX) {
+                        const uint32_t kk = (qi >= c0 ? 1u : 0u) + (qi >= c01 ? 1u : 0u);
+                        const uint4 r0 = sub_rows[5u * kk], r1 = sub_rows[5u * kk + 1u];
+                        qp = PT_GPTR(const uint32_t, r0.x, r0.y); qk = qi - r1.w;
+                    }
+                    w = qp ? qp[qk] : qk;   // (the loaded word as it is: anything computed from it here would make the wave wait for the prefetch)
+                }
+                return w;
+            };
             if (!exhausted) {
                 // work fetch: the wave reserves kChunk consecutive queue entries with one atomic and hands them
                 // out over several refills (consecutive entries are spatially coherent rays)
@@ -299,41 +340,78 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     chunk_left = (chunk_next < count) ? min((uint32_t)kChunk, count - chunk_next) : 0u;
                     if (chunk_left == 0) exhausted = true;
                 }
+                if (chunk_left != 0u && win_base != chunk_next) { qwin = load_window(chunk_next, chunk_left); win_base = chunk_next; }   // a fresh chunk: not prefetched (once per kChunk rays)
                 // PROBE: lanes that went on to their chain's next segment are in `donem` but not idle any more
                 const unsigned long long idlem = PROBE ? __ballot(state == ST_IDLE) : donem;
-                const uint32_t rank = (uint32_t)__popcll(idlem & ((1ull << lane) - 1ull));
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idlem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idlem, 0u));   // set bits below this lane (v_mbcnt: no per-lane mask registers)
                 const uint32_t take = min(chunk_left, (uint32_t)__popcll(idlem));
+                const uint32_t wsel = (uint32_t)__shfl((int)qwin, (int)(rank & 63u));   // entry chunk_next + rank (the window starts at chunk_next)
                 const uint32_t qi = chunk_next + rank;
-                const bool get = state == ST_IDLE && rank < take;
+                get = state == ST_IDLE && rank < take;
                 chunk_next += take; chunk_left -= take;
                 if (get) {
-                    uint32_t qk = qi;
+                    gcf4 *rays = (gcf4 *)PT_SUB(ray); uint32_t ray_stride = PT_SUB(ray_stride);
+                    pid = wsel;
                     if constexpr (MIX) {
                         ksel = (qi >= c0 ? 1u : 0u) + (qi >= c01 ? 1u : 0u);
-                        qk = qi - (ksel == 0u ? 0u : (ksel == 1u ? c0 : c01));
-                        lane_any = PT_SUB(any) != 0u;
-                        n_nodes = 0u; n_tris = 0u;
+                        const uint4 r0 = sub_rows[5u * ksel], r1 = sub_rows[5u * ksel + 1u];
+                        rays = PT_GPTR(const v4f_, r0.z, r0.w);
+                        ray_stride = r1.x; per_ray_tmax = (r1.y & 1u) != 0u; lane_any = (r1.y & 2u) != 0u; scalar_tmax = __uint_as_float(r1.z);
                     }
-                    const uint32_t *const qp = PT_SUB(queue);
-                    pid = qp ? qp[qk] : qk;
-                    const float4 *const rp = PT_SUB(ray) + (size_t)pid * PT_SUB(ray_stride);
+                    gcf4 *const rp = rays + (size_t)pid * ray_stride;
                     // (measured round 4 and dropped: requesting the record here and unpacking it after this iteration's record step, so that the wave's busy
                     //  lanes do not stand still for the round trip -- every refilled lane then starts one iteration later: node-step occupancy 80 -> 75 %,
                     //  C2 trace 134 -> 147 ms)
-                    const float4 r0 = rp[0], r1 = rp[1];   // one 32-byte record
-                    ro = V3(r0.x, r0.y, r0.z);
-                    rd = V3(r0.w, r1.x, r1.y);
-                    t_max = PT_SUB(per_ray_tmax) ? r1.z : PT_SUB(scalar_tmax);
-                    inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
-                    PT_TRI_RAY();
-                    sp = 0; pending = 0;
-                    hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
-                    in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
-                    if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; cur_med = PT_NONE; }
-                    n_rays++;
-                    state = ST_DONE;
-                    if (s.n_nodes > 0) {  // the root node's own test (bvh.rs:725-727)
+                    rr0 = rp[0]; rr1 = rp[1];   // one 32-byte record
+                }
+            }
+            // (every lane consumes what (A) and (B) requested, here, once: consumed only inside the conditional blocks below, the loads stay "possibly pending" on the
+            //  paths around those blocks as far as the compiler's wait-count bookkeeping can tell, and it then waits for EVERYTHING -- the prefetch of (E) included --
+            //  at the first reuse of one of their registers in the record step)
+            asm volatile("" :: "v"(hit_prim), "v"(hit_fl), "v"(rr0), "v"(rr1));
+            // (C)
+            if (retire) {
+                gf4 *o_hit = (gf4 *)PT_SUB(out_hit), *o_hit2 = (gf4 *)PT_SUB(out_hit2); gu32 *o_word = (gu32 *)PT_SUB(out_word); gf32 *o_t = (gf32 *)PT_SUB(out_t);
+                uint32_t o_hit_stride = PT_SUB(out_hit_stride), o_word_stride = PT_SUB(out_word_stride), o_t_stride = PT_SUB(out_t_stride);
+                if constexpr (MIX) {
+                    const uint4 r2 = sub_rows[5u * r_ksel + 2u], r3 = sub_rows[5u * r_ksel + 3u], r4 = sub_rows[5u * r_ksel + 4u];
+                    o_hit = PT_GPTR(v4f_, r2.x, r2.y); o_hit2 = PT_GPTR(v4f_, r2.z, r2.w); o_word = PT_GPTR(uint32_t, r3.x, r3.y); o_t = PT_GPTR(float, r3.z, r3.w);
+                    o_hit_stride = r4.x; o_word_stride = r4.y; o_t_stride = r4.z;
+                }
+                if (r_any) o_word[(size_t)r_pid * o_word_stride] = r_pkt != PT_NONE ? 1u : 0u;   // (an any-hit ray records the packet that stopped it)
+                else {
+                    if (o_hit) o_hit[(size_t)r_pid * o_hit_stride] = v4f_{__uint_as_float(hit_prim), r_b0, r_b1, r_b2};   // one quad
+                    else o_word[(size_t)r_pid * o_word_stride] = hit_prim;   // only the hit / miss matters (volpath shadow rays)
+                    if (o_hit2) o_hit2[(size_t)r_pid * o_hit_stride] = v4f_{__uint_as_float(INST ? r_inst : PT_NONE), r_t, __uint_as_float(r_pkt), __uint_as_float(hit_fl)};
+                    if (o_t) o_t[(size_t)r_pid * o_t_stride] = r_t;
+                }
+                if constexpr (MIX) {   // per-kind work counters (LDS atomics of the wave's own slots)
+                    atomicAdd(&kcnt[3u * r_ksel], r_nn); atomicAdd(&kcnt[3u * r_ksel + 1u], r_nt); atomicAdd(&kcnt[3u * r_ksel + 2u], 1u);   // (MIX: n_nodes / n_tris count the lane's current ray only)
+                }
+            }
+            // (D)
+            if (get) {
+                if constexpr (MIX) { n_nodes = 0u; n_tris = 0u; }
+                ro = V3(rr0.x, rr0.y, rr0.z);
+                rd = V3(rr0.w, rr1.x, rr1.y);
+                t_max = per_ray_tmax ? rr1.z : scalar_tmax;
+                inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
+                PT_TRI_RAY();
+                sp = 0; pending = 0;
+                hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
+                in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
+                if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; cur_med = PT_NONE; }
+                n_rays++;
+                state = ST_DONE;
+                if (s.n_nodes > 0) {
+                    if (QUAD && !(root_ref & kLeafBit)) {
+                        // The production walk enters an interior root without the root's own slab test (bvh.rs:725-727): a ray that misses the root's box misses
+                        // the boxes of the root record's four slots (they lie inside it and the slab arithmetic is monotone in the planes -- the argument that
+                        // lets the walk skip the collapsed L and R), so it reaches no leaf either way; ~50 vector instructions per ray that only rays starting
+                        // outside the scene's bounds and pointing away ever needed. (The exact walk counts the test as the reference does.)
+                        cur = root_ref & kRefMask; state = ST_ENTER;
+                    } else {   // the root node's own test (bvh.rs:725-727)
                         n_nodes++;
                         if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
                             cur = root_ref & kRefMask;
@@ -342,6 +420,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     }
                 }
             }
+            // (E) (a coalesced 256-byte read per refill; it has the record steps until the next refill to arrive)
+            if (!exhausted) { if (chunk_left != 0u) { qwin = load_window(chunk_next, chunk_left); win_base = chunk_next; } else win_base = 0xffffffffu; }   // (a drained chunk: the next one may start right where this one ended)
         }
         if (__ballot(state != ST_IDLE) == 0ull) break;   // queue drained and every lane retired
 
@@ -640,6 +720,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #endif
 }
 #undef PT_SUB
+#undef PT_GPTR
 #undef PT_UTIL
 #undef PT_UTIL_MARK
 #undef PT_SGN3
