@@ -163,15 +163,24 @@ PT_DEV void flush_paths(const GenStage &g, const PathSoA &ps, uint32_t pid0, uin
 }
 
 __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters) {
-    // LDS copies of what every lane needs: Sobol' rows of dimensions 0..4 and the two van-der-Corput matrices of m
-    __shared__ uint32_t s_rows[5 * 52];
-    __shared__ uint64_t s_vdc[2 * 52];
+    // LDS copies of what every lane needs, folded by NIBBLE of the word they are indexed with (the XORs of lowdiscrepancy.rs:512-569 regrouped, as in the shade
+    // kernels' Sobol' windows): the generator matrices of dimensions 0..4 (SobolTables::nib) and the two van-der-Corput matrices of m. A look-up per nibble
+    // replaces a count-trailing-zeros step per set bit -- the kernel issued vector instructions 99.7 % of its cycles, two thirds of them in those bit loops.
+    constexpr uint32_t kVdcNibbles = 13;   // 52 columns
+    __shared__ uint32_t s_nib[kSobolNibbles * 5 * 16];
+    __shared__ uint64_t s_vdc[2 * kVdcNibbles * 16];   // [M | MI][nibble][16]
     __shared__ LdsQueue<1024> s_q;
     __shared__ GenStage s_gen;
     lq_init(s_q);
     const uint32_t m = (uint32_t)rc.sobol.log2_resolution;
-    for (uint32_t i = threadIdx.x; i < 5 * 52; i += blockDim.x) s_rows[i] = tabs.m32[i];
-    if (m > 0) for (uint32_t i = threadIdx.x; i < 2 * 52; i += blockDim.x) s_vdc[i] = (i < 52) ? tabs.vdc[(m - 1) * 52 + i] : tabs.vdc_inv[(m - 1) * 52 + (i - 52)];
+    sobol_stage_lds(s_nib, tabs.nib, 5u, threadIdx.x, blockDim.x);
+    if (m > 0) for (uint32_t i = threadIdx.x; i < 2 * kVdcNibbles * 16; i += blockDim.x) {
+        const uint32_t which = i / (kVdcNibbles * 16), e = i - which * (kVdcNibbles * 16), j = e >> 4, n = e & 15u;
+        const uint64_t *col = (which ? tabs.vdc_inv : tabs.vdc) + (m - 1) * 52 + 4 * j;
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < 4; ++b) if (n & (1u << b)) v ^= col[b];
+        s_vdc[i] = v;
+    }
     __syncthreads();
     const uint32_t total = rc.n_pix_slots * rc.s_count;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -195,13 +204,18 @@ __global__ __launch_bounds__(256) void k_generate(RenderConst rc, SobolTables ta
                     stage_path(s_gen, threadIdx.x, pfx, pfy, o, d, index, rc.volpath ? rc.camera_medium : PT_NONE);
                     alive = true;
                 } else {
-                const uint64_t index = sobol_interval_to_index(s_vdc, s_vdc + 52, m, sample, (uint32_t)(px - rc.sobol.sb_min[0]), (uint32_t)(py - rc.sobol.sb_min[1]));
-                // get_camera_sample (sampler.rs:170-180): pfilm = get_2d, time = get_1d, plens = get_2d; one pass over the index bits
-                uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-                for (uint64_t a = index; a != 0; a &= a - 1) {
-                    const int i = __builtin_ctzll(a);
-                    v0 ^= s_rows[i]; v1 ^= s_rows[52 + i]; v2 ^= s_rows[104 + i]; v3 ^= s_rows[156 + i]; v4 ^= s_rows[208 + i];
+                // sobol_interval_to_index (lowdiscrepancy.rs:512-543) through the nibble tables
+                uint64_t index = 0;
+                if (m != 0) {
+                    index = sample << (m << 1);
+                    uint64_t delta = 0;
+                    for (uint64_t f = sample, j = 0; f != 0; f >>= 4, ++j) delta ^= s_vdc[j * 16 + (f & 15u)];
+                    uint64_t b = ((uint64_t)((uint32_t)(px - rc.sobol.sb_min[0]) << m) | (uint64_t)(uint32_t)(py - rc.sobol.sb_min[1])) ^ delta;
+                    for (uint32_t j = 0; b != 0; b >>= 4, ++j) index ^= s_vdc[kVdcNibbles * 16 + j * 16 + (b & 15u)];
                 }
+                // get_camera_sample (sampler.rs:170-180): pfilm = get_2d, time = get_1d, plens = get_2d
+                const uint32_t v0 = sobol_bits_nib(s_nib, 5u * 16u, tabs.m32, index), v1 = sobol_bits_nib(s_nib + 16, 5u * 16u, tabs.m32 + 52, index), v2 = sobol_bits_nib(s_nib + 32, 5u * 16u, tabs.m32 + 104, index),
+                               v3 = sobol_bits_nib(s_nib + 48, 5u * 16u, tabs.m32 + 156, index), v4 = sobol_bits_nib(s_nib + 64, 5u * 16u, tabs.m32 + 208, index);
                 // sobol.rs:77-81: film dimensions are remapped to the pixel
                 float fx = sobol_to_float(v0) * (float)rc.sobol.resolution + (float)rc.sobol.sb_min[0];
                 fx = clampf(fx - (float)px, 0.0f, kOneMinusEps);
