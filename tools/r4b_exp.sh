@@ -26,6 +26,8 @@ ab35:*) vs="tree,${what#ab35:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) o
 knobs)
   for r in 8,8,8,48 12,12,12,48 16,16,16,48 24,24,24,48 16,16,16,32 16,16,16,64; do PT_TRACE_REFILL_MIN=$r one c2_rf_$r --config C2 --steps 2 --warmup 1; done
   for r in 4 8 12; do PT_TRACE_REFILL_MIN=$r one c4_rf_$r --config C4 --spp 64 --steps 1 --warmup 1; done ;;
+c4v:*)  v=${what#c4v:}; one c4_tree --config C4 --spp 64 --steps 1 --warmup 1; PT_LIB_PATH=$(lib $v) one c4_$v --config C4 --spp 64 --steps 1 --warmup 1
+  for q in 6 8 12 24; do PT_TRACE_INST_QUORUM=$q PT_LIB_PATH=$(lib $v) one c4_${v}_iq$q --config C4 --spp 64 --steps 1 --warmup 1; done ;;
 quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
 quick) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 ;;
 full) timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ;;
