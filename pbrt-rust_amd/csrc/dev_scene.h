@@ -52,7 +52,6 @@ struct QuadNode {
 };
 static_assert(sizeof(QuadNode) == 128, "QuadNode is one 128-byte line");
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr uint32_t kInstLeafBit = 0x40000000u;   // four-wide records only: the leaf's first packet is an object instance (the walk skips the leaf step for it)
 constexpr uint32_t kRefMask = 0x01ffffffu;   // 25 bits: 33 M records / packets (stack entries pack 6 more bits above)
 
 // TransformedPrimitive (primitive.rs:40-88) on device: transforms + entry into the object's BVH

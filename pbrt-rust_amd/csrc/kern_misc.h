@@ -11,7 +11,7 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
     TriPacket p;
     if (prim & PT_TOP_INSTANCE) {
         p.x[0] = p.x[1] = p.x[2] = p.y[0] = p.y[1] = p.y[2] = p.z[0] = p.z[1] = p.z[2] = 0.0f;
-        p.prim = prim & ~PT_TOP_INSTANCE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;   // (prim: the instance index again, | bit 31 once the packet is known to end its leaf: the one word the transform step needs, kern_trace.h ST_INSTP)
+        p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
         out[i] = p;
         return;
     }
@@ -40,7 +40,7 @@ __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t
 // Mark the last packet of every leaf (offsets of the last primitive of each leaf, computed on the host).
 __global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { TriPacket &p = leaf[last_index[i]]; p.flags |= TP_LAST; if (p.flags & TP_INSTANCE) p.prim |= 0x80000000u; }
+    if (i < n) leaf[last_index[i]].flags |= TP_LAST;
 }
 
 __global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // DiffuseAreaLight::new -> shape.area(); DeviceScene::light_rec

@@ -63,11 +63,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
     constexpr int kLds = QUAD ? kLdsStackQuad : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
-    // RETV (the production walk in scenes with instances): a lane that has popped the marker of the instance it was in goes back to world space at the top of the next
-    // iteration, by itself -- what was derived from the world ray (reciprocal direction, the shear of the triangle test) stayed in five registers while the lane was inside
-    // the instance, so coming back is six LDS reads and a few selects, no division. In the two-wide walk the return is a lane state of the transform step (ST_RET: ~80
-    // instructions with five divisions, after waiting for that step's quorum). (Measured and dropped: the return inside pop_next, profiles/r4/NOTES.md.)
-    constexpr bool RETV = QUAD && MODE == 3;   // (the general-geometry kernels sit at 125-127 registers: five more would cost them a wave)
     constexpr int kMaxS = QUAD ? kMaxStackQuad : kMaxStack;   // deepest stack (the four-wide walk pushes up to three entries per record)
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * (kLds + 1) * 2 * 64];   // (+1: the scratch slot of `push`)
     __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
@@ -140,7 +135,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     // ST_INST (an instance packet at `cur` waits to be entered) and ST_RET (the instance's marker was popped, the world ray waits to
     // be restored) are the two transform steps of TransformedPrimitive (primitive.rs:58-88): ~200 instructions that only a few lanes
     // need in any one iteration, so they run in a step of their own once `inst_quorum` lanes wait for it (like leaves, below)
-    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5, ST_LEAFS = 6, ST_INSTP = 7 };   // ST_INSTP (four-wide walk): arrived at a leaf whose first packet is an instance -- becomes ST_INST at the top of the next iteration   // ST_LEAFS: at a leaf and being served (leaf_quorum below)
+    enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5, ST_LEAFS = 6 };   // ST_LEAFS: at a leaf and being served (leaf_quorum below)
     uint32_t state = ST_IDLE;
     bool exhausted = false;
 #ifndef PT_TRACE_CHUNK
@@ -155,8 +150,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     TriRay tray; tray.kz = 2; tray.Sx = tray.Sy = tray.Sz = 0.0f;   // per-ray half of the triangle test
     V3 rop;              // the ray origin permuted like the packet quads the lane loads (dev_scene.h: TriPacket)
     uint32_t lofs = 0;   // byte offsets of a packet's quads in the ray's order (kx, ky, kz): 16 kx | 16 ky << 8 | 16 kz << 16
-#define PT_TRI_RAY_REST() do { rop = tri_permute(ro, tray.kz); const uint32_t kz_ = (uint32_t)tray.kz, kx_ = kz_ == 2u ? 0u : kz_ + 1u, ky_ = kx_ == 2u ? 0u : kx_ + 1u; lofs = (kx_ << 4) | (ky_ << 12) | (kz_ << 20); } while (0)
-#define PT_TRI_RAY() do { tray = tri_ray_setup(rd); PT_TRI_RAY_REST(); } while (0)
+#define PT_TRI_RAY() do { tray = tri_ray_setup(rd); rop = tri_permute(ro, tray.kz); const uint32_t kz_ = (uint32_t)tray.kz, kx_ = kz_ == 2u ? 0u : kz_ + 1u, ky_ = kx_ == 2u ? 0u : kx_ + 1u; lofs = (kx_ << 4) | (ky_ << 12) | (kz_ << 20); } while (0)
     bool nx = false, ny = false, nz = false;
     uint32_t sgn3 = 0;   // QUAD: 3 x the ray's sign octant (nx | ny << 1 | nz << 2): the shift that finds the octant's slot order in a record's order word
 #define PT_SGN3() do { if (QUAD) sgn3 = 3u * ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u)); } while (0)
@@ -166,7 +160,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     uint32_t hit_pkt = PT_NONE; float hit_t = 0.0f, hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f;
     // instancing (primitive.rs:58-88): while inside an instance the lane's ray is the object-space ray
     uint32_t in_inst = PT_NONE, hit_inst = PT_NONE; float t_max_world = 0.0f; bool inst_hit = false;
-    V3 w_inv(0.0f, 0.0f, 0.0f); float w_sx = 0.0f, w_sy = 0.0f;   // RETV: inv_dir, tray.Sx, tray.Sy of the world ray of a lane that is inside an instance
     uint32_t xf_arg = 0;   // ST_INST: instance index | TP_LAST of its packet in bit 31; ST_RET: word 0 of the popped marker entry
     constexpr uint32_t kMarker = 0xFFC0DEADu;   // stack word 1 of an "end of instance" entry (never a real tmin)
     // PROBE: chain state of the lane. A chain with more than kProbeRing matches after the selected one is walked a second time
@@ -179,9 +172,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     uint32_t sv_nodes = 0, sv_tris = 0, sv_rays = 0, sv_sph = 0;
     uint4 *ring = PROBE ? job.ring + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * (kProbeRing * 3 * 64) + lane : nullptr;
 
-    // where a lane goes for a child reference: an interior record, a leaf's packets, or (four-wide records of instanced scenes) straight to the transform step when the
-    // leaf's first packet is an object instance -- the leaf step would only read that packet's flag word and hand the lane on
-    auto ref_state = [&](uint32_t ref) -> uint32_t { return (ref & kLeafBit) ? ((QUAD && INST && (ref & kInstLeafBit)) ? (uint32_t)ST_INSTP : (uint32_t)ST_LEAF) : (uint32_t)ST_ENTER; };
     // Pop entries until one passes its deferred `tmin < t_max` test (or the stack is empty).
     auto pop_next = [&]() {
         for (;;) {
@@ -201,7 +191,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
             if (!QUAD) { n_nodes++; pending = (w0 >> 25) & 63u; }   // the reference tests the popped node now
             if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
                 cur = w0 & kRefMask;
-                state = ref_state(w0);
+                state = (w0 & kLeafBit) ? ST_LEAF : ST_ENTER;
                 return;
             }
         }
@@ -219,24 +209,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     const uint32_t root_ref = QUAD ? s.root_ref4 : s.root_ref;
 
     for (;;) {
-        if constexpr (RETV) {
-            if (state == ST_RET) {   // back to world space (primitive.rs:70-77)
-                const uint32_t w0 = xf_arg;
-                ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
-                inv_dir = w_inv;
-                nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
-                tray.kz = max_dimension(vabs(rd)); tray.Sx = w_sx; tray.Sy = w_sy;
-                tray.Sz = tray.kz == 0 ? inv_dir.x : (tray.kz == 1 ? inv_dir.y : inv_dir.z);   // 1 / d[kz]: the very quotient inv_dir holds
-                PT_TRI_RAY_REST();
-                t_max = inst_hit ? t_max : t_max_world;   // r.t_max = ray.t_max only when the instance was hit
-                in_inst = PT_NONE; inst_hit = false;
-                if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; }   // remaining packets of the outer leaf
-                else pop_next();
-            }
-        }
-        if constexpr (QUAD && INST) {
-            if (state == ST_INSTP) { xf_arg = s.leaf[cur].prim; state = ST_INST; }   // instance index | the packet ends its leaf << 31 (k_build_packets / k_mark_leaf_ends); in flight until the transform step reads it
-        }
         // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
         //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
         //      paid once per batch instead of once per ray.
@@ -318,7 +290,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                             n_nodes++;
                             if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
                                 cur = root_ref & kRefMask;
-                                state = ref_state(root_ref);
+                                state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                             }
                         }
                     } else {
@@ -443,7 +415,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         n_nodes++;
                         if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
                             cur = root_ref & kRefMask;
-                            state = ref_state(root_ref);
+                            state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                         }
                     }
                 }
@@ -471,14 +443,14 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
         const bool at_leaf = state == ST_LEAFS;
         if constexpr (INST) {
             // ---- transform step: enter instances / return from them, once enough lanes wait (or nothing else can run)
-            const unsigned long long xf_m = __ballot(state == ST_INST || (!RETV && state == ST_RET));
+            const unsigned long long xf_m = __ballot(state == ST_INST || state == ST_RET);
             if (xf_m != 0ull && ((uint32_t)__popcll(xf_m) >= job.inst_quorum || __ballot(at_node || at_leaf) == 0ull)) {
                 bool need_pop = false;
 #ifdef PT_TRACE_UTIL
                 PT_UTIL(u_it3, u_act3, state == ST_INST || state == ST_RET);
                 const long long u_c0 = clock64();
 #endif
-                if (!RETV && state == ST_RET) {
+                if (state == ST_RET) {
                     const uint32_t w0 = xf_arg;
                     if (!QUAD) pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
                     ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
@@ -511,7 +483,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         pending = 0;
                         wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
-                        if constexpr (RETV) { w_inv = inv_dir; w_sx = tray.Sx; w_sy = tray.Sy; }
                         ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; PT_SGN3(); t_max = tm2;
                         PT_TRI_RAY();
                         const uint32_t iroot = QUAD ? I.root_ref4 : I.root_ref;
@@ -610,7 +581,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     if (m0 | m1 | m2 | m3) {
                         const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
                         cur = nr & kRefMask;
-                        state = ref_state(nr);
+                        state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
                     } else need_pop = true;
                 }
                 PT_UTIL_MARK(u_cnode);
@@ -754,4 +725,3 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #undef PT_UTIL_MARK
 #undef PT_SGN3
 #undef PT_TRI_RAY
-#undef PT_TRI_RAY_REST

@@ -224,7 +224,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             const float inf = std::numeric_limits<float>::infinity();
             std::vector<uint32_t> todo;   // binary interior nodes that root a record, in emission order (their record = quad[qbase + position])
             std::vector<uint32_t> quad_id(nn.size(), PT_NONE);
-            auto qref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | ((refs[nn[i].offset] & PT_TOP_INSTANCE) ? kInstLeafBit : 0u) | (pbase + nn[i].offset)) : quad_id[i]; };
+            auto qref_of = [&](uint32_t i) { return nn[i].n_prims ? (kLeafBit | (pbase + nn[i].offset)) : quad_id[i]; };
             const uint32_t qbase = (uint32_t)quad.size();
             if (!nn.empty() && nn[0].n_prims == 0) {
                 // pre-order numbering: a record's interior grandchildren root the next records, left to right
