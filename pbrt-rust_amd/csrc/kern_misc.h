@@ -79,10 +79,12 @@ __global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // Diff
 }
 // ---- material-class routing (material-sorted shade queues) ------------------------------------------------------
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
-// material's class (escaped rays -> the miss class). Block-level staged appends: one global atomic per ~1000 entries per class.
+// material's class (escaped rays -> the miss class). Block-level staged appends, one global atomic per ~1800 entries per class: the returning atomics on the two or three
+// class counters every block hammers are most of what the kernel waits on (tools/microbench/route_bench.hip: 14 ps per entry with 1024-entry staging queues WHATEVER the
+// class is read from, 6.7 ps with 2048-entry ones; the gather of the hit records' flag words adds 6 ps) -- three blocks per CU is what six 8 KB queues leave room for.
 __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
                                               uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c6) {
-    __shared__ LdsQueue<1024> q0, q1, q2, q3, q4, q6;
+    __shared__ LdsQueue<kRouteQueueCap> q0, q1, q2, q3, q4, q6;
     lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q6);
     __syncthreads();
     const uint32_t count = *count_ptr;

@@ -14,6 +14,7 @@ constexpr int kNumClasses = 7;      // material-sorted shade queues: 0 matte, 1 
 //       // 6 = perfectly specular materials (mirror, smooth glass): no next-event estimation at their vertices (path.rs:131-146);
 //       //     the volumetric integrator estimates direct light at every vertex, so its router folds this class into class 1
 constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6;
+constexpr int kRouteQueueCap = 2048;   // k_route's LDS staging queues (entries)
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 9
 #endif

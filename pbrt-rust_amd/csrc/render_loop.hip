@@ -433,7 +433,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         } else if (n_ext) {  // material-sorted shade queues
             sc->begin("route", n_ext); sc->set_kernel("k_route");
             #ifndef PT_ROUTE_BLOCKS_PER_CU
-#define PT_ROUTE_BLOCKS_PER_CU 6u   // what a CU's LDS holds of this kernel (six 4 KB staging queues per block): with 8 the last two blocks of every CU ran after the first six, alone
+#define PT_ROUTE_BLOCKS_PER_CU 3u   // what a CU's LDS holds of this kernel (six 8 KB staging queues per block)
 #endif
             hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * PT_ROUTE_BLOCKS_PER_CU)), dim3(256), 0, sc->stream, sc->ds,
                                (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0],
