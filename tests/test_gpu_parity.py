@@ -90,6 +90,34 @@ def test_trace_closest_and_any_bit_exact(pkg, gpu, oracle):
         assert gc[k] == oc[k], k
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 511, 512, 513, 1000, 4097])
+def test_trace_ragged_ray_counts_and_rays_outside_the_bounds(pkg, gpu, oracle, n):
+    """The traversal kernel's refill block hands queue entries out of a 64-entry window of a 512-entry bite (kern_trace.h): counts around those sizes. A third of the rays start
+    outside the scene's bounds and point away, a third start outside and point at it -- the four-wide walk enters the root record without the root's own slab test (bvh.rs:725-727)
+    and must still return the reference's hits, misses and triangle-test count."""
+    sd, rp = _small_scene(pkg, n=24)
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    rng = np.random.default_rng(1000 + n)
+    o, d = _random_rays(n, 77 + n)
+    far = (rng.random((n, 3)) * 2 - 1).astype(np.float32); far /= np.maximum(np.linalg.norm(far, axis=1, keepdims=True), 1e-6); far *= 50.0
+    kind = rng.integers(0, 3, n)
+    o = np.where((kind > 0)[:, None], far, o).astype(np.float32)
+    away = far / 50.0
+    d = np.where((kind == 1)[:, None], away, np.where((kind == 2)[:, None], -away + (rng.random((n, 3)).astype(np.float32) - 0.5) * 0.05, d)).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(o, d, tmax); gc = g.counters()
+    op, ot, ob = orc.trace_closest(o, d, tmax); oc = orc.counters()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "intersect_tests")):
+        assert gc[k] == oc[k], k
+    gh = g.trace_any(o, d, tmax); gc = g.counters()
+    oh = orc.trace_any(o, d, tmax); oc = orc.counters()
+    assert np.array_equal(gh, oh)
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "shadow_tests")):
+        assert gc[k] == oc[k], k
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(env=False), dict(with_normals=True), dict(strategy="uniform"), dict(maxdepth=1)])
 def test_film_matches_oracle(pkg, gpu, oracle, kw):
     sd, rp = _small_scene(pkg, **kw)
