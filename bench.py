@@ -123,9 +123,9 @@ def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
         l2_hit_rate=l2_hit if code_match else None,
         frac_of_gather_ceiling=None if gather_frac is None else round(gather_frac, 4),
         gather_ceiling="fabric read requests per second of this kernel / 54 G/s, the measured chip-wide rate of dependent random 64-byte gathers (profiles/r2_gather_calibration.json)",
-        limiter=("vector-instruction issue of a per-lane BVH walk (valu_busy_frac) with, close behind it, the CU's vector L1 holding ~35 of the ~48 line requests it can keep in flight at the "
+        limiter=("vector-instruction issue of a per-lane BVH walk (valu_busy_frac) with, close behind it, the CU's vector L1 holding ~35 of the 64 line requests it can keep in flight at the "
                  "memory system's loaded latency (profiles/r4/tcp_counters_C2_spp32.txt; DESIGN.md section 7 has the SQ and TCP counters)" if is_trace
-                 else "bursts of gathers that fill the CU's ~48 line requests in flight (the vector L1 stalls on pending requests 60 % of its cycles) between long stretches of arithmetic at 2-3 "
+                 else "bursts of gathers that fill the CU's 64 line requests in flight (the vector L1 stalls on pending requests 60 % of its cycles) between long stretches of arithmetic at 2-3 "
                       "waves/SIMD (VGPR-limited): neither bytes nor vector issue alone (DESIGN.md section 7)"),
         launches=g["launches"], avg_launch_ms=round(avg_ms, 4),
         algorithmic_bytes_per_launch=int(g["bytes"] / max(1, g["launches"])))

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for CTRS in "$@"; do
   i=$((i+1))
-  timeout -k 5 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp ${PMC_SPP:-32} --cpu-seconds 0 > $OUT/p${i}_bench.json 2> $OUT/p$i.err
+  timeout -k 5 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -- python3 $REPO/bench.py --steps 1 --warmup 0 --spp ${PMC_SPP:-32} --cpu-seconds 0 ${PMC_ARGS:-} > $OUT/p${i}_bench.json 2> $OUT/p$i.err
 done
 python3 - $OUT $i <<'PY'
 import csv, glob, os, re, sys
