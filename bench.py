@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"], help="BASELINE config (default: the headline C2)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C3M", "C4", "C5"], help="BASELINE config (default: the headline C2)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: the config's named spp; C2: 256)")
     ap.add_argument("--mesh-n", type=int, default=1466, help="C2 / C5: displaced-sphere grid (1466 -> 4,298,312 triangles)")
     ap.add_argument("--xres", type=int, default=1920)

@@ -8,6 +8,16 @@
 #include "ref_math.h"
 #include "../include/mi355pt.h"
 #include <vector>
+#ifdef ORC_STUDY   // study builds only (tools/study/orc_study.h): never defined for oracle/liboracle.so
+#include "../tools/study/orc_study.h"
+#define ORC_STUDY_INSTANCE(sc, ii, r, ray) ::orc_study_instance(sc, ii, r, ray)
+#define ORC_STUDY_COUNT(k) (::g_orc_study[k]++)
+#define ORC_STUDY_LEAF(sc, ord, top, node, r, any) ::orc_study_leaf(sc, ord, top, node, r, any)
+#else
+#define ORC_STUDY_INSTANCE(sc, ii, r, ray) ((void)0)
+#define ORC_STUDY_COUNT(k) ((void)0)
+#define ORC_STUDY_LEAF(sc, ord, top, node, r, any) ((void)0)
+#endif
 
 namespace ref {
 
@@ -358,6 +368,7 @@ inline bool Scene::ref_intersect(uint32_t ref, Ray &r, SurfaceInteraction &si, C
     const PtInstance &I = instances[ref & ~PT_TOP_INSTANCE];
     const PtObject &O = objects[I.object];
     Ray ray = xf_ray(m4_from(I.world_to_instance), r);
+    ORC_STUDY_INSTANCE(*this, ref & ~PT_TOP_INSTANCE, r, ray);
     SurfaceInteraction tmp = si;
     bool hit = (O.n_prims == 1) ? prim_intersect(O.first_prim, ray, tmp, c)
                                 : accel_intersect(obj_accel[I.object].nodes, obj_accel[I.object].ordered, false, ray, tmp, c);
@@ -371,6 +382,7 @@ inline bool Scene::ref_intersect_p(uint32_t ref, const Ray &r, Counters &c) cons
     const PtInstance &I = instances[ref & ~PT_TOP_INSTANCE];
     const PtObject &O = objects[I.object];
     Ray ray = xf_ray(m4_from(I.world_to_instance), r);
+    ORC_STUDY_INSTANCE(*this, ref & ~PT_TOP_INSTANCE, r, ray);
     return (O.n_prims == 1) ? prim_intersect_p(O.first_prim, ray, c) : accel_intersect_p(obj_accel[I.object].nodes, obj_accel[I.object].ordered, false, ray, c);
 }
 
@@ -387,6 +399,7 @@ inline bool Scene::accel_intersect(const std::vector<PtBVHNode> &nn, const std::
         c.nodes++;
         if (bounds_intersect_p2(node, r, inv_dir, neg)) {
             if (node.n_prims > 0) {
+                ORC_STUDY_LEAF(*this, ord, top, node, r, false);
                 for (uint32_t i = 0; i < node.n_prims; ++i) {
                     uint32_t e = ord[node.offset + i];
                     if (ref_intersect(top ? top_ref(e) : e, r, si, c)) hit = true;
@@ -450,6 +463,7 @@ inline bool Scene::accel_intersect_p(const std::vector<PtBVHNode> &nn, const std
         c.nodes++;
         if (bounds_intersect_p2(node, r, inv_dir, neg)) {
             if (node.n_prims > 0) {
+                ORC_STUDY_LEAF(*this, ord, top, node, r, true);
                 for (uint32_t i = 0; i < node.n_prims; ++i) {
                     uint32_t e = ord[node.offset + i];
                     if (ref_intersect_p(top ? top_ref(e) : e, r, c)) return true;

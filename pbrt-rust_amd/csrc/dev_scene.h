@@ -18,10 +18,10 @@ struct TriPacket {           // 48 bytes, 16-byte aligned, one quad per AXIS: {p
     float y[3]; uint32_t shape;  // vertices arrive permuted and the test's 18 selects per packet are gone; the three id words arrive permuted with them (tp_aux).
     float z[3]; uint32_t flags;
 };
-enum { TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11, TP_ALPHA = 1u << 12 };  // flags: low 8 bits = PT_TRI_* bits; LAST = last packet of its leaf
-// flags bits 13-15: shade-queue class of the primitive's material (what k_route needs), bits 16-31: its material index, 0xffff =
-// "none or too large: read prim_material" -- so that neither routing nor shading has to chase prim -> material -> class through HBM
-constexpr uint32_t kTpClassShift = 13, kTpMatShift = 16, kTpMatNone = 0xffffu;
+enum { TP_ALPHA = 1u << 7, TP_BOGUS = 1u << 8, TP_SPHERE = 1u << 9, TP_LAST = 1u << 10, TP_INSTANCE = 1u << 11 };  // flags: bits 0-4 = PT_TRI_* bits; LAST = last packet of its leaf
+// flags bits 12-15: shade-queue class of the primitive's material (what k_route needs; kernels.h: kNumClasses), bits 16-31: its material index,
+// 0xffff = "none or too large: read prim_material" -- so that neither routing nor shading has to chase prim -> material -> class through HBM
+constexpr uint32_t kTpClassShift = 12, kTpClassMask = 15u, kTpMatShift = 16, kTpMatNone = 0xffffu;
 
 // Two-wide traversal record (64 B, four dwordx4 loads): one per INTERIOR node of the reference tree, holding the
 // bounds of both children, so that a ray fetches once per interior node it enters instead of once per node it tests.

@@ -74,11 +74,7 @@ struct pt_scene {
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
-    bool class_used[kNumClasses] = {true, false, false, false, true, false, false};
-    bool class3_sss_smooth = false;   // every many-lobe material is a subsurface material with constant zero roughness (one FresnelSpecular lobe + BSSRDF): k_shade<1, MODE, 6>
-    bool class3_uber_only = false;    // every many-lobe material is an uber (Lambert + microfacet + specular reflection / transmission): k_shade<5, MODE, 5>
-    bool class2_plastic_like = false; // every two-lobe material is plastic or an opaque uber without specular terms (no rough glass): k_shade<2, MODE, 4>
-    bool class1_metal_only = false;   // every one-lobe material of the scene is a metal: its vertices are shaded by the conductor-microfacet specialisation k_shade<1, MODE, 3>
+    bool class_used[kNumClasses] = {true, false, false, false, true, false, false, false, false, false, false};   // shade classes the scene's materials map to (kernels.h: kNumClasses; scene_create.hip: material_class)
     bool has_null_material = false;   // a primitive without a material: a medium-interface shell (api.rs:597). The path integrator steps over it (path.rs:124-129);
                                       // the volumetric one also walks its shadow / MIS rays through it, segment by segment (kern_shade_common.h: vol_chain_step)
     void *ext_slab = nullptr; size_t ext_capacity = 0;   // PathSoA::ext, allocated for volpath renders of scenes with shells
@@ -175,7 +171,7 @@ struct pt_multi_scene {
 
 namespace pth {
 // scene_create.hip
-uint8_t material_class(const PtMaterial &m);
+uint8_t material_class(const PtMaterial &m, bool specialise);
 void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func_int);
 // render_loop.hip
 int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe = false);

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_medium_route(DeviceScene s, RenderConst
         if (valid) {
             pid = queue[qi];
             const uint32_t hp = ps.hit_prim(pid);
-            cls = (ps.hit_pflags(pid) >> kTpClassShift) & 7u;   // the hit packet's class bits, kMissClass for a miss (written by k_trace)
+            cls = class_general((ps.hit_pflags(pid) >> kTpClassShift) & kTpClassMask);   // the hit packet's class bits, kMissClass for a miss (written by k_trace); the lobe-set classes fold into their lobe-count class (general kernels here)
             if (cls == (uint32_t)kSpecClass) cls = 1u;            // volpath.rs:136-138 estimates direct light at every vertex: no specular-only class here
             const uint32_t med = ps.medium(pid);
             if (med != PT_NONE) {

@@ -13,8 +13,7 @@ __global__ void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, 
 __global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out);
 __global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n);
 __global__ void k_light_area(DeviceScene s, float *area, float4 *rec);
-__global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
-                        uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c6);
+template <int NQ, int CAP> __global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps, uint32_t *class_count, RouteJob rj);
 __global__ void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters);
 __global__ void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
 __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix);

@@ -81,11 +81,14 @@ __global__ void k_light_area(DeviceScene s, float *area, float4 *rec) {  // Diff
 // Reads the hit record of every traced continuation ray and appends the path id to the shade queue of the hit
 // material's class (escaped rays -> the miss class). Block-level staged appends, one global atomic per ~1800 entries per class: the returning atomics on the two or three
 // class counters every block hammers are most of what the kernel waits on (tools/microbench/route_bench.hip: 14 ps per entry with 1024-entry staging queues WHATEVER the
-// class is read from, 6.7 ps with 2048-entry ones; the gather of the hit records' flag words adds 6 ps) -- three blocks per CU is what six 8 KB queues leave room for.
-__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps,
-                                              uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c6) {
-    __shared__ LdsQueue<kRouteQueueCap> q0, q1, q2, q3, q4, q6;
-    lq_init(q0); lq_init(q1); lq_init(q2); lq_init(q3); lq_init(q4); lq_init(q6);
+// class is read from, 6.7 ps with 2048-entry ones; the gather of the hit records' flag words adds 6 ps) -- three blocks per CU is what 48 KB of staging queues per block leave room for.
+// One staging queue per class the SCENE uses (RouteJob: at most NQ of them): <6, 2048> for scenes of up to six classes (every config of BASELINE.json), <12, 1024> beyond that
+// (more classes spread the appends over more counters, which is what the longer queues were for).
+template <int NQ, int CAP>
+__global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps, uint32_t *class_count, RouteJob rj) {
+    __shared__ LdsQueue<CAP> q[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) lq_init(q[k]);
     __syncthreads();
     const uint32_t count = *count_ptr;
     const uint32_t rounded = (count + 255u) & ~255u;
@@ -94,20 +97,18 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
         uint32_t pid = 0, cls = (uint32_t)kMissClass;   // escaped rays: their own light kernel (k_shade_miss)
         if (valid) {
             pid = queue[qi];
-            cls = (ps.hit_pflags(pid) >> kTpClassShift) & 7u;   // written by k_trace with the hit: the packet's class bits, kMissClass for a miss
+            cls = (ps.hit_pflags(pid) >> kTpClassShift) & kTpClassMask;   // written by k_trace with the hit: the packet's class bits, kMissClass for a miss
         }
-        lq_push(q0, pid, valid && cls == 0u); lq_push(q1, pid, valid && cls == 1u);
-        lq_push(q2, pid, valid && cls == 2u); lq_push(q3, pid, valid && cls == 3u); lq_push(q4, pid, valid && cls == 4u);
-        lq_push(q6, pid, valid && cls == (uint32_t)kSpecClass);
+        const uint32_t slot = (uint32_t)(rj.slot_map >> (4u * cls)) & 15u;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) if ((uint32_t)k < rj.n_slots) lq_push(q[k], pid, valid && slot == (uint32_t)k);
         __syncthreads();
-        lq_flush_nosync(q0, class_count + 0, c0, 256u, false); lq_flush_nosync(q1, class_count + 1, c1, 256u, false);
-        lq_flush_nosync(q2, class_count + 2, c2, 256u, false); lq_flush_nosync(q3, class_count + 3, c3, 256u, false);
-        lq_flush_nosync(q4, class_count + 4, c4, 256u, false); lq_flush_nosync(q6, class_count + kSpecClass, c6, 256u, false);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) if ((uint32_t)k < rj.n_slots) lq_flush_nosync(q[k], class_count + rj.cls_of_slot[k], rj.buf[k], 256u, false);
         __syncthreads();
     }
-    lq_flush_nosync(q0, class_count + 0, c0, 0u, true); lq_flush_nosync(q1, class_count + 1, c1, 0u, true);
-    lq_flush_nosync(q2, class_count + 2, c2, 0u, true); lq_flush_nosync(q3, class_count + 3, c3, 0u, true);
-    lq_flush_nosync(q4, class_count + 4, c4, 0u, true); lq_flush_nosync(q6, class_count + kSpecClass, c6, 0u, true);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) if ((uint32_t)k < rj.n_slots) lq_flush_nosync(q[k], class_count + rj.cls_of_slot[k], rj.buf[k], 0u, true);
 }
 // ---- camera rays -------------------------------------------------------------------------------------
 // pixel slot -> pixel: slot = tile_slot*256 + ty*16 + tx, tile index = tile_rank + tile_slot*tile_world

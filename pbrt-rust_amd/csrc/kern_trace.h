@@ -62,16 +62,20 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
-    constexpr int kLds = QUAD ? kLdsStackQuad : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
+    constexpr int kLds = QUAD ? (INST ? kLdsStackQuadInst : kLdsStackQuad) : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
     constexpr int kMaxS = QUAD ? kMaxStackQuad : kMaxStack;   // deepest stack (the four-wide walk pushes up to three entries per record)
-    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * (kLds + 1) * 2 * 64];   // (+1: the scratch slot of `push`)
+    __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLds * 2 * 64];
     __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    uint32_t *stack = lds_stack + wave_in_block * ((kLds + 1) * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
+    // (stack and spill slab through pointers that NAME their address space: a push or pop that picks between them can then only be a branch -- left generic, the
+    //  compiler turned `sp < kLds ? LDS : HBM` into flat accesses through a selected address, ~27 instructions per push and a wait on both memory counters per pop;
+    //  until round 5 a scratch entry behind the LDS ones took the unconditional write instead, which cost every lane an entry of LDS: each one is worth ~1.4 % of C4's traversal)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32; typedef __attribute__((address_space(1))) uint32_t glb_u32;
+    lds_u32 *stack = (lds_u32 *)lds_stack + wave_in_block * (kLds * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
     float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
-    uint32_t *spill = job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * kSpillEntries) + lane;   // (the slab is sized for the deeper of the two walks: both index it the same way)
+    glb_u32 *spill = (glb_u32 *)job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * kSpillEntries) + lane;   // (the slab is sized for the deeper of the two walks: both index it the same way)
     // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
     // (measured and dropped, round 2: one work head per XCD group, each group draining "its" contiguous eighth of the queues first -- no
     //  change on any config with the segments on or off, and the dozen wave-uniform words of segment state overflowed the SGPR file into
@@ -197,13 +201,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
         }
     };
 
-    // (an entry is written to LDS unconditionally -- beyond the LDS entries into a scratch slot behind them -- and the rare deep entry goes to the HBM slab
-    //  as well: written as `sp < kLds ? LDS : HBM` the two stores of an entry became flat stores through a selected address, ~27 instructions per push)
     auto push = [&](uint32_t w0, uint32_t w1) {
-        const uint32_t se = min(sp, (uint32_t)kLds);
-        stack[(2 * se) * 64] = w0; stack[(2 * se + 1) * 64] = w1;
-        asm volatile("" ::: "memory");
-        if (sp >= (uint32_t)kLds) { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
+        if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
+        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
         sp++;
     };
     const uint32_t root_ref = QUAD ? s.root_ref4 : s.root_ref;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         if (c2) { stack[(2 * p2) * 64] = r2; stack[(2 * p2 + 1) * 64] = __float_as_uint(t2); }
                         if (c1) { stack[(2 * p1) * 64] = r1; stack[(2 * p1 + 1) * 64] = __float_as_uint(t1); }
                         sp = p1 + (c1 ? 1u : 0u);
-                    } else if (sp + 3u > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
+                    } else if (sp + (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) > (uint32_t)kMaxS) atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW);
                     else {
                         if (c3) push(r3, __float_as_uint(t3));
                         if (c2) push(r2, __float_as_uint(t2));

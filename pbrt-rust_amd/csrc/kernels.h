@@ -8,30 +8,45 @@
 
 namespace ptd {
 
-constexpr int kNumClasses = 7;      // material-sorted shade queues: 0 matte, 1 one-lobe, 2 two-lobe, 3 uber + subsurface,
+constexpr int kNumClasses = 11;     // material-sorted shade queues, one per shade KERNEL: by lobe count 0 matte, 1 one-lobe, 2 two-lobe, 3 many-lobe (general kernels),
 //       // 4 = rays that escaped + resolve-only (dead) paths: a light kernel of their own
 //       // 5 = medium vertices of the volumetric integrator (k_shade_medium)
 //       // 6 = perfectly specular materials (mirror, smooth glass): no next-event estimation at their vertices (path.rs:131-146);
 //       //     the volumetric integrator estimates direct light at every vertex, so its router folds this class into class 1
-constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6;
+//       // and by lobe SET, the kernels specialised for one material's BxDFs (round 5: a class each, so that one substrate, rough glass or translucent
+//       // material in a scene no longer sends every metal / plastic / uber vertex back to the general kernel of its lobe count):
+//       // 7 metal (k_shade<1, ., 3>), 8 plastic-like: plastic and the opaque uber without specular terms (k_shade<2, ., 4>), 9 uber (k_shade<5, ., 5>),
+//       // 10 smooth subsurface (k_shade<1, ., 6>). The specialised forms exist for the untextured path integrator: material_class() (scene_create.hip)
+//       // hands these classes out only to scenes without textures, and the volumetric router folds them back (class_general).
+constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6, kMetalClass = 7, kPlasticClass = 8, kUberClass = 9, kSssClass = 10;
+PT_HD inline uint32_t class_general(uint32_t c) { return c == (uint32_t)kMetalClass ? 1u : c == (uint32_t)kPlasticClass ? 2u : (c == (uint32_t)kUberClass || c == (uint32_t)kSssClass) ? 3u : c; }
+constexpr int kRouteSlots = 12;        // most staging queues a k_route block holds
+// k_route's staging queues: one per shade class the scene uses ("slot"), so that a scene pays LDS only for the classes it has.
+// slot_map: the slot of class c in nibble c (15 = the class does not occur in this scene).
+struct RouteJob { uint32_t n_slots; unsigned long long slot_map; uint32_t cls_of_slot[kRouteSlots]; uint32_t *buf[kRouteSlots]; };
 constexpr int kRouteQueueCap = 2048;   // k_route's LDS staging queues (entries)
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 9
+#define PT_LDS_STACK 10
 #endif
 constexpr int kLdsStack = PT_LDS_STACK;       // traversal stack entries (2 words each) kept in LDS per lane; deeper entries spill to HBM. Triangle-only scenes: 10, so
                                               // that seven workgroups fit a CU's LDS; scenes with instances push a marker entry per instance entered and run five
                                               // waves per SIMD: 12 (C4 with 10: trace +2.3 %)
 #ifndef PT_LDS_STACK_GENERAL
-#define PT_LDS_STACK_GENERAL 11
+#define PT_LDS_STACK_GENERAL 12
 #endif
 constexpr int kLdsStackGeneral = PT_LDS_STACK_GENERAL;
 constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/bvh.rs:722)
 #ifndef PT_LDS_STACK_QUAD
-#define PT_LDS_STACK_QUAD 14
+#define PT_LDS_STACK_QUAD 15
 #endif
 constexpr int kLdsStackQuad = PT_LDS_STACK_QUAD;   // the four-wide walk (kern_trace.h, QUAD): up to three pushes per record; five waves per SIMD x 7 KB per wave of LDS
+#ifndef PT_LDS_STACK_QUAD_INST
+#define PT_LDS_STACK_QUAD_INST 16
+#endif
+constexpr int kLdsStackQuadInst = PT_LDS_STACK_QUAD_INST;   // the four-wide walk of scenes with instances (outer tree + marker + object tree on one stack): four waves per SIMD share a CU's LDS
 constexpr int kMaxStackQuad = 96;   // a reference tree of depth 64 collapses to 32 four-wide levels x 3 pushes
-constexpr int kSpillEntries = (kMaxStackQuad - kLdsStackQuad) > (kMaxStack - (kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral)) ? (kMaxStackQuad - kLdsStackQuad) : (kMaxStack - (kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral));   // per-lane HBM stack entries behind the LDS ones
+constexpr int kLdsStackMinQuad = kLdsStackQuad < kLdsStackQuadInst ? kLdsStackQuad : kLdsStackQuadInst, kLdsStackMinTwo = kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral;
+constexpr int kSpillEntries = (kMaxStackQuad - kLdsStackMinQuad) > (kMaxStack - kLdsStackMinTwo) ? (kMaxStackQuad - kLdsStackMinQuad) : (kMaxStack - kLdsStackMinTwo);   // per-lane HBM stack entries behind the LDS ones
 constexpr int kTraceBlock = 256;
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
 

@@ -9,6 +9,10 @@ __global__ void k_trace_util_fold(DevCounters *dc, uint32_t kind, uint32_t waves
 }
 #endif
 
+// Shade queues exist for the seven lobe-count / service classes always (the volumetric integrator uses all of them) and for the lobe-set classes the scene's materials map to.
+static bool class_has_queue(const pt_scene *sc, int c) { return c <= kSpecClass || sc->class_used[c]; }
+static size_t n_class_queues(const pt_scene *sc) { size_t n = 0; for (int c = 0; c < kNumClasses; ++c) n += class_has_queue(sc, c) ? 1 : 0; return n; }
+
 // any: 0 closest hit, 1 any hit (rays of job.sub[0]); 2 mixed: the queues of job.sub[0..2] in one launch (n_upper covers all three)
 int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe) {
     if (n_upper == 0) return PT_OK;
@@ -77,12 +81,12 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
             static_assert(sizeof(ba) / sizeof(ba[0]) + 3 == kBssSoAArrays, "BssSoA layout");
         }
         // queues: ext[2] + shade[2][classes] + shadow + mis (+ probe[2])
-        size_t nq = 2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0);
+        size_t nq = 2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0);
         e = hipMalloc((void **)&sc->qbuf, nq * capacity * 4);
         if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "queues: " + std::string(hipGetErrorString(e)));
         uint32_t *qp = sc->qbuf;
         for (int i = 0; i < 2; ++i) { sc->q.ext[i] = qp; qp += capacity; }
-        for (int i = 0; i < 2; ++i) for (int c = 0; c < kNumClasses; ++c) { sc->q.shade[i][c] = qp; qp += capacity; }
+        for (int i = 0; i < 2; ++i) for (int c = 0; c < kNumClasses; ++c) { sc->q.shade[i][c] = nullptr; if (class_has_queue(sc, c)) { sc->q.shade[i][c] = qp; qp += capacity; } }
         sc->q.shadow = qp; qp += capacity; sc->q.mis = qp; qp += capacity;
         sc->q.probe[0] = sc->q.probe[1] = nullptr;
         if (sc->has_bssrdf) { sc->q.probe[0] = qp; qp += capacity; sc->q.probe[1] = qp; }
@@ -277,7 +281,7 @@ constexpr double kPassMemFraction = 0.65;   // of the device's free memory
 uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share, bool volpath) {
     // per path: the five state records, the queues, the probe state of scenes with subsurface materials and -- volpath through material-less shells -- the
     // 128-byte chain record (PathSoA::ext, allocated after the main slab: left out of this sum, a shell scene asked for ~1.4x its budget)
-    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * kNumClasses + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u)
+    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u)
                             + ((volpath && sc->has_null_material) ? 4u * (size_t)PathSoA::kExtWords : 0u);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -349,7 +353,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * PT_GEN_BLOCKS_PER_CU)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
     int cur = 0;
-    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
+    static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_manylobe", "shade_miss", "shade_medium", "shade_specular", "shade_metal", "shade_plastic", "shade_uber", "shade_sss"};
     const int kMaxIterations = 1 << 20;   // a path needs <= max_depth + null-surface skips + probe segments iterations
     for (int iter = 0; iter <= kMaxIterations; ++iter) {
         QCounters h;
@@ -431,20 +435,25 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
                                sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4], sc->q.shade[cur][5], &qc->error);
             sc->end();
         } else if (n_ext) {  // material-sorted shade queues
-            sc->begin("route", n_ext); sc->set_kernel("k_route");
+            sc->begin("route", n_ext); sc->set_kernel("k_route<6, 2048>");
             #ifndef PT_ROUTE_BLOCKS_PER_CU
 #define PT_ROUTE_BLOCKS_PER_CU 3u   // what a CU's LDS holds of this kernel (six 8 KB staging queues per block)
 #endif
-            hipLaunchKernelGGL(k_route, dim3(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * PT_ROUTE_BLOCKS_PER_CU)), dim3(256), 0, sc->stream, sc->ds,
-                               (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0],
-                               sc->q.shade[cur][0], sc->q.shade[cur][1], sc->q.shade[cur][2], sc->q.shade[cur][3], sc->q.shade[cur][4], sc->q.shade[cur][kSpecClass]);
+            RouteJob rj{}; rj.slot_map = ~0ull;
+            for (int c = 0; c < kNumClasses; ++c) if (c != kMediumClass && (c == kMissClass || sc->class_used[c])) {
+                rj.slot_map = (rj.slot_map & ~(15ull << (4 * c))) | ((unsigned long long)rj.n_slots << (4 * c));
+                rj.cls_of_slot[rj.n_slots] = (uint32_t)c; rj.buf[rj.n_slots] = sc->q.shade[cur][c]; rj.n_slots++;
+            }
+            const dim3 rgrid(std::min<uint32_t>((n_ext + 255) / 256, (uint32_t)g_num_cus * PT_ROUTE_BLOCKS_PER_CU));
+            if (rj.n_slots <= 6) hipLaunchKernelGGL((k_route<6, 2048>), rgrid, dim3(256), 0, sc->stream, sc->ds, (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0], rj);
+            else { sc->set_kernel("k_route<12, 1024>"); hipLaunchKernelGGL((k_route<12, 1024>), rgrid, dim3(256), 0, sc->stream, sc->ds, (const uint32_t *)sc->q.ext[cur], (const uint32_t *)&qc->ext[cur], sc->ps, &qc->shade[cur][0], rj); }
             sc->end();
         }
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 2u, cur);
         if (grid.cell_ptr) {   // first-touch voxels: the vertices of every shade class name theirs, then the new ones are computed
             const uint32_t upper0 = n_ext + n_resolve;
             for (int c = 0; c < kNumClasses; ++c) {
-                if (c == kMissClass) continue;
+                if (c == kMissClass || !class_has_queue(sc, c)) continue;
                 if ((st = lazy_light_touch(sc, rc, grid, sc->q.shade[cur][c], &qc->shade[cur][c], upper0 + n_stage_b, c == kMediumClass ? 1u : 0u))) return st;
             }
             if ((st = lazy_light_fill(sc, grid))) return st;
@@ -489,7 +498,8 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             for (int c = 0; c < kNumClasses; ++c) class_n[c] = h2.shade[cur][c];
         } else for (int c = 0; c < kNumClasses; ++c) class_n[c] = upper;
         for (int c = 0; c < kNumClasses; ++c) {
-            const bool used = sc->class_used[c] || (c == 1 && rc.volpath && sc->class_used[kSpecClass]);   // (the volumetric router folds class 6 into class 1)
+            bool used = sc->class_used[c] || (c == 1 && rc.volpath && sc->class_used[kSpecClass]);   // (the volumetric router folds class 6 into class 1)
+            if (rc.volpath) { if (c > kSpecClass) used = false; else for (int k = kSpecClass + 1; k < kNumClasses; ++k) if (sc->class_used[k] && class_general((uint32_t)k) == (uint32_t)c) used = true; }   // (... and the lobe-set classes into their lobe-count class)
             if (c == kSpecClass && rc.volpath) {   // exit-point vertices of subsurface chains in stage B (k_bssrdf put them here an iteration ago)
                 if (!sc->has_bssrdf || !(sc->ds.has_grid || sc->ds.has_shells) || class_n[c] == 0) continue;
                 BssrdfJob bj{};
@@ -513,7 +523,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
             sj.self_next = sc->q.shade[1 - cur][c]; sj.self_next_count = &qc->shade[1 - cur][c];
-            if (c == 3 && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
+            if ((c == 3 || c == kSssClass) && sc->has_bssrdf) { sj.probe_next = sc->q.probe[1 - cur]; sj.probe_next_count = &qc->probe[1 - cur]; sj.bs = sc->bs; }
             sc->begin(shade_names[c], rp_profile_exact ? class_n[c] : 0);
             if (c == kMediumClass) {
                 const uint32_t blocks = std::min<uint32_t>((class_n[c] + 255) / 256, (uint32_t)g_num_cus * 8u);
@@ -532,10 +542,12 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             }
             else if (c == 0) launch_shade<1, 1>(sc, rc, grid, sj, class_n[c]);
             else if (c == kSpecClass) launch_shade<1, 2>(sc, rc, grid, sj, class_n[c]);
-            else if (c == 1) { if (sc->class1_metal_only && g_shade_specialise) launch_shade<1, 3>(sc, rc, grid, sj, class_n[c]); else launch_shade<1>(sc, rc, grid, sj, class_n[c]); }
-            else if (c == 2) { if (sc->class2_plastic_like && g_shade_specialise) launch_shade<2, 4>(sc, rc, grid, sj, class_n[c]); else launch_shade<2>(sc, rc, grid, sj, class_n[c]); }
-            else if (sc->class3_sss_smooth && g_shade_specialise && !rc.volpath && sc->ds.n_textures == 0) launch_shade<1, 6>(sc, rc, grid, sj, class_n[c]);   // (the form exists for the untextured path integrator)
-            else if (sc->class3_uber_only && g_shade_specialise) launch_shade<5, 5>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 1) launch_shade<1>(sc, rc, grid, sj, class_n[c]);
+            else if (c == 2) launch_shade<2>(sc, rc, grid, sj, class_n[c]);
+            else if (c == kMetalClass) launch_shade<1, 3>(sc, rc, grid, sj, class_n[c]);     // (the lobe-set classes exist in untextured scenes only and never reach this loop under volpath)
+            else if (c == kPlasticClass) launch_shade<2, 4>(sc, rc, grid, sj, class_n[c]);
+            else if (c == kUberClass) launch_shade<5, 5>(sc, rc, grid, sj, class_n[c]);
+            else if (c == kSssClass) launch_shade<1, 6>(sc, rc, grid, sj, class_n[c]);
             else launch_shade<5>(sc, rc, grid, sj, class_n[c]);
             sc->end();
         }
@@ -562,7 +574,7 @@ void read_counters(pt_scene *sc) {
     for (int i = 0; i < 16; ++i) c.path_length_hist[i] = d.path_len[i];
     c.sanitized_nan = d.san_nan; c.sanitized_negative = d.san_neg; c.sanitized_infinite = d.san_inf;
     c.film_splats = d.splats; c.wavefront_stages = d.stages; c.reference_asserts = d.ref_asserts;
-    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_miss", "shade_medium", "shade_specular"};
+    static const char *sn[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_manylobe", "shade_miss", "shade_medium", "shade_specular", "shade_metal", "shade_plastic", "shade_uber", "shade_sss"};
     for (int k = 0; k < kNumClasses; ++k) for (auto &s : sc->stats) if (s.name == sn[k]) { s.items = d.shade_items[k]; s.nodes = d.shade_bytes[k]; }
     static const char *kn[5] = {"extend", "extend_mis", "shadow", "extend_camera", "extend_probe"};
     for (int k = 0; k < 5; ++k) for (auto &s : sc->stats) if (s.name == kn[k]) { s.nodes = d.k_nodes[k]; s.tris = d.k_tris[k]; if (k == 4) s.items = d.k_rays[k]; }   // probe chains: items = segments traced

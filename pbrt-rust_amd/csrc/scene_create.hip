@@ -4,22 +4,28 @@
 namespace pth {
 // Shade class of a material = the kernel its vertices are shaded by (kernels.h: kNumClasses): by the number of BxDFs the material
 // can produce, decided from its constant parameters (a textured parameter can take any value).
-uint8_t material_class(const PtMaterial &m) {
+uint8_t material_class(const PtMaterial &m, bool specialise) {
+    // `specialise`: hand out the classes of the lobe-SET kernels (metal, plastic-like, uber, smooth subsurface; kernels.h) -- untextured scenes only, PT_SHADE_SPECIALISE != 0
     auto textured = [&](int slot) { return m.tex[slot] >= 0; };
     auto black = [](const float c[3]) { return !(c[0] > 0.0f) && !(c[1] > 0.0f) && !(c[2] > 0.0f); };   // .clamps(0, inf).is_black()
     switch (m.type) {
     case PT_MAT_MATTE: return 0;
     case PT_MAT_MIRROR: return (uint8_t)kSpecClass;
-    case PT_MAT_METAL: case PT_MAT_SUBSTRATE: return 1;
+    case PT_MAT_METAL: return specialise ? (uint8_t)kMetalClass : 1;
+    case PT_MAT_SUBSTRATE: return 1;
     case PT_MAT_GLASS:   // glass.rs:57-92: one FresnelSpecular lobe when both roughnesses are 0, else up to two microfacet lobes
         if (textured(PT_MP_U_ROUGHNESS) || textured(PT_MP_V_ROUGHNESS)) return 2;
         return (m.u_roughness == 0.0f && m.v_roughness == 0.0f) ? (uint8_t)kSpecClass : 2;
-    case PT_MAT_PLASTIC: return 2;
+    case PT_MAT_PLASTIC: return specialise ? (uint8_t)kPlasticClass : 2;
     case PT_MAT_UBER: {   // uber.rs:40-106: without specular reflection / transmission and fully opaque it is Lambertian + microfacet
         const bool opaque = !textured(PT_MP_OPACITY) && m.opacity[0] >= 1.0f && m.opacity[1] >= 1.0f && m.opacity[2] >= 1.0f;
         const bool no_spec = !textured(PT_MP_KR) && !textured(PT_MP_KT) && black(m.kr) && black(m.kt);
-        return (opaque && no_spec) ? 2 : 3;
+        if (opaque && no_spec) return specialise ? (uint8_t)kPlasticClass : 2;
+        return specialise ? (uint8_t)kUberClass : 3;
     }
+    case PT_MAT_SUBSURFACE:   // constant zero roughness: one FresnelSpecular lobe + the BSSRDF (subsurface.rs:84-109)
+        if (specialise && m.u_roughness == 0.0f && m.v_roughness == 0.0f && !textured(PT_MP_U_ROUGHNESS) && !textured(PT_MP_V_ROUGHNESS)) return (uint8_t)kSssClass;
+        return 3;
     default: return 3;
     }
 }
@@ -345,16 +351,10 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     if (d->env_texels) { sc->env_w = d->env_width; sc->env_h = d->env_height; for (int k = 0; k < 3; ++k) sc->env_texel0[k] = d->env_power_lookup[k]; }
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
-        for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i]); sc->class_used[mc[i]] = true; }
-        sc->class1_metal_only = sc->class_used[1];
-        sc->class2_plastic_like = sc->class_used[2];
-        sc->class3_uber_only = sc->class_used[3];
-        sc->class3_sss_smooth = sc->class_used[3];
-        for (uint32_t i = 0; i < d->n_materials; ++i) { const PtMaterial &m = d->materials[i];
-            if (mc[i] == 3 && !(m.type == PT_MAT_SUBSURFACE && m.u_roughness == 0.0f && m.v_roughness == 0.0f && m.tex[PT_MP_U_ROUGHNESS] < 0 && m.tex[PT_MP_V_ROUGHNESS] < 0)) sc->class3_sss_smooth = false; }
-        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 3 && d->materials[i].type != PT_MAT_UBER) sc->class3_uber_only = false;
-        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 2 && d->materials[i].type != PT_MAT_PLASTIC && d->materials[i].type != PT_MAT_UBER) sc->class2_plastic_like = false;
-        for (uint32_t i = 0; i < d->n_materials; ++i) if (mc[i] == 1 && d->materials[i].type != PT_MAT_METAL) sc->class1_metal_only = false;
+        // (the lobe-set kernels exist for the untextured path integrator: a textured scene keeps the general classes, and the volumetric router folds the
+        //  specialised ones back into them -- kern_aux.h: k_medium_route)
+        const bool specialise = g_shade_specialise && d->n_textures == 0;
+        for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i], specialise); sc->class_used[mc[i]] = true; }
         UP(mat_class, mc.data(), mc.size());
         std::vector<DevBssTable> bt(d->n_bssrdf_tables);
         for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {

@@ -738,11 +738,13 @@ def pot_mesh(nu, nv):
     return P.astype(F), tris.astype(np.uint32)
 
 
-def country_kitchen_s3(xres=1920, yres=1080, spp=1024, maxdepth=5, wall_n=280, box_n=48, obj_n=112, n_objects=8):
+def country_kitchen_s3(xres=1920, yres=1080, spp=1024, maxdepth=5, wall_n=280, box_n=48, obj_n=112, n_objects=8, mixed=False):
     """S3 / config C3: Cornell-style closed room, ~1 M triangles from subdivided walls and boxes (6 walls of wall_n^2
     quads + two boxes of box_n^2 quads per face) + ~200 k triangles of tessellated tori / lathe pots (n_objects x 2*obj_n^2),
     materials assigned round-robin from {matte, plastic roughness .1, uber, metal (copper defaults, metal.rs:13-53,116-117),
-    mirror, glass index 1.5} and 64 emissive triangles (a 8x4 grid of quads under the ceiling, one DiffuseAreaLight each)."""
+    mirror, glass index 1.5} and 64 emissive triangles (a 8x4 grid of quads under the ceiling, one DiffuseAreaLight each).
+    `mixed=True` adds substrate, rough glass and translucent to the round-robin (the materials SURVEY 8's C3 row lists besides S3's six): one of each
+    lobe count that the lobe-set shade kernels do not cover, next to the metals, plastics and ubers that they do."""
     b = SceneBuilder()
     b.film.update(xres=xres, yres=yres); b.spp = spp
     b.integ.update(maxdepth=maxdepth)
@@ -751,6 +753,9 @@ def country_kitchen_s3(xres=1920, yres=1080, spp=1024, maxdepth=5, wall_n=280, b
     palette = [("matte", dict(Kd=(0.6, 0.6, 0.6))), ("plastic", dict(Kd=(0.25, 0.35, 0.6), Ks=(0.25, 0.25, 0.25), roughness=0.1)),
                ("uber", dict(Kd=(0.5, 0.25, 0.2), Ks=(0.25, 0.25, 0.25), Kr=(0.1, 0.1, 0.1), roughness=0.1)), ("metal", dict()),
                ("mirror", dict(Kr=(0.9, 0.9, 0.9))), ("glass", dict(eta=1.5))]
+    if mixed:
+        palette += [("substrate", dict(Kd=(0.5, 0.3, 0.1), Ks=(0.2, 0.2, 0.2), uroughness=0.1, vroughness=0.2)), ("glass", dict(eta=1.4, uroughness=0.2, vroughness=0.2)),
+                    ("translucent", dict(Kd=(0.6, 0.5, 0.3), Ks=(0.3, 0.3, 0.3), reflect=(0.4, 0.4, 0.4), transmit=(0.7, 0.7, 0.7), roughness=0.2))]
     counter = [0]
     def next_material():
         kind, kw = palette[counter[0] % len(palette)]; counter[0] += 1
@@ -896,6 +901,7 @@ def dragon_s5(xres=1920, yres=1080, spp=4096, maxdepth=5, n=1466, env_size=(512,
 
 CONFIG_SCENES = {   # bench.py --config / tests: name -> (builder, spp named by BASELINE.json, description)
     "C2": (ganesha_scale, 256, "S2 Ganesha-scale: 4,298,312-triangle displaced sphere (matte) + ground + quad area light + constant env"),
+    "C3M": (lambda **kw: country_kitchen_s3(mixed=True, **kw), 1024, "S3 with substrate, rough glass and translucent added to the material round-robin (round 5: the lobe-set shade classes in a mixed scene)"),
     "C3": (country_kitchen_s3, 1024, "S3 Country-Kitchen-scale: closed room of subdivided walls/boxes (~1.0 M triangles) + 8 tessellated tori/pots (~0.2 M), "
            "materials round-robin {matte, plastic, uber, metal, mirror, glass}, 64 emissive triangles"),
     "C4": (ecosystem_s4, 2048, "S4 Ecosystem-scale: 2,000 object instances of three 50 k-triangle plants over a 500 k-triangle terrain, 512x256 environment map only"),

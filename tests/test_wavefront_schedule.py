@@ -103,28 +103,40 @@ def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
     sd, rp = pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=4).world_end()
     g = pkg.Scene(gpu, sd); g.render(rp)
     names = {s["name"] for s in g.kernel_stats() if s["launches"]}
-    assert {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_specular", "shade_miss"} <= names
+    assert {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_specular", "shade_miss", "shade_metal", "shade_plastic"} <= names   # (substrate, rough glass: the general kernels; metal, plastic, uber: their own)
 
 
-def test_lobe_set_specialised_kernels_are_chosen_per_scene_and_change_nothing(pkg, gpu, oracle, tmp_path):
-    """Round 4: a scene whose one-lobe materials are all metals, whose two-lobe materials are all plastic-like and whose many-lobe materials are all ubers
-    (the C3 palette) is shaded by k_shade<1, 0, 3> / <2, 0, 4> / <5, 0, 5>; one substrate, one rough glass or one translucent material in the scene brings
-    the general kernel of that class back (the zoo). Either way GPU == oracle, and PT_SHADE_SPECIALISE=0 (general kernels everywhere, a process of its own:
-    pt_init reads it) renders the same film."""
+def test_lobe_set_specialised_kernels_are_chosen_per_material_and_change_nothing(pkg, gpu, oracle, tmp_path):
+    """Round 5: every metal vertex is shaded by k_shade<1, 0, 3>, every plastic-like one by <2, 0, 4>, every uber by <5, 0, 5> -- a class each (kernels.h:
+    kMetalClass ...), whatever else the scene holds: the C3 palette, and the same room with substrate, rough glass and translucent surfaces added, whose
+    vertices go to the general kernels of their lobe count next to them (round 4 switched per SCENE: one such material sent the whole lobe-count class
+    back to the general kernel). Either way GPU == oracle, and PT_SHADE_SPECIALISE=0 (general kernels everywhere, a process of its own: pt_init reads
+    it) renders the same film."""
     sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     st = {s["name"]: s["kernel"] for s in g.kernel_stats() if s["launches"]}
-    assert st["shade_1lobe"] == "k_shade<1, 0, 3>" and st["shade_2lobe"] == "k_shade<2, 0, 4>" and st["shade_uber"] == "k_shade<5, 0, 5>", st
+    assert st["shade_metal"] == "k_shade<1, 0, 3>" and st["shade_plastic"] == "k_shade<2, 0, 4>" and st["shade_uber"] == "k_shade<5, 0, 5>", st
+    assert not ({"shade_1lobe", "shade_2lobe", "shade_manylobe"} & set(st)) and st["route"] == "k_route<6, 2048>", st
     gc, oc = g.counters(), orc.counters()
     for k in ckeys(COUNTERS):
         assert gc[k] == oc[k], k
     assert np.array_equal(film[..., 3], ref[..., 3])
     np.testing.assert_allclose(film[..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)
-    sd2, rp2 = pkg.scenes.material_zoo(n=16, xres=96, yres=64, spp=4).world_end()
-    g2 = pkg.Scene(gpu, sd2); g2.render(rp2)
+    sd2, rp2 = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6, mixed=True).world_end()
+    g2 = pkg.Scene(gpu, sd2); orc2 = oracle.scene(sd2)
+    film2, ref2 = g2.render(rp2), orc2.render(rp2, nthreads=4)
     st2 = {s["name"]: s["kernel"] for s in g2.kernel_stats() if s["launches"]}
-    assert st2["shade_1lobe"] == "k_shade<1, 0, 0>" and st2["shade_2lobe"] == "k_shade<2, 0, 0>", st2   # substrate in class 1, rough glass in class 2
+    assert st2["shade_metal"] == "k_shade<1, 0, 3>" and st2["shade_plastic"] == "k_shade<2, 0, 4>" and st2["shade_uber"] == "k_shade<5, 0, 5>", st2
+    assert st2["shade_1lobe"] == "k_shade<1, 0, 0>" and st2["shade_2lobe"] == "k_shade<2, 0, 0>" and st2["shade_manylobe"] == "k_shade<5, 0, 0>", st2   # substrate, rough glass, translucent
+    assert st2["route"] == "k_route<12, 1024>", st2   # nine shade classes + the miss class
+    items = {s["name"]: s["items"] for s in g2.kernel_stats() if s["launches"]}
+    assert all(items[k] > 0 for k in ("shade_metal", "shade_plastic", "shade_uber", "shade_1lobe", "shade_2lobe", "shade_manylobe", "shade_matte", "shade_specular")), items
+    gc, oc = g2.counters(), orc2.counters()
+    for k in ckeys(COUNTERS):
+        assert gc[k] == oc[k], k
+    assert np.array_equal(film2[..., 3], ref2[..., 3])
+    np.testing.assert_allclose(film2[..., :3], ref2[..., :3], rtol=3e-6, atol=1e-6)
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r})
@@ -135,7 +147,8 @@ torch.cuda.init()
 lib = pkg.load_library(); lib.init(0)
 sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
 g = pkg.Scene(lib, sd); film = g.render(rp)
-assert all("k_shade<1, 0, 0>" == s["kernel"] for s in g.kernel_stats() if s["launches"] and s["name"] == "shade_1lobe")
+ks = {{s["name"]: s["kernel"] for s in g.kernel_stats() if s["launches"]}}
+assert ks["shade_1lobe"] == "k_shade<1, 0, 0>" and ks["shade_2lobe"] == "k_shade<2, 0, 0>" and ks["shade_manylobe"] == "k_shade<5, 0, 0>" and "shade_metal" not in ks, ks
 np.save({out!r}, film)
 """.format(root=ROOT, out=str(tmp_path / "general.npy"))
     r = subprocess.run([sys.executable, "-c", code], env=trace_env(dict(os.environ, PT_SHADE_SPECIALISE="0")), capture_output=True, text=True, timeout=600)
@@ -162,17 +175,17 @@ def _uber_ball(pkg, uber):
     return b
 
 
-@pytest.mark.parametrize("uber,expect_class", [(dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2), "shade_2lobe"),
+@pytest.mark.parametrize("uber,expect_class", [(dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), roughness=0.2), "shade_plastic"),
                                                (dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), Kr=(0.1, 0.1, 0.1), roughness=0.2), "shade_uber"),
                                                (dict(Kd=(0.3, 0.5, 0.2), Ks=(0.3, 0.3, 0.3), opacity=(0.6, 0.6, 0.6), roughness=0.2), "shade_uber")])
 def test_uber_without_specular_terms_is_a_two_lobe_material(pkg, gpu, oracle, uber, expect_class):
     """uber.rs:40-106 adds its specular reflection / transmission lobes only for non-black Kr / Kt and its pass-through lobe only for
-    opacity < 1: an opaque uber with Kr = Kt = 0 is Lambertian + microfacet and is shaded by the two-lobe kernel. GPU == oracle either way."""
+    opacity < 1: an opaque uber with Kr = Kt = 0 is Lambertian + microfacet and is shaded by the plastic-like two-lobe kernel. GPU == oracle either way."""
     sd, rp = _uber_ball(pkg, uber).world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
     names = {s["name"] for s in g.kernel_stats() if s["launches"]}
-    assert expect_class in names and ({"shade_2lobe", "shade_uber"} - {expect_class}).isdisjoint(names), names
+    assert expect_class in names and ({"shade_plastic", "shade_uber", "shade_2lobe", "shade_manylobe"} - {expect_class}).isdisjoint(names), names
     gc, oc = g.counters(), orc.counters()
     for k in ckeys(COUNTERS):
         assert gc[k] == oc[k], k

@@ -1,0 +1,39 @@
+#!/bin/bash
+# round-5 A/B runs on the GPU box: tools/r5_exp.sh <tag> <what...>      (variants: tools/build_variant.sh <name> <-D flags>, listed in tools/variants.txt)
+#   ab:<variant>[,<variant>...]   C2 (3 steps) with the in-tree library and with each pbrt-rust_amd/csrc/variants/<variant>, twice, interleaved
+#   ab4:<variant>[,...]           the same on C4 at 64 spp;  ab3 / ab5: C3 at 256 spp / C5 at 216 spp
+#   quickv:<variant>              parity + golden + config tests with a variant library;  quick / full: the in-tree library
+set -o pipefail
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
+tag=$1; shift
+OUT=gpurun_out/$tag; mkdir -p $OUT
+one() {   # one <label> <bench args...>   (env of the caller applies)
+  local label=$1; shift
+  python bench.py "$@" --cpu-seconds 0 --other-configs off 2>$OUT/err_$label.log | tail -1 > $OUT/bench_$label.json || { tail -5 $OUT/err_$label.log; return 1; }
+  python3 - $OUT/bench_$label.json "$label" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); k=d['kernels_ms_per_step']
+print('%-22s %9.2f Msamples/s  %8.2f ms/step  ' % (sys.argv[2], d['value'], d['ms_per_step']) + ' '.join('%s=%.1f' % (n, x['ms']) for n, x in k.items() if x['ms'] >= 1.0), flush=True)
+PY
+}
+lib() { if [ "$1" = tree ]; then echo ""; else echo "pbrt-rust_amd/csrc/variants/$1"; fi; }
+for what in "$@"; do
+case $what in
+ab:*)  vs="tree,${what#ab:}"; for i in 1 2; do for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c2_${v}_$i --config C2 --steps 3 --warmup 1 || exit 1; done; done ;;
+ab4:*) vs="tree,${what#ab4:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c4_${v} --config C4 --spp 64 --steps 1 --warmup 1 || exit 1; done ;;
+ab3:*) vs="tree,${what#ab3:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c3_${v} --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; done ;;
+c3m) one c3_plain --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; one c3_mixed --config C3M --spp 256 --steps 1 --warmup 1 || exit 1 ;;
+ab5:*) vs="tree,${what#ab5:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c5_${v} --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; done ;;
+quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
+quick) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -5 || exit 1 ;;
+inst) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_configs.py -m gpu -x -q -k "instanc or c4 or foliage or garden" 2>&1 | tail -5 || exit 1 ;;
+full) timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 || exit 1 ;;
+parity) timeout -k 10 900 python tools/full_frame_parity.py C2:16 C5:8 C3:8 C4:4 > $OUT/full_frame_parity.jsonl 2>$OUT/parity_err.log; python3 -c "
+import json
+for l in open('$OUT/full_frame_parity.jsonl'):
+    d=json.loads(l); print(d['config'], d['spp'], 'differing', d['counters_differing'], 'weights', d['weights_identical'], 'rel', d['max_rel_diff_film'], 'linf', d['linf_normalised'])
+" ;;
+*) echo "unknown step $what"; exit 2 ;;
+esac
+done
