@@ -65,7 +65,13 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     constexpr int kLds = QUAD ? (INST ? kLdsStackQuadInst : kLdsStackQuad) : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
     constexpr int kMaxS = QUAD ? kMaxStackQuad : kMaxStack;   // deepest stack (the four-wide walk pushes up to three entries per record)
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLds * 2 * 64];
-    __shared__ float lds_wray[INST ? (kTraceBlock / 64) * 6 * 64 : 1];   // the world-space ray of a lane that is inside an instance
+#ifndef PT_WRAY_HBM
+#define PT_WRAY_HBM 1
+#endif
+    // the world-space ray of a lane that is inside an instance: six words, written when the instance is entered and read when its marker is popped. The production walk keeps
+    // them in the wave's HBM slab behind the spilled stack entries -- the 1.5 KB per wave buy three more LDS stack entries
+    constexpr bool kWrayHbm = INST && QUAD && PT_WRAY_HBM != 0;
+    __shared__ float lds_wray[(INST && !kWrayHbm) ? (kTraceBlock / 64) * 6 * 64 : 1];
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
     // (stack and spill slab through pointers that NAME their address space: a push or pop that picks between them can then only be a branch -- left generic, the
@@ -73,9 +79,11 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     //  until round 5 a scratch entry behind the LDS ones took the unconditional write instead, which cost every lane an entry of LDS: each one is worth ~1.4 % of C4's traversal)
     typedef __attribute__((address_space(3))) uint32_t lds_u32; typedef __attribute__((address_space(1))) uint32_t glb_u32;
     lds_u32 *stack = (lds_u32 *)lds_stack + wave_in_block * (kLds * 2 * 64) + lane;   // entry e: words at [2e*64], [(2e+1)*64]
-    float *wray = lds_wray + (INST ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
+    float *wray_l = lds_wray + ((INST && !kWrayHbm) ? wave_in_block * (6 * 64) + lane : 0u);        // word k at [k*64]
     // spilled entries: [wave][word][lane], so that lanes at the same depth touch consecutive dwords
-    glb_u32 *spill = (glb_u32 *)job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * (2 * kSpillEntries) + lane;   // (the slab is sized for the deeper of the two walks: both index it the same way)
+    glb_u32 *spill = (glb_u32 *)job.spill + (size_t)(blockIdx.x * (kTraceBlock / 64) + wave_in_block) * 64 * kSpillWords + lane;
+    typedef __attribute__((address_space(1))) float glb_f32;
+    glb_f32 *wray_g = (glb_f32 *)(spill + (2 * kSpillEntries) * 64);   // (the slab is sized for the deeper of the two walks: both index it the same way)
     // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
     // (measured and dropped, round 2: one work head per XCD group, each group draining "its" contiguous eighth of the queues first -- no
     //  change on any config with the segments on or off, and the dozen wave-uniform words of segment state overflowed the SGPR file into
@@ -141,12 +149,22 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     // need in any one iteration, so they run in a step of their own once `inst_quorum` lanes wait for it (like leaves, below)
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5, ST_LEAFS = 6 };   // ST_LEAFS: at a leaf and being served (leaf_quorum below)
     uint32_t state = ST_IDLE;
-    bool exhausted = false;
 #ifndef PT_TRACE_CHUNK
 #define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (round 4: 512 against 256: C2 trace 136.5 -> 135.1 ms, camera rays 36.1 -> 35.6; measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
                              // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
 #endif
     constexpr int kChunk = PT_TRACE_CHUNK;
+    // Scenes with instances: the bites shrink near the end of the queue (guided self-scheduling). Their rays are long (S4: 50 records and 20 triangle tests on average, some
+    // ten times that), so a wave that bites 512 entries when nothing is left behind them works them off while the chip idles. What is left is known for free: the atomic
+    // returns the old head. Within the last `PT_TRACE_TAIL_ROUNDS` rounds of the grid the bite is a quarter, within the last quarter round a sixteenth (C4 trace 932 -> 915 ms).
+    // Triangle-only scenes keep the full bite to the end: their launches end on single long rays, not on bites (C2: 131.4 -> 133.5 ms with the small ones, the eighth
+    // of the job that rank 0 of 8 renders 22.1 -> 22.7 ms; a plain look at the head before every bite cost more than the tail it saved, round 2).
+#ifndef PT_TRACE_TAIL_ROUNDS
+#define PT_TRACE_TAIL_ROUNDS 2
+#endif
+    constexpr bool kTailBites = MODE != 0 && PT_TRACE_TAIL_ROUNDS > 0;
+    uint32_t bite = kChunk;   // wave-uniform; 0 = the queue is drained
+#define exhausted (bite == 0u)
     uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
     uint32_t qwin = 0u, win_base = 0xffffffffu;   // the prefetched queue window (per lane) and the queue index it starts at (wave-uniform); see the refill block
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
@@ -335,10 +353,15 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 // out over several refills (consecutive entries are spatially coherent rays)
                 if (chunk_left == 0) {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(job.head, (uint32_t)kChunk);
+                    if (lane == 0) base = atomicAdd(job.head, bite);
                     chunk_next = __shfl(base, 0);
-                    chunk_left = (chunk_next < count) ? min((uint32_t)kChunk, count - chunk_next) : 0u;
-                    if (chunk_left == 0) exhausted = true;
+                    chunk_left = (chunk_next < count) ? min(bite, count - chunk_next) : 0u;
+                    if constexpr (kTailBites) {
+                        const uint32_t grid_round = gridDim.x * (kTraceBlock / 64) * (uint32_t)kChunk;   // entries one full bite of every wave takes
+                        const uint32_t behind = count > chunk_next + bite ? count - chunk_next - bite : 0u;   // entries nobody had taken when this bite was
+                        bite = behind < grid_round / 4u ? (uint32_t)kChunk / 16u : behind < (uint32_t)PT_TRACE_TAIL_ROUNDS * grid_round ? (uint32_t)kChunk / 4u : (uint32_t)kChunk;
+                    }
+                    if (chunk_left == 0) bite = 0u;
                 }
                 if (chunk_left != 0u && win_base != chunk_next) { qwin = load_window(chunk_next, chunk_left); win_base = chunk_next; }   // a fresh chunk: not prefetched (once per kChunk rays)
                 // PROBE: lanes that went on to their chain's next segment are in `donem` but not idle any more
@@ -453,7 +476,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 if (state == ST_RET) {
                     const uint32_t w0 = xf_arg;
                     if (!QUAD) pending = (w0 >> 25) & 63u;            // the outer traversal's skipped entries
-                    ro = V3(wray[0], wray[64], wray[128]); rd = V3(wray[192], wray[256], wray[320]);
+                    if constexpr (kWrayHbm) { ro = V3(wray_g[0], wray_g[64], wray_g[128]); rd = V3(wray_g[192], wray_g[256], wray_g[320]); }
+                    else { ro = V3(wray_l[0], wray_l[64], wray_l[128]); rd = V3(wray_l[192], wray_l[256], wray_l[320]); }
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
                     PT_TRI_RAY();
@@ -481,7 +505,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         // remember where to resume: the rest of this leaf (if any) and the outer skip count
                         push((more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (QUAD ? 0u : (pending << 25)), kMarker);
                         pending = 0;
-                        wray[0] = ro.x; wray[64] = ro.y; wray[128] = ro.z; wray[192] = rd.x; wray[256] = rd.y; wray[320] = rd.z;
+                        if constexpr (kWrayHbm) { wray_g[0] = ro.x; wray_g[64] = ro.y; wray_g[128] = ro.z; wray_g[192] = rd.x; wray_g[256] = rd.y; wray_g[320] = rd.z; }
+                        else { wray_l[0] = ro.x; wray_l[64] = ro.y; wray_l[128] = ro.z; wray_l[192] = rd.x; wray_l[256] = rd.y; wray_l[320] = rd.z; }
                         t_max_world = t_max; in_inst = ii; inst_hit = false;
                         ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; PT_SGN3(); t_max = tm2;
                         PT_TRI_RAY();
@@ -720,6 +745,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
 #endif
 }
 #undef PT_SUB
+#undef exhausted
 #undef PT_GPTR
 #undef PT_UTIL
 #undef PT_UTIL_MARK

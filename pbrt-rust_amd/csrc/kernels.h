@@ -41,12 +41,13 @@ constexpr int kMaxStack = 64;       // the reference's stack size (accelerators/
 #endif
 constexpr int kLdsStackQuad = PT_LDS_STACK_QUAD;   // the four-wide walk (kern_trace.h, QUAD): up to three pushes per record; five waves per SIMD x 7 KB per wave of LDS
 #ifndef PT_LDS_STACK_QUAD_INST
-#define PT_LDS_STACK_QUAD_INST 16
+#define PT_LDS_STACK_QUAD_INST 19
 #endif
 constexpr int kLdsStackQuadInst = PT_LDS_STACK_QUAD_INST;   // the four-wide walk of scenes with instances (outer tree + marker + object tree on one stack): four waves per SIMD share a CU's LDS
 constexpr int kMaxStackQuad = 96;   // a reference tree of depth 64 collapses to 32 four-wide levels x 3 pushes
 constexpr int kLdsStackMinQuad = kLdsStackQuad < kLdsStackQuadInst ? kLdsStackQuad : kLdsStackQuadInst, kLdsStackMinTwo = kLdsStack < kLdsStackGeneral ? kLdsStack : kLdsStackGeneral;
 constexpr int kSpillEntries = (kMaxStackQuad - kLdsStackMinQuad) > (kMaxStack - kLdsStackMinTwo) ? (kMaxStackQuad - kLdsStackMinQuad) : (kMaxStack - kLdsStackMinTwo);   // per-lane HBM stack entries behind the LDS ones
+constexpr int kSpillWords = 2 * kSpillEntries + 8;   // per lane in the HBM slab of a wave: the stack entries behind the LDS ones, then the world-space ray of a lane inside an instance (six words; the four-wide walk of instanced scenes keeps it here, kern_trace.h)
 constexpr int kTraceBlock = 256;
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
 

@@ -51,7 +51,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         if ((st = sc->dalloc(&sc->qc, 1))) return st;
         if ((st = sc->dalloc(&sc->dc, 1))) return st;
         sc->spill_waves = (uint32_t)g_num_cus * g_trace_waves_per_cu;  // resident persistent waves (LDS: 5 KB per wave)
-        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * 2 * kSpillEntries))) return st;
+        if ((st = sc->dalloc(&sc->spill, (size_t)sc->spill_waves * 64 * kSpillWords))) return st;
         if ((st = sc->dalloc(&sc->d_filter, 256))) return st;
         if (sc->has_bssrdf && (st = sc->dalloc(&sc->probe_ring, (size_t)sc->spill_waves * 64 * kProbeRing * 3))) return st;
     }

@@ -31,6 +31,7 @@ if ent:
     print(f"instance entries {ent} ({ent / rays:.2f} per ray); object root test rejects {v[1]} = {100 * v[1] / ent:.1f} %")
     for name, k in (("box of the instance", 2), ("+ xz diagonals", 4), ("oriented box, bf16 rows", 6)):
         print(f"  gate [{name:24s}] rejects {v[k]} = {100 * v[k] / ent:.1f} % of the entries = {100 * v[k] / max(v[1], 1):.1f} % of the root test's; rejects the root test admits: {v[k + 1]}")
+    print(f"  gate [world boxes of the object's four root slots] rejects {v[8]} = {100 * v[8] / ent:.1f} % of the entries ({v[10]} the root test rejects too, {v[9]} it admits -- no leaf reached either way)")
     print("top-level leaf visits by packets:", {n: v[16 + n] for n in range(8) if v[16 + n]}, " by instances in the leaf:", {n: v[40 + n] for n in range(8) if v[40 + n]})
 ol = {n: v[24 + n] for n in range(8) if v[24 + n]}
 tot = sum(ol.values()); pk = sum(n * k for n, k in ol.items())

@@ -10,7 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-enum { OS_ENTRIES = 0, OS_ROOT_FAIL, OS_AABB_REJ, OS_AABB_FALSE, OS_DIAG_REJ, OS_DIAG_FALSE, OS_OBB_REJ, OS_OBB_FALSE, OS_TOP_LEAF = 16 /* +n_prims (<=7) */,
+enum { OS_ENTRIES = 0, OS_ROOT_FAIL, OS_AABB_REJ, OS_AABB_FALSE, OS_DIAG_REJ, OS_DIAG_FALSE, OS_OBB_REJ, OS_OBB_FALSE, OS_QUAD_REJ, OS_QUAD_FALSE_ROOT /* rejected although the root test admits: fine as long as no leaf is reached */, OS_QUAD_REJ_ROOTFAIL, OS_TOP_LEAF = 16 /* +n_prims (<=7) */,
        OS_OBJ_LEAF = 24 /* +n_prims */, OS_OBJ_LEAF_MULTIHIT = 32, OS_OBJ_LEAF_VISITS_CLOSEST = 33, OS_TOP_LEAF_INST = 40 /* + instances in the leaf */, OS_N = 64 };
 inline std::atomic<uint64_t> g_orc_study[OS_N];
 extern "C" __attribute__((used)) inline void orc_study_read(uint64_t *out) { for (int i = 0; i < OS_N; ++i) out[i] = g_orc_study[i].load(); }
@@ -70,6 +70,24 @@ template <class S, class R> void orc_study_instance(const S &sc, uint32_t ii, co
         h[i] *= 1.0 + 1.0 / 128.0;
         eo[i] = 0; fo[i] = 0; for (int j = 0; j < 3; ++j) { eo[i] += A[i][j] * (o[j] - cw[j]); fo[i] += A[i][j] * d[j]; }
         lo1[i] = -h[i]; hi1[i] = h[i];
+    }
+    {   // (d) "gate record": world-space boxes (inflated) of the four slots of the object's four-wide root record; rejected when the ray misses all four
+        const auto &nn = sc.obj_accel[I.object].nodes;
+        int slots[4]; int ns = 0;
+        if (nn[0].n_prims > 0) slots[ns++] = 0;
+        else for (int side = 0; side < 2; ++side) { const int ci = side == 0 ? 1 : (int)nn[0].offset; if (nn[ci].n_prims > 0) slots[ns++] = ci; else { slots[ns++] = ci + 1; slots[ns++] = (int)nn[ci].offset; } }
+        bool any = false;
+        for (int k = 0; k < ns && !any; ++k) {
+            const auto &b = nn[slots[k]];
+            double wl[3] = {1e300, 1e300, 1e300}, wh[3] = {-1e300, -1e300, -1e300};
+            for (int q = 0; q < 8; ++q) {
+                double ext[3], p[3];
+                for (int a = 0; a < 3; ++a) { ext[a] = (double)b.bmax[a] - b.bmin[a]; p[a] = ((q >> a) & 1) ? b.bmax[a] + 1e-4 * ext[a] + 1e-6 : b.bmin[a] - 1e-4 * ext[a] - 1e-6; }
+                for (int a = 0; a < 3; ++a) { const double v = m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3]; if (v < wl[a]) wl[a] = v; if (v > wh[a]) wh[a] = v; }
+            }
+            any = os_slabs(3, e, f, wl, wh, tm);
+        }
+        if (!any) { g_orc_study[OS_QUAD_REJ]++; if (pass) g_orc_study[OS_QUAD_FALSE_ROOT]++; else g_orc_study[OS_QUAD_REJ_ROOTFAIL]++; }
     }
     const bool obb = os_slabs(3, eo, fo, lo1, hi1, tm);
     if (!obb) { g_orc_study[OS_OBB_REJ]++; if (pass) g_orc_study[OS_OBB_FALSE]++; }
