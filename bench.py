@@ -44,13 +44,32 @@ def algo_bytes(name, s):
     visited in the exact walk) + 48 B per shape packet tested + 44 B per ray (pid 4, ray 24, hit record 16); shade kernels count their
     path-state / mesh / queue quads in-kernel."""
     if name in TRACE_KINDS:
-        # production traversal (kernel symbol k_trace<.., true>): the node counter counts four-wide records fetched, 128 B each; the exact walk
-        # (pt_set_trace_exact, k_trace<.., false>) counts the reference's node visits, 32 B each
-        node_bytes = 128 if str(s.get("kernel", "")).rstrip().endswith("true>") else 32
+        # production traversal (kernel symbol k_trace<.., 1> / <.., 2>): the node counter counts four-wide records fetched, 128 B each; the exact walk
+        # (pt_set_trace_exact, k_trace<.., 0>) counts the reference's node visits, 32 B each
+        node_bytes = 32 if str(s.get("kernel", "")).rstrip().endswith(", 0>") else 128
         return node_bytes * s["bvh_nodes"] + 48 * s["triangle_tests"] + 44 * s["items"]
     if name.startswith("shade_") or name == "bssrdf":
         return s["bvh_nodes"]
     return None
+
+
+_TRAFFIC = {}
+
+
+def traffic_record(config, kernel, eff_spp_per_pass, workload_key):
+    """(record, code_match) of profiles/pmc_traffic.json for one kernel symbol of one config at this pass size, or (None, None). The byte counts are a
+    property of the CODE that was profiled: code_match says whether the committed record was taken from these sources (tools/code_hash.py)."""
+    if "data" not in _TRAFFIC:
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            _TRAFFIC["data"] = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        except Exception:
+            _TRAFFIC["data"] = {}
+        _TRAFFIC["hash"] = code_hash(ROOT)
+    r = _TRAFFIC["data"].get(config, {}).get(kernel)
+    if r and r.get("spp_per_pass") == eff_spp_per_pass and r.get("workload") == workload_key:
+        return r, r.get("code_hash") == _TRAFFIC["hash"]
+    return None, None
 
 
 def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
@@ -74,19 +93,7 @@ def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = g["ms"] / max(1, g["launches"])
     achieved = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-    rec = None
-    code_match = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            data = json.load(open(tpath))
-            r = data.get(config, {}).get(name)
-            if r and r.get("spp_per_pass") == eff_spp_per_pass and r.get("workload") == workload_key:
-                # the byte counts are a property of the CODE that was profiled: a record taken from other sources is reported, not used
-                code_match = r.get("code_hash") == code_hash(ROOT)
-                rec = r
-        except Exception:
-            rec = None
+    rec, code_match = traffic_record(config, name, eff_spp_per_pass, workload_key)
     traffic = hbm_achieved = hbm_frac = l2_hit = gather_frac = valu_busy = None
     if rec:
         traffic, l2_hit = rec.get("hbm_bytes_per_launch"), rec.get("l2_hit_rate")
@@ -99,13 +106,23 @@ def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
             if rd:
                 gather_frac = rd / disp / (avg_ms * 1e-3) / 1e9 / GATHER_CEILING_GREQ_S
     is_trace = any(k in TRACE_KINDS for k in g["kinds"])
-    # `bound` names the limiter the committed counters show, not the roof one would like to be measured against: a per-lane BVH walk issues vector
-    # instructions most of the time (valu_busy_frac from the SQ counters of the same kernel) while its fabric bytes stay well below the HBM peak;
-    # the HBM fraction is kept beside it (`hbm_frac` == `frac`, the figure BASELINE.json asks for).
-    if is_trace or name.startswith("k_shade") or name.startswith("k_bssrdf"):
+    # `bound` names the limiter the committed counters of THIS kernel show (profiles/pmc_traffic.json, code-hash-gated), not the roof one would like to be measured
+    # against: "hbm" when its fabric bytes run at >= 60 % of the HBM peak, "valu_issue" when vector instructions issue in >= 60 % of its SIMD cycles, "gather_latency"
+    # when neither does (dependent gathers: the CU's line requests in flight x the loaded latency), "unknown" without a record taken from these sources.
+    if not (rec and code_match):
+        bound = "unknown"
+    elif hbm_frac is not None and hbm_frac >= 0.6:
+        bound = "hbm"
+    elif valu_busy is not None and valu_busy >= 0.6:
         bound = "valu_issue"
     else:
-        bound = "hbm"
+        bound = "gather_latency"
+    limiter = {"hbm": "fabric bytes at %s of the HBM peak" % (None if hbm_frac is None else round(hbm_frac, 3)),
+               "valu_issue": "vector-instruction issue (valu_busy_frac %s) of a per-lane %s; fabric bytes at %s of the HBM peak, %s of the dependent-gather request ceiling"
+                             % (valu_busy, "BVH walk" if is_trace else "shading loop", None if hbm_frac is None else round(hbm_frac, 3), None if gather_frac is None else round(gather_frac, 3)),
+               "gather_latency": "neither bytes (%s of the HBM peak) nor vector issue (valu_busy_frac %s): scattered 32-128-byte gathers, bounded by the CU's 64 line requests in flight at "
+                                 "the memory system's loaded latency (profiles/r4/tcp_counters_*.txt; DESIGN.md section 7)" % (None if hbm_frac is None else round(hbm_frac, 3), valu_busy),
+               "unknown": "no committed counter record of this kernel from these sources (profiles/pmc_traffic.json: traffic_code_match)"}[bound]
     return dict(
         bound=bound, kernel=name, launch_kinds=g["kinds"], unit="GB/s", peak=HBM_PEAK_GBS,
         achieved=round(achieved, 2),
@@ -123,18 +140,26 @@ def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
         l2_hit_rate=l2_hit if code_match else None,
         frac_of_gather_ceiling=None if gather_frac is None else round(gather_frac, 4),
         gather_ceiling="fabric read requests per second of this kernel / 54 G/s, the measured chip-wide rate of dependent random 64-byte gathers (profiles/r2_gather_calibration.json)",
-        limiter=("vector-instruction issue of a per-lane BVH walk (valu_busy_frac) with, close behind it, the CU's vector L1 holding ~35 of the 64 line requests it can keep in flight at the "
-                 "memory system's loaded latency (profiles/r4/tcp_counters_C2_spp32.txt; DESIGN.md section 7 has the SQ and TCP counters)" if is_trace
-                 else "bursts of gathers that fill the CU's 64 line requests in flight (the vector L1 stalls on pending requests 60 % of its cycles) between long stretches of arithmetic at 2-3 "
-                      "waves/SIMD (VGPR-limited): neither bytes nor vector issue alone (DESIGN.md section 7)"),
+        limiter=limiter,
         launches=g["launches"], avg_launch_ms=round(avg_ms, 4),
         algorithmic_bytes_per_launch=int(g["bytes"] / max(1, g["launches"])))
 
 
-def kernel_table(kstats, steps):
+def kernel_table(kstats, steps, config=None, eff_spp_per_pass=None, workload_key=None):
     def gbs(n, v):
         ab = algo_bytes(n, v)
-        return {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
+        out = {} if ab is None else {"algo_GBs": round(ab / max(1e-9, v["total_ms"]) / 1e6, 1)}
+        # fabric-side bytes of the kernel symbol from the committed PMC profile (code-hash-gated like roofline.frac) over THIS run's launch times: hbm_frac and,
+        # where the kernel counts its algorithmic bytes, traffic_over_algorithmic (> 1: lines fetched for bytes nobody asked for)
+        rec, match = traffic_record(config, v["kernel"], eff_spp_per_pass, workload_key) if config and v.get("kernel") else (None, None)
+        if rec and match and rec.get("hbm_bytes_per_launch") and v["launches"] and v["total_ms"] > 0:
+            fabric = rec["hbm_bytes_per_launch"] * v["launches"]
+            out["hbm_frac"] = round(fabric / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if ab:
+                out["traffic_over_algorithmic"] = round(fabric / ab, 3)
+            if rec.get("valu_busy_frac") is not None:
+                out["valu_busy_frac"] = rec["valu_busy_frac"]
+        return out
     kernels = {n: dict(ms=round(v["total_ms"] / steps, 3), launches=v["launches"] // steps, kernel=v["kernel"], **gbs(n, v),
                        **({"Mitems": round(v["items"] / steps / 1e6, 2), "ns_per_item": round(v["total_ms"] * 1e6 / v["items"], 3)} if v["items"] and n not in TRACE_KINDS else {}),
                        **({"Mrays_s": round(v["items"] / max(1e-9, v["total_ms"]) / 1e3, 1), "nodes_per_ray": round(v["bvh_nodes"] / max(1, v["items"]), 1)} if n in TRACE_KINDS else {}))
@@ -296,7 +321,7 @@ def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, device
     roofline = build_roofline(kstats, config, eff_spp_per_pass, [args.mesh_n, args.xres, args.yres]) if nrep == 1 or in_process else None
     if roofline and nrep > 1:
         roofline["note"] = f"launch times and bytes are summed over the {nrep} replicas (each renders 1/{nrep} of the tiles)"
-    kernels, trace_kinds = kernel_table(kstats, steps)
+    kernels, trace_kinds = kernel_table(kstats, steps, config, eff_spp_per_pass, [args.mesh_n, args.xres, args.yres])
 
     cpu_baseline = None
     if want_cpu_baseline and args.cpu_seconds > 0 and world == 1:
@@ -426,7 +451,8 @@ def main():
                                dominant_kernel=rf.get("kernel"), dominant_avg_launch_ms=rf.get("avg_launch_ms"), algorithmic_GBs=rf.get("achieved"),
                                hbm_frac=rf.get("hbm_frac"), rays_per_sample=r["rays_per_sample"], nodes_per_ray=r["nodes_per_ray"],
                                **({"scaling_projection": r["scaling_projection"]} if r.get("scaling_projection") else {}),
-                               kernels_ms_per_step={k: v["ms"] for k, v in r["kernels_ms_per_step"].items()})
+                               bound=rf.get("bound"), valu_busy_frac=rf.get("valu_busy_frac"),
+                               kernels_ms_per_step={k: {kk: v[kk] for kk in ("ms", "kernel", "hbm_frac", "traffic_over_algorithmic") if kk in v} for k, v in r["kernels_ms_per_step"].items()})
             except Exception as e:   # the headline line must not be lost to a side measurement
                 oc[cfg] = dict(error=f"{type(e).__name__}: {e}")
         out["other_configs"] = oc

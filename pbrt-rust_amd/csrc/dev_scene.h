@@ -52,7 +52,8 @@ struct QuadNode {
 };
 static_assert(sizeof(QuadNode) == 128, "QuadNode is one 128-byte line");
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr uint32_t kRefMask = 0x01ffffffu;   // 25 bits: 33 M records / packets (stack entries pack 6 more bits above)
+constexpr uint32_t kRefMask = 0x01ffffffu;   // the two-wide (exact) walk: 25 bits, 33 M records / packets -- its stack entries pack the 6 bits of a skipped-entry count above them
+constexpr uint32_t kRefMaskQuad = 0x7fffffffu;   // the production walk: 31 bits; what bounds a scene there is the pool of records + packets, addressed in 16-byte quads (64 GB)
 
 // TransformedPrimitive (primitive.rs:40-88) on device: transforms + entry into the object's BVH
 struct DevInstance {
@@ -76,7 +77,7 @@ struct DevImage { uint32_t width, height, n_levels, channels; const float *texel
 struct DeviceScene {
     const WideNode *wide; uint32_t n_nodes;   // n_nodes = nodes of the reference tree (0 => empty scene)
     float root_min[3], root_max[3]; uint32_t root_ref;  // the root's own bounds and reference
-    const QuadNode *quad; uint32_t root_ref4; uint32_t leaf_off, pool_bytes;   // (leaf_off: byte offset of `leaf` from `quad` -- one allocation of pool_bytes < 3.5 GB)
+    const QuadNode *quad; uint32_t root_ref4; uint32_t leaf_off, pool_quads;   // (leaf_off: offset of `leaf` from `quad` in 16-byte quads -- one allocation of pool_quads quads, < 64 GB)
     //         // four-wide records of the same trees (production traversal) and the root's reference among them
     const TriPacket *leaf; uint32_t n_prims;
     const float *P; const float *N; const float *S; const float *UV;

@@ -39,6 +39,7 @@ extern bool g_trace_exact;
 extern uint32_t g_inst_quorum;
 extern bool g_shade_specialise;
 extern uint32_t g_trace_waves_per_cu;
+extern uint32_t g_test_pool_pad_records;
 extern thread_local SobolTables g_tabs;
 constexpr int kMaxDevices = kMaxReplicas;
 struct DevCtx { bool ready = false; int num_cus = 256; SobolTables tabs = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
@@ -74,6 +75,9 @@ struct pt_scene {
     DeviceScene ds{};
     std::vector<PtBVHNode> nodes;
     std::vector<uint32_t> ordered;
+    bool pool_big = false;          // four-wide records + packets beyond 4 GB: k_trace<.., 2> (64-bit addresses)
+    bool quad_walk_only = false;    // more than 2^25 two-wide records or packets: the scene has no exact (two-wide) walk, pt_set_trace_exact(1) renders are refused
+    bool exact_walk_only = false;   // an adopted top-level tree whose child boxes do not nest: the two-wide walk tests every box like the reference (scene_create.hip)
     bool class_used[kNumClasses] = {true, false, false, false, true, false, false, false, false, false, false};   // shade classes the scene's materials map to (kernels.h: kNumClasses; scene_create.hip: material_class)
     bool has_null_material = false;   // a primitive without a material: a medium-interface shell (api.rs:597). The path integrator steps over it (path.rs:124-129);
                                       // the volumetric one also walks its shadow / MIS rays through it, segment by segment (kern_shade_common.h: vol_chain_step)

@@ -3,7 +3,7 @@
 #pragma once
 #include "kern_common.h"
 
-template <int ANY, int MODE, bool PROBE, bool QUAD> __global__ void k_trace(DeviceScene s, TraceJob job);   // ANY: 0 closest hit, 1 any hit, 2 mixed (per-lane kind)
+template <int ANY, int MODE, bool PROBE, int QUADK> __global__ void k_trace(DeviceScene s, TraceJob job);   // ANY: 0 closest hit, 1 any hit, 2 mixed (per-lane kind); QUADK: 0 two-wide (exact) walk, 1 production walk, 2 production walk of a pool beyond 4 GB
 template <int MAXL, int MODE, int DIFF> __global__ void k_shade(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);
 template <bool SPH, bool VOL> __global__ void k_shade_miss(DeviceScene s, RenderConst rc, PathSoA ps, ShadeJob job);
 template <bool SPH, bool VOL> __global__ void k_bssrdf(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, BssrdfJob job);

@@ -46,7 +46,7 @@
 // visited in the reference's order, so every hit (primitive, t, barycentrics) and the triangle / sphere test counters are the reference's; the node
 // counter then counts RECORDS fetched (128 B each). QUAD = false walks the two-wide records and reproduces the reference's node-visit counter
 // (pt_set_trace_exact / PT_TRACE_EXACT=1: the counter tests and the oracle comparisons of bvh_nodes_visited).
-template <int ANY, int MODE, bool PROBE, bool QUAD>
+template <int ANY, int MODE, bool PROBE, int QUADK>
 #ifndef PT_TRACE_WAVES_PROBE
 #define PT_TRACE_WAVES_PROBE 1   // experiment hook: waves per SIMD of the triangle-only probe-chain kernel (125 VGPRs = four by itself)
 #endif
@@ -56,12 +56,16 @@ template <int ANY, int MODE, bool PROBE, bool QUAD>
 #ifndef PT_TRACE_WAVES_QUAD_INST
 #define PT_TRACE_WAVES_QUAD_INST 4
 #endif
-__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRACE_WAVES_QUAD : PT_TRACE_WAVES) : (MODE == 3 && !PROBE) ? (QUAD ? PT_TRACE_WAVES_QUAD_INST : PT_TRACE_WAVES_INST) : (MODE == 0 && PROBE) ? PT_TRACE_WAVES_PROBE : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
+__global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) ? PT_TRACE_WAVES_QUAD : PT_TRACE_WAVES) : (MODE == 3 && !PROBE) ? ((QUADK != 0) ? PT_TRACE_WAVES_QUAD_INST : PT_TRACE_WAVES_INST) : (MODE == 0 && PROBE) ? PT_TRACE_WAVES_PROBE : 1) PT_TRACE_ATTR void k_trace(DeviceScene s, TraceJob job) {
     static_assert(!(ANY != 0 && PROBE), "probe chains are closest-hit queries");
+    // QUADK: 0 = the two-wide (exact) walk, 1 = the production walk, 2 = the production walk of a scene whose records + packets exceed the 4 GB that a buffer load's
+    // 32-bit byte offset reaches: the same walk through global loads with 64-bit addresses (~15 more vector instructions per step for the address arithmetic)
+    constexpr bool QUAD = QUADK != 0, BIG = QUADK == 2;
     constexpr bool MIX = ANY == 2;
     // MODE: 0 triangles only; 1 general geometry (spheres / disks and object instances); 2 general + alpha-masked triangles;
     //       3 triangles + object instances (no quadrics, no masks: config C4's kind of scene)
     constexpr bool SPH = MODE == 1 || MODE == 2, INST = MODE >= 1, ALPHA = MODE == 2;
+    constexpr uint32_t kMaskRef = QUAD ? kRefMaskQuad : kRefMask;   // index bits of a child reference / stack word
     constexpr int kLds = QUAD ? (INST ? kLdsStackQuadInst : kLdsStackQuad) : (MODE == 0 ? kLdsStack : kLdsStackGeneral);   // LDS stack entries per lane
     constexpr int kMaxS = QUAD ? kMaxStackQuad : kMaxStack;   // deepest stack (the four-wide walk pushes up to three entries per record)
     __shared__ uint32_t lds_stack[(kTraceBlock / 64) * kLds * 2 * 64];
@@ -127,7 +131,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
     // QUAD: records and packets live in ONE allocation, addressed by 32-bit byte offsets from its start through a buffer resource
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<QuadNode *>(s.quad), 0, (int)s.pool_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<QuadNode *>(s.quad), 0, BIG ? 0 : (int)(s.pool_quads << 4), 0x00020000);
+    typedef __attribute__((address_space(1))) const v4u gpool_u32;   // BIG: the pool as global quads
+    gpool_u32 *const gpool = (gpool_u32 *)s.quad;
     const uint4 *leaf4 = reinterpret_cast<const uint4 *>(s.leaf);
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
             }
             if (!QUAD) { n_nodes++; pending = (w0 >> 25) & 63u; }   // the reference tests the popped node now
             if (__uint_as_float(w1) < t_max) {         // deferred half of intersect_p2
-                cur = w0 & kRefMask;
+                cur = w0 & kMaskRef;
                 state = (w0 & kLeafBit) ? ST_LEAF : ST_ENTER;
                 return;
             }
@@ -305,10 +311,13 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         n_rays++;                                  // Scene::intersect of the next segment
                         state = ST_DONE;                           // (a segment that misses the world bound is a miss: resolved at the next refill round)
                         if (s.n_nodes > 0) {
-                            n_nodes++;
-                            if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
-                                cur = root_ref & kRefMask;
-                                state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                            if (QUAD && !(root_ref & kLeafBit)) { cur = root_ref & kMaskRef; state = ST_ENTER; }   // (as at a refill: no root test in the production walk)
+                            else {
+                                n_nodes++;
+                                if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
+                                    cur = root_ref & kMaskRef;
+                                    state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
+                                }
                             }
                         }
                     } else {
@@ -433,11 +442,11 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         // the boxes of the root record's four slots (they lie inside it and the slab arithmetic is monotone in the planes -- the argument that
                         // lets the walk skip the collapsed L and R), so it reaches no leaf either way; ~50 vector instructions per ray that only rays starting
                         // outside the scene's bounds and pointing away ever needed. (The exact walk counts the test as the reference does.)
-                        cur = root_ref & kRefMask; state = ST_ENTER;
+                        cur = root_ref & kMaskRef; state = ST_ENTER;
                     } else {   // the root node's own test (bvh.rs:725-727)
-                        n_nodes++;
+                        if (!QUAD) n_nodes++;   // (production walk: the counter counts four-wide RECORDS fetched, nothing else)
                         if (slab_test(s.root_min, s.root_max, ro, inv_dir, nx, ny, nz, t_max)) {
-                            cur = root_ref & kRefMask;
+                            cur = root_ref & kMaskRef;
                             state = (root_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                         }
                     }
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     PT_TRI_RAY();
                     t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
                     in_inst = PT_NONE; inst_hit = false;
-                    if (w0 & kLeafBit) { cur = w0 & kRefMask; state = ST_LEAF; }  // remaining packets of the outer leaf
+                    if (w0 & kLeafBit) { cur = w0 & kMaskRef; state = ST_LEAF; }  // remaining packets of the outer leaf
                     else need_pop = true;
                 } else if (state == ST_INST) {   // TransformedPrimitive::intersect / intersect_p (primitive.rs:58-88)
                     const uint32_t li = cur;
@@ -499,11 +508,11 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     const V3 inv2(1.0f / d2.x, 1.0f / d2.y, 1.0f / d2.z);
                     const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
                     bool enter = true;
-                    if (!I.single) { n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+                    if (!I.single) { if (!QUAD) n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
                     if (enter && ((!QUAD && pending > 63u) || sp >= (uint32_t)kMaxS)) { atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW); enter = false; }
                     if (enter) {
                         // remember where to resume: the rest of this leaf (if any) and the outer skip count
-                        push((more ? (kLeafBit | ((li + 1u) & kRefMask)) : 0u) | (QUAD ? 0u : (pending << 25)), kMarker);
+                        push((more ? (kLeafBit | ((li + 1u) & kMaskRef)) : 0u) | (QUAD ? 0u : (pending << 25)), kMarker);
                         pending = 0;
                         if constexpr (kWrayHbm) { wray_g[0] = ro.x; wray_g[64] = ro.y; wray_g[128] = ro.z; wray_g[192] = rd.x; wray_g[256] = rd.y; wray_g[320] = rd.z; }
                         else { wray_l[0] = ro.x; wray_l[64] = ro.y; wray_l[128] = ro.z; wray_l[192] = rd.x; wray_l[256] = rd.y; wray_l[320] = rd.z; }
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                         ro = o2; rd = d2; inv_dir = inv2; nx = nx2; ny = ny2; nz = nz2; PT_SGN3(); t_max = tm2;
                         PT_TRI_RAY();
                         const uint32_t iroot = QUAD ? I.root_ref4 : I.root_ref;
-                        cur = iroot & kRefMask;
+                        cur = iroot & kMaskRef;
                         state = (iroot & kLeafBit) ? ST_LEAF : ST_ENTER;
                     } else if (more) { cur = li + 1u; state = ST_LEAF; }
                     else need_pop = true;
@@ -538,17 +547,25 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 // Bounds3f::intersect_p2 indexes them (`bounds[dir_is_neg[k]]`, bounds.rs:561-566) without a select per plane. A node lane's other five
                 // loads of the same 128-byte line (far planes, references, order word) go out with them -- a leaf lane aims them past the end --, so a step is
                 // one round trip and nobody waits inside a branch.
-                const uint32_t onx = nx ? 48u : 0u, ony = ny ? 64u : 16u, onz = nz ? 80u : 32u;
-                const uint32_t c3x = (cur << 1) + cur, qb = at_leaf ? (c3x << 4) + s.leaf_off : (cur << 7);
-                const uint32_t nb = at_node ? qb : 0xffffff00u;
-                const v4u a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs & 0xffu) : onx), 0, 0);
-                const v4u a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? ((lofs >> 8) & 0xffu) : ony), 0, 0);
-                const v4u a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs >> 16) : onz), 0, 0);
-                const v4u b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (48u - onx), 0, 0);
-                const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (80u - ony), 0, 0);
-                const v4u b2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (112u - onz), 0, 0);
-                const v4u rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + 96u, 0, 0);
-                const uint32_t meta = __builtin_amdgcn_raw_buffer_load_b32(rsrc, nb + 112u, 0, 0);
+                v4u a0, a1, a2, b0, b1, b2, rf; uint32_t meta;
+                if constexpr (!BIG) {
+                    const uint32_t onx = nx ? 48u : 0u, ony = ny ? 64u : 16u, onz = nz ? 80u : 32u;
+                    const uint32_t c3x = (cur << 1) + cur, qb = at_leaf ? (c3x << 4) + (s.leaf_off << 4) : (cur << 7);
+                    const uint32_t nb = at_node ? qb : 0xffffff00u;
+                    a0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs & 0xffu) : onx), 0, 0);
+                    a1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? ((lofs >> 8) & 0xffu) : ony), 0, 0);
+                    a2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, qb + (at_leaf ? (lofs >> 16) : onz), 0, 0);
+                    b0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (48u - onx), 0, 0);
+                    b1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (80u - ony), 0, 0);
+                    b2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + (112u - onz), 0, 0);
+                    rf = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nb + 96u, 0, 0);
+                    meta = __builtin_amdgcn_raw_buffer_load_b32(rsrc, nb + 112u, 0, 0);
+                } else {   // quads of the pool through 64-bit addresses; a leaf lane aims its five node loads at record 0 (one line the whole wave shares)
+                    const uint32_t onx = nx ? 3u : 0u, ony = ny ? 4u : 1u, onz = nz ? 5u : 2u;
+                    gpool_u32 *const rec = gpool + (at_leaf ? (size_t)cur * 3u + s.leaf_off : (size_t)cur * 8u), *const nrec = at_node ? rec : gpool;
+                    a0 = rec[at_leaf ? ((lofs >> 4) & 0xfu) : onx]; a1 = rec[at_leaf ? ((lofs >> 12) & 0xfu) : ony]; a2 = rec[at_leaf ? (lofs >> 20) : onz];
+                    b0 = nrec[3u - onx]; b1 = nrec[5u - ony]; b2 = nrec[7u - onz]; rf = nrec[6]; meta = nrec[7].x;
+                }
                 asm volatile("" :: "v"(a0.x), "v"(a1.x), "v"(a2.x), "v"(a2.w), "v"(b0.x), "v"(b1.x), "v"(b2.x), "v"(rf.x), "v"(meta));   // all eight before the node / leaf branch
                 PT_UTIL_MARK(u_cfetch);
                 q0 = make_uint4(a0.x, a0.y, a0.z, a0.w); q1 = make_uint4(a1.x, a1.y, a1.z, a1.w); q2 = make_uint4(a2.x, a2.y, a2.z, a2.w); q3 = make_uint4(0u, 0u, 0u, 0u);
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                     }
                     if (m0 | m1 | m2 | m3) {
                         const uint32_t nr = m0 ? r0 : (m1 ? r1 : (m2 ? r2 : r3));
-                        cur = nr & kRefMask;
+                        cur = nr & kMaskRef;
                         state = (nr & kLeafBit) ? ST_LEAF : ST_ENTER;
                     } else need_pop = true;
                 }
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? (QUAD ? PT_TRA
                 } else pending++;
                 n_nodes++;  // the near child's test
                 if (geo_near && tmin_near < t_max) {
-                    cur = near_ref & kRefMask;
+                    cur = near_ref & kMaskRef;
                     state = (near_ref & kLeafBit) ? ST_LEAF : ST_ENTER;
                 } else need_pop = true;
             } else {

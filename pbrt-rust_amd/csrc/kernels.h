@@ -19,7 +19,7 @@ constexpr int kNumClasses = 11;     // material-sorted shade queues, one per sha
 //       // 10 smooth subsurface (k_shade<1, ., 6>). The specialised forms exist for the untextured path integrator: material_class() (scene_create.hip)
 //       // hands these classes out only to scenes without textures, and the volumetric router folds them back (class_general).
 constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6, kMetalClass = 7, kPlasticClass = 8, kUberClass = 9, kSssClass = 10;
-PT_HD inline uint32_t class_general(uint32_t c) { return c == (uint32_t)kMetalClass ? 1u : c == (uint32_t)kPlasticClass ? 2u : (c == (uint32_t)kUberClass || c == (uint32_t)kSssClass) ? 3u : c; }
+PT_HD uint32_t class_general(uint32_t c) { return c == (uint32_t)kMetalClass ? 1u : c == (uint32_t)kPlasticClass ? 2u : (c == (uint32_t)kUberClass || c == (uint32_t)kSssClass) ? 3u : c; }
 constexpr int kRouteSlots = 12;        // most staging queues a k_route block holds
 // k_route's staging queues: one per shade class the scene uses ("slot"), so that a scene pays LDS only for the classes it has.
 // slot_map: the slot of class c in nibble c (15 = the class does not occur in this scene).

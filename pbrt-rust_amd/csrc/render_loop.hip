@@ -26,9 +26,12 @@ int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool pro
 #ifdef PT_TRACE_UTIL
     hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, 0u, 1);
 #endif
-    const bool quad = !g_trace_exact;   // production: the four-wide records; pt_set_trace_exact(1): the two-wide walk with the reference's node-visit counter
-    #define PT_LAUNCH_TRACE(A, M, P) do { if (quad) hipLaunchKernelGGL((k_trace<A, M, P, true>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); \
-                                          else hipLaunchKernelGGL((k_trace<A, M, P, false>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); } while (0)
+    if (sc->quad_walk_only && (g_trace_exact || sc->exact_walk_only)) return fail(PT_ERR_UNSUPPORTED, "the two-wide (exact) walk addresses 2^25 records / packets: this scene has the production walk only");
+    const bool quad = !g_trace_exact && !sc->exact_walk_only;   // production: the four-wide records; pt_set_trace_exact(1): the two-wide walk with the reference's node-visit counter
+    const bool big = sc->pool_big;   // records + packets beyond 4 GB: the production walk through 64-bit addresses
+    #define PT_LAUNCH_TRACE(A, M, P) do { if (quad && big) hipLaunchKernelGGL((k_trace<A, M, P, 2>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); \
+                                          else if (quad) hipLaunchKernelGGL((k_trace<A, M, P, 1>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); \
+                                          else hipLaunchKernelGGL((k_trace<A, M, P, 0>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); } while (0)
     #define PT_LAUNCH_TRACE_MODE(A, P) do { if (mode == 3) PT_LAUNCH_TRACE(A, 3, P); else if (mode == 2) PT_LAUNCH_TRACE(A, 2, P); else if (mode == 1) PT_LAUNCH_TRACE(A, 1, P); else PT_LAUNCH_TRACE(A, 0, P); } while (0)
     if (probe) PT_LAUNCH_TRACE_MODE(0, true);
     else if (any == 2) PT_LAUNCH_TRACE_MODE(2, false);
@@ -39,7 +42,7 @@ int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool pro
 #ifdef PT_TRACE_UTIL
     hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, blocks * (kTraceBlock / 64), 0);
 #endif
-    sc->set_kernel(std::string("k_trace<") + std::to_string(any) + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ", " + (quad ? "true" : "false") + ">");
+    sc->set_kernel(std::string("k_trace<") + std::to_string(any) + ", " + std::to_string(mode) + ", " + (probe ? "true" : "false") + ", " + (quad ? (big ? "2" : "1") : "0") + ">");
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }

@@ -176,8 +176,18 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         for (uint32_t i = 0; i < n_top; ++i) if (sc->ordered[i] >= n_top) return bail(fail(PT_ERR_INVALID_ARG, "ordered_prims entry out of range"));
         for (uint32_t i = 0; i < d->n_nodes; ++i) {
             const PtBVHNode &n = sc->nodes[i];
-            bool ok = n.n_prims ? ((uint64_t)n.offset + n.n_prims <= n_top) : (n.offset < d->n_nodes && i + 1 < d->n_nodes && n.axis < 3);
+            // (an interior node's second child lies behind its first child's whole subtree -- the flattened tree is in pre-order, bvh.rs:662-703: a back edge would
+            //  send the depth-first walks below, and the device's, round in circles)
+            bool ok = n.n_prims ? ((uint64_t)n.offset + n.n_prims <= n_top) : (n.offset < d->n_nodes && n.offset > i + 1 && n.axis < 3);
             if (!ok) return bail(fail(PT_ERR_INVALID_ARG, "malformed BVH node"));
+        }
+        // The four-wide walk never tests the boxes of a record's collapsed children nor the root's: sound when every child's box lies inside its parent's, as in
+        // every tree a union of primitive bounds builds. An adopted tree that is not nested is walked two-wide, box by box, like the reference does.
+        for (uint32_t i = 0; i < d->n_nodes && !sc->exact_walk_only; ++i) {
+            const PtBVHNode &n = sc->nodes[i];
+            if (n.n_prims) continue;
+            for (uint32_t c : {i + 1u, (uint32_t)n.offset}) for (int k = 0; k < 3; ++k)
+                if (!(sc->nodes[c].bmin[k] >= n.bmin[k] && sc->nodes[c].bmax[k] <= n.bmax[k])) sc->exact_walk_only = true;
         }
     } else {
         std::vector<pth::PrimBound> pb(n_top);
@@ -237,7 +247,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
                 std::vector<uint32_t> stack{0};
                 while (!stack.empty()) {
                     const uint32_t i = stack.back(); stack.pop_back();
-                    quad_id[i] = qbase + (uint32_t)todo.size(); todo.push_back(i);
+                    quad_id[i] = g_test_pool_pad_records + qbase + (uint32_t)todo.size(); todo.push_back(i);   // (test hook: unused records in front of the pool, host_device.hip)
                     uint32_t kids[4]; int nk = 0;
                     for (uint32_t c : {(uint32_t)i + 1u, (uint32_t)nn[i].offset}) {
                         if (nn[c].n_prims) continue;
@@ -297,7 +307,10 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
             for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ident = ident && I.instance_to_world[4 * r + c] == ((r == c) ? 1.0f : 0.0f);
             D.identity = ident;
         }
-        if (wide.size() > (size_t)kRefMask || packet_refs.size() > (size_t)kRefMask) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^25 BVH records / packets"));
+        // The production walk addresses records and packets as 16-byte quads of one pool (checked where the pool is allocated: < 2^31 of each, < 64 GB together). The
+        // two-wide walk of pt_set_trace_exact packs a skipped-entry count above 25-bit references: a larger scene has no exact walk (launch_trace refuses it).
+        if (quad.size() + g_test_pool_pad_records >= ((size_t)1 << 28) || packet_refs.size() >= ((size_t)1 << 31) - 2) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^28 four-wide BVH records / 2^31 packets"));
+        if (wide.size() > (size_t)kRefMask || packet_refs.size() > (size_t)kRefMask) { sc->quad_walk_only = true; wide.clear(); wide.shrink_to_fit(); }
         if (wide.empty()) wide.resize(1);
         UP(wide, wide.data(), wide.size());
         UP(instances, dinst.data(), dinst.size()); ds.n_instances = (uint32_t)dinst.size();
@@ -441,16 +454,18 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         const uint32_t n_packets = (uint32_t)packet_refs.size();
         if ((st = sc->upload(&d_ordered, packet_refs.data(), packet_refs.size()))) return bail(st);
         TriPacket *leaf = nullptr; float *area = nullptr; float4 *lrec = nullptr;
-        // the four-wide records and the packets share ONE allocation, so that the production traversal addresses both with 32-bit byte offsets from
-        // one base (at most 2^24 records x 128 B + 2^25 packets x 48 B < 4 GB): [records][packets + 2] (+2: a packet's fourth quad is loaded with it)
+        // the four-wide records and the packets share ONE allocation, so that the production traversal addresses both with 32-bit quad indices from
+        // one base (records of 8 quads, packets of 3; < 64 GB): [records][packets + 2] (+2: a packet's fourth quad is loaded with it)
         if (quad.empty()) quad.resize(1);
-        const size_t quad_bytes = quad.size() * sizeof(QuadNode), pool_bytes = quad_bytes + ((size_t)n_packets + 2) * sizeof(TriPacket);
-        if (pool_bytes >= (size_t)0xE0000000u) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 4 GB of traversal records + packets"));
+        const size_t pad_bytes = (size_t)g_test_pool_pad_records * sizeof(QuadNode);
+        const size_t quad_bytes = pad_bytes + quad.size() * sizeof(QuadNode), pool_bytes = quad_bytes + ((size_t)n_packets + 2) * sizeof(TriPacket);
+        if (pool_bytes / 16 >= (size_t)0xfffffff0u) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 64 GB of traversal records + packets"));
         uint8_t *pool = nullptr;
         if ((st = sc->dalloc(&pool, pool_bytes))) return bail(st);
-        if (hipMemcpy(pool, quad.data(), quad_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PT_ERR_HIP, "upload of the four-wide records"));
+        if (hipMemcpy(pool + pad_bytes, quad.data(), quad_bytes - pad_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PT_ERR_HIP, "upload of the four-wide records"));
         leaf = reinterpret_cast<TriPacket *>(pool + quad_bytes);
-        ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)quad_bytes; ds.pool_bytes = (uint32_t)pool_bytes;
+        ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)(quad_bytes / 16); ds.pool_quads = (uint32_t)(pool_bytes / 16);
+        sc->pool_big = pool_bytes >= (size_t)0xE0000000u;   // (beyond what the buffer loads' 32-bit byte offsets reach: k_trace<.., 2>)
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         if ((st = sc->dalloc(&lrec, 6 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);

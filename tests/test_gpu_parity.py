@@ -1,9 +1,14 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 Integer/index work must be bit-exact; radiance is compared with the tolerance stated per test."""
 import ctypes as C
+import os
+import subprocess
+import sys
 import numpy as np
 import pytest
-from conftest import ckeys
+from conftest import ckeys, trace_env
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -628,3 +633,49 @@ def test_reference_asserts_counter_matches_oracle(pkg, gpu, oracle):
     film, ref = _compare_render(pkg, gpu, oracle, sd, rp)      # compares reference_asserts exactly
     g = pkg.Scene(gpu, sd); g.render(rp)
     assert g.counters()["reference_asserts"] > 0
+
+
+_PAD_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from _pkg import import_pkg
+pkg = import_pkg()
+import torch
+torch.cuda.init()
+lib = pkg.load_library(); lib.init(0)
+sd, rp = pkg.scenes.instanced_garden(xres=96, yres=64, spp=8).world_end()
+g = pkg.Scene(lib, sd)
+d = np.load({rays!r})
+gp, gt, gb = g.trace_closest(d["o"], d["d"], d["tmax"]); c1 = g.counters()
+gh = g.trace_any(d["o"], d["d"], d["tm2"]); c2 = g.counters()
+film = g.render(rp); c3 = g.counters()
+np.savez({out!r}, gp=gp, gt=gt, gb=gb, gh=gh, film=film, tri1=c1["triangle_tests"], tri2=c2["triangle_tests"], tri3=c3["triangle_tests"], rays3=c3["intersect_tests"] + c3["shadow_tests"])
+"""
+
+
+def test_records_and_packets_beyond_four_gigabytes(pkg, gpu, oracle, tmp_path, trace_mode):
+    """Round 5: the production walk addresses its pool of four-wide records and packets in 16-byte quads through a structured buffer resource (64 GB; until round 4
+    32-bit BYTE offsets: 4 GB, 2^25 records). PT_TEST_POOL_PAD_RECORDS puts 34 M unused records (4.35 GB) in front of a small instanced scene's pool, in a process of
+    its own (pt_init reads it): every record and packet -- top-level tree, object trees, instance packets -- then lies beyond the old reach. Hits, films and
+    triangle counters == oracle. (tools/big_scene_parity.py does the same with a scene that is that large by itself.)"""
+    if trace_mode == "exact":
+        pytest.skip("the pool is the production walk's (the two-wide records have their own array)")
+    sd, rp = pkg.scenes.instanced_garden(xres=96, yres=64, spp=8).world_end()
+    orc = oracle.scene(sd)
+    o, d = _random_rays(60000, 11)
+    o = (o * np.float32(3.0)).astype(np.float32)
+    tmax = np.full(len(o), np.inf, np.float32); tm2 = np.full(len(o), 3.0, np.float32)
+    np.savez(tmp_path / "rays.npz", o=o, d=d, tmax=tmax, tm2=tm2)
+    code = _PAD_CHILD.format(root=ROOT, rays=str(tmp_path / "rays.npz"), out=str(tmp_path / "out.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(trace_env(), PT_TEST_POOL_PAD_RECORDS="34000000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = np.load(tmp_path / "out.npz")
+    op, ot, ob = orc.trace_closest(o, d, tmax); t1 = orc.counters()["triangle_tests"]
+    assert np.array_equal(g["gp"], op) and np.array_equal(g["gt"].view(np.uint32), ot.view(np.uint32)) and np.array_equal(g["gb"].view(np.uint32), ob.view(np.uint32))
+    assert (op != 0xFFFFFFFF).mean() > 0.05 and int(g["tri1"]) == t1
+    oh = orc.trace_any(o, d, tm2); t2 = orc.counters()["triangle_tests"]
+    assert np.array_equal(g["gh"], oh) and int(g["tri2"]) == t2
+    ref = orc.render(rp, nthreads=4); oc = orc.counters()
+    assert int(g["tri3"]) == oc["triangle_tests"] and int(g["rays3"]) == oc["intersect_tests"] + oc["shadow_tests"]
+    assert np.array_equal(g["film"][..., 3], ref[..., 3])
+    np.testing.assert_allclose(g["film"][..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)

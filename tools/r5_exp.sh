@@ -32,6 +32,8 @@ shard)   # rank 0's shard of an 8-rank C2 job: one render, and two / three half-
   one sh_1 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off || exit 1
   one sh_2 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off --gpus 2 --devices 0,0 --in-process || exit 1
   one sh_3 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off --gpus 3 --devices 0,0,0 --in-process || exit 1 ;;
+big) one c2_plain --config C2 --steps 3 --warmup 1 || exit 1; PT_TEST_POOL_PAD_RECORDS=34000000 one c2_bigpool --config C2 --steps 3 --warmup 1 || exit 1
+     one c4_plain --config C4 --spp 64 --steps 1 --warmup 1 || exit 1; PT_TEST_POOL_PAD_RECORDS=34000000 one c4_bigpool --config C4 --spp 64 --steps 1 --warmup 1 || exit 1 ;;
 c3m) one c3_plain --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; one c3_mixed --config C3M --spp 256 --steps 1 --warmup 1 || exit 1 ;;
 ab5:*) vs="tree,${what#ab5:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c5_${v} --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; done ;;
 quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
