@@ -19,18 +19,13 @@
 // ("if-if"); lanes at a leaf join once a quorum of them waits. Instance entry / exit is a step of its own (ST_INST / ST_RET).
 
 #ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 6   // waves per SIMD the triangle-only kernels of the EXACT walk are compiled for (round 4: six, 80 VGPRs without scratch -- the walk serves the counter
-                           // comparisons now, its seventh wave cost 12-20 B of scratch once the shared code grew). History of the knob (rounds 2-3, when this was the production kernel):
-                           // Round 2: 71 VGPRs without scratch, and with a 10-entry LDS stack (kernels.h) seven workgroups share a CU's LDS: trace -3 %, camera
-                           // rays -6 % against six waves; eight waves need 64 VGPRs = 24 bytes of scratch per lane and lose 9 %. The loop waits on its gathers.
+#define PT_TRACE_WAVES 6        // waves per SIMD of the triangle-only kernels of the exact (two-wide) walk: 80 VGPRs, no scratch (knob history: profiles/HISTORY.md)
 #endif
 #ifndef PT_TRACE_WAVES_INST
-#define PT_TRACE_WAVES_INST 4   // exact walk, triangles + instances (MODE 3): four since round 4 (no scratch; it serves the counter comparisons). Rounds 2-3 ran five at 89 VGPRs. Six waves (-DPT_TRACE_WAVES_INST=6 -DPT_LDS_STACK_GENERAL=10: 80 VGPRs + 52 B of scratch per
-                                // lane, 161 KB of LDS per CU) measured on S4: mixed launches -2.4 %, camera rays +4 %, 94.0 -> 95.4 Msamples/s -- not worth the scratch
+#define PT_TRACE_WAVES_INST 4   // exact walk, triangles + instances (MODE 3)
 #endif
 #ifndef PT_TRACE_ATTR
-#define PT_TRACE_ATTR   // experiment hook: e.g. __attribute__((amdgpu_waves_per_eu(6,6))) -- measured: 6 waves/SIMD needs 64-72 B of
-                        // scratch and loses 12 %; 5 waves/SIMD (the launch bound below) is free for both triangle-only kernels
+#define PT_TRACE_ATTR   // experiment hook, e.g. __attribute__((amdgpu_waves_per_eu(6,6)))
 #endif
 // MODE: 0 = triangle-only scenes, 1 = general geometry (spheres, instances), 2 = general geometry + alpha-masked triangles
 // PROBE (closest hit only): every queue entry is a whole BSSRDF probe chain (TabulatedBSSRDF::sample_sp, bssrdf.rs:367-402). The lane
@@ -89,9 +84,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     typedef __attribute__((address_space(1))) float glb_f32;
     glb_f32 *wray_g = (glb_f32 *)(spill + (2 * kSpillEntries) * 64);   // (the slab is sized for the deeper of the two walks: both index it the same way)
     // MIX: queue entry qi belongs to sub 0 below c0, to sub 1 below c01, to sub 2 otherwise
-    // (measured and dropped, round 2: one work head per XCD group, each group draining "its" contiguous eighth of the queues first -- no
-    //  change on any config with the segments on or off, and the dozen wave-uniform words of segment state overflowed the SGPR file into
-    //  VGPRs: 75 -> 87, six -> five waves per SIMD, 7 % slower)
     const uint32_t c0 = *job.sub[0].count, c01 = c0 + (MIX ? *job.sub[1].count : 0u);
     const uint32_t count = c01 + (MIX ? *job.sub[2].count : 0u);
     uint32_t ksel = 0; bool lane_any = ANY == 1;   // the lane's ray: its sub and whether it is an any-hit query
@@ -138,6 +130,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
     uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0, u_it3 = 0, u_act3 = 0;
+    uint32_t u_ent = 0, u_rej = 0, u_ihit = 0, u_spill = 0;   // instance entries tried / turned away by the object's root test / left with a hit; stack entries written beyond the LDS ones
     unsigned long long u_cxf = 0, u_cmain = 0;   // wave cycles inside the transform step / the record step
     unsigned long long u_cfetch = 0, u_cnode = 0, u_cleaf = 0, u_cpop = 0;   // of the record step: issue + wait of the loads, the node branch, the leaf branch, the pops
     long long u_cm = 0;
@@ -156,8 +149,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     enum : uint32_t { ST_IDLE = 0, ST_ENTER = 1, ST_LEAF = 2, ST_DONE = 3, ST_INST = 4, ST_RET = 5, ST_LEAFS = 6 };   // ST_LEAFS: at a leaf and being served (leaf_quorum below)
     uint32_t state = ST_IDLE;
 #ifndef PT_TRACE_CHUNK
-#define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (round 4: 512 against 256: C2 trace 136.5 -> 135.1 ms, camera rays 36.1 -> 35.6; measured round 2: 128 is 1.5 % slower; a smaller bite near the end of the queue needs a look
-                             // at the head first, and a plain load of that contended line costs more than the tail it saves: 194 -> 369 ms)
+#define PT_TRACE_CHUNK 512   // queue entries a wave reserves per atomic (sweeps: profiles/HISTORY.md)
 #endif
     constexpr int kChunk = PT_TRACE_CHUNK;
     // Scenes with instances: the bites shrink near the end of the queue (guided self-scheduling). Their rays are long (S4: 50 records and 20 triangle tests on average, some
@@ -227,7 +219,12 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
 
     auto push = [&](uint32_t w0, uint32_t w1) {
         if (sp < (uint32_t)kLds) { stack[(2 * sp) * 64] = w0; stack[(2 * sp + 1) * 64] = w1; }
-        else { spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1; }
+        else {
+            spill[(2 * (sp - kLds)) * 64] = w0; spill[(2 * (sp - kLds) + 1) * 64] = w1;
+#ifdef PT_TRACE_UTIL
+            u_spill++;
+#endif
+        }
         sp++;
     };
     const uint32_t root_ref = QUAD ? s.root_ref4 : s.root_ref;
@@ -391,9 +388,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                         ray_stride = r1.x; per_ray_tmax = (r1.y & 1u) != 0u; lane_any = (r1.y & 2u) != 0u; scalar_tmax = __uint_as_float(r1.z);
                     }
                     gcf4 *const rp = rays + (size_t)pid * ray_stride;
-                    // (measured round 4 and dropped: requesting the record here and unpacking it after this iteration's record step, so that the wave's busy
-                    //  lanes do not stand still for the round trip -- every refilled lane then starts one iteration later: node-step occupancy 80 -> 75 %,
-                    //  C2 trace 134 -> 147 ms)
                     rr0 = rp[0]; rr1 = rp[1];   // one 32-byte record
                 }
             }
@@ -490,6 +484,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                     inv_dir = V3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                     nx = inv_dir.x < 0.0f; ny = inv_dir.y < 0.0f; nz = inv_dir.z < 0.0f; PT_SGN3();
                     PT_TRI_RAY();
+#ifdef PT_TRACE_UTIL
+                    if (inst_hit) u_ihit++;
+#endif
                     t_max = inst_hit ? t_max : t_max_world;  // r.t_max = ray.t_max only when the instance was hit
                     in_inst = PT_NONE; inst_hit = false;
                     if (w0 & kLeafBit) { cur = w0 & kMaskRef; state = ST_LEAF; }  // remaining packets of the outer leaf
@@ -509,6 +506,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                     const bool nx2 = inv2.x < 0.0f, ny2 = inv2.y < 0.0f, nz2 = inv2.z < 0.0f;
                     bool enter = true;
                     if (!I.single) { if (!QUAD) n_nodes++; enter = slab_test(I.root_min, I.root_max, o2, inv2, nx2, ny2, nz2, tm2); }  // object BVH root (bvh.rs:725-727)
+#ifdef PT_TRACE_UTIL
+                    u_ent++; if (!enter) u_rej++;
+#endif
                     if (enter && ((!QUAD && pending > 63u) || sp >= (uint32_t)kMaxS)) { atomicMax(job.error, (uint32_t)PT_ERR_STACK_OVERFLOW); enter = false; }
                     if (enter) {
                         // remember where to resume: the rest of this leaf (if any) and the outer skip count
@@ -748,7 +748,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
         const unsigned long long u_t1 = wall_clock64();
         atomicMin(&job.counters->tail[0], u_t0); atomicMax(&job.counters->tail[1], u_t1); atomicAdd(&job.counters->tail[4 + 2 * (job.sub[0].kind & 3)], u_t1 - u_t0);
     }
-    for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); }
+    for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); u_ent += __shfl_xor(u_ent, o); u_rej += __shfl_xor(u_rej, o); u_ihit += __shfl_xor(u_ihit, o); u_spill += __shfl_xor(u_spill, o); }
+    if (lane == 0) { atomicAdd(&job.counters->util2[4], (unsigned long long)u_ent); atomicAdd(&job.counters->util2[5], (unsigned long long)u_rej); atomicAdd(&job.counters->util2[6], (unsigned long long)u_ihit); atomicAdd(&job.counters->util2[7], (unsigned long long)u_spill); }
     if (lane == 0) {
         atomicAdd(&job.counters->tail[12], (unsigned long long)u_it3); atomicAdd(&job.counters->tail[13], (unsigned long long)u_act3);
         atomicAdd(&job.counters->tail[14], u_cxf); atomicAdd(&job.counters->tail[15], u_cmain);

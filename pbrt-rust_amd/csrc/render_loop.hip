@@ -593,6 +593,8 @@ void read_counters(pt_scene *sc) {
         fprintf(stderr, "[trace-util] %-14s wave slots busy %.1f %% of launch span x resident waves (the rest: launch ramp + tail after the queue drained)\n", kn[k], 100.0 * (double)d.tail[4 + 2 * k] / (double)d.tail[5 + 2 * k]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] all trace launches: transform step %.3e wave iterations, %.1f %% lanes active, %.1f %% of the waves' cycles; record step (fetch + node / leaf + pop) %.1f %% of the cycles\n",
                            (double)d.tail[12], d.tail[12] ? 100.0 * (double)d.tail[13] / (64.0 * (double)d.tail[12]) : 0.0, 100.0 * (double)d.tail[14] / (double)d.tail[2], 100.0 * (double)d.tail[15] / (double)d.tail[2]);
+    if (d.tail[2]) fprintf(stderr, "[trace-util] instance entries tried %.4e, turned away by the object's root test %.4e (%.1f %%), left with a hit %.4e (%.1f %%); stack entries written beyond the LDS ones %.4e\n",
+                           (double)d.util2[4], (double)d.util2[5], d.util2[4] ? 100.0 * (double)d.util2[5] / (double)d.util2[4] : 0.0, (double)d.util2[6], d.util2[4] ? 100.0 * (double)d.util2[6] / (double)d.util2[4] : 0.0, (double)d.util2[7]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] record step by part, %% of the waves' cycles: loads issued + waited for %.1f, node branch %.1f, leaf branch %.1f, pops %.1f\n",
                            100.0 * (double)d.util2[0] / (double)d.tail[2], 100.0 * (double)d.util2[1] / (double)d.tail[2], 100.0 * (double)d.util2[2] / (double)d.tail[2], 100.0 * (double)d.util2[3] / (double)d.tail[2]);
     for (int k = 0; k < 4; ++k)

@@ -181,7 +181,9 @@ def test_oracle_renders_random_scenes(pkg, oracle, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(160)) + [2005, 13269] + list(range(50000, 50024)) + list(range(70000, 70016)) + list(range(90000, 90096)) + list(range(95000, 95060)) + list(range(140000, 140060)))   # >= 90000: + material-less medium shells under volpath (28 of the 96); >= 95000: + subsurface materials under volpath (10 of the 60); >= 140000: those next to grid media and shells as well   # found by a 14 000-seed sweep (tools/fuzz_sweep.py): 2005 volpath's `if beta.is_black() { break }` outside any medium; 13269 `L += beta * Ld` with a black Ld and a NaN beta (BSSRDF exit point a few ulps from the entry point)
-def test_gpu_matches_oracle_on_random_scenes(pkg, gpu, oracle, seed):
+def test_gpu_matches_oracle_on_random_scenes(pkg, gpu, oracle, seed, trace_mode):
+    if trace_mode == "exact" and seed % 3 != 0 and seed not in (2005, 13269):
+        pytest.skip("the exact (two-wide) walk runs every third seed: the shading code under test is the same in both walks, and the -m gpu suite has a time budget (round 5)")
     b = random_scene(pkg, seed)
     sd, rp = b.world_end()
     if seed >= 90000 and seed % 3 == 0 and rp.light_strategy == pkg._abi.PT_LS_SPATIAL: rp.light_strategy = pkg._abi.PT_LS_SPATIAL_LAZY   # the first-touch form of the light grid (the same distribution: the oracle does not care)
