@@ -54,9 +54,11 @@ def test_first_touch_voxels_equal_the_precomputed_grid(pkg, gpu, oracle, scene):
 
 
 @pytest.mark.gpu
-def test_fifty_thousand_emissive_triangles_under_the_spatial_strategy(pkg, gpu, oracle):
+def test_fifty_thousand_emissive_triangles_under_the_spatial_strategy(pkg, gpu, oracle, trace_mode):
     """VERDICT r2 item 7's bar: 50 000 emissive triangles = 50 000 lights under the DEFAULT "spatial" strategy (the precomputed grid would
     need 98 304 voxels x 50 000 lights) -- GPU == oracle, counters exact. The oracle's side is 128 x 50 000 sample_li per touched voxel."""
+    if trace_mode == "exact":
+        pytest.skip("26 s of oracle time for a test of the light grid, which is the same under both walks (the -m gpu suite's time budget)")
     sd, rp = pkg.scenes.emissive_field(n_lights=50000, xres=16, yres=12, spp=1, maxdepth=2).world_end()
     assert rp.light_strategy == pkg._abi.PT_LS_SPATIAL and sd.desc().n_lights == 50000
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)

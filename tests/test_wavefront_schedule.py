@@ -106,12 +106,14 @@ def test_specular_materials_have_a_shade_class_of_their_own(pkg, gpu, oracle):
     assert {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_uber", "shade_specular", "shade_miss", "shade_metal", "shade_plastic"} <= names   # (substrate, rough glass: the general kernels; metal, plastic, uber: their own)
 
 
-def test_lobe_set_specialised_kernels_are_chosen_per_material_and_change_nothing(pkg, gpu, oracle, tmp_path):
+def test_lobe_set_specialised_kernels_are_chosen_per_material_and_change_nothing(pkg, gpu, oracle, tmp_path, trace_mode):
     """Round 5: every metal vertex is shaded by k_shade<1, 0, 3>, every plastic-like one by <2, 0, 4>, every uber by <5, 0, 5> -- a class each (kernels.h:
     kMetalClass ...), whatever else the scene holds: the C3 palette, and the same room with substrate, rough glass and translucent surfaces added, whose
     vertices go to the general kernels of their lobe count next to them (round 4 switched per SCENE: one such material sent the whole lobe-count class
     back to the general kernel). Either way GPU == oracle, and PT_SHADE_SPECIALISE=0 (general kernels everywhere, a process of its own: pt_init reads
     it) renders the same film."""
+    if trace_mode == "exact":
+        pytest.skip("a test of the shade kernels' choice, the same under both walks (the -m gpu suite's time budget)")
     sd, rp = pkg.scenes.country_kitchen_s3(xres=96, yres=64, spp=4, wall_n=6, box_n=3, obj_n=6).world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
     film, ref = g.render(rp), orc.render(rp, nthreads=4)
