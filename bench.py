@@ -199,7 +199,7 @@ def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, device
     t_up = time.time() - t_up
     rp.tile_rank, rp.tile_world = rank, world
     if args.sim_world > 1 and world == 1:
-        rp.tile_rank, rp.tile_world = 0, args.sim_world
+        rp.tile_rank, rp.tile_world = args.sim_rank, args.sim_world
     rp.spp_per_pass = args.spp_per_pass
     rp.profile = int(os.environ.get("PT_BENCH_PROFILE", "1"))   # 1: HIP events around every launch, on the render stream; 2: + exact per-class launch sizes
     cb = rp.cropped_pixel_bounds
@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 disables)")
     ap.add_argument("--dump-image", default="")
+    ap.add_argument("--sim-rank", type=int, default=0, help="with --sim-world: which rank's shard")
     ap.add_argument("--sim-world", type=int, default=0, help="single-GPU study: render rank 0's shard of an N-rank job (value is then this rank's share only)")
     ap.add_argument("--in-process", action="store_true", help="force the one-process pt_multi_render form (it is the default for --gpus N > 1 without a launcher)")
     ap.add_argument("--devices", default="", help="one-process form: explicit device ordinals, e.g. 0,1,2,3 (an ordinal may repeat: replicas share the device; default 0..gpus-1)")

@@ -4,13 +4,17 @@
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
 // (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
-__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out) {
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out, const uint32_t *inst_gate) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_refs) return;
     uint32_t prim = ordered[i];      // primitive index, or PT_TOP_INSTANCE | instance index
     TriPacket p;
     if (prim & PT_TOP_INSTANCE) {
         p.x[0] = p.x[1] = p.x[2] = p.y[0] = p.y[1] = p.y[2] = p.z[0] = p.z[1] = p.z[2] = 0.0f;
+        if (inst_gate) {   // the oriented box of the instance (scene_create.hip), one triple per world axis
+            const uint32_t *g = inst_gate + 9u * (prim & ~PT_TOP_INSTANCE);
+            for (int k = 0; k < 3; ++k) { p.x[k] = __uint_as_float(g[k]); p.y[k] = __uint_as_float(g[3 + k]); p.z[k] = __uint_as_float(g[6 + k]); }
+        }
         p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
         out[i] = p;
         return;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
     uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0, u_it3 = 0, u_act3 = 0;
-    uint32_t u_ent = 0, u_rej = 0, u_ihit = 0, u_spill = 0;   // instance entries tried / turned away by the object's root test / left with a hit; stack entries written beyond the LDS ones
+    uint32_t u_ent = 0, u_rej = 0, u_ihit = 0, u_spill = 0, u_gate = 0, u_gate_rej = 0;   // instance entries tried / turned away by the object's root test / left with a hit; stack entries written beyond the LDS ones
     unsigned long long u_cxf = 0, u_cmain = 0;   // wave cycles inside the transform step / the record step
     unsigned long long u_cfetch = 0, u_cnode = 0, u_cleaf = 0, u_cpop = 0;   // of the record step: issue + wait of the loads, the node branch, the leaf branch, the pops
     long long u_cm = 0;
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
 #define PT_TRACE_TAIL_ROUNDS 2
 #endif
     constexpr bool kTailBites = MODE != 0 && PT_TRACE_TAIL_ROUNDS > 0;
-    uint32_t bite = kChunk;   // wave-uniform; 0 = the queue is drained
-#define exhausted (bite == 0u)
+    uint32_t bite = kChunk;   // wave-uniform (only the kernels with shrinking bites ever change it)
+    bool exhausted = false;
     uint32_t chunk_next = 0, chunk_left = 0;   // wave-uniform
     uint32_t qwin = 0u, win_base = 0xffffffffu;   // the prefetched queue window (per lane) and the queue index it starts at (wave-uniform); see the refill block
     uint32_t pid = 0, cur = 0, sp = 0, pending = 0;
@@ -359,15 +359,15 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                 // out over several refills (consecutive entries are spatially coherent rays)
                 if (chunk_left == 0) {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(job.head, bite);
+                    if (lane == 0) base = atomicAdd(job.head, kTailBites ? bite : (uint32_t)kChunk);
                     chunk_next = __shfl(base, 0);
-                    chunk_left = (chunk_next < count) ? min(bite, count - chunk_next) : 0u;
+                    chunk_left = (chunk_next < count) ? min(kTailBites ? bite : (uint32_t)kChunk, count - chunk_next) : 0u;
                     if constexpr (kTailBites) {
                         const uint32_t grid_round = gridDim.x * (kTraceBlock / 64) * (uint32_t)kChunk;   // entries one full bite of every wave takes
                         const uint32_t behind = count > chunk_next + bite ? count - chunk_next - bite : 0u;   // entries nobody had taken when this bite was
                         bite = behind < grid_round / 4u ? (uint32_t)kChunk / 16u : behind < (uint32_t)PT_TRACE_TAIL_ROUNDS * grid_round ? (uint32_t)kChunk / 4u : (uint32_t)kChunk;
                     }
-                    if (chunk_left == 0) bite = 0u;
+                    if (chunk_left == 0) exhausted = true;
                 }
                 if (chunk_left != 0u && win_base != chunk_next) { qwin = load_window(chunk_next, chunk_left); win_base = chunk_next; }   // a fresh chunk: not prefetched (once per kChunk rays)
                 // PROBE: lanes that went on to their chain's next segment are in `donem` but not idle any more
@@ -667,7 +667,39 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                 const uint32_t shw = tp_aux(q0.w, q1.w, q2.w, tray.kz, 1);
                 bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
                 if (fl & TP_INSTANCE) {
-                    if constexpr (INST) { xf_arg = shw | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
+                    if constexpr (INST) {
+                        bool gate_pass = true;
+#ifdef PT_INST_GATE   // EXPERIMENT (profiles/r5/NOTES.md section 1): a conservative world-space test against the oriented box in the packet's nine spare words, before the lane
+                      // commits to the transform step; a ray it turns away fails the object's root test too (the box is the root box inflated, its rows rounded outwards)
+                        if constexpr (QUAD) {
+                            // quad j came for the ray's j-th permuted axis: {bf16 A0 | A1 << 16, bf16 A2, c}: u_i(t) = -e_i + t f_i, |u_i| <= T
+                            const V3 dp = tri_permute(rd, tray.kz);
+                            const float v0 = __uint_as_float(q0.z) - rop.x, v1 = __uint_as_float(q1.z) - rop.y, v2 = __uint_as_float(q2.z) - rop.z;
+                            float e[3], f[3];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const float a0 = __uint_as_float(i == 0 ? q0.x << 16 : i == 1 ? q0.x & 0xffff0000u : q0.y << 16);
+                                const float a1 = __uint_as_float(i == 0 ? q1.x << 16 : i == 1 ? q1.x & 0xffff0000u : q1.y << 16);
+                                const float a2 = __uint_as_float(i == 0 ? q2.x << 16 : i == 1 ? q2.x & 0xffff0000u : q2.y << 16);
+                                e[i] = __builtin_fmaf(a2, v2, __builtin_fmaf(a1, v1, a0 * v0));
+                                f[i] = __builtin_fmaf(a2, dp.z, __builtin_fmaf(a1, dp.y, a0 * dp.x));
+                            }
+                            const float T = 1.0f + 1.0f / 32.0f;
+                            float tn = 0.0f, tf = t_max * (1.0f + 1.0e-5f);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const float r = __builtin_amdgcn_rcpf(f[i]);
+                                const float ta = (e[i] - T) * r, tb = (e[i] + T) * r;
+                                tn = __builtin_fmaxf(tn, __builtin_fminf(ta, tb)); tf = __builtin_fminf(tf, __builtin_fmaxf(ta, tb));
+                            }
+                            gate_pass = !(tn > tf * (1.0f + 1.0e-5f));
+#ifdef PT_TRACE_UTIL
+                            u_gate++; if (!gate_pass) u_gate_rej++;
+#endif
+                        }
+#endif
+                        if (gate_pass) { xf_arg = shw | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
+                    }
                 } else if (fl & TP_SPHERE) {
                     if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
                         n_sph++;
@@ -743,12 +775,14 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
         counter_add(&job.counters->k_rays[job.sub[0].kind], n_rays);
     }
 #ifdef PT_TRACE_UTIL
-    if (blockIdx.x == 0 && threadIdx.x == 0) { job.counters->dbg[0] = job.leaf_quorum; job.counters->dbg[1] = job.refill_min; job.counters->dbg[2] = job.inst_quorum; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { job.counters->dbg[0] = job.leaf_quorum; job.counters->dbg[1] = job.refill_min; }
     if (lane == 0) {   // how long the launch's wave slots were occupied: a wave leaves when the queue is drained and its own rays are done
         const unsigned long long u_t1 = wall_clock64();
         atomicMin(&job.counters->tail[0], u_t0); atomicMax(&job.counters->tail[1], u_t1); atomicAdd(&job.counters->tail[4 + 2 * (job.sub[0].kind & 3)], u_t1 - u_t0);
     }
     for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); u_ent += __shfl_xor(u_ent, o); u_rej += __shfl_xor(u_rej, o); u_ihit += __shfl_xor(u_ihit, o); u_spill += __shfl_xor(u_spill, o); }
+    for (int o = 32; o > 0; o >>= 1) { u_gate += __shfl_xor(u_gate, o); u_gate_rej += __shfl_xor(u_gate_rej, o); }
+    if (lane == 0) { atomicAdd(&job.counters->dbg[2], (unsigned long long)u_gate); atomicAdd(&job.counters->dbg[3], (unsigned long long)u_gate_rej); }
     if (lane == 0) { atomicAdd(&job.counters->util2[4], (unsigned long long)u_ent); atomicAdd(&job.counters->util2[5], (unsigned long long)u_rej); atomicAdd(&job.counters->util2[6], (unsigned long long)u_ihit); atomicAdd(&job.counters->util2[7], (unsigned long long)u_spill); }
     if (lane == 0) {
         atomicAdd(&job.counters->tail[12], (unsigned long long)u_it3); atomicAdd(&job.counters->tail[13], (unsigned long long)u_act3);
@@ -763,7 +797,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
 #endif
 }
 #undef PT_SUB
-#undef exhausted
 #undef PT_GPTR
 #undef PT_UTIL
 #undef PT_UTIL_MARK

@@ -595,6 +595,7 @@ void read_counters(pt_scene *sc) {
                            (double)d.tail[12], d.tail[12] ? 100.0 * (double)d.tail[13] / (64.0 * (double)d.tail[12]) : 0.0, 100.0 * (double)d.tail[14] / (double)d.tail[2], 100.0 * (double)d.tail[15] / (double)d.tail[2]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] instance entries tried %.4e, turned away by the object's root test %.4e (%.1f %%), left with a hit %.4e (%.1f %%); stack entries written beyond the LDS ones %.4e\n",
                            (double)d.util2[4], (double)d.util2[5], d.util2[4] ? 100.0 * (double)d.util2[5] / (double)d.util2[4] : 0.0, (double)d.util2[6], d.util2[4] ? 100.0 * (double)d.util2[6] / (double)d.util2[4] : 0.0, (double)d.util2[7]);
+    if (d.dbg[2]) fprintf(stderr, "[trace-util] instance packets tested against the oriented box in the leaf step (PT_INST_GATE) %.4e, turned away there %.4e (%.1f %%)\n", (double)d.dbg[2], (double)d.dbg[3], 100.0 * (double)d.dbg[3] / (double)d.dbg[2]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] record step by part, %% of the waves' cycles: loads issued + waited for %.1f, node branch %.1f, leaf branch %.1f, pops %.1f\n",
                            100.0 * (double)d.util2[0] / (double)d.tail[2], 100.0 * (double)d.util2[1] / (double)d.tail[2], 100.0 * (double)d.util2[2] / (double)d.tail[2], 100.0 * (double)d.util2[3] / (double)d.tail[2]);
     for (int k = 0; k < 4; ++k)

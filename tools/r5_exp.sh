@@ -28,12 +28,14 @@ knobs4)
   for q in 4 12 16; do PT_TRACE_LEAF_QUORUM=$q one c4_lq$q --config C4 --spp 64 --steps 1 --warmup 1; done
   for q in 4 12; do PT_TRACE_REFILL_MIN=$q one c4_rf$q --config C4 --spp 64 --steps 1 --warmup 1; done ;;
 shardab:*)  vs="tree,${what#shardab:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one sh_${v} --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off || exit 1; done ;;
+ranks) for r in 0 1 2 3 4 5 6 7; do one sh_rank$r --config C2 --sim-world 8 --sim-rank $r --steps 3 --warmup 1 --projection off || exit 1; done ;;
 shard)   # rank 0's shard of an 8-rank C2 job: one render, and two / three half-shards in flight on the same device (pt_multi_render, replicas 0,0[,0])
   one sh_1 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off || exit 1
   one sh_2 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off --gpus 2 --devices 0,0 --in-process || exit 1
   one sh_3 --config C2 --sim-world 8 --steps 5 --warmup 2 --projection off --gpus 3 --devices 0,0,0 --in-process || exit 1 ;;
 big) one c2_plain --config C2 --steps 3 --warmup 1 || exit 1; PT_TEST_POOL_PAD_RECORDS=34000000 one c2_bigpool --config C2 --steps 3 --warmup 1 || exit 1
      one c4_plain --config C4 --spp 64 --steps 1 --warmup 1 || exit 1; PT_TEST_POOL_PAD_RECORDS=34000000 one c4_bigpool --config C4 --spp 64 --steps 1 --warmup 1 || exit 1 ;;
+gateq) for q in 8 10 12 16 20; do PT_TRACE_INST_QUORUM=$q PT_LIB_PATH=pbrt-rust_amd/csrc/variants/gate one c4_gate_iq$q --config C4 --spp 64 --steps 1 --warmup 1; done; one c4_tree --config C4 --spp 64 --steps 1 --warmup 1 ;;
 c3m) one c3_plain --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; one c3_mixed --config C3M --spp 256 --steps 1 --warmup 1 || exit 1 ;;
 ab5:*) vs="tree,${what#ab5:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c5_${v} --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; done ;;
 quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
