@@ -35,7 +35,7 @@ from code_hash import code_hash   # noqa: E402  (hash of the device library's so
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 GATHER_CEILING_GREQ_S = 54.0  # profiles/r2_gather_calibration.json: dependent random 64-byte gathers, 128-byte fabric requests per ns, whole chip
 TRACE_KINDS = ("trace", "extend", "extend_mis", "shadow", "extend_camera", "extend_probe")   # "trace" = the mixed launch: continuation + MIS + shadow rays of one wavefront iteration
-OTHER_CONFIG_SPP = {"C3": 1024, "C4": 256, "C5": 216}   # one step each after the headline: C3 (a 1-GPU config in BASELINE.json) as its WHOLE job (1024 spp = four passes); C4 / C5 (8-GPU configs) ONE pass of the size the library picks at their named spp
+OTHER_CONFIG_SPP = {"C3": 1024, "C4": -1, "C5": -1}   # one step each after the headline: C3 (a 1-GPU config in BASELINE.json) as its WHOLE job (1024 spp = four passes); C4 / C5 (8-GPU configs) ONE pass of the size the library picks at their named spp (-1: asked of the library, pt_pass_size)
                                                      # (so the rate is the named-spp rate and the committed PMC profile applies): C3 1.4 s, C4 5.6 s, C5 0.4 s of render per step
 
 
@@ -180,6 +180,7 @@ def accumulate(kstats, entries):
 def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, devices, in_process, rank, world, want_cpu_baseline, proj_world=0):
     """Build the config's scene, run `warmup` untimed + `steps` timed renders, return the result dict (rank 0) or None."""
     builder_fn, named_spp, workload_desc = pkg.scenes.CONFIG_SCENES[config]
+    one_pass = spp == -1    # one wavefront pass of the size the library picks for the whole job at the named spp
     spp = spp if spp > 0 else named_spp
     t_gen = time.time()
     kw = dict(xres=args.xres, yres=args.yres, spp=spp)
@@ -201,6 +202,8 @@ def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, device
     if args.sim_world > 1 and world == 1:
         rp.tile_rank, rp.tile_world = args.sim_rank, args.sim_world
     rp.spp_per_pass = args.spp_per_pass
+    if one_pass and scene is not None:
+        spp = scene.pass_size(rp); rp.spp = spp
     rp.profile = int(os.environ.get("PT_BENCH_PROFILE", "1"))   # 1: HIP events around every launch, on the render stream; 2: + exact per-class launch sizes
     cb = rp.cropped_pixel_bounds
     W, H = cb[2] - cb[0], cb[3] - cb[1]
@@ -447,7 +450,7 @@ def main():
             try:
                 r = measure(pkg, lib, torch, dev, None, args, cfg, cspp, 1, 1, devices, in_process, 0, 1, want_cpu_baseline=False, proj_world=proj if cfg in ("C4", "C5") else 0)
                 rf = r["roofline"] or {}
-                oc[cfg] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], steps=1, warmup=1, spp=cspp, named_spp=pkg.scenes.CONFIG_SCENES[cfg][1],
+                oc[cfg] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"], steps=1, warmup=1, spp=r["config"]["spp"], named_spp=pkg.scenes.CONFIG_SCENES[cfg][1],
                                workload=r["config"]["workload"], spp_per_pass=r["config"]["spp_per_pass"],
                                dominant_kernel=rf.get("kernel"), dominant_avg_launch_ms=rf.get("avg_launch_ms"), algorithmic_GBs=rf.get("achieved"),
                                hbm_frac=rf.get("hbm_frac"), rays_per_sample=r["rays_per_sample"], nodes_per_ray=r["nodes_per_ray"],

@@ -466,6 +466,9 @@ int pt_scene_bvh_read(const pt_scene *scene, PtBVHNode *nodes, uint32_t *ordered
  * caller zeroes it), so shards from several ranks can be summed. If film_is_device != 0 the
  * pointer is a HIP device pointer on the selected device. */
 int pt_render(pt_scene *scene, const PtRenderParams *params, float *film_xyzw, int film_is_device);
+/* The samples per pixel per wavefront pass pt_render would use for these parameters on the device as it is now (params->spp_per_pass, or the library's choice from
+ * the free memory when that is 0; passes are of equal size). No reference counterpart: the reference renders a tile at a time. */
+int pt_pass_size(pt_scene *scene, const PtRenderParams *params, uint32_t *spp_per_pass);
 
 /* Film::write_image normalisation (film.rs:217-258): rgb = max(0, xyz_to_rgb(xyz)/w) * scale.
  * Pure host arithmetic on a host buffer. */

@@ -156,6 +156,7 @@ ENTRY_POINTS = {
     "pt_scene_bvh_info": (C.c_int, [VP, u32p, u32p]),
     "pt_scene_bvh_read": (C.c_int, [VP, C.POINTER(PtBVHNode), u32p]),
     "pt_render": (C.c_int, [VP, C.POINTER(PtRenderParams), VP, C.c_int]),
+    "pt_pass_size": (C.c_int, [VP, C.POINTER(PtRenderParams), u32p]),
     "pt_film_resolve": (C.c_int, [fp, u32, f32, fp]),
     "pt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "pt_set_trace_exact": (C.c_int, [C.c_int]),

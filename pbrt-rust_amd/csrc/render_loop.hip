@@ -10,7 +10,14 @@ __global__ void k_trace_util_fold(DevCounters *dc, uint32_t kind, uint32_t waves
 #endif
 
 // Shade queues exist for the seven lobe-count / service classes always (the volumetric integrator uses all of them) and for the lobe-set classes the scene's materials map to.
-static bool class_has_queue(const pt_scene *sc, int c) { return c <= kSpecClass || sc->class_used[c]; }
+static bool class_has_queue(const pt_scene *sc, int c) {
+    // matte and the three service classes always (4 dead / escaped paths, 5 medium vertices, 6 also the waiting exit points of subsurface chains under volpath); a material
+    // class when the scene has such materials, a lobe-count class also when a lobe-set class of the scene folds into it under volpath (class_general)
+    if (c == 0 || c == kMissClass || c == kMediumClass || c == kSpecClass || sc->class_used[c]) return true;
+    if (c == 1 && sc->class_used[kSpecClass]) return true;   // (the volumetric router folds the specular class into class 1)
+    for (int k = kSpecClass + 1; k < kNumClasses; ++k) if (sc->class_used[k] && class_general((uint32_t)k) == (uint32_t)c) return true;
+    return false;
+}
 static size_t n_class_queues(const pt_scene *sc) { size_t n = 0; for (int c = 0; c < kNumClasses; ++c) n += class_has_queue(sc, c) ? 1 : 0; return n; }
 
 // any: 0 closest hit, 1 any hit (rays of job.sub[0]); 2 mixed: the queues of job.sub[0..2] in one launch (n_upper covers all three)
@@ -616,6 +623,19 @@ void read_counters(pt_scene *sc) {
 }  // namespace pth
 
 extern "C" {
+
+int pt_pass_size(pt_scene *sc, const PtRenderParams *rp, uint32_t *spp_per_pass) {
+    if (!sc || !rp || !spp_per_pass || rp->spp == 0) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (sc->device != g_device) { int bst = bind_device(sc->device); if (bst) return bst; }
+    RenderConst rc;
+    fill_render_const(rp, rc);
+    const uint32_t ntiles = rc.ntx * rc.nty;
+    const uint32_t slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world * 256u : 0u;
+    uint32_t S = rp->spp_per_pass;
+    if (S == 0) S = slots ? choose_pass_size(sc, slots, rp->spp, 1, rc.volpath != 0) : rp->spp;
+    *spp_per_pass = std::min(S, rp->spp);
+    return PT_OK;
+}
 
 int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film_is_device) {
     if (!sc || !rp || !film_xyzw) return fail(PT_ERR_INVALID_ARG, "null argument");

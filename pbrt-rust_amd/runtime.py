@@ -83,6 +83,12 @@ class Scene:
         self.L.check(self.L.lib.pt_scene_bvh_read(self.h, nodes, ordered.ctypes.data_as(A.u32p)))
         return nodes, ordered
 
+    def pass_size(self, rp):
+        """Samples per pixel per wavefront pass pt_render would use for `rp` now (the library's choice from the free memory when rp.spp_per_pass == 0)."""
+        s = C.c_uint32()
+        self.L.check(self.L.lib.pt_pass_size(self.h, C.byref(rp), C.byref(s)), "pt_pass_size")
+        return int(s.value)
+
     def render(self, rp, film=None, device_ptr=None):
         """Returns the un-normalised film (H, W, 4) = XYZ sums + weight sum."""
         cb = rp.cropped_pixel_bounds
