@@ -13,7 +13,7 @@ bad = []
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     try:
         T.test_gpu_matches_oracle_on_random_scenes.__wrapped__ if False else None
-        T.test_gpu_matches_oracle_on_random_scenes(pkg, lib, orc, seed)
+        T.test_gpu_matches_oracle_on_random_scenes(pkg, lib, orc, seed, "quad")
     except Exception as e:
         bad.append(seed); print("seed", seed, "FAILED:", str(e).splitlines()[0][:200], flush=True)
     if seed % 500 == 499: print("..", seed + 1, "checked,", len(bad), "failures so far", flush=True)   # (a silent GPU run is taken to be hung)
