@@ -38,6 +38,7 @@ extern bool g_trace_split;
 extern bool g_trace_exact;
 extern uint32_t g_inst_quorum;
 extern bool g_shade_specialise;
+extern bool g_film_final;
 extern uint32_t g_trace_waves_per_cu;
 extern uint32_t g_test_pool_pad_records;
 extern thread_local SobolTables g_tabs;

@@ -21,6 +21,7 @@ bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one 
 bool g_trace_exact = false;                        // pt_set_trace_exact / env PT_TRACE_EXACT=1: walk the two-wide records, PtCounters.bvh_nodes_visited is then the reference's count
 uint32_t g_test_pool_pad_records = 0;              // TEST HOOK (env PT_TEST_POOL_PAD_RECORDS): that many unused 128-byte records in front of every scene's record / packet pool, so that a small
                                                    // scene's records and packets lie beyond the 4 GB a 32-bit byte offset reaches (tests/test_gpu_parity.py: the production walk addresses 16-byte quads)
+bool g_film_final = true;                          // env PT_FILM_FINAL=0: the per-iteration k_shade_miss pass instead of ending the paths in the film kernel (plain path integrator without subsurface materials)
 bool g_shade_specialise = true;                        // env PT_SHADE_SPECIALISE=0: every shade class runs its general kernel (no per-scene lobe-set forms)
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)
 uint32_t g_trace_waves_per_cu = 28;               // persistent trace waves per CU the grid (and the per-wave HBM stack slab) is sized for: 7 per SIMD, what the exact walk of triangle-only scenes fits; the production walk fits 5 (4 with instances) and its surplus blocks start as the first ones drain (env PT_TRACE_WAVES_PER_CU; 20 / 24 / 28: the same, profiles/r4/NOTES.md)
@@ -126,6 +127,7 @@ int pt_init(int device_ordinal) {
     if (const char *e = getenv("PT_TRACE_SPLIT")) g_trace_split = atoi(e) != 0;
     if (const char *e = getenv("PT_TRACE_EXACT")) g_trace_exact = atoi(e) != 0;
     if (const char *e = getenv("PT_SHADE_SPECIALISE")) g_shade_specialise = atoi(e) != 0;
+    if (const char *e = getenv("PT_FILM_FINAL")) g_film_final = atoi(e) != 0;
     if (const char *e = getenv("PT_TEST_POOL_PAD_RECORDS")) { const long long v = atoll(e); if (v >= 0 && v < (1ll << 27)) g_test_pool_pad_records = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_INST_QUORUM")) { int v = atoi(e); if (v >= 1 && v <= 64) g_inst_quorum = (uint32_t)v; }
     if (const char *e = getenv("PT_TRACE_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 32) g_trace_waves_per_cu = (uint32_t)(v & ~3); }

@@ -1,6 +1,7 @@
 // kern_aux.h -- split out of the former single-file kernels.hip so that the translation units compile in parallel.
 #pragma once
 #include "kern_shade_common.h"
+#include "kern_film.h"
 // ---- volumetric path integrator: medium sampling between traversal and shading ---------------------------------------
 // volpath.rs:98-104: after Scene::intersect, a ray that travels in a medium samples it (two sampler dimensions) and scales beta;
 // a sampled medium vertex goes to the medium class, a black beta ends the path, everything else is routed as k_route does.
@@ -223,4 +224,50 @@ __global__ __launch_bounds__(256, PT_MISS_WAVES) void k_shade_miss(DeviceScene s
     counter_add(&job.counters->shade_items[kMissClass], n_valid);
     counter_add(&job.counters->shade_bytes[kMissClass], n_bytes);
     (void)rc;
+}
+
+// ---- the film kernel that also ends the paths (plain path integrator, round 5) ------------------------------------------------
+// Every path ends exactly once, by leaving the scene or by dying with its last vertex's next-event estimate still pending, and all k_shade_miss does for it is read its
+// records (core, the pending NEE / MIS records, the ray for the environment's Le), add to L and write L back -- 54 % of S2's vertices, fetched by path id out of queues:
+// scattered 64-byte gathers at 1.8x their useful bytes. The film kernel reads every path's core record anyway, in path-id order: it now does that last step itself,
+// on fully coalesced streams, and the per-iteration miss pass (a queue append in the shade kernels and the router, a launch, a gather and a write-back) is gone.
+// The arithmetic on L is k_shade_miss's, in its order (resolve_pending, then Le): the same bits reach the film.
+#ifndef PT_FILM_WAVES
+#define PT_FILM_WAVES 4   // waves per SIMD the kernel is compiled for: 128 registers + 32 B of scratch; C2 film 21.9 (three waves, no scratch) -> 19.2 ms, five / six / eight: 24.3 / 28.9 / 33.7
+#endif
+template <bool SPH>
+__global__ __launch_bounds__(256, PT_FILM_WAVES) void k_film_final(DeviceScene s, RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters) {
+    __shared__ uint32_t s_hist[16];
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long zero_num = 0, n_final = 0, n_bytes = 0;
+    uint32_t n_assert = 0;
+    film_slot(rc, ps, filter_table, film_rgbw, counters, [&](uint32_t pid, RGB &L) {
+        const float4 c1 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 1];
+        uint32_t hp = ps.hit_prim(pid);   // (with the core record: one round trip)
+        asm volatile("" : "+v"(hp) : "v"(c1.w));
+        const uint32_t meta = __float_as_uint(c1.w);
+        uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
+        const bool pend = (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) != 0u;
+        const bool escaped = !(flags & (PF_DEAD | PF_FINISHED)) && hp == PT_NONE;   // (PF_FINISHED: ended at a vertex with nothing pending, or on a subsurface probe chain that found no exit point -- its kernel did the last step)
+        if (!pend && !escaped) return;
+        n_final++; n_bytes += 32 + 4;
+        resolve_pending<SPH, false, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes);
+        if (escaped && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
+            n_bytes += 32;
+            const RGB beta(c1.x, c1.y, c1.z);
+            const float4 *rq = reinterpret_cast<const float4 *>(ps.ray) + 2 * (size_t)pid;
+            const float4 r0 = rq[0], r1 = rq[1];
+            const V3 rd(r0.w, r1.x, r1.y);
+            for (uint32_t k = 0; k < s.n_infinite; ++k) L = L + light_le(s, s.lights[s.infinite_lights[k]], rd) * beta;
+        }
+        atomicAdd(&s_hist[bounces > 15u ? 15u : bounces], 1u);   // path.rs:219
+    });
+    __syncthreads();
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&counters->path_len[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+    counter_add(&counters->zero_num, zero_num);
+    counter_add(&counters->ref_asserts, (unsigned long long)n_assert);
+    counter_add(&counters->stages, n_final);
+    counter_add(&counters->shade_items[kMissClass], n_final);
+    counter_add(&counters->shade_bytes[kMissClass], n_bytes);
 }

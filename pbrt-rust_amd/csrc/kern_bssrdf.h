@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
             }
             if (terminated) {
                 if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
-                else finished_bounces = (int)bounces;
+                else { finished_bounces = (int)bounces; flags |= PF_FINISHED; }
             }
             if (smp.overflow) atomicMax(job.error, (uint32_t)PT_ERR_SOBOL_DIMENSIONS);
             ps.L_r(pid) = L.r; ps.L_g(pid) = L.g; ps.L_b(pid) = L.b;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
         }
     }
     lq_push(s_qext, pid, push_ext);
-    lq_push(s_qres, pid, push_resolve);
+    lq_push(s_qres, pid, push_resolve && job.shade_next0 != nullptr);   // (no miss pass: k_film_final ends the dead paths)
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (VOL) lq_push(s_qself, pid, push_self);

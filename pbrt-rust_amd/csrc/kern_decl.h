@@ -16,6 +16,7 @@ __global__ void k_light_area(DeviceScene s, float *area, float4 *rec);
 template <int NQ, int CAP> __global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps, uint32_t *class_count, RouteJob rj);
 __global__ void k_generate(RenderConst rc, SobolTables tabs, PathSoA ps, uint32_t *q_ext, uint32_t *q_ext_count, DevCounters *counters);
 __global__ void k_film(RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
+template <bool SPH> __global__ void k_film_final(DeviceScene s, RenderConst rc, PathSoA ps, const float *filter_table, float *film_rgbw, DevCounters *counters);
 __global__ void k_film_finish(const float *film_rgbw, float *film_xyzw, uint32_t npix);
 __global__ void k_film_sum(FilmSumArgs a, float4 *dst, int accumulate, size_t n_quads);
 __global__ void k_light_grid_contrib(DeviceScene s, uint32_t nvx, uint32_t nvy, uint32_t nvz, float *func, const uint32_t *cells, size_t n_cells, size_t stride);

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
             }
             if (terminated) {
                 if (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) { flags |= PF_DEAD; push_resolve = true; }
-                else finished_bounces = (int)bounces;
+                else { finished_bounces = (int)bounces; flags |= PF_FINISHED; }
             }
         }
         PT_T(12);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
 #else
     lq_push(s_qext, pid, push_ext);
 #endif
-    lq_push(s_qres, pid, push_resolve);
+    lq_push(s_qres, pid, push_resolve && job.shade_next0 != nullptr);   // (no miss pass: the film kernel ends the dead paths, k_film_final)
     lq_push(s_qsh, pid, push_shadow);
     lq_push(s_qmis, pid, push_mis);
     if (finished_bounces >= 0) atomicAdd(&s_hist[finished_bounces > 15 ? 15 : finished_bounces], 1u);  // path.rs:219 (LDS)

@@ -24,13 +24,20 @@ struct Prof { long long *t; int *r; unsigned long long *acc; };
 // continuation sample. Such vertices are therefore resolved in a second stage of the SAME vertex (PF_STAGE_B, kern_shade.h) and pass
 // their sampler here; `smp` is NULL everywhere else.
 // n_assert: the reference's `assert!(Ld.y() >= 0.0)` (path.rs:143) on the regular vertices' estimate, counted instead of panicking.
-template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
+// EARLY (k_film_final): the MIS record is requested together with the NEE record, before either is used -- one round trip instead of two in a kernel whose threads walk
+// their samples one after the other (the shade kernels keep the later request: batching their front cost registers and time, profiles/r4/NOTES.md).
+template <bool SPH, bool VOL = false, bool EARLY = false> PT_DEV void resolve_pending(const DeviceScene &s, const PathSoA &ps, uint32_t pid, uint32_t &flags, RGB &L,
                                                 unsigned long long &zero_num, uint32_t &n_assert, unsigned long long &n_bytes PT_PROF_ARG, Sampler *smp = nullptr) {
     if (!(flags & (PF_PEND_SHADOW | PF_PEND_MIS))) return;
     PT_T(1);
     // the pending records as whole quads: nee {sh_d.yz, occluded | sh_prim, nee_light} {A, choice_pdf} {nb, shadow grid medium}; mis {o, d.x} {d.yz, w, spdf} {prim, b} {f, t}
     const float4 *nq = reinterpret_cast<const float4 *>(ps.nee) + 4 * (size_t)pid;
     const float4 n1 = nq[1], n2 = nq[2], n3 = nq[3];
+    float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0, e3 = e0;
+    if constexpr (EARLY) {
+        if (flags & PF_PEND_MIS) { const float4 *mq = reinterpret_cast<const float4 *>(ps.mis) + 4 * (size_t)pid; e0 = mq[0]; e1 = mq[1]; e2 = mq[2]; e3 = mq[3]; }
+        asm volatile("" :: "v"(n1.x), "v"(n2.x), "v"(n3.x), "v"(e0.x), "v"(e1.x), "v"(e2.x), "v"(e3.x));
+    }
     n_bytes += 48 + ((flags & PF_PEND_MIS) ? 64 : 0);
     RGB Ld(0.0f);
     const uint32_t li = __float_as_uint(n1.w);
@@ -49,7 +56,7 @@ template <bool SPH, bool VOL = false> PT_DEV void resolve_pending(const DeviceSc
     }
     if (flags & PF_PEND_MIS) {
         const float4 *mq = reinterpret_cast<const float4 *>(ps.mis) + 4 * (size_t)pid;
-        const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+        const float4 m0 = EARLY ? e0 : mq[0], m1 = EARLY ? e1 : mq[1], m2 = EARLY ? e2 : mq[2], m3 = EARLY ? e3 : mq[3];
         const PtLight &Lt = s.lights[li];
         V3 wi(m0.w, m1.x, m1.y);
         RGB lrad(0.0f);

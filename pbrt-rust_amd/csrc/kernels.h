@@ -54,7 +54,8 @@ constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersection
 // path flags (meta >> 24)
 enum : uint32_t { PF_SPECULAR = 1u, PF_PEND_SHADOW = 2u, PF_PEND_MIS = 4u, PF_DEAD = 8u, PF_NEE_UNCOUNTED = 16u,
                   PF_CAMERA_RAY = 32u,     // the ray still carries the camera's differentials (cleared at the first shaded vertex)
-                  PF_STAGE_B = 64u };      // volpath with grid media or material-less shells: the vertex has done its NEE set-up and waits, in its own shade class, for the traced rays before it samples on
+                  PF_STAGE_B = 64u,        // volpath with grid media or material-less shells: the vertex has done its NEE set-up and waits, in its own shade class, for the traced rays before it samples on
+                  PF_FINISHED = 128u };    // the path ended at a vertex with nothing pending: its shade kernel did its last step (k_film_final leaves it alone)
 
 // Path state in HBM: five arrays of 16-byte-aligned RECORDS indexed by path id (pid). A record holds what one kernel reads or
 // writes together, so a lane moves whole 16-byte quads of one 32- or 64-byte line (dwordx4 accesses, every fetched sector fully

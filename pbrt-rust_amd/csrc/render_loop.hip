@@ -362,6 +362,9 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
 #endif
     hipLaunchKernelGGL(k_generate, dim3(std::min<uint32_t>((total + 255) / 256, (uint32_t)g_num_cus * PT_GEN_BLOCKS_PER_CU)), dim3(256), 0, sc->stream, rc, g_tabs, sc->ps, sc->q.ext[0], &qc->ext[0], sc->dc);
     sc->end();
+    // The plain path integrator's paths are ended by the film kernel (k_film_final, kern_aux.h): no miss class, no k_shade_miss pass. Volpath keeps the pass (its
+    // transmittance estimates draw sampler dimensions in iteration order).
+    const bool fin = g_film_final && !rc.volpath;
     int cur = 0;
     static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_manylobe", "shade_miss", "shade_medium", "shade_specular", "shade_metal", "shade_plastic", "shade_uber", "shade_sss"};
     const int kMaxIterations = 1 << 20;   // a path needs <= max_depth + null-surface skips + probe segments iterations
@@ -380,7 +383,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         // volpath with grid media: vertices that did their NEE set-up last iteration wait in their own shade class for stage B
         uint32_t n_stage_b = 0;
         if (rc.volpath && (sc->ds.has_grid || sc->ds.has_shells)) for (int c = 0; c < kNumClasses; ++c) if (c != kMissClass) n_stage_b += h.shade[cur][c];
-        if (n_ext == 0 && n_resolve == 0 && n_probe == 0 && n_stage_b == 0) break;
+        if (n_ext == 0 && n_resolve == 0 && n_probe == 0 && n_stage_b == 0 && (!fin || (n_shadow == 0 && n_mis == 0))) break;   // (fin: the last vertices' shadow / MIS rays are still to be traced)
         hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, sc->stream, qc, 4u | 1u, cur);
         TraceJob tj{};
         tj.spill = sc->spill; tj.error = &qc->error; tj.counters = sc->dc; tj.head = &qc->head[0];
@@ -450,7 +453,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
 #define PT_ROUTE_BLOCKS_PER_CU 3u   // what a CU's LDS holds of this kernel (six 8 KB staging queues per block)
 #endif
             RouteJob rj{}; rj.slot_map = ~0ull;
-            for (int c = 0; c < kNumClasses; ++c) if (c != kMediumClass && (c == kMissClass || sc->class_used[c])) {
+            for (int c = 0; c < kNumClasses; ++c) if (c != kMediumClass && ((c == kMissClass && !fin) || (c != kMissClass && sc->class_used[c]))) {   // (fin: escaped rays are dropped here, the film kernel ends them)
                 rj.slot_map = (rj.slot_map & ~(15ull << (4 * c))) | ((unsigned long long)rj.n_slots << (4 * c));
                 rj.cls_of_slot[rj.n_slots] = (uint32_t)c; rj.buf[rj.n_slots] = sc->q.shade[cur][c]; rj.n_slots++;
             }
@@ -487,7 +490,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             bj.queue = sc->q.probe[cur]; bj.count = &qc->probe[cur];
             bj.self_next = sc->q.shade[1 - cur][kSpecClass]; bj.self_next_count = &qc->shade[1 - cur][kSpecClass];   // (volpath has no specular-only class: its queue serves the waiting exit-point vertices)
             bj.ext_next = sc->q.ext[1 - cur]; bj.ext_next_count = &qc->ext[1 - cur];
-            bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
+            if (!fin) { bj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; bj.shade_next0_count = &qc->shade[1 - cur][kMissClass]; }
             bj.shadow = sc->q.shadow; bj.shadow_count = &qc->shadow; bj.mis = sc->q.mis; bj.mis_count = &qc->mis;
             bj.error = &qc->error; bj.counters = sc->dc; bj.bs = sc->bs;
             const uint32_t blocks = std::min<uint32_t>((n_probe + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);
@@ -525,11 +528,11 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
                 sc->end();
                 continue;
             }
-            if (!used || class_n[c] == 0) continue;
+            if (!used || class_n[c] == 0 || (c == kMissClass && fin)) continue;
             ShadeJob sj{};
             sj.queue = sc->q.shade[cur][c]; sj.count = &qc->shade[cur][c];
             sj.ext_next = sc->q.ext[1 - cur]; sj.ext_next_count = &qc->ext[1 - cur];
-            sj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; sj.shade_next0_count = &qc->shade[1 - cur][kMissClass];
+            if (!fin) { sj.shade_next0 = sc->q.shade[1 - cur][kMissClass]; sj.shade_next0_count = &qc->shade[1 - cur][kMissClass]; }
             sj.shadow = sc->q.shadow; sj.shadow_count = &qc->shadow; sj.mis = sc->q.mis; sj.mis_count = &qc->mis;
             sj.error = &qc->error; sj.counters = sc->dc; sj.cls = (uint32_t)c;
             sj.self_next = sc->q.shade[1 - cur][c]; sj.self_next_count = &qc->shade[1 - cur][c];
@@ -566,8 +569,11 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
         cur = 1 - cur;
     }
     sc->begin("film", total);
-        sc->set_kernel("k_film");
-    hipLaunchKernelGGL(k_film, dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    const bool fsph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;
+    sc->set_kernel(fin ? (fsph ? "k_film_final<true>" : "k_film_final<false>") : "k_film");
+    if (fin && fsph) hipLaunchKernelGGL((k_film_final<true>), dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    else if (fin) hipLaunchKernelGGL((k_film_final<false>), dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    else hipLaunchKernelGGL(k_film, dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
     sc->end();
     HIP_TRY(hipGetLastError());
     return PT_OK;

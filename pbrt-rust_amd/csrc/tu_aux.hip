@@ -3,3 +3,5 @@
 template __global__ void k_shade_miss<false, false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
 template __global__ void k_shade_miss<true, false>(DeviceScene, RenderConst, PathSoA, ShadeJob);
 template __global__ void k_shade_miss<true, true>(DeviceScene, RenderConst, PathSoA, ShadeJob);
+template __global__ void k_film_final<false>(DeviceScene, RenderConst, PathSoA, const float *, float *, DevCounters *);
+template __global__ void k_film_final<true>(DeviceScene, RenderConst, PathSoA, const float *, float *, DevCounters *);

@@ -38,6 +38,11 @@ big) one c2_plain --config C2 --steps 3 --warmup 1 || exit 1; PT_TEST_POOL_PAD_R
 gateq) for q in 8 10 12 16 20; do PT_TRACE_INST_QUORUM=$q PT_LIB_PATH=pbrt-rust_amd/csrc/variants/gate one c4_gate_iq$q --config C4 --spp 64 --steps 1 --warmup 1; done; one c4_tree --config C4 --spp 64 --steps 1 --warmup 1 ;;
 c5proj) for v in tree base; do PT_LIB_PATH=$(lib $v) one c5p_$v --config C5 --steps 1 --warmup 1 --projection on || exit 1; python3 -c "
 import json; d=json.loads(open('$OUT/bench_c5p_$v.json').read().strip().split('\n')[-1]); print('$v', d['config']['spp_per_pass'], d.get('scaling_projection'))"; done ;;
+nofin)  # A/B of the film kernel that ends the paths against the per-iteration miss pass (PT_FILM_FINAL=0), same library
+  for i in 1 2; do one c2_fin_$i --config C2 --steps 3 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c2_miss_$i --config C2 --steps 3 --warmup 1 || exit 1; done
+  one c3_fin --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c3_miss --config C3 --spp 256 --steps 1 --warmup 1 || exit 1
+  one c4_fin --config C4 --spp 64 --steps 1 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c4_miss --config C4 --spp 64 --steps 1 --warmup 1 || exit 1 ;;
+nofin5) one c5_fin --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c5_miss --config C5 --spp 216 --steps 2 --warmup 1 || exit 1 ;;
 c3m) one c3_plain --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; one c3_mixed --config C3M --spp 256 --steps 1 --warmup 1 || exit 1 ;;
 ab5:*) vs="tree,${what#ab5:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c5_${v} --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; done ;;
 quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
