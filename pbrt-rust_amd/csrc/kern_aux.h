@@ -244,12 +244,12 @@ __global__ __launch_bounds__(256, PT_FILM_WAVES) void k_film_final(DeviceScene s
     uint32_t n_assert = 0;
     film_slot(rc, ps, filter_table, film_rgbw, counters, [&](uint32_t pid, RGB &L) {
         const float4 c1 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 1];
-        uint32_t hp = ps.hit_prim(pid);   // (with the core record: one round trip)
-        asm volatile("" : "+v"(hp) : "v"(c1.w));
         const uint32_t meta = __float_as_uint(c1.w);
         uint32_t flags = meta >> 24; const uint32_t bounces = (meta >> 16) & 0xffu;
         const bool pend = (flags & (PF_PEND_SHADOW | PF_PEND_MIS)) != 0u;
-        const bool escaped = !(flags & (PF_DEAD | PF_FINISHED)) && hp == PT_NONE;   // (PF_FINISHED: ended at a vertex with nothing pending, or on a subsurface probe chain that found no exit point -- its kernel did the last step)
+        // When the pass's queues are empty every path has ended in one of three ways: its shade kernel finished it (PF_FINISHED: nothing was pending, or a subsurface probe
+        // chain found no exit point), it died with an estimate pending (PF_DEAD), or -- neither flag -- its last ray left the scene. No look at the hit record needed.
+        const bool escaped = !(flags & (PF_DEAD | PF_FINISHED));
         if (!pend && !escaped) return;
         n_final++; n_bytes += 32 + 4;
         resolve_pending<SPH, false, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes);
