@@ -204,6 +204,40 @@ def test_prebuilt_bvh_is_adopted(pkg, gpu, oracle):
     _compare_render(pkg, gpu, oracle, sd, rp)
 
 
+def test_adopted_trees_are_validated(pkg, gpu, oracle):
+    """an adopted tree is the caller's data. (1) An interior node whose second child does not lie behind its first child's subtree (a back edge: the flattened
+    tree is in pre-order, bvh.rs:662-703) would send the depth-first walks round in circles: refused with PT_ERR_INVALID_ARG. (2) A tree whose child boxes are NOT nested
+    in their parents' (here: every leaf box blown up to the root's) is legal for the reference, which tests every box it meets; the four-wide walk
+    skips the boxes of collapsed children, so such a scene is walked two-wide, box by box, in both modes -- hits, counters and film == the oracle on the same tree."""
+    import copy
+    sd, rp = _small_scene(pkg, n=12)
+    nodes, ordered = oracle.scene(sd).bvh()
+    interior = [i for i in range(len(nodes)) if nodes[i].n_prims == 0]
+    bad = type(nodes)(); C.memmove(bad, nodes, C.sizeof(nodes))
+    i = interior[len(interior) // 2]
+    bad[i].offset = i                      # back edge
+    sd_bad = copy.copy(sd); sd_bad.set_bvh(bad, ordered)
+    with pytest.raises(Exception, match="malformed BVH node"):
+        pkg.Scene(gpu, sd_bad)
+    loose = type(nodes)(); C.memmove(loose, nodes, C.sizeof(nodes))
+    root = nodes[0]
+    # not nested: every LEAF box blown up to the root's box (the interior boxes below the root stay tight, so their children stick out of them)
+    for i in range(len(loose)):
+        if loose[i].n_prims:
+            for k in range(3):
+                loose[i].bmin[k] = root.bmin[k]; loose[i].bmax[k] = root.bmax[k]
+    sd2 = copy.copy(sd); sd2.set_bvh(loose, ordered)
+    g = pkg.Scene(gpu, sd2); orc = oracle.scene(sd2)
+    o, d = _random_rays(20000, 9)
+    tmax = np.full(len(o), np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(o, d, tmax); gc = g.counters()
+    op, ot, ob = orc.trace_closest(o, d, tmax); oc = orc.counters()
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    for k in ("bvh_nodes_visited", "triangle_tests", "intersect_tests"):   # the node counter in BOTH modes: this scene has no production walk
+        assert gc[k] == oc[k], k
+    assert any(k["kernel"].endswith(", 0>") for k in g.kernel_stats() if k["kernel"].startswith("k_trace"))
+
+
 def test_tile_sharding_sums_to_full_render(pkg, gpu):
     sd, rp = _small_scene(pkg, n=16, xres=80, yres=48)
     g = pkg.Scene(gpu, sd)
