@@ -68,6 +68,31 @@ def test_mixed_traversal_launch_equals_one_launch_per_ray_kind(pkg, gpu, tmp_pat
         assert {"extend", "shadow"} <= set(split[name]["stats"]) and "trace" not in split[name]["stats"], split[name]["stats"]
 
 
+def test_film_kernel_that_ends_the_paths_equals_the_miss_pass(pkg, gpu, tmp_path):
+    """Round 5: the plain path integrator's paths are ended by the film kernel (k_film_final: the last vertex's pending estimate, the escaped ray's Le, the histogram entry)
+    instead of by a k_shade_miss pass per wavefront iteration. PT_FILM_FINAL=0 (read by pt_init: a process of its own) brings the pass back: same counters (incl. the
+    path-length histogram, the zero-radiance count and the reference's asserts), same weights bit for bit, same radiance up to the order of the film's corner-sample atomics;
+    only the launch kinds differ."""
+    env = trace_env(dict(os.environ, PT_FILM_FINAL="0"))
+    code = _CHILD.format(root=ROOT, out=str(tmp_path), counters=COUNTERS)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    old = json.load(open(tmp_path / "out.json"))
+    for name, make in _scenes(pkg).items():
+        sd, rp = make().world_end()
+        g = pkg.Scene(gpu, sd)
+        film = g.render(rp)
+        c = g.counters()
+        st = {s["name"]: s["kernel"] for s in g.kernel_stats() if s["launches"]}
+        for k in ckeys(COUNTERS):
+            assert c[k] == old[name]["counters"][k], (name, k)
+        other = np.load(tmp_path / (name + ".npy"))
+        assert np.array_equal(film[..., 3], other[..., 3]), name
+        np.testing.assert_allclose(film[..., :3], other[..., :3], rtol=2e-6, atol=1e-7, err_msg=name)
+        assert "shade_miss" not in st and st["film"].startswith("k_film_final<"), st
+        assert "shade_miss" in old[name]["stats"], old[name]["stats"]
+
+
 @pytest.mark.parametrize("per_pass", [1, 3, 5])
 def test_pass_size_does_not_change_the_image(pkg, gpu, per_pass):
     """spp_per_pass = 0 lets the library size its passes from the free memory (here: one pass); explicit pass sizes that do not divide the
