@@ -43,6 +43,11 @@ nofin)  # A/B of the film kernel that ends the paths against the per-iteration m
   one c3_fin --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c3_miss --config C3 --spp 256 --steps 1 --warmup 1 || exit 1
   one c4_fin --config C4 --spp 64 --steps 1 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c4_miss --config C4 --spp 64 --steps 1 --warmup 1 || exit 1 ;;
 nofin5) one c5_fin --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; PT_FILM_FINAL=0 one c5_miss --config C5 --spp 216 --steps 2 --warmup 1 || exit 1 ;;
+aos) PT_LIB_PATH=pbrt-rust_amd/csrc/variants/aos timeout -k 10 500 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -4
+  for i in 1 2; do one c2_tree_$i --config C2 --steps 3 --warmup 1 || exit 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/aos one c2_aos_$i --config C2 --steps 3 --warmup 1 || exit 1; done
+  one c3_tree --config C3 --spp 256 --steps 1 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/aos one c3_aos --config C3 --spp 256 --steps 1 --warmup 1
+  one c4_tree --config C4 --spp 64 --steps 1 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/aos one c4_aos --config C4 --spp 64 --steps 1 --warmup 1
+  one c5_tree --config C5 --spp 216 --steps 2 --warmup 1; PT_LIB_PATH=pbrt-rust_amd/csrc/variants/aos one c5_aos --config C5 --spp 216 --steps 2 --warmup 1 ;;
 c3m) one c3_plain --config C3 --spp 256 --steps 1 --warmup 1 || exit 1; one c3_mixed --config C3M --spp 256 --steps 1 --warmup 1 || exit 1 ;;
 ab5:*) vs="tree,${what#ab5:}"; for v in ${vs//,/ }; do PT_LIB_PATH=$(lib $v) one c5_${v} --config C5 --spp 216 --steps 2 --warmup 1 || exit 1; done ;;
 quickv:*) PT_LIB_PATH=$(lib ${what#quickv:}) timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_configs.py -m gpu -x -q 2>&1 | tail -5 ;;
