@@ -240,6 +240,11 @@ __global__ __launch_bounds__(256, PT_FILM_WAVES) void k_film_final(DeviceScene s
     __shared__ uint32_t s_hist[16];
     if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
     __syncthreads();
+#ifdef PT_REGION_PROFILE
+    __shared__ long long s_pt[4]; __shared__ int s_pr[4]; __shared__ unsigned long long s_pacc[64];
+    if (threadIdx.x < 4) { s_pt[threadIdx.x] = clock64(); s_pr[threadIdx.x] = 15; }
+    Prof prof{s_pt, s_pr, s_pacc};   // not reported: the region table is k_shade's
+#endif
     unsigned long long zero_num = 0, n_final = 0, n_bytes = 0;
     uint32_t n_assert = 0;
     film_slot(rc, ps, filter_table, film_rgbw, counters, [&](uint32_t pid, RGB &L) {
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256, PT_FILM_WAVES) void k_film_final(DeviceScene s
         const bool escaped = !(flags & (PF_DEAD | PF_FINISHED));
         if (!pend && !escaped) return;
         n_final++; n_bytes += 32 + 4;
-        resolve_pending<SPH, false, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes);
+        resolve_pending<SPH, false, true>(s, ps, pid, flags, L, zero_num, n_assert, n_bytes PT_PROF_PASS);
         if (escaped && (bounces == 0 || (flags & PF_SPECULAR)) && s.n_infinite > 0) {   // path.rs:106-117, ray escaped
             n_bytes += 32;
             const RGB beta(c1.x, c1.y, c1.z);
