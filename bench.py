@@ -363,6 +363,7 @@ def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, device
                    "name": config, "triangles": n_tris, "instances": n_inst, "spp": spp, "spp_per_pass": eff_spp_per_pass, "resolution": [args.xres, args.yres],
                    "film": "stays on the device (no read-back in the timed region; film_readback_ms / value_with_readback give SURVEY 8(d)'s read-back-inclusive figure)",
                    "parallelism": par},
+        "code_hash": code_hash(ROOT),   # tools/code_hash.py: the device sources this line was measured on (tools/check_profiles.py holds committed records against it)
         "film_readback_ms": round(film_readback_ms, 3),
         "value_with_readback": round(n_samples / (elapsed / steps + film_readback_ms * 1e-3) / 1e6, 3),
         "roofline": roofline, "cpu_baseline": cpu_baseline,
@@ -371,7 +372,9 @@ def measure(pkg, lib, torch, dev, dist, args, config, spp, steps, warmup, device
         "kernels_ms_per_step": kernels, **({"trace_kinds": trace_kinds} if trace_kinds else {}),
         "rays_per_sample": round((counters["intersect_tests"] + counters["shadow_tests"]) / max(1, counters["camera_rays"]), 3) if counters else None,
         "nodes_per_ray": round(counters["bvh_nodes_visited"] / max(1, counters["intersect_tests"] + counters["shadow_tests"]), 2) if counters else None,
-        "setup_s": {"scene_gen": round(t_gen, 1), "bvh_build_upload": round(t_up, 1)},
+        "setup_s": {"scene_gen": round(t_gen, 1), "bvh_build_upload": round(t_up, 1),
+                    **({"multi_scene_create": {k: (round(v / 1e3, 2) if not isinstance(v, list) else [round(x / 1e3, 2) for x in v]) for k, v in multi.create_timing().items()},
+                        "multi_scene_create_note": "wall_ms / replica_ms in seconds: replica 0 builds the BVH, replicas 1.. adopt it and upload concurrently, one host thread each"} if multi is not None else {})},
     }
     if args.sim_world > 1 and world == 1:
         out["sim_world"] = args.sim_world

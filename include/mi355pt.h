@@ -38,9 +38,11 @@ typedef enum PtStatus {
     PT_ERR_UNSUPPORTED = 4,       /* scene uses a feature outside the implemented rows      */
     PT_ERR_SOBOL_DIMENSIONS = 5,  /* a path consumed >= 1024 Sobol' dimensions
                                      (the reference panics: samplers/sobol.rs:69-73)         */
-    PT_ERR_STACK_OVERFLOW = 6,    /* BVH traversal stack deeper than 64 entries
-                                     (the reference has no check: accelerators/bvh.rs:722)   */
-    PT_ERR_OUT_OF_MEMORY = 7,
+    PT_ERR_STACK_OVERFLOW = 6,    /* a ray's BVH traversal stack grew beyond what the walk holds: 96 pending entries in the
+                                     four-wide production walk, 64 in the two-wide exact walk (= the reference's stack size;
+                                     the reference indexes its 64-entry Vec without a check of its own: accelerators/bvh.rs:722) */
+    PT_ERR_OUT_OF_MEMORY = 7,     /* a device allocation failed (e.g. spp_per_pass asks for more path state than the device has free);
+                                     the scene stays usable: the next pt_render allocates its workspace afresh */
     PT_ERR_PROBE_CHAIN = 8        /* a BSSRDF probe chain (core/bssrdf.rs:376-394) found more than 32767 intersections or a
                                      pass needed more than 65536 wavefront iterations: the reference would still be walking its
                                      linked list; the render is abandoned instead of returning a truncated chain          */
@@ -494,6 +496,9 @@ int pt_multi_get_kernel_stats(const pt_multi_scene *scene, uint32_t replica, PtK
  * copy, and `merge_ms` = from the moment the LAST replica finished rendering to the summed film (copy tail + the sum kernel).
  * render_ms / copy_ms hold max_replicas entries (either may be NULL). */
 int pt_multi_get_timing(const pt_multi_scene *scene, double *merge_ms, double *render_ms, double *copy_ms, uint32_t max_replicas);
+/* Wall-clock time of pt_multi_scene_create: the whole call (`wall_ms`) and per replica its own scene creation (`replica_ms`, max_replicas entries; either may be
+ * NULL). Replica 0 is created first (it builds the top-level BVH), replicas 1.. adopt its tree and are created concurrently, one host thread per replica. */
+int pt_multi_get_create_timing(const pt_multi_scene *scene, double *wall_ms, double *replica_ms, uint32_t max_replicas);
 /* How replica i's film reaches the first device (decided once, at pt_multi_scene_create): PT_PEER_SAME_DEVICE (it lives there: no copy),
  * PT_PEER_ENABLED (hipDeviceEnablePeerAccess succeeded in both directions: hipMemcpyPeerAsync goes device to device over xGMI) or
  * PT_PEER_STAGED (no peer access: the runtime stages the copy through host memory -- correct, slower). `peer` holds max_replicas entries. */
@@ -526,6 +531,12 @@ int pt_halton_samples(const int32_t sample_bounds[4], uint32_t sample_at_pixel_c
  * (pfilm.xy, time, plens.xy) -> origin, direction (cameras/perspective.rs:120-179). */
 int pt_camera_rays(const PtRenderParams *params, uint32_t n, const float *camera_samples,
                    float *out_origins, float *out_dirs);
+/* Distribution1D (core/sampling.rs:6-85) over func[n], built as the library builds the environment map's rows and the light
+ * distributions; for each of n_u numbers u: discrete == 0: sample_continous (sampling.rs:38-64, the routine behind
+ * InfiniteAreaLight::sample_li) -> out_x = the sampled value in [0,1), out_pdf, out_offset; discrete != 0: sample_discrete
+ * (sampling.rs:66-85, the light choice) -> out_offset, out_pdf (out_x = 0). Twin of the reference's tests/sampling.rs:202-283. */
+int pt_dist1d_sample(const float *func, uint32_t n, int discrete, uint32_t n_u, const float *u,
+                     float *out_x, float *out_pdf, int32_t *out_offset);
 
 #ifdef __cplusplus
 }

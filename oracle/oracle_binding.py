@@ -48,7 +48,7 @@ class Oracle:
         lib.orc_rng_u32_stream.argtypes = [C.c_uint64, C.c_int, C.c_uint32, A.u32p, A.fp]
         lib.orc_dist1d_sample_discrete.argtypes = [A.fp, C.c_int, f, A.fp, A.fp]
         lib.orc_dist1d_discrete_pdf.restype = f; lib.orc_dist1d_discrete_pdf.argtypes = [A.fp, C.c_int, C.c_int]
-        lib.orc_dist1d_sample_continuous.restype = f; lib.orc_dist1d_sample_continuous.argtypes = [A.fp, C.c_int, f, A.fp]
+        lib.orc_dist1d_sample_continuous.restype = f; lib.orc_dist1d_sample_continuous.argtypes = [A.fp, C.c_int, f, A.fp, C.POINTER(C.c_int)]
         lib.orc_tri_intersect.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, f, A.fp, A.fp, A.fp, A.fp, A.fp]
         lib.orc_tri_intersect_p.argtypes = [C.c_void_p, C.c_uint32, A.fp, A.fp, f]
         lib.orc_offset_ray_origin.argtypes = [A.fp] * 5

@@ -1,7 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see ref_math.h header).
 // ref_kats.cpp: the reference's own test loops for code this oracle restates, run in C++ for speed and reported to
 // tests/test_oracle_kats.py:  tests/fp.rs:125-226 (EFloat abs / sqrt / add / sub / mul / div containment, 10^6 seeds each),
-// tests/bitops.rs:7-64 (log2_int, round_up_pow2), tests/sampling.rs:55-97 (generator matrices, Gray-code samples).
+// tests/fp.rs:46-57 (float_bits), tests/bitops.rs:7-64 (log2_int, round_up_pow2), tests/sampling.rs:55-97 (generator matrices, Gray-code samples).
 #include "ref_efloat.h"
 #include "ref_sampler.h"
 #include <cmath>
@@ -72,6 +72,23 @@ int orc_test_efloat(int op, int iters, int *n_tested) {
             ++tested;
             if (!(pr >= (double)r.low && pr <= (double)r.high)) ++failures;
         }
+    }
+    if (n_tested) *n_tested = tested;
+    return failures;
+}
+
+// tests/fp.rs:46-57 float_bits: RNG::new(1), `iters` (the reference: 100 000) draws ui; f = bits_to_float(ui); NaNs skipped; float_to_bits(f) == ui -- on
+// ref_math.h's float_to_bits / bits_to_float (pbrt.rs:57-78), the pair under next_float_up / next_float_down and offset_ray_origin.
+// Returns the number of mismatches; *n_tested = the draws that were not NaN.
+int orc_test_float_bits(int iters, int *n_tested) {
+    Rng rng(1);
+    int failures = 0, tested = 0;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t ui = rng.u32();
+        const Float f = ref::bits_to_float(ui);
+        if (f != f) continue;
+        ++tested;
+        if (ref::float_to_bits(f) != ui) ++failures;
     }
     if (n_tested) *n_tested = tested;
     return failures;

@@ -10,6 +10,8 @@
 //                            Sphere::solid_angle, sphere.rs:397-407)
 //   tests/shapes.rs:407-419  disk_solid_angle      (Disk::intersect_p Monte Carlo vs the default Shape::solid_angle, shape.rs:84-107:
 //                            Disk::sample through sample_interaction + a self-occlusion intersect_p)
+//   tests/shapes.rs:36-146   triangle_watertight   (Triangle::intersect over a closed triangulated sphere: every ray from inside hits;
+//                            the reference keeps this test DISABLED -- `//#[test]` at :35 -- see orc_test_triangle_watertight)
 // Same seeds (RNG::new(i) / RNG::new(100 + i)), same sample counts, same radical-inverse points, same tolerances.
 #include "ref_shading.h"
 #include <cmath>
@@ -184,5 +186,82 @@ int orc_test_disk_solid_angle(const PtSphere *D, int nsamples, double *out) {
     const Float dsa = (Float)(acc / (double)nsamples);
     if (out) { out[0] = mc; out[1] = dsa; }
     return std::fabs(mc - dsa) < 0.001f ? 0 : 1;
+}
+
+// tests/shapes.rs:36-146 triangle_watertight. The mesh (:37-107): a 16 x 16 (theta, phi) grid of vertices on a sphere whose interior
+// vertices are pushed out along their normal by 5 * RNG::new(12111).uniform_float(), the two poles coincident, triangulated as a fan at
+// each pole and two triangles per quad between (420 triangles over 256 vertices). Two forms:
+//   as_written != 0  the vertex loop exactly as the Rust file has it. Its seam branch tests `t == nphi - 1` (:60); with ntheta == nphi that
+//                    row was already taken by the `t == ntheta - 1` branch above it, so the branch is dead, the column phi = 2 pi gets radii of
+//                    its own and the mesh is NOT closed: a sheet whose two ends at phi = 0 and phi = 2 pi sit at different radii, with a slit in the
+//                    half plane y = 0, x > 0 between them. Rays through the slit hit nothing -- which is why the reference carries the
+//                    test commented out (`//#[test]`, :35). pbrt-v3's C++ original tests `p == nPhi - 1`.
+//   as_written == 0  that branch on `p == nphi - 1`, as evidently meant ("Close it up exactly at the end", :61): vertices.len() - (nphi - 1) is the
+//                    row's first vertex, and the mesh is closed. This is the form whose assertion can hold.
+// The loop (:109-145): for every seed i < n_seeds, r = RNG::new(i): a point in the ball of radius 0.5 (uniform_sample_sphere * 0.5), a uniform
+// direction, t_max = INFINITY; count the triangles Triangle::intersect reports (every triangle against the same t_max, as the test does:
+// it calls the shape, not the primitive); then "now tougher: shoot directly at a vertex": d = vertices[r.uniform_int32_2(256)] - o.
+// Outputs (any may be null): verts[256 * 3], indices[420 * 3], rays_o / rays_d[2 * n_seeds * 3] (ray 2 i = the random direction of seed i,
+// 2 i + 1 = its vertex ray), nhits[2 * n_seeds]. Returns the number of rays with nhits < 1 (the reference's `assert!(nhits >= 1)`).
+// cos / sin are the oracle's deterministic ones (ref_math.h), <= 1 ulp from the platform libm the reference calls.
+int orc_test_triangle_watertight(int n_seeds, int as_written, float *verts, uint32_t *indices, float *rays_o, float *rays_d, int *nhits) {
+    RNG rng(12111);
+    const int ntheta = 16, nphi = 16;
+    const int nvertices = ntheta * nphi;
+    std::vector<V3> vertices; vertices.reserve(nvertices);
+    for (int t = 0; t < ntheta; ++t) {
+        const Float theta = PI * (Float)t / (Float)(ntheta - 1);
+        const Float cos_theta = dm_cosf(theta), sin_theta = dm_sinf(theta);
+        for (int p = 0; p < nphi; ++p) {
+            const Float phi = 2.0f * PI * (Float)p / (Float)(nphi - 1);
+            Float radius = 1.0f;
+            if (t == 0) vertices.push_back(V3(0.0f, 0.0f, radius));
+            else if (t == ntheta - 1) vertices.push_back(V3(0.0f, 0.0f, -radius));
+            else if ((as_written ? t : p) == nphi - 1) vertices.push_back(vertices[vertices.size() - (size_t)(nphi - 1)]);
+            else {
+                radius += 5.0f * rng.uniform_float();
+                const V3 dir(sin_theta * dm_cosf(phi), sin_theta * dm_sinf(phi), cos_theta);   // spherical_direction (geometry.rs:26-32)
+                vertices.push_back(V3(0.0f, 0.0f, 0.0f) + dir * radius);
+            }
+        }
+    }
+    if ((int)vertices.size() != nvertices) return -1;
+    std::vector<uint32_t> idx;
+    auto offset = [&](int t, int p) { return (uint32_t)(t * nphi + p); };
+    for (int p = 0; p < nphi - 1; ++p) { idx.push_back(offset(0, 0)); idx.push_back(offset(1, p)); idx.push_back(offset(1, p + 1)); }
+    for (int t = 1; t < ntheta - 2; ++t)
+        for (int p = 0; p < nphi - 1; ++p) {
+            idx.push_back(offset(t, p)); idx.push_back(offset(t + 1, p)); idx.push_back(offset(t + 1, p + 1));
+            idx.push_back(offset(t, p)); idx.push_back(offset(t + 1, p + 1)); idx.push_back(offset(t, p + 1));
+        }
+    for (int p = 0; p < nphi - 1; ++p) { idx.push_back(offset(ntheta - 1, 0)); idx.push_back(offset(ntheta - 2, p)); idx.push_back(offset(ntheta - 2, p + 1)); }
+    const uint32_t ntris = (uint32_t)(idx.size() / 3);
+    Scene s;
+    s.P = vertices; s.idx = idx; s.tri_flags.assign(ntris, 0);
+    if (verts) for (int i = 0; i < nvertices; ++i) { verts[3 * i] = vertices[i].x; verts[3 * i + 1] = vertices[i].y; verts[3 * i + 2] = vertices[i].z; }
+    if (indices) for (size_t i = 0; i < idx.size(); ++i) indices[i] = idx[i];
+    auto count_hits = [&](const Ray &ray) {
+        int n = 0;
+        for (uint32_t tri = 0; tri < ntris; ++tri) { Float t, b[3]; if (s.tri_intersect(tri, ray, t, b)) ++n; }
+        return n;
+    };
+    auto put = [&](float *dst, size_t k, V3 v) { if (dst) { dst[3 * k] = v.x; dst[3 * k + 1] = v.y; dst[3 * k + 2] = v.z; } };
+    int failures = 0;
+    for (int i = 0; i < n_seeds; ++i) {
+        RNG r((uint64_t)i);
+        P2 u; u.x = r.uniform_float(); u.y = r.uniform_float();
+        const V3 p = V3(0.0f, 0.0f, 0.0f) + uniform_sample_sphere(u) * 0.5f;
+        u.x = r.uniform_float(); u.y = r.uniform_float();
+        Ray ray(p, uniform_sample_sphere(u), INF, 0.0f);
+        int n = count_hits(ray);
+        if (n < 1) ++failures;
+        put(rays_o, 2 * (size_t)i, ray.o); put(rays_d, 2 * (size_t)i, ray.d); if (nhits) nhits[2 * i] = n;
+        const V3 pvertex = vertices[r.uniform_u32_bounded((uint32_t)vertices.size())];
+        ray.d = pvertex - ray.o;
+        n = count_hits(ray);
+        if (n < 1) ++failures;
+        put(rays_o, 2 * (size_t)i + 1, ray.o); put(rays_d, 2 * (size_t)i + 1, ray.d); if (nhits) nhits[2 * i + 1] = n;
+    }
+    return failures;
 }
 }  // extern "C"

@@ -1242,7 +1242,12 @@ int orc_dist1d_sample_discrete(const float *func, int n, float u, float *pdf, fl
     return (int)d.sample_discrete(u, pdf, uremapped);
 }
 float orc_dist1d_discrete_pdf(const float *func, int n, int index) { return Distribution1D(std::vector<Float>(func, func + n)).discrete_pdf((size_t)index); }
-float orc_dist1d_sample_continuous(const float *func, int n, float u, float *pdf) { return Distribution1D(std::vector<Float>(func, func + n)).sample_continuous(u, pdf, nullptr); }
+float orc_dist1d_sample_continuous(const float *func, int n, float u, float *pdf, int *offset) {   // Distribution1D::sample_continous (sampling.rs:38-64); pdf / offset may be null like the reference's Options
+    size_t off = 0;
+    const float x = Distribution1D(std::vector<Float>(func, func + n)).sample_continuous(u, pdf, &off);
+    if (offset) *offset = (int)off;
+    return x;
+}
 // deterministic math
 float orc_dm_sin(float x) { return dm_sinf(x); }
 float orc_dm_cos(float x) { return dm_cosf(x); }

@@ -85,6 +85,8 @@ PT_MAP_UV, PT_MAP_PLANAR, PT_MAP_SPHERICAL, PT_MAP_CYLINDRICAL = range(4)
 PT_WRAP_REPEAT, PT_WRAP_BLACK = range(2)
 (PT_MP_KD, PT_MP_KS, PT_MP_KR, PT_MP_KT, PT_MP_OPACITY, PT_MP_ETA_RGB, PT_MP_K_RGB, PT_MP_SIGMA_A, PT_MP_SIGMA_S,
  PT_MP_SIGMA, PT_MP_ROUGHNESS, PT_MP_U_ROUGHNESS, PT_MP_V_ROUGHNESS, PT_MP_ETA, PT_MP_BUMP, PT_MP_MFP) = range(16)
+PT_MP_COUNT = 16
+PT_PEER_SAME_DEVICE, PT_PEER_ENABLED, PT_PEER_STAGED = range(3)
 
 
 class PtTexture(C.Structure):
@@ -167,6 +169,7 @@ ENTRY_POINTS = {
     "pt_multi_get_kernel_stats": (C.c_int, [VP, u32, C.POINTER(PtKernelStat), u32, u32p]),
     "pt_multi_get_timing": (C.c_int, [VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), u32]),
     "pt_multi_get_peer_access": (C.c_int, [VP, C.POINTER(C.c_int), u32]),
+    "pt_multi_get_create_timing": (C.c_int, [VP, C.POINTER(C.c_double), C.POINTER(C.c_double), u32]),
     "pt_multi_tile_shard": (None, [u32, u32, u32, u32, u32p, u32p]),
     "pt_get_counters": (C.c_int, [VP, C.POINTER(PtCounters)]),
     "pt_get_kernel_stats": (C.c_int, [VP, C.POINTER(PtKernelStat), u32, u32p]),
@@ -175,6 +178,7 @@ ENTRY_POINTS = {
     "pt_sobol_samples": (C.c_int, [i32p, u32, i32p, u32p, u32, fp, u64p]),
     "pt_halton_samples": (C.c_int, [i32p, u32, u32, i32p, u32p, u32, fp, u64p]),
     "pt_camera_rays": (C.c_int, [C.POINTER(PtRenderParams), u32, fp, fp, fp]),
+    "pt_dist1d_sample": (C.c_int, [fp, u32, C.c_int, u32, fp, fp, fp, i32p]),
 }
 
 

@@ -313,9 +313,6 @@ template <bool SPH> PT_DEV float light_pdf_li(const DeviceScene &s, uint32_t li,
         }
     }
     const PtLight &L = s.lights[li];
-#ifdef PT_ABL_LIGHTPDF   // timing ablation only
-    return 0.5f + 0.0f * L.L[0];
-#endif
     if (SPH && L.type == PT_LIGHT_DIFFUSE_AREA && (s.prim_shape[L.prim] >> 30) == PT_SHAPE_SPHERE && s.spheres[s.prim_shape[L.prim] & 0x3fffffffu].kind == PT_QUADRIC_DISK) {
         // Shape::pdf_wi (shape.rs:59-73): intersect without a shape (no orientation flip), signed cosine
         const PtSphere &S = s.spheres[s.prim_shape[L.prim] & 0x3fffffffu];

@@ -115,9 +115,6 @@ PT_HD void dm_sincosf_impl(float xf, float &s, float &c);
 PT_HDM DmSC dm_sincosf2(float xf) { DmSC r; dm_sincosf_impl(xf, r.s, r.c); return r; }
 PT_HD void dm_sincosf(float xf, float &s, float &c) { DmSC r = dm_sincosf2(xf); s = r.s; c = r.c; }
 PT_HD void dm_sincosf_impl(float xf, float &s, float &c) {
-#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
-    s = __sinf(xf); c = __cosf(xf); return;   // timing ablation only (results differ)
-#endif
     double x = xf;
     if (!(__builtin_fabs(x) < 1.0e9)) { s = c = __builtin_nanf(""); return; }
     double kd = __builtin_floor(x * kDm2OverPi + 0.5);
@@ -171,15 +168,8 @@ PT_HDM double dm_atan2d(double y, double x) {
     if (__builtin_signbit(x)) a = kDmPi - a;
     return __builtin_signbit(y) ? -a : a;
 }
-#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
-PT_HD float dm_atan2f(float y, float x) { return atan2f(y, x); }
-#else
 PT_HD float dm_atan2f(float y, float x) { return (float)dm_atan2d((double)y, (double)x); }
-#endif
 PT_HD float dm_acosf(float xf) {
-#if defined(PT_ABL_TRIG) && defined(__HIP_DEVICE_COMPILE__)
-    return acosf(xf);
-#endif
     double x = xf;
     if (!(x >= -1.0 && x <= 1.0)) return __builtin_nanf("");
     double s = __builtin_sqrt((1.0 - x) * (1.0 + x));

@@ -161,10 +161,6 @@ struct Sampler {
             w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3]; w4 = w[4]; w5 = w[5]; w6 = w[6]; w7 = w[7];
             return;
         }
-#ifdef PT_ABL_SOBOL   // timing ablation only: a cheap hash instead of the generator-matrix products (results differ)
-        { uint32_t h = (uint32_t)index * 0x9E3779B9u ^ (uint32_t)(index >> 32) ^ (base * 0x85EBCA6Bu);
-          w0 = h; w1 = h * 3u; w2 = h * 5u; w3 = h * 7u; w4 = h * 11u; w5 = h * 13u; w6 = h * 17u; w7 = h * 19u; return; }
-#endif
         if (base + 8 <= lds_dims) nib_window(lds + base * 16u, lds_dims * 16u);
         else if (base + 8 <= 1024u) nib_window(nib + base * 16u, 1024u * 16u);
         else base = 0xffffffffu;  // the last dimensions: one at a time

@@ -39,6 +39,7 @@ extern bool g_trace_exact;
 extern uint32_t g_inst_quorum;
 extern bool g_shade_specialise;
 extern bool g_film_final;
+extern int g_test_max_iterations;
 extern uint32_t g_trace_waves_per_cu;
 extern uint32_t g_test_pool_pad_records;
 extern thread_local SobolTables g_tabs;
@@ -170,6 +171,7 @@ struct pt_multi_scene {
     std::vector<size_t> stage_cap;    // sources are in flight together (one xGMI link each), issued by the replicas' own host threads
     std::vector<double> render_ms, copy_ms;   // last pt_multi_render, per replica: wall time of its pt_render / of its peer copy
     std::vector<int> peer;            // per replica: PT_PEER_* -- how its film reaches the first device
+    std::vector<double> create_ms; double create_wall_ms = 0;   // pt_multi_scene_create: per replica its pt_scene_create, and the whole call (replicas 1.. are created concurrently)
     double merge_ms = 0;              // last pt_multi_render: from the last replica's render end to the summed film (copy tails + the sum kernel)
     PtCounters counters{};
 };
@@ -180,6 +182,7 @@ uint8_t material_class(const PtMaterial &m, bool specialise);
 void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func_int);
 // render_loop.hip
 int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe = false);
+const char *device_error_text(uint32_t code);
 int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px);
 int ensure_light_grid(pt_scene *sc, int requested, int &effective);
 void fill_render_const(const PtRenderParams *rp, RenderConst &rc);

@@ -21,6 +21,7 @@ bool g_trace_split = false;                        // env PT_TRACE_SPLIT=1: one 
 bool g_trace_exact = false;                        // pt_set_trace_exact / env PT_TRACE_EXACT=1: walk the two-wide records, PtCounters.bvh_nodes_visited is then the reference's count
 uint32_t g_test_pool_pad_records = 0;              // TEST HOOK (env PT_TEST_POOL_PAD_RECORDS): that many unused 128-byte records in front of every scene's record / packet pool, so that a small
                                                    // scene's records and packets lie beyond the 4 GB a 32-bit byte offset reaches (tests/test_gpu_parity.py: the production walk addresses 16-byte quads)
+int g_test_max_iterations = 0;                     // TEST HOOK (env PT_TEST_MAX_ITERATIONS, read at every pt_render): the cap on wavefront iterations per pass (2^20 otherwise), so that the PT_ERR_PROBE_CHAIN return of a pass that does not end can be tested
 bool g_film_final = true;                          // env PT_FILM_FINAL=0: the per-iteration k_shade_miss pass instead of ending the paths in the film kernel (plain path integrator without subsurface materials)
 bool g_shade_specialise = true;                        // env PT_SHADE_SPECIALISE=0: every shade class runs its general kernel (no per-scene lobe-set forms)
 uint32_t g_inst_quorum = 16;                      // lanes waiting for the instance transform step (env PT_TRACE_INST_QUORUM)

@@ -10,7 +10,7 @@ template <bool SPH, bool VOL> __global__ void k_bssrdf(DeviceScene s, RenderCons
 __global__ void k_medium_route(DeviceScene s, RenderConst rc, SobolTables tabs, PathSoA ps, const uint32_t *queue, const uint32_t *count_ptr,
                                uint32_t *class_count, uint32_t *c0, uint32_t *c1, uint32_t *c2, uint32_t *c3, uint32_t *c4, uint32_t *c5, uint32_t *error);
 __global__ void k_shade_medium(DeviceScene s, RenderConst rc, SobolTables tabs, LightGrid grid, PathSoA ps, ShadeJob job);
-__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out, const uint32_t *inst_gate);
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out);
 __global__ void k_mark_leaf_ends(TriPacket *leaf, const uint32_t *last_index, uint32_t n);
 __global__ void k_light_area(DeviceScene s, float *area, float4 *rec);
 template <int NQ, int CAP> __global__ void k_route(DeviceScene s, const uint32_t *queue, const uint32_t *count_ptr, PathSoA ps, uint32_t *class_count, RouteJob rj);
@@ -27,3 +27,4 @@ __global__ void k_halton_samples(SobolTables tabs, HaltonParams hp, uint32_t n, 
 __global__ void k_sobol_samples(SobolTables tabs, SobolParams sp, uint32_t n, const int32_t *pixel_xy, const uint32_t *sample_num,
                                 uint32_t n_dims, float *out, uint64_t *out_index);
 __global__ void k_camera_rays(RenderConst rc, uint32_t n, const float *cs, float *out_o, float *out_d);
+__global__ void k_dist1d_sample(const float *func, const float *cdf, float func_int, int n, int discrete, uint32_t n_u, const float *u, float *out_x, float *out_pdf, int32_t *out_off);

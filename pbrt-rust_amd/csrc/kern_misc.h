@@ -5,17 +5,13 @@
 // ---- scene preparation ---------------------------------------------------------------------------
 // Triangle packets in leaf order + the per-triangle "degenerate -> intersect() always fails" flag
 // (triangle.rs:254-261, evaluated once here instead of per accepted candidate).
-__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out, const uint32_t *inst_gate) {
+__global__ void k_build_packets(DeviceScene s, const uint32_t *ordered, uint32_t n_refs, TriPacket *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_refs) return;
     uint32_t prim = ordered[i];      // primitive index, or PT_TOP_INSTANCE | instance index
     TriPacket p;
     if (prim & PT_TOP_INSTANCE) {
         p.x[0] = p.x[1] = p.x[2] = p.y[0] = p.y[1] = p.y[2] = p.z[0] = p.z[1] = p.z[2] = 0.0f;
-        if (inst_gate) {   // the oriented box of the instance (scene_create.hip), one triple per world axis
-            const uint32_t *g = inst_gate + 9u * (prim & ~PT_TOP_INSTANCE);
-            for (int k = 0; k < 3; ++k) { p.x[k] = __uint_as_float(g[k]); p.y[k] = __uint_as_float(g[3 + k]); p.z[k] = __uint_as_float(g[6 + k]); }
-        }
         p.prim = PT_NONE; p.shape = prim & ~PT_TOP_INSTANCE; p.flags = TP_INSTANCE;
         out[i] = p;
         return;
@@ -105,6 +101,7 @@ __global__ __launch_bounds__(256) void k_route(DeviceScene s, const uint32_t *qu
             cls = (ps.hit_pflags(pid) >> kTpClassShift) & kTpClassMask;   // written by k_trace with the hit: the packet's class bits, kMissClass for a miss
         }
         const uint32_t slot = (uint32_t)(rj.slot_map >> (4u * cls)) & 15u;
+        if (valid && slot == 15u && cls != rj.drop_cls) atomicMax(rj.error, (uint32_t)PT_ERR_UNSUPPORTED);   // a hit whose material class has no queue in this render would vanish silently (and k_film_final would take it for an escaped ray)
 #pragma unroll
         for (int k = 0; k < NQ; ++k) if ((uint32_t)k < rj.n_slots) lq_push(q[k], pid, valid && slot == (uint32_t)k);
         __syncthreads();
@@ -372,4 +369,15 @@ __global__ void k_camera_rays(RenderConst rc, uint32_t n, const float *cs, float
     camera_ray(rc, cs[5 * i], cs[5 * i + 1], cs[5 * i + 2], P2(cs[5 * i + 3], cs[5 * i + 4]), o, d);
     out_o[3 * i] = o.x; out_o[3 * i + 1] = o.y; out_o[3 * i + 2] = o.z;
     out_d[3 * i] = d.x; out_d[3 * i + 1] = d.y; out_d[3 * i + 2] = d.z;
+}
+// Parity entry (pt_dist1d_sample): the device's Distribution1D -- dist_sample_continuous (the environment map's rows and marginal, sampling.rs:38-64) or
+// dist_sample_discrete (the light choice, sampling.rs:66-85) -- on a distribution the host built with Distribution1D::new (scene_create.hip: dist1d).
+__global__ void k_dist1d_sample(const float *func, const float *cdf, float func_int, int n, int discrete, uint32_t n_u, const float *u, float *out_x, float *out_pdf, int32_t *out_off) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_u) return;
+    Dist1D d{func, cdf, func_int, n};
+    float pdf = 0.0f; int off = 0; float x = 0.0f;
+    if (discrete) off = dist_sample_discrete(d, u[i], pdf);
+    else x = dist_sample_continuous(d, u[i], pdf, off);
+    out_x[i] = x; out_pdf[i] = pdf; out_off[i] = off;
 }

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     uint32_t n_nodes = 0, n_tris = 0, n_rays = 0, n_sph = 0;
 #ifdef PT_TRACE_UTIL   // SIMD utilisation study: wave iterations and active lanes of the node phase / the leaf phase
     uint32_t u_it1 = 0, u_act1 = 0, u_it2 = 0, u_act2 = 0, u_it3 = 0, u_act3 = 0;
-    uint32_t u_ent = 0, u_rej = 0, u_ihit = 0, u_spill = 0, u_gate = 0, u_gate_rej = 0;   // instance entries tried / turned away by the object's root test / left with a hit; stack entries written beyond the LDS ones
+    uint32_t u_ent = 0, u_rej = 0, u_ihit = 0, u_spill = 0;   // instance entries tried / turned away by the object's root test / left with a hit; stack entries written beyond the LDS ones
     unsigned long long u_cxf = 0, u_cmain = 0;   // wave cycles inside the transform step / the record step
     unsigned long long u_cfetch = 0, u_cnode = 0, u_cleaf = 0, u_cpop = 0;   // of the record step: issue + wait of the loads, the node branch, the leaf branch, the pops
     long long u_cm = 0;
@@ -233,12 +233,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
         // ---- retire finished rays and refill their lanes, in batches: finished lanes wait (idle) until at least
         //      `refill_min` of them have accumulated or nothing else is running, so the queue atomics below are
         //      paid once per batch instead of once per ray.
-#ifdef PT_DROP_TAIL   // EXPERIMENT (wrong results, timing only): what the tail of straggling rays costs -- a wave whose queue is drained abandons its last few rays
-        if (exhausted && count > 65536u) {
-            const unsigned long long b_ = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_LEAFS || state == ST_INST || state == ST_RET);
-            if (b_ != 0ull && (uint32_t)__popcll(b_) <= (uint32_t)(PT_DROP_TAIL) && state != ST_DONE) state = ST_IDLE;
-        }
-#endif
         const unsigned long long donem = __ballot(state == ST_DONE || state == ST_IDLE);
         const unsigned long long busy = __ballot(state == ST_ENTER || state == ST_LEAF || state == ST_LEAFS || state == ST_INST || state == ST_RET);
         if (donem != 0ull && ((uint32_t)__popcll(donem) >= job.refill_min || busy == 0ull)) {
@@ -604,10 +598,19 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                     const uint32_t ra = n1 ? rf.y : rf.x, rb = n1 ? rf.x : rf.y, rc = n2 ? rf.w : rf.z, rd4 = n2 ? rf.z : rf.w;
                     const float t0 = n0 ? tc : ta, t1 = n0 ? td : tb, t2 = n0 ? ta : tc, t3 = n0 ? tb : td;
                     const uint32_t r0 = n0 ? rc : ra, r1 = n0 ? rd4 : rb, r2 = n0 ? ra : rc, r3 = n0 ? rb : rd4;
-                    // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max); later ones are pushed with
-                    // their entry distance and pass or fail the same comparison when popped, against the t_max of then; one that fails now fails then too
+                    // the first slot that passes `tmin < t_max` now is entered (the reference tests it with this very t_max: the slots before it fail at this
+                    // moment too, nothing is visited in between); later ones are pushed with their entry distance and pass or fail the same comparison when
+                    // popped, against the t_max of then. A later slot that fails NOW may only be dropped if it fails then too -- and t_max is NOT monotone in
+                    // the reference: Triangle::intersect accepts tscaled < t_max * det in scaled space (triangle.rs:202-206) and then rounds t = tscaled *
+                    // (1 / det) (:208-213), which can land up to three roundings ABOVE the t_max it was tested against; `r.t_max = thit` (primitive.rs:137) then
+                    // RAISES t_max by at most (1 + 3 * 2^-24) per accepted hit. A ray through a vertex shared by six triangles does it (the reference's own
+                    // tests/shapes.rs:132-144, "shoot directly at a vertex": round 6 found 6 of its 200 000 rays returning another triangle of the fan than the
+                    // reference, whose walk re-admitted a box it would have culled one hit earlier). So a later slot is dropped only beyond a slack of
+                    // 2^-10: below that it is pushed and meets the exact comparison at its pop. t_max would have to be rounded upwards by more than 5 400
+                    // SUCCESSIVE hits of one ray, each within three ulps of the last, to cross the slack (round-6 notes).
                     const bool m0 = t0 < t_max, m1 = t1 < t_max, m2 = t2 < t_max, m3 = t3 < t_max;
-                    const bool c3 = m3 & (m0 | m1 | m2), c2 = m2 & (m0 | m1), c1 = m1 & m0;
+                    const float t_slack = t_max * (1.0f + 0x1p-10f);
+                    const bool c3 = (t3 < t_slack) & (m0 | m1 | m2), c2 = (t2 < t_slack) & (m0 | m1), c1 = (t1 < t_slack) & m0;
                     if (sp + 3u <= (uint32_t)kLds) {   // the usual case: all three land in LDS, at slots known without a chain of sp updates
                         const uint32_t p2 = sp + (c3 ? 1u : 0u), p1 = p2 + (c2 ? 1u : 0u);
                         if (c3) { stack[(2 * sp) * 64] = r3; stack[(2 * sp + 1) * 64] = __float_as_uint(t3); }
@@ -668,37 +671,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                 bool advance = true;   // false: the lane left the leaf (entered an instance / finished an any-hit ray)
                 if (fl & TP_INSTANCE) {
                     if constexpr (INST) {
-                        bool gate_pass = true;
-#ifdef PT_INST_GATE   // EXPERIMENT (profiles/r5/NOTES.md section 1): a conservative world-space test against the oriented box in the packet's nine spare words, before the lane
-                      // commits to the transform step; a ray it turns away fails the object's root test too (the box is the root box inflated, its rows rounded outwards)
-                        if constexpr (QUAD) {
-                            // quad j came for the ray's j-th permuted axis: {bf16 A0 | A1 << 16, bf16 A2, c}: u_i(t) = -e_i + t f_i, |u_i| <= T
-                            const V3 dp = tri_permute(rd, tray.kz);
-                            const float v0 = __uint_as_float(q0.z) - rop.x, v1 = __uint_as_float(q1.z) - rop.y, v2 = __uint_as_float(q2.z) - rop.z;
-                            float e[3], f[3];
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                const float a0 = __uint_as_float(i == 0 ? q0.x << 16 : i == 1 ? q0.x & 0xffff0000u : q0.y << 16);
-                                const float a1 = __uint_as_float(i == 0 ? q1.x << 16 : i == 1 ? q1.x & 0xffff0000u : q1.y << 16);
-                                const float a2 = __uint_as_float(i == 0 ? q2.x << 16 : i == 1 ? q2.x & 0xffff0000u : q2.y << 16);
-                                e[i] = __builtin_fmaf(a2, v2, __builtin_fmaf(a1, v1, a0 * v0));
-                                f[i] = __builtin_fmaf(a2, dp.z, __builtin_fmaf(a1, dp.y, a0 * dp.x));
-                            }
-                            const float T = 1.0f + 1.0f / 32.0f;
-                            float tn = 0.0f, tf = t_max * (1.0f + 1.0e-5f);
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                const float r = __builtin_amdgcn_rcpf(f[i]);
-                                const float ta = (e[i] - T) * r, tb = (e[i] + T) * r;
-                                tn = __builtin_fmaxf(tn, __builtin_fminf(ta, tb)); tf = __builtin_fminf(tf, __builtin_fmaxf(ta, tb));
-                            }
-                            gate_pass = !(tn > tf * (1.0f + 1.0e-5f));
-#ifdef PT_TRACE_UTIL
-                            u_gate++; if (!gate_pass) u_gate_rej++;
-#endif
-                        }
-#endif
-                        if (gate_pass) { xf_arg = shw | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false; }   // entered in the transform step below
+                        xf_arg = shw | ((fl & TP_LAST) ? 0x80000000u : 0u); state = ST_INST; advance = false;   // entered in the transform step below
                     }
                 } else if (fl & TP_SPHERE) {
                     if constexpr (SPH) {  // GeometricPrimitive -> Sphere::intersect / intersect_p (sphere.rs:59-286)
@@ -781,8 +754,6 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
         atomicMin(&job.counters->tail[0], u_t0); atomicMax(&job.counters->tail[1], u_t1); atomicAdd(&job.counters->tail[4 + 2 * (job.sub[0].kind & 3)], u_t1 - u_t0);
     }
     for (int o = 32; o > 0; o >>= 1) { u_it3 += __shfl_xor(u_it3, o); u_act3 += __shfl_xor(u_act3, o); u_ent += __shfl_xor(u_ent, o); u_rej += __shfl_xor(u_rej, o); u_ihit += __shfl_xor(u_ihit, o); u_spill += __shfl_xor(u_spill, o); }
-    for (int o = 32; o > 0; o >>= 1) { u_gate += __shfl_xor(u_gate, o); u_gate_rej += __shfl_xor(u_gate_rej, o); }
-    if (lane == 0) { atomicAdd(&job.counters->dbg[2], (unsigned long long)u_gate); atomicAdd(&job.counters->dbg[3], (unsigned long long)u_gate_rej); }
     if (lane == 0) { atomicAdd(&job.counters->util2[4], (unsigned long long)u_ent); atomicAdd(&job.counters->util2[5], (unsigned long long)u_rej); atomicAdd(&job.counters->util2[6], (unsigned long long)u_ihit); atomicAdd(&job.counters->util2[7], (unsigned long long)u_spill); }
     if (lane == 0) {
         atomicAdd(&job.counters->tail[12], (unsigned long long)u_it3); atomicAdd(&job.counters->tail[13], (unsigned long long)u_act3);

@@ -23,7 +23,7 @@ PT_HD uint32_t class_general(uint32_t c) { return c == (uint32_t)kMetalClass ? 1
 constexpr int kRouteSlots = 12;        // most staging queues a k_route block holds
 // k_route's staging queues: one per shade class the scene uses ("slot"), so that a scene pays LDS only for the classes it has.
 // slot_map: the slot of class c in nibble c (15 = the class does not occur in this scene).
-struct RouteJob { uint32_t n_slots; unsigned long long slot_map; uint32_t cls_of_slot[kRouteSlots]; uint32_t *buf[kRouteSlots]; };
+struct RouteJob { uint32_t n_slots; unsigned long long slot_map; uint32_t cls_of_slot[kRouteSlots]; uint32_t *buf[kRouteSlots]; uint32_t *error; uint32_t drop_cls; };   // slot_map: 4 bits per class, 15 = no queue; drop_cls: the one class whose entries are dropped on purpose (escaped rays when the film kernel ends the paths), any other class without a queue raises *error
 constexpr int kRouteQueueCap = 2048;   // k_route's LDS staging queues (entries)
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 10

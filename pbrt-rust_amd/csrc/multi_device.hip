@@ -21,17 +21,33 @@ int pt_multi_scene_create(const PtSceneDesc *desc, const int *device_ordinals, u
     pt_multi_scene *ms = new pt_multi_scene();
     auto bail = [&](int code) { const std::string msg = g_error; pt_multi_scene_destroy(ms); bind_device(home); g_error = msg; return code; };
     PtSceneDesc d = *desc;
-    for (uint32_t i = 0; i < n_devices; ++i) {
-        if ((st = bind_device(device_ordinals[i]))) return bail(st);
-        pt_scene *sc = nullptr;
-        if ((st = pt_scene_create(&d, &sc))) return bail(st);
-        ms->sc.push_back(sc); ms->dev.push_back(device_ordinals[i]);
-        ms->film.push_back(nullptr); ms->film_cap.push_back(0); ms->stage.push_back(nullptr); ms->stage_cap.push_back(0);
-        ms->render_ms.push_back(0); ms->copy_ms.push_back(0);
-        if (i == 0) {   // the replicas adopt the first replica's top-level tree instead of building it again
-            d.nodes = sc->nodes.data(); d.n_nodes = (uint32_t)sc->nodes.size(); d.ordered_prims = sc->ordered.data();
-        }
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_begin = clk::now();
+    ms->sc.assign(n_devices, nullptr); ms->dev.assign(device_ordinals, device_ordinals + n_devices);
+    ms->film.assign(n_devices, nullptr); ms->film_cap.assign(n_devices, 0); ms->stage.assign(n_devices, nullptr); ms->stage_cap.assign(n_devices, 0);
+    ms->render_ms.assign(n_devices, 0); ms->copy_ms.assign(n_devices, 0); ms->create_ms.assign(n_devices, 0);
+    // The first replica builds the top-level tree on the calling thread; the others ADOPT it (no second build) and are created concurrently, one host thread per replica bound
+    // to its device -- as pt_multi_render runs them -- so that seven uploads of a 0.5 GB scene overlap instead of queueing behind each other.
+    {
+        if ((st = bind_device(device_ordinals[0]))) return bail(st);
+        if ((st = pt_scene_create(&d, &ms->sc[0]))) return bail(st);
+        ms->create_ms[0] = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+        d.nodes = ms->sc[0]->nodes.data(); d.n_nodes = (uint32_t)ms->sc[0]->nodes.size(); d.ordered_prims = ms->sc[0]->ordered.data();
     }
+    if (n_devices > 1) {
+        std::vector<int> status(n_devices, PT_OK); std::vector<std::string> message(n_devices);
+        std::vector<std::thread> workers;
+        for (uint32_t i = 1; i < n_devices; ++i) workers.emplace_back([&, i]() {
+            const clk::time_point t0 = clk::now();
+            int s2 = bind_device(device_ordinals[i]);
+            if (!s2) s2 = pt_scene_create(&d, &ms->sc[i]);
+            if (s2) { status[i] = s2; message[i] = g_error; }   // (g_error is thread-local: handed back to the caller's thread below)
+            ms->create_ms[i] = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        });
+        for (auto &w : workers) w.join();
+        for (uint32_t i = 1; i < n_devices; ++i) if (status[i]) { g_error = "replica " + std::to_string(i) + " (device " + std::to_string(device_ordinals[i]) + "): " + message[i]; return bail(status[i]); }
+    }
+    ms->create_wall_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     // peer access first device <-> the others (the film merge copies device to device; without access the runtime stages the copies through the
     // host): the outcome per replica is kept and reported (pt_multi_get_peer_access), so that a run which fell back says so instead of just being slow
     ms->peer.assign(n_devices, PT_PEER_SAME_DEVICE);
@@ -58,7 +74,7 @@ void pt_multi_scene_destroy(pt_multi_scene *ms) {
     if (!ms->dev.empty() && bind_device(ms->dev[0]) == PT_OK) for (float *p : ms->stage) if (p) hipFree(p);
     for (size_t i = 0; i < ms->sc.size(); ++i) {
         if (bind_device(ms->dev[i]) == PT_OK && ms->film[i]) hipFree(ms->film[i]);
-        pt_scene_destroy(ms->sc[i]);
+        if (ms->sc[i]) pt_scene_destroy(ms->sc[i]);
     }
     if (home >= 0) bind_device(home);
     delete ms;
@@ -172,6 +188,13 @@ int pt_multi_get_timing(const pt_multi_scene *ms, double *merge_ms, double *rend
     if (!ms) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (merge_ms) *merge_ms = ms->merge_ms;
     for (uint32_t i = 0; i < max_replicas && i < ms->sc.size(); ++i) { if (render_ms) render_ms[i] = ms->render_ms[i]; if (copy_ms) copy_ms[i] = ms->copy_ms[i]; }
+    return PT_OK;
+}
+
+int pt_multi_get_create_timing(const pt_multi_scene *ms, double *wall_ms, double *replica_ms, uint32_t max_replicas) {
+    if (!ms) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (wall_ms) *wall_ms = ms->create_wall_ms;
+    for (uint32_t i = 0; replica_ms && i < max_replicas && i < ms->create_ms.size(); ++i) replica_ms[i] = ms->create_ms[i];
     return PT_OK;
 }
 

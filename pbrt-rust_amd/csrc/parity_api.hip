@@ -54,7 +54,7 @@ static int trace_api(pt_scene *sc, bool any, uint32_t n, const float *o, const f
         for (uint32_t i = 0; i < n; ++i) { std::memcpy(&prim[i], &res[4 * (size_t)i], 4); for (int k = 0; k < 3; ++k) b[3 * (size_t)i + k] = res[4 * (size_t)i + 1 + k]; }
     }
     read_counters(sc);
-    if (h.error) return fail((int)h.error, "traversal error raised on device");
+    if (h.error) return fail((int)h.error, device_error_text(h.error));
     return PT_OK;
 }
 
@@ -120,6 +120,28 @@ int pt_camera_rays(const PtRenderParams *rp, uint32_t n, const float *cs, float 
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_o, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_d, dout + 3 * (size_t)n, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_dist1d_sample(const float *func, uint32_t n, int discrete, uint32_t n_u, const float *u, float *out_x, float *out_pdf, int32_t *out_offset) {
+    DevTmp scratch;
+    if (!func || !u || !out_x || !out_pdf || !out_offset) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return fail(PT_ERR_INVALID_ARG, "a Distribution1D needs at least one function value");
+    int st = ensure_device();
+    if (st || n_u == 0) return st;
+    std::vector<float> f(func, func + n), cdf; float fint = 0.0f;
+    dist1d(f, cdf, fint);   // Distribution1D::new (sampling.rs:12-34), the construction the environment map and the light distributions use
+    float *dfunc, *dcdf, *du, *dx, *dpdf; int32_t *doff;
+    HIP_TRY(scratch.alloc(&dfunc, (size_t)n * 4)); HIP_TRY(scratch.alloc(&dcdf, ((size_t)n + 1) * 4)); HIP_TRY(scratch.alloc(&du, (size_t)n_u * 4));
+    HIP_TRY(scratch.alloc(&dx, (size_t)n_u * 4)); HIP_TRY(scratch.alloc(&dpdf, (size_t)n_u * 4)); HIP_TRY(scratch.alloc(&doff, (size_t)n_u * 4));
+    HIP_TRY(hipMemcpy(dfunc, f.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dcdf, cdf.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du, u, (size_t)n_u * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dist1d_sample, dim3((n_u + 255) / 256), dim3(256), 0, 0, dfunc, dcdf, fint, (int)n, discrete, n_u, du, dx, dpdf, doff);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_x, dx, (size_t)n_u * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_pdf, dpdf, (size_t)n_u * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offset, doff, (size_t)n_u * 4, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

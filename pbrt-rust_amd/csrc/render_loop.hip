@@ -30,10 +30,10 @@ int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool pro
     uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, sc->spill_waves / 4);
     const int mode = (sc->ds.tri_alpha || sc->ds.tri_shadow_alpha) ? 2 : sc->ds.n_spheres > 0 ? 1 : sc->ds.n_instances > 0 ? 3 : 0;  // kern_trace.h: k_trace MODE
     job.inst_quorum = g_inst_quorum;
+    if (sc->quad_walk_only && (g_trace_exact || sc->exact_walk_only)) return fail(PT_ERR_UNSUPPORTED, "the two-wide (exact) walk addresses 2^25 records / packets: this scene has the production walk only");
 #ifdef PT_TRACE_UTIL
     hipLaunchKernelGGL(k_trace_util_fold, dim3(1), dim3(1), 0, sc->stream, sc->dc, job.sub[0].kind & 3u, 0u, 1);
 #endif
-    if (sc->quad_walk_only && (g_trace_exact || sc->exact_walk_only)) return fail(PT_ERR_UNSUPPORTED, "the two-wide (exact) walk addresses 2^25 records / packets: this scene has the production walk only");
     const bool quad = !g_trace_exact && !sc->exact_walk_only;   // production: the four-wide records; pt_set_trace_exact(1): the two-wide walk with the reference's node-visit counter
     const bool big = sc->pool_big;   // records + packets beyond 4 GB: the production walk through 64-bit addresses
     #define PT_LAUNCH_TRACE(A, M, P) do { if (quad && big) hipLaunchKernelGGL((k_trace<A, M, P, 2>), dim3(blocks), dim3(kTraceBlock), 0, sc->stream, sc->ds, job); \
@@ -66,12 +66,17 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         if (sc->has_bssrdf && (st = sc->dalloc(&sc->probe_ring, (size_t)sc->spill_waves * 64 * kProbeRing * 3))) return st;
     }
     if (capacity > sc->capacity) {
-        if (sc->slab) { hipFree(sc->slab); hipFree(sc->qbuf); sc->slab = nullptr; sc->qbuf = nullptr; }
-        if (sc->ext_slab) { hipFree(sc->ext_slab); sc->ext_slab = nullptr; sc->ext_capacity = 0; }
-        if (sc->bss_slab) { hipFree(sc->bss_slab); sc->bss_slab = nullptr; }
+        // the present workspace goes first (its memory is needed for the larger one); from here to the last allocation the scene HAS no workspace: a failure
+        // leaves capacity 0 and every pointer null, so the next render allocates afresh instead of running on a freed slab behind the old capacity
+        auto drop = [&]() {
+            if (sc->slab) hipFree(sc->slab); if (sc->qbuf) hipFree(sc->qbuf); if (sc->ext_slab) hipFree(sc->ext_slab); if (sc->bss_slab) hipFree(sc->bss_slab);
+            sc->slab = nullptr; sc->qbuf = nullptr; sc->ext_slab = nullptr; sc->bss_slab = nullptr; sc->ext_capacity = 0; sc->capacity = 0;
+        };
+        auto oom = [&](const char *what, hipError_t e) { (void)hipGetLastError(); drop(); return fail(PT_ERR_OUT_OF_MEMORY, std::string(what) + ": " + hipGetErrorString(e)); };
+        drop();
         size_t bytes = capacity * (size_t)kPathBytes + 4096;
         hipError_t e = hipMalloc(&sc->slab, bytes);
-        if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "path-state slab: " + std::string(hipGetErrorString(e)));
+        if (e != hipSuccess) { sc->slab = nullptr; return oom("path-state slab", e); }
         char *p = (char *)sc->slab;   // hipMalloc returns 256-byte aligned memory; every record array starts on a 64-byte line
         PathSoA &ps = sc->ps;
         ps.core = (float *)p; p += capacity * (size_t)PathSoA::kCoreWords * 4;
@@ -81,7 +86,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         ps.hit = (float *)p; p += capacity * (size_t)PathSoA::kHitWords * 4;
         if (sc->has_bssrdf) {
             e = hipMalloc(&sc->bss_slab, capacity * (size_t)kBssSoAArrays * 4);
-            if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "BSSRDF probe state: " + std::string(hipGetErrorString(e)));
+            if (e != hipSuccess) { sc->bss_slab = nullptr; return oom("BSSRDF probe state", e); }
             BssSoA &bs = sc->bs;
             float *bp = (float *)sc->bss_slab;
             float **ba[] = {&bs.start_x, &bs.start_y, &bs.start_z, &bs.target_x, &bs.target_y, &bs.target_z, &bs.po_x, &bs.po_y, &bs.po_z,
@@ -93,7 +98,7 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         // queues: ext[2] + shade[2][classes] + shadow + mis (+ probe[2])
         size_t nq = 2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0);
         e = hipMalloc((void **)&sc->qbuf, nq * capacity * 4);
-        if (e != hipSuccess) return fail(PT_ERR_OUT_OF_MEMORY, "queues: " + std::string(hipGetErrorString(e)));
+        if (e != hipSuccess) { sc->qbuf = nullptr; return oom("queues", e); }
         uint32_t *qp = sc->qbuf;
         for (int i = 0; i < 2; ++i) { sc->q.ext[i] = qp; qp += capacity; }
         for (int i = 0; i < 2; ++i) for (int c = 0; c < kNumClasses; ++c) { sc->q.shade[i][c] = nullptr; if (class_has_queue(sc, c)) { sc->q.shade[i][c] = qp; qp += capacity; } }
@@ -104,7 +109,8 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
     }
     if (film_px > sc->film_px) {
         if (sc->film_rgbw) hipFree(sc->film_rgbw);
-        HIP_TRY(hipMalloc((void **)&sc->film_rgbw, film_px * 16));
+        sc->film_rgbw = nullptr; sc->film_px = 0;
+        if (hipError_t e = hipMalloc((void **)&sc->film_rgbw, film_px * 16); e != hipSuccess) { (void)hipGetLastError(); sc->film_rgbw = nullptr; return fail(PT_ERR_OUT_OF_MEMORY, std::string("device film: ") + hipGetErrorString(e)); }
         sc->film_px = film_px;
     }
     return PT_OK;
@@ -351,6 +357,17 @@ int lazy_light_fill(pt_scene *sc, const LightGrid &grid) {
     return PT_OK;
 }
 
+// The text behind a status a kernel raised (QCounters::error; the largest code wins when several were raised)
+const char *device_error_text(uint32_t code) {
+    switch (code) {
+    case PT_ERR_STACK_OVERFLOW: return "BVH traversal stack overflow: a ray needed more than 96 pending entries in the four-wide production walk / 64 in the two-wide exact walk (the reference's 64-entry stack, accelerators/bvh.rs:722, has no check)";
+    case PT_ERR_PROBE_CHAIN: return "BSSRDF probe chain with more than 2^32 - 1 intersections";
+    case PT_ERR_SOBOL_DIMENSIONS: return "a path asked for sampler dimension >= 1024 (Sobol') / 1000 (Halton): the reference panics there (samplers/sobol.rs:69-73)";
+    case PT_ERR_UNSUPPORTED: return "a hit's material class has no shade queue in this render (internal: k_route)";
+    default: return "error raised on the device";
+    }
+}
+
 int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profile_exact) {
     const uint32_t total = rc.n_pix_slots * rc.s_count;
     QCounters *qc = sc->qc;
@@ -367,13 +384,13 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     const bool fin = g_film_final && !rc.volpath;
     int cur = 0;
     static const char *shade_names[kNumClasses] = {"shade_matte", "shade_1lobe", "shade_2lobe", "shade_manylobe", "shade_miss", "shade_medium", "shade_specular", "shade_metal", "shade_plastic", "shade_uber", "shade_sss"};
-    const int kMaxIterations = 1 << 20;   // a path needs <= max_depth + null-surface skips + probe segments iterations
+    const int kMaxIterations = g_test_max_iterations > 0 ? g_test_max_iterations : 1 << 20;   // a path needs <= max_depth + null-surface skips + probe segments iterations (PT_TEST_MAX_ITERATIONS: the error path's test)
     for (int iter = 0; iter <= kMaxIterations; ++iter) {
         QCounters h;
         HIP_TRY(hipMemcpyAsync(&h, qc, sizeof h, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
-        if (h.error) return fail((int)h.error, h.error == PT_ERR_STACK_OVERFLOW ? "BVH traversal stack overflow (> 64 entries)" : h.error == PT_ERR_PROBE_CHAIN ? "BSSRDF probe chain with more than 2^32 - 1 intersections" : "Sobol dimension overflow (>= 1024)");
-        if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within 2^20 wavefront iterations");
+        if (h.error) return fail((int)h.error, device_error_text(h.error));
+        if (iter == kMaxIterations) return fail(PT_ERR_PROBE_CHAIN, "pass did not finish within " + std::to_string(kMaxIterations) + " wavefront iterations");
         if (iter > 0 && iter % 2048 == 0 && getenv("PT_DEBUG_ITER")) {
             fprintf(stderr, "[iter %d] ext %u shadow %u mis %u probe %u shade:", iter, h.ext[cur], h.shadow, h.mis, h.probe[cur]);
             for (int c = 0; c < kNumClasses; ++c) fprintf(stderr, " %u", h.shade[cur][c]);
@@ -452,7 +469,7 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
             #ifndef PT_ROUTE_BLOCKS_PER_CU
 #define PT_ROUTE_BLOCKS_PER_CU 3u   // what a CU's LDS holds of this kernel (six 8 KB staging queues per block)
 #endif
-            RouteJob rj{}; rj.slot_map = ~0ull;
+            RouteJob rj{}; rj.slot_map = ~0ull; rj.error = &qc->error; rj.drop_cls = fin ? (uint32_t)kMissClass : ~0u;
             for (int c = 0; c < kNumClasses; ++c) if (c != kMediumClass && ((c == kMissClass && !fin) || (c != kMissClass && sc->class_used[c]))) {   // (fin: escaped rays are dropped here, the film kernel ends them)
                 rj.slot_map = (rj.slot_map & ~(15ull << (4 * c))) | ((unsigned long long)rj.n_slots << (4 * c));
                 rj.cls_of_slot[rj.n_slots] = (uint32_t)c; rj.buf[rj.n_slots] = sc->q.shade[cur][c]; rj.n_slots++;
@@ -608,7 +625,6 @@ void read_counters(pt_scene *sc) {
                            (double)d.tail[12], d.tail[12] ? 100.0 * (double)d.tail[13] / (64.0 * (double)d.tail[12]) : 0.0, 100.0 * (double)d.tail[14] / (double)d.tail[2], 100.0 * (double)d.tail[15] / (double)d.tail[2]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] instance entries tried %.4e, turned away by the object's root test %.4e (%.1f %%), left with a hit %.4e (%.1f %%); stack entries written beyond the LDS ones %.4e\n",
                            (double)d.util2[4], (double)d.util2[5], d.util2[4] ? 100.0 * (double)d.util2[5] / (double)d.util2[4] : 0.0, (double)d.util2[6], d.util2[4] ? 100.0 * (double)d.util2[6] / (double)d.util2[4] : 0.0, (double)d.util2[7]);
-    if (d.dbg[2]) fprintf(stderr, "[trace-util] instance packets tested against the oriented box in the leaf step (PT_INST_GATE) %.4e, turned away there %.4e (%.1f %%)\n", (double)d.dbg[2], (double)d.dbg[3], 100.0 * (double)d.dbg[3] / (double)d.dbg[2]);
     if (d.tail[2]) fprintf(stderr, "[trace-util] record step by part, %% of the waves' cycles: loads issued + waited for %.1f, node branch %.1f, leaf branch %.1f, pops %.1f\n",
                            100.0 * (double)d.util2[0] / (double)d.tail[2], 100.0 * (double)d.util2[1] / (double)d.tail[2], 100.0 * (double)d.util2[2] / (double)d.tail[2], 100.0 * (double)d.util2[3] / (double)d.tail[2]);
     for (int k = 0; k < 4; ++k)
@@ -630,26 +646,14 @@ void read_counters(pt_scene *sc) {
 
 extern "C" {
 
-int pt_pass_size(pt_scene *sc, const PtRenderParams *rp, uint32_t *spp_per_pass) {
-    if (!sc || !rp || !spp_per_pass || rp->spp == 0) return fail(PT_ERR_INVALID_ARG, "null argument");
-    if (sc->device != g_device) { int bst = bind_device(sc->device); if (bst) return bst; }
-    RenderConst rc;
-    fill_render_const(rp, rc);
-    const uint32_t ntiles = rc.ntx * rc.nty;
-    const uint32_t slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world * 256u : 0u;
-    uint32_t S = rp->spp_per_pass;
-    if (S == 0) S = slots ? choose_pass_size(sc, slots, rp->spp, 1, rc.volpath != 0) : rp->spp;
-    *spp_per_pass = std::min(S, rp->spp);
-    return PT_OK;
-}
-
-int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film_is_device) {
-    if (!sc || !rp || !film_xyzw) return fail(PT_ERR_INVALID_ARG, "null argument");
+// What pt_render checks before it touches the device and the pass size it then uses -- ONE function for pt_render and pt_pass_size, so that the size pt_pass_size
+// reports is the size of a render that would be accepted (the two had drifted apart). Fills rc (incl. n_tile_slots / n_pix_slots); *S = samples per pixel
+// per wavefront pass (0 when this rank owns no tile).
+static int render_geometry(pt_scene *sc, const PtRenderParams *rp, RenderConst &rc, uint32_t *S_out) {
     if (rp->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (!(rp->filter_radius[0] > 0.0f) || !(rp->filter_radius[1] > 0.0f)) return fail(PT_ERR_INVALID_ARG, "filter radius must be > 0");
     if (rp->tile_world > 1 && rp->tile_rank >= rp->tile_world) return fail(PT_ERR_INVALID_ARG, "tile_rank >= tile_world");
     if (sc->device != g_device) { int bst = bind_device(sc->device); if (bst) return bst; }
-    RenderConst rc;
     fill_render_const(rp, rc);
     if (rc.film_w == 0 || rc.film_h == 0 || rc.ntx == 0 || rc.nty == 0) return fail(PT_ERR_INVALID_ARG, "empty film or sample bounds");
     if (rc.sobol.log2_resolution > 25) return fail(PT_ERR_INVALID_ARG, "sample bounds exceed the 2^25 Sobol' pixel grid");
@@ -661,16 +665,37 @@ int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film
     const uint32_t ntiles = rc.ntx * rc.nty;
     rc.n_tile_slots = rc.tile_rank < ntiles ? (ntiles - rc.tile_rank + rc.tile_world - 1) / rc.tile_world : 0;
     rc.n_pix_slots = rc.n_tile_slots * 256u;
+    uint32_t S = 0;
+    if (rc.n_pix_slots > 0) {
+        S = rp->spp_per_pass;
+        if (S == 0) S = choose_pass_size(sc, rc.n_pix_slots, rp->spp, 1, rc.volpath != 0);
+        S = std::min(S, rp->spp);
+        if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large: pixel slots x samples per pass > 2^31 paths (lower spp_per_pass)");
+    }
+    *S_out = S;
+    return PT_OK;
+}
+
+int pt_pass_size(pt_scene *sc, const PtRenderParams *rp, uint32_t *spp_per_pass) {
+    if (!sc || !rp || !spp_per_pass) return fail(PT_ERR_INVALID_ARG, "null argument");
+    RenderConst rc; uint32_t S = 0;
+    if (int st = render_geometry(sc, rp, rc, &S)) return st;
+    *spp_per_pass = S ? S : rp->spp;   // (a rank that owns no tile renders nothing: any size)
+    return PT_OK;
+}
+
+int pt_render(pt_scene *sc, const PtRenderParams *rp, float *film_xyzw, int film_is_device) {
+    if (!sc || !rp || !film_xyzw) return fail(PT_ERR_INVALID_ARG, "null argument");
+    RenderConst rc; uint32_t S = 0;
+    if (int gst = render_geometry(sc, rp, rc, &S)) return gst;
+    g_test_max_iterations = 0;
+    if (const char *e = getenv("PT_TEST_MAX_ITERATIONS")) { const int v = atoi(e); if (v > 0) g_test_max_iterations = v; }
     const size_t film_px = (size_t)rc.film_w * rc.film_h;
     sc->profile = rp->profile != 0;
     sc->drop_timings();
     sc->stats.clear();
     int st = PT_OK;
     if (rc.n_pix_slots > 0) {
-        uint32_t S = rp->spp_per_pass;
-        if (S == 0) S = choose_pass_size(sc, rc.n_pix_slots, rp->spp, 1, rc.volpath != 0);
-        S = std::min(S, rp->spp);
-        if ((size_t)rc.n_pix_slots * S > ((size_t)1 << 31)) return fail(PT_ERR_INVALID_ARG, "pass too large");
         if ((st = ensure_workspace(sc, (size_t)rc.n_pix_slots * S, film_px))) return st;
         if (rc.volpath && sc->has_null_material && sc->ext_capacity < sc->capacity) {   // the shells' chain state (PathSoA::ext)
             if (sc->ext_slab) { hipFree(sc->ext_slab); sc->ext_slab = nullptr; sc->ext_capacity = 0; }

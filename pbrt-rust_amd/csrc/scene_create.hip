@@ -218,7 +218,6 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     std::vector<WideNode> wide;
     std::vector<DevInstance> dinst(instanced ? d->n_instances : 0);
     std::vector<QuadNode> quad;
-    std::vector<uint32_t> inst_gate;
     auto append_accel = [&](const std::vector<PtBVHNode> &nn, const std::vector<uint32_t> &refs, uint32_t &root_ref, uint32_t &root_ref4) {
         const uint32_t wbase = (uint32_t)wide.size(), pbase = (uint32_t)packet_refs.size();
         std::vector<uint32_t> wide_id(nn.size(), 0);
@@ -310,46 +309,12 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         }
         // The production walk addresses records and packets as 16-byte quads of one pool (checked where the pool is allocated: < 2^31 of each, < 64 GB together). The
         // two-wide walk of pt_set_trace_exact packs a skipped-entry count above 25-bit references: a larger scene has no exact walk (launch_trace refuses it).
-#ifdef PT_INST_GATE
-        // EXPERIMENT (PT_INST_GATE builds of k_trace; profiles/r5/NOTES.md): an oriented box around the object's root box in the nine spare words of every instance packet --
-        // per world axis j {bf16 A0j | A1j << 16, bf16 A2j, c_j}: u = A (p - c) maps the root box, inflated by 1e-4 of its extent, into [-1, 1]^3 (rows of world_to_instance
-        // over the half extents, rounded to bf16 and re-scaled so that no corner leaves the cube); all zero = no gate (single-primitive objects have no root test).
-        inst_gate.assign(9 * dinst.size(), 0u);
-        for (size_t i = 0; i < dinst.size(); ++i) {
-            const DevInstance &D = dinst[i];
-            if (D.single) continue;
-            double lo[3], hi[3], cw[3] = {0, 0, 0}, corner[8][3];
-            for (int k = 0; k < 3; ++k) { const double ext = (double)D.root_max[k] - D.root_min[k]; lo[k] = D.root_min[k] - 1e-4 * ext - 1e-6 * (std::fabs((double)D.root_max[k]) + std::fabs((double)D.root_min[k])) - 1e-30; hi[k] = D.root_max[k] + (D.root_min[k] - lo[k]); }
-            for (int q = 0; q < 8; ++q) for (int r = 0; r < 3; ++r) {
-                const double px = (q & 1) ? hi[0] : lo[0], py = (q & 2) ? hi[1] : lo[1], pz = (q & 4) ? hi[2] : lo[2];
-                corner[q][r] = (double)D.instance_to_world[4 * r] * px + (double)D.instance_to_world[4 * r + 1] * py + (double)D.instance_to_world[4 * r + 2] * pz + (double)D.instance_to_world[4 * r + 3];
-                cw[r] += corner[q][r] / 8.0;
-            }
-            auto bf16 = [](double v) { float f = (float)v; uint32_t u; std::memcpy(&u, &f, 4); u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; return u & 0xffffu; };
-            auto bf16f = [](uint32_t h) { uint32_t u = h << 16; float f; std::memcpy(&f, &u, 4); return (double)f; };
-            float cf[3]; for (int r = 0; r < 3; ++r) cf[r] = (float)cw[r];
-            uint32_t A[3][3]; bool ok = true;
-            for (int r = 0; r < 3; ++r) {
-                double row[3]; const double h = 0.5 * (hi[r] - lo[r]);
-                if (!(h > 0.0) || !std::isfinite(h)) { ok = false; break; }
-                for (int c = 0; c < 3; ++c) row[c] = (double)D.world_to_instance[4 * r + c] / h;
-                for (int pass = 0; pass < 3; ++pass) {   // round, measure the farthest corner, re-scale
-                    double m = 0.0;
-                    for (int c = 0; c < 3; ++c) A[r][c] = bf16(row[c]);
-                    for (int q = 0; q < 8; ++q) { double u = 0.0; for (int c = 0; c < 3; ++c) u += bf16f(A[r][c]) * (corner[q][c] - (double)cf[c]); m = std::fmax(m, std::fabs(u)); }
-                    if (!(m > 0.0) || !std::isfinite(m)) { ok = false; break; }
-                    if (m <= 1.0 + 1.0 / 128.0 && pass > 0) break;
-                    for (int c = 0; c < 3; ++c) row[c] = bf16f(A[r][c]) / (m * (1.0 - 1.0 / 512.0));
-                    if (pass == 2) ok = false;
-                }
-                if (!ok) break;
-            }
-            if (!ok) continue;
-            for (int c = 0; c < 3; ++c) { inst_gate[9 * i + 3 * c] = A[0][c] | (A[1][c] << 16); inst_gate[9 * i + 3 * c + 1] = A[2][c]; std::memcpy(&inst_gate[9 * i + 3 * c + 2], &cf[c], 4); }
-        }
-#endif
         if (quad.size() + g_test_pool_pad_records >= ((size_t)1 << 28) || packet_refs.size() >= ((size_t)1 << 31) - 2) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 2^28 four-wide BVH records / 2^31 packets"));
         if (wide.size() > (size_t)kRefMask || packet_refs.size() > (size_t)kRefMask) { sc->quad_walk_only = true; wide.clear(); wide.shrink_to_fit(); }
+        // an adopted tree that is not nested can only be walked two-wide, a scene beyond 2^25 records only four-wide: together no walk is left (such a scene
+        // used to be accepted here and then failed at every traversal launch)
+        if (sc->exact_walk_only && sc->quad_walk_only) return bail(fail(PT_ERR_UNSUPPORTED, "adopted BVH whose child boxes do not nest inside their parents' (needs the two-wide walk) in a scene beyond 2^25 records / packets (has the four-wide walk only)"));
+        if (sc->exact_walk_only) fprintf(stderr, "mi355pt: warning: the adopted BVH's child boxes do not nest inside their parents'; this scene is walked two-wide, box by box (slower than the four-wide production walk)\n");
         if (wide.empty()) wide.resize(1);
         UP(wide, wide.data(), wide.size());
         UP(instances, dinst.data(), dinst.size()); ds.n_instances = (uint32_t)dinst.size();
@@ -501,6 +466,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (pool_bytes / 16 >= (size_t)0xfffffff0u) return bail(fail(PT_ERR_UNSUPPORTED, "scene exceeds 64 GB of traversal records + packets"));
         uint8_t *pool = nullptr;
         if ((st = sc->dalloc(&pool, pool_bytes))) return bail(st);
+        // (record 0 is read as a dummy by the leaf lanes of k_trace<.., 2>, which aim their five node-only loads at it: with the test hook's pad in front of the pool that is pad memory)
+        if (pad_bytes && hipMemset(pool, 0, pad_bytes) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset of the pool pad"));
         if (hipMemcpy(pool + pad_bytes, quad.data(), quad_bytes - pad_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PT_ERR_HIP, "upload of the four-wide records"));
         leaf = reinterpret_cast<TriPacket *>(pool + quad_bytes);
         ds.quad = reinterpret_cast<const QuadNode *>(pool); ds.leaf_off = (uint32_t)(quad_bytes / 16); ds.pool_quads = (uint32_t)(pool_bytes / 16);
@@ -508,9 +475,7 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
         if (hipMemset(leaf, 0, ((size_t)n_packets + 2) * sizeof(TriPacket)) != hipSuccess) return bail(fail(PT_ERR_HIP, "memset"));
         if ((st = sc->dalloc(&area, std::max<uint32_t>(1, d->n_lights)))) return bail(st);
         if ((st = sc->dalloc(&lrec, 6 * (size_t)std::max<uint32_t>(1, d->n_lights)))) return bail(st);
-        const uint32_t *d_gate = nullptr;
-        if (!inst_gate.empty() && (st = sc->upload(&d_gate, inst_gate.data(), inst_gate.size()))) return bail(st);
-        hipLaunchKernelGGL(k_build_packets, dim3((n_packets + 255) / 256), dim3(256), 0, 0, ds, d_ordered, n_packets, leaf, d_gate);
+        hipLaunchKernelGGL(k_build_packets, dim3((n_packets + 255) / 256), dim3(256), 0, 0, ds, d_ordered, n_packets, leaf);
         ds.leaf = leaf;
         {
             const uint32_t *d_last = nullptr;

@@ -177,6 +177,13 @@ class MultiScene:
         self.L.check(self.L.lib.pt_multi_get_timing(self.h, C.byref(merge), r, c, n))
         return dict(merge_ms=merge.value, render_ms=list(r), copy_ms=list(c))
 
+    def create_timing(self):
+        """pt_multi_scene_create: wall time of the call and, per replica, of its own scene creation (replicas 1.. are created concurrently), in ms."""
+        n = len(self.devices)
+        wall = C.c_double(); r = (C.c_double * n)()
+        self.L.check(self.L.lib.pt_multi_get_create_timing(self.h, C.byref(wall), r, n))
+        return dict(wall_ms=wall.value, replica_ms=list(r))
+
     def peer_access(self):
         """Per replica: "same device", "peer access" (device-to-device copies) or "staged through the host" -- how its film reaches the first device."""
         n = len(self.devices)

@@ -688,8 +688,9 @@ np.savez({out!r}, gp=gp, gt=gt, gb=gb, gh=gh, film=film, tri1=c1["triangle_tests
 
 
 def test_records_and_packets_beyond_four_gigabytes(pkg, gpu, oracle, tmp_path, trace_mode):
-    """Round 5: the production walk addresses its pool of four-wide records and packets in 16-byte quads through a structured buffer resource (64 GB; until round 4
-    32-bit BYTE offsets: 4 GB, 2^25 records). PT_TEST_POOL_PAD_RECORDS puts 34 M unused records (4.35 GB) in front of a small instanced scene's pool, in a process of
+    """Round 5: a pool of four-wide records and packets beyond 4 GB (what the buffer loads' 32-bit BYTE offsets of k_trace<.., 1> reach) is walked by k_trace<.., 2>: the same
+    walk through 64-bit global loads (up to 64 GB; a structured buffer resource was tried first and dropped -- its index x stride wraps at 32 bits, profiles/r5/NOTES.md section 5).
+    PT_TEST_POOL_PAD_RECORDS puts 34 M unused records (4.35 GB) in front of a small instanced scene's pool, in a process of
     its own (pt_init reads it): every record and packet -- top-level tree, object trees, instance packets -- then lies beyond the old reach. Hits, films and
     triangle counters == oracle. (tools/big_scene_parity.py does the same with a scene that is that large by itself.)"""
     if trace_mode == "exact":
@@ -713,3 +714,60 @@ def test_records_and_packets_beyond_four_gigabytes(pkg, gpu, oracle, tmp_path, t
     assert int(g["tri3"]) == oc["triangle_tests"] and int(g["rays3"]) == oc["intersect_tests"] + oc["shadow_tests"]
     assert np.array_equal(g["film"][..., 3], ref[..., 3])
     np.testing.assert_allclose(g["film"][..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("as_written", [0, 1])
+def test_triangle_watertight_twin_through_the_hip_path(pkg, gpu, oracle, as_written):
+    """tests/shapes.rs:36-146 triangle_watertight through pt_trace_closest: the reference's mesh (RNG::new(12111), 16 x 16) as a scene, the 200 000 rays of its
+    100 000 seeds (oracle/ref_kats_shapes.cpp generates both from the same PCG32 streams). Every ray must hit (closed mesh; on the mesh as the Rust file
+    writes it, which is open along phi = 0 -- tests/test_oracle_kats.py -- exactly the rays that hit no triangle one by one must miss), and (prim, t, b) must be
+    the oracle's BVHAccel::intersect over the same scene, bit for bit."""
+    from test_oracle_kats import _watertight
+    failures, v, idx, ro, rd, nh = _watertight(oracle, 100000, as_written)
+    b = pkg.host.SceneBuilder()
+    b.trianglemesh(v, idx)
+    sd, _ = b.world_end()
+    g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
+    tmax = np.full(len(ro), np.inf, np.float32)
+    gp, gt, gb = g.trace_closest(ro, rd, tmax); gc = g.counters()
+    op, ot, ob = orc.trace_closest(ro, rd, tmax); oc = orc.counters()
+    assert np.array_equal(gp != 0xFFFFFFFF, nh >= 1)
+    if not as_written:
+        assert failures == 0 and (gp != 0xFFFFFFFF).all()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32)) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    for k in ckeys(("bvh_nodes_visited", "triangle_tests", "intersect_tests")):
+        assert gc[k] == oc[k], k
+
+
+def test_distribution1d_twins_on_the_device(pkg, gpu, oracle):
+    """tests/sampling.rs:259-283 distribution1d_continuous on the device's dist_sample_continuous (csrc/dev_light.h, the environment map's sampler) through
+    pt_dist1d_sample, the same checks as the oracle twin; then device == oracle bit for bit on 20 000 numbers incl. both ends and every cdf knot +- 1 ulp, for the
+    continuous and the discrete routine (tests/sampling.rs:202-257's distribution [0, 1, 0, 3] among them)."""
+    from test_oracle_kats import dist1d_continuous_checks
+    A = pkg._abi
+
+    def device(func, u, discrete):
+        func = np.ascontiguousarray(func, np.float32); u = np.ascontiguousarray(u, np.float32)
+        x = np.zeros(len(u), np.float32); pdf = np.zeros(len(u), np.float32); off = np.zeros(len(u), np.int32)
+        assert gpu.lib.pt_dist1d_sample(func.ctypes.data_as(A.fp), len(func), discrete, len(u), u.ctypes.data_as(A.fp), x.ctypes.data_as(A.fp),
+                                        pdf.ctypes.data_as(A.fp), off.ctypes.data_as(A.i32p)) == 0
+        return x, pdf, off
+    func = [1.0, 1.0, 2.0, 4.0, 8.0]
+    dist1d_continuous_checks(lambda u: tuple(a[0].item() for a in device(func, [u], 0)))
+    rng = np.random.default_rng(5)
+    for func in ([1.0, 1.0, 2.0, 4.0, 8.0], [0.0, 1.0, 0.0, 3.0], [0.0, 0.0, 0.0], [5.0], list(rng.random(257) ** 4), [0.0] * 7 + [2.0] + [0.0] * 9):
+        f32 = np.array(func, np.float32)
+        cdf = np.concatenate([[0], np.cumsum(f32.astype(np.float64)) / max(f32.sum(dtype=np.float64), 1e-30)]).astype(np.float32)
+        knots = np.concatenate([np.nextafter(cdf, np.float32(-1)), cdf, np.nextafter(cdf, np.float32(2))]).clip(0, 1)
+        u = np.concatenate([[0.0, 1.0, np.float32(1) - np.float32(2 ** -24)], knots, rng.random(20000)]).astype(np.float32)
+        for discrete in (0, 1):
+            gx, gpdf, goff = device(f32, u, discrete)
+            for i, ui in enumerate(u):
+                pdf = C.c_float(); off = C.c_int(-1)
+                if discrete:
+                    o_off = oracle.lib.orc_dist1d_sample_discrete(f32.ctypes.data_as(A.fp), len(f32), float(ui), C.byref(pdf), None); o_x = 0.0
+                else:
+                    o_x = oracle.lib.orc_dist1d_sample_continuous(f32.ctypes.data_as(A.fp), len(f32), float(ui), C.byref(pdf), C.byref(off)); o_off = off.value
+                assert goff[i] == o_off, (func[:5], discrete, ui)
+                assert np.float32(gx[i]).view(np.uint32) == np.float32(o_x).view(np.uint32) and np.float32(gpdf[i]).view(np.uint32) == np.float32(pdf.value).view(np.uint32), (func[:5], discrete, ui)

@@ -718,3 +718,71 @@ def test_oracle_counts_the_asserts_the_reference_would_panic_on(pkg, oracle):
     sd, rp = pkg.scenes.ganesha_scale(n=16, xres=32, yres=24, spp=2).world_end()
     s = oracle.scene(sd); s.render(rp, nthreads=2)
     assert s.counters()["reference_asserts"] == 0
+
+
+def _watertight(oracle, n_seeds, as_written):
+    fn = oracle.lib.orc_test_triangle_watertight
+    fp = C.POINTER(C.c_float)
+    fn.argtypes = [C.c_int, C.c_int, fp, C.POINTER(C.c_uint32), fp, fp, C.POINTER(C.c_int)]
+    v = np.zeros((256, 3), np.float32); idx = np.zeros((420, 3), np.uint32)
+    ro = np.zeros((2 * n_seeds, 3), np.float32); rd = np.zeros((2 * n_seeds, 3), np.float32); nh = np.zeros(2 * n_seeds, np.int32)
+    failures = fn(n_seeds, as_written, v.ctypes.data_as(fp), idx.ctypes.data_as(C.POINTER(C.c_uint32)), ro.ctypes.data_as(fp), rd.ctypes.data_as(fp),
+                  nh.ctypes.data_as(C.POINTER(C.c_int)))
+    return failures, v, idx, ro, rd, nh
+
+
+def test_triangle_watertight_twin(oracle):
+    """tests/shapes.rs:36-146 triangle_watertight on the oracle's Triangle::intersect: RNG::new(12111) mesh, the reference's 100 000 seeds, both rays of every
+    seed (a uniform direction, then "shoot directly at a vertex") must hit at least one of the 420 triangles. The reference keeps the test switched off
+    (`//#[test]`, :35); the mesh loop as the Rust file has it leaves the sphere open along phi = 0 (`t == nphi - 1` at :60 where pbrt-v3 has `p == nPhi - 1`:
+    oracle/ref_kats_shapes.cpp), so the assertion is held on the closed mesh and, on the mesh as written, every ray that hits nothing must go through that slit."""
+    failures, v, idx, ro, rd, nh = _watertight(oracle, 100000, 0)
+    assert failures == 0 and int(nh.min()) >= 1
+    assert np.array_equal(v[15::16][1:15], v[0::16][1:15])            # closed: the last vertex of every interior row is its first
+    failures_w, vw, idxw, row, rdw, nhw = _watertight(oracle, 100000, 1)
+    assert np.array_equal(idx, idxw) and np.array_equal(ro, row)       # same connectivity, same ray origins (RNG::new(i) streams do not depend on the mesh)
+    assert 0 < failures_w == int((nhw < 1).sum()) < 2000
+    assert not np.array_equal(vw[15::16][1:15], vw[0::16][1:15])
+    bad = np.nonzero(nhw < 1)[0]
+    o = row[bad].astype(np.float64); d = rdw[bad].astype(np.float64)
+    t = -o[:, 1] / d[:, 1]                                               # where the ray crosses the plane y = 0 ...
+    assert (t > 0).all() and ((o[:, 0] + t * d[:, 0]) > -1e-6).all()     # ... ahead of its origin, on the x >= 0 side: through the seam's half plane (x = 0: the two rays aimed at a pole, the slit's end)
+
+
+def test_float_bits_twin(oracle):
+    # tests/fp.rs:46-57: RNG::new(1), 100 000 draws, float_to_bits(bits_to_float(ui)) == ui for every non-NaN pattern
+    n = C.c_int()
+    oracle.lib.orc_test_float_bits.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    assert oracle.lib.orc_test_float_bits(100000, C.byref(n)) == 0
+    assert 99000 < n.value <= 100000      # 2^24 - 2 of 2^32 patterns are NaNs: ~390 of the 100 000
+
+
+def dist1d_continuous_checks(sample):
+    """tests/sampling.rs:259-283 distribution1d_continuous; `sample(u)` -> (value, pdf, offset) of Distribution1D::new([1, 1, 2, 4, 8]).sample_continous(u).
+    The file's four assert_eq!s, and its five relative_eq!s (whose results the Rust test drops) held as real assertions at the epsilon written there."""
+    count = 5
+    x, pdf, off = sample(0.0)
+    assert x == 0.0                                                      # :267 assert_eq!(0.0, ...)
+    assert abs(pdf - 5.0 * 1.0 / 16.0) <= 1e-5 * 5.0 / 16.0              # (the file's `count + 1.0` at :268 is not the pdf of this distribution: func[0] / func_int = 1 / (16 / 5); its result is dropped there)
+    assert off == 0                                                      # :269
+    x, pdf, off = sample(0.5)
+    assert abs(x - 0.8) <= 1e-5 * 0.8                                    # :272 right at the boundary between the 4 and the 8 segments
+    x, pdf, off = sample(0.75)
+    assert abs(x - 0.9) <= 1e-5 * 0.9                                    # :275 middle of the 8 segment
+    assert abs(pdf - count * 8.0 / 16.0) <= 1e-5 * count * 8.0 / 16.0    # (:276 writes `count * 0.8 / 16`; the pdf of the 8 segment is 8 / (16 / 5) = 2.5)
+    assert off == 4                                                      # :277
+    assert abs(sample(0.0)[0] - 0.0) <= 1e-5                             # :279
+    assert abs(sample(1.0)[0] - 1.0) <= 1e-5                             # :280
+
+
+def test_distribution1d_continuous_twin(oracle, pkg):
+    A = pkg._abi
+    func = np.array([1.0, 1.0, 2.0, 4.0, 8.0], np.float32)
+
+    def sample(u):
+        pdf = C.c_float(); off = C.c_int(-1)
+        x = oracle.lib.orc_dist1d_sample_continuous(func.ctypes.data_as(A.fp), 5, u, C.byref(pdf), C.byref(off))
+        return x, pdf.value, off.value
+    dist1d_continuous_checks(sample)
+    # count() == 5 (:263): the discrete pdfs of the same distribution sum to one over its five entries
+    assert abs(sum(oracle.lib.orc_dist1d_discrete_pdf(func.ctypes.data_as(A.fp), 5, i) for i in range(5)) - 1.0) < 1e-6
