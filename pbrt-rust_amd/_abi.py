@@ -182,10 +182,14 @@ ENTRY_POINTS = {
 }
 
 
-def bind(lib, table=ENTRY_POINTS, prefix_from="pt_", prefix_to="pt_"):
-    """Attach restype/argtypes; raises AttributeError if a declared symbol is missing."""
+def bind(lib, table=ENTRY_POINTS, prefix_from="pt_", prefix_to="pt_", strict=True):
+    """Attach restype/argtypes; raises AttributeError if a declared symbol is missing (strict=False: an older library variant of an A/B run may lack the newest entry points)."""
     for name, (res, args) in table.items():
-        fn = getattr(lib, name.replace(prefix_from, prefix_to, 1))
+        fn = getattr(lib, name.replace(prefix_from, prefix_to, 1), None)
+        if fn is None:
+            if strict:
+                raise AttributeError(f"{name}: symbol declared in include/mi355pt.h is missing from the library")
+            continue
         fn.restype = res
         fn.argtypes = args
     return lib

@@ -46,8 +46,11 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
         // the BSSRDF's material, S = 0), ps.ox.. / ps.dx.. the segment that found it, bs.cnt the chain's nfound
         const V3 ro(ps.ox(pid), ps.oy(pid), ps.oz(pid)), rd(ps.dx(pid), ps.dy(pid), ps.dz(pid));
         const uint32_t hp = ps.hit_prim(pid);
-        const uint32_t mat = bs.mat[pid];
-        const uint32_t nfound = bs.cnt[pid];
+        // the frame record (kernels.h: BssSoA): {po, nfound} {ns, iface} {ss, material} -- three quads of one 48-byte record, requested together
+        const float4 *const fq = bs.frame + (size_t)pid * BssSoA::kFrameQuads;
+        const float4 fr0 = fq[0], fr1 = fq[1], fr2 = fq[2];
+        const uint32_t mat = __float_as_uint(fr2.w);
+        const uint32_t nfound = __float_as_uint(fr0.w);
         const bool at_exit = hp != PT_NONE, dead = !at_exit;
         SurfaceInteraction si;
         if (at_exit) fill_hit_pkt<SPH>(s, ps.hit_pkt(pid), SPH ? ps.hit_inst(pid) : PT_NONE, ro, rd, ps.hit_b0(pid), ps.hit_b1(pid), ps.hit_b2(pid), si);
@@ -74,10 +77,14 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                 const PtMaterial &m = s.materials[mat];
                 DevBssrdf bss;   // the BSSRDF of the entry point: tabulated, with the sigma_a / sigma_s its textures gave there, or DisneyBSSRDF
                 if (m.type == PT_MAT_DISNEY) bss.init_disney(m);
-                else bss.init_medium(m, s.bss_tables, RGB(bs.sa_r[pid], bs.sa_g[pid], bs.sa_b[pid]), RGB(bs.sc_r[pid], bs.sc_g[pid], bs.sc_b[pid]));
-                bss.ns = V3(bs.ns_x[pid], bs.ns_y[pid], bs.ns_z[pid]); bss.ss = V3(bs.ss_x[pid], bs.ss_y[pid], bs.ss_z[pid]);
-                bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(bs.po_x[pid], bs.po_y[pid], bs.po_z[pid]);
-                n_bytes += 36 + 24;
+                else if (bss_coef_stored(s.n_textures, m)) {   // sigma_a / sigma_s came from textures (or a kdsubsurface conversion) at the entry point
+                    const float4 *const cq = bs.coef + (size_t)pid * BssSoA::kCoefQuads; const float4 c0 = cq[0], c1 = cq[1];
+                    bss.init_medium(m, s.bss_tables, RGB(c0.x, c0.y, c0.z), RGB(c1.x, c1.y, c1.z));
+                    n_bytes += 32;
+                } else bss.init_medium(m, s.bss_tables, rgb3(m.sigma_a), rgb3(m.sigma_s));   // the material's constants, as kern_shade.h took them (subsurface.rs:100-101 with constant textures)
+                bss.ns = V3(fr1.x, fr1.y, fr1.z); bss.ss = V3(fr2.x, fr2.y, fr2.z);
+                bss.ts = cross(bss.ns, bss.ss); bss.po_p = V3(fr0.x, fr0.y, fr0.z);
+                n_bytes += 48 - 8;   // (the frame record; its two id words are in the 4 + 24 + 16 + 8 above)
                 // bssrdf.rs:403-405: pdf = pdf_sp(pi) / nfound ; Sp = sr(|po - pi|)
                 float pdf = 0.0f;
                 bool go = true;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, PT_BSSRDF_WAVES) void k_bssrdf(DeviceScene s, 
                     IData it; it.p = si.p; it.p_error = si.p_error; it.n = si.n;
                     // path.rs:188-192: direct lighting at pi (not part of the zero-radiance statistic)
                     MedIface mif{PT_NONE, PT_NONE};
-                    if (VOL) { const uint32_t pk = bs.iface[pid]; mif.inside = (pk & 0xffffu) == 0xffffu ? PT_NONE : (pk & 0xffffu); mif.outside = (pk >> 16) == 0xffffu ? PT_NONE : (pk >> 16); }
+                    if (VOL) { const uint32_t pk = __float_as_uint(fr1.w); mif.inside = (pk & 0xffffu) == 0xffffu ? PT_NONE : (pk & 0xffffu); mif.outside = (pk >> 16) == 0xffffu ? PT_NONE : (pk >> 16); }
                     if (!stage_b) {
                         if (nee_vertex<SPH, BssrdfAdapterBsdf, VOL, false>(s, grid, ps, pid, smp, si, it, bsdf, beta, flags, push_shadow, push_mis, n_bytes PT_PROF_PASS, mif)) flags |= PF_NEE_UNCOUNTED;
                         else L = L + beta * RGB(0.0f);   // path.rs:190-192 `L += beta * uniform_sample_one_light(..)` with a black estimate: 0, or NaN when pdf_sp was (an exit point a few ulps from po: inf x 0)

@@ -15,15 +15,26 @@ PT_DEV bool slot_to_pixel(const RenderConst &rc, uint32_t slot, int32_t &px, int
 
 
 // ---- film ----------------------------------------------------------------------------------------------------
-// One thread per pixel slot; its s_count samples are added in sample order (integrator.rs:331-376),
-// FilmTile::add_sample (film.rs:292-331) with the tile's pixel bounds == footprint clipped to the crop window.
+// One thread per pixel slot (kFilmLanes = 1, kernels.h); its s_count samples are added in sample order (integrator.rs:331-376), FilmTile::add_sample (film.rs:292-331) with
+// the tile's pixel bounds == footprint clipped to the crop window. Splats onto the thread's own pixel are accumulated in registers, seeded with the pixel's current value, and
+// written back once: the additions happen in sample order exactly as FilmTile::add_sample makes them, without one L2 atomic per channel per sample. Splats onto other pixels
+// (wide filters; for the box filter only the pfilm == pixel-corner case) are float atomics; should one of them land on this pixel meanwhile, the final compare-and-swap fails
+// and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
+// kFilmLanes > 1 (-DPT_FILM_LANES=2|4|8|16, round 6's experiment for VERDICT r5 item 5): that many lanes share a pixel slot, lane j takes the samples j, j + kFilmLanes, ...
+// (their record loads and last path steps are independent) and each round's own-pixel terms are handed to the group's first lane with `__shfl` and added there IN ORDER, so the
+// film keeps its bits. Measured on C2 (profiles/r6/NOTES.md section 4): 1 lane 18.3 ms, 2: 19.6, 4: 20.0, 8: 21.1, 16: 24.3 -- the kernel is not short of independent chains, it
+// streams 102 GB at 5.6 TB/s, and a wave that reads four 1 KB runs instead of one 4 KB run does that worse. The default stays one lane.
 // `fin(pid, L)`: called for every sample before it is sanitised and splatted (k_film: nothing; k_film_final, kern_aux.h: the path's last step -- its pending
 // next-event estimate, the environment's Le -- where the plain path integrator has no k_shade_miss pass any more).
 template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA &ps, const float *filter_table, float *film_rgbw, DevCounters *counters, Fin fin) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = gtid / kFilmLanes, sub = gtid % kFilmLanes;
+    const int lane0 = (int)(lane_id() & ~(kFilmLanes - 1u));   // the group's first lane: it owns the pixel's running sums
+    (void)lane0;
     unsigned long long nan_c = 0, neg_c = 0, inf_c = 0, splats = 0;
-    int32_t px, py;
-    if (slot < rc.n_pix_slots && slot_to_pixel(rc, slot, px, py)) {
+    int32_t px = 0, py = 0;
+    const bool live = slot < rc.n_pix_slots && slot_to_pixel(rc, slot, px, py);   // (uniform over a group)
+    if (live) {
         // tile pixel bounds (Film::get_film_tile, film.rs:125-140)
         uint32_t tile_slot = slot >> 8;
         uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
@@ -34,46 +45,56 @@ template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA 
         int64_t tb2 = min(f2i_sat(floorf((float)tx1 - 0.5f + rc.filter_radius[0])) + 1, (int64_t)rc.crop[2]);
         int64_t tb3 = min(f2i_sat(floorf((float)ty1 - 0.5f + rc.filter_radius[1])) + 1, (int64_t)rc.crop[3]);
         const float invrx = 1.0f / rc.filter_radius[0], invry = 1.0f / rc.filter_radius[1];
-        // Splats onto this thread's own pixel are accumulated in registers, seeded with the pixel's current value, and written
-        // back once: the additions happen in sample order exactly as before (and as FilmTile::add_sample does), without one
-        // L2 atomic per channel per sample. Splats onto other pixels (wide filters; for the box filter only the pfilm == px
-        // edge case) still use atomics; should one of them land on this pixel meanwhile, the final compare-and-swap fails
-        // and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
         const bool own_ok = px >= tb0 && px < tb2 && py >= tb1 && py < tb3;
         float *own = film_rgbw + 4 * ((size_t)(py - rc.crop[1]) * rc.film_w + (size_t)(px - rc.crop[0]));
         float seed[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
-        for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
-            const uint32_t pid = sl * rc.n_pix_slots + slot;
-            const float4 c0 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid], c2 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 2];
-            RGB L(c0.x, c0.y, c0.z);
-            fin(pid, L);
-            // integrator.rs:350-368
-            if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
-            else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
-            else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
-            if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
-            const float dx = c2.z - 0.5f, dy = c2.w - 0.5f;   // pfilm
-            int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
-            int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
-            for (int64_t y = p0y; y < p1y; ++y) {
-                const float fy = fabsf(((float)y - dy) * invry * 16.0f);
-                const uint32_t iy = min(f2u32_sat(floorf(fy)), 15u);
-                for (int64_t x = p0x; x < p1x; ++x) {
-                    const float fx = fabsf(((float)x - dx) * invrx * 16.0f);
-                    const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
-                    const float fw = filter_table[iy * 16 + ix];
-                    const RGB c = L * RGB(1.0f) * RGB(fw);
-                    if (own_ok && x == (int64_t)px && y == (int64_t)py) { acc[0] += c.r; acc[1] += c.g; acc[2] += c.b; acc[3] += fw; }
-                    else {
-                        float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
-                        atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+        if (own_ok && sub == 0u) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
+        for (uint32_t s0 = 0; s0 < rc.s_count; s0 += kFilmLanes) {   // one round: samples s0 .. s0 + kFilmLanes - 1, one per lane of the group
+            const uint32_t sl = s0 + sub;
+            // this lane's sample: what it adds to the group's own pixel (o_*; has_own: it does), everything else goes out as atomics right here
+            float o_r = 0.0f, o_g = 0.0f, o_b = 0.0f, o_w = 0.0f; uint32_t n_own = 0u;
+            if (sl < rc.s_count) {
+                const uint32_t pid = sl * rc.n_pix_slots + slot;
+                const float4 c0 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid], c2 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 2];
+                RGB L(c0.x, c0.y, c0.z);
+                fin(pid, L);
+                // integrator.rs:350-368
+                if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
+                else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
+                else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
+                if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
+                const float dx = c2.z - 0.5f, dy = c2.w - 0.5f;   // pfilm
+                int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
+                int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
+                for (int64_t y = p0y; y < p1y; ++y) {
+                    const float fy = fabsf(((float)y - dy) * invry * 16.0f);
+                    const uint32_t iy = min(f2u32_sat(floorf(fy)), 15u);
+                    for (int64_t x = p0x; x < p1x; ++x) {
+                        const float fx = fabsf(((float)x - dx) * invrx * 16.0f);
+                        const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
+                        const float fw = filter_table[iy * 16 + ix];
+                        const RGB c = L * RGB(1.0f) * RGB(fw);
+                        if (own_ok && x == (int64_t)px && y == (int64_t)py) { o_r = c.r; o_g = c.g; o_b = c.b; o_w = fw; n_own = 1u; }   // (a footprint names a pixel once)
+                        else {
+                            float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
+                            atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                        }
+                        splats++;
                     }
-                    splats++;
+                }
+            }
+            // the round's own-pixel terms, added by the group's first lane in sample order
+            if constexpr (kFilmLanes == 1u) { if (n_own) { acc[0] += o_r; acc[1] += o_g; acc[2] += o_b; acc[3] += o_w; } }
+            else {
+#pragma unroll
+                for (uint32_t j = 0; j < kFilmLanes; ++j) {
+                    const float r = __shfl(o_r, lane0 + (int)j), g = __shfl(o_g, lane0 + (int)j), b = __shfl(o_b, lane0 + (int)j), w = __shfl(o_w, lane0 + (int)j);
+                    const uint32_t has = (uint32_t)__shfl((int)n_own, lane0 + (int)j);
+                    if (sub == 0u && has) { acc[0] += r; acc[1] += g; acc[2] += b; acc[3] += w; }
                 }
             }
         }
-        if (own_ok) for (int k = 0; k < 4; ++k) {
+        if (own_ok && sub == 0u) for (int k = 0; k < 4; ++k) {
             if (__float_as_uint(acc[k]) == __float_as_uint(seed[k])) continue;
             const uint32_t old = atomicCAS((uint32_t *)(own + k), __float_as_uint(seed[k]), __float_as_uint(acc[k]));
             if (old != __float_as_uint(seed[k])) atomicAdd(own + k, acc[k] - seed[k]);
@@ -82,4 +103,3 @@ template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA 
     counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
     counter_add(&counters->san_inf, inf_c); counter_add(&counters->splats, splats);
 }
-

@@ -233,16 +233,20 @@ __global__ __launch_bounds__(256, (MAXL == 2 && MODE == 0 && DIFF == 4) ? PT_P2_
                                     const V3 pd = target - start;
                                     if (pd.x == 0.0f && pd.y == 0.0f && pd.z == 0.0f) rr_kill = true;  // empty chain: nfound == 0
                                     else {
-                                        bs.start_x[pid] = start.x; bs.start_y[pid] = start.y; bs.start_z[pid] = start.z;
-                                        bs.target_x[pid] = target.x; bs.target_y[pid] = target.y; bs.target_z[pid] = target.z;
-                                        bs.po_x[pid] = si.p.x; bs.po_y[pid] = si.p.y; bs.po_z[pid] = si.p.z;
-                                        bs.ns_x[pid] = bss.ns.x; bs.ns_y[pid] = bss.ns.y; bs.ns_z[pid] = bss.ns.z;
-                                        bs.ss_x[pid] = bss.ss.x; bs.ss_y[pid] = bss.ss.y; bs.ss_z[pid] = bss.ss.z;
-                                        bs.u1n[pid] = u1n; bs.mat[pid] = mi; bs.cnt[pid] = 0u;
-                                        if (is_sss) { bs.sa_r[pid] = bss_sa.r; bs.sa_g[pid] = bss_sa.g; bs.sa_b[pid] = bss_sa.b; bs.sc_r[pid] = bss_ss.r; bs.sc_g[pid] = bss_ss.g; bs.sc_b[pid] = bss_ss.b; }
+                                        // the probe state as whole quads (kernels.h: BssSoA): probe 32 B, frame 48 B, coef 32 B only where sigma_a / sigma_s are not the material's constants
+                                        float4 *const pq = bs.probe + (size_t)pid * BssSoA::kProbeQuads, *const fq = bs.frame + (size_t)pid * BssSoA::kFrameQuads;
+                                        pq[0] = make_float4(start.x, start.y, start.z, u1n); pq[1] = make_float4(target.x, target.y, target.z, __uint_as_float(mi));
+                                        fq[0] = make_float4(si.p.x, si.p.y, si.p.z, __uint_as_float(0u)); fq[1] = make_float4(bss.ns.x, bss.ns.y, bss.ns.z, __uint_as_float(0xffffffffu));
+                                        fq[2] = make_float4(bss.ss.x, bss.ss.y, bss.ss.z, __uint_as_float(mi));
+                                        n_bytes += 32 + 48;
+                                        if (is_sss && bss_coef_stored(s.n_textures, s.materials[mi])) {
+                                            float4 *const cq = bs.coef + (size_t)pid * BssSoA::kCoefQuads;
+                                            cq[0] = make_float4(bss_sa.r, bss_sa.g, bss_sa.b, 0.0f); cq[1] = make_float4(bss_ss.r, bss_ss.g, bss_ss.b, 0.0f);
+                                            n_bytes += 32;
+                                        }
                                         // base = {p: start, p_error: 0, n: 0}: spawn_rayto_point leaves the origin at `start`
                                         rq[0] = make_float4(start.x, start.y, start.z, pd.x); rq[1] = make_float4(pd.y, pd.z, 0.0f, 0.0f);
-                                        to_probe = true; push_probe = true; n_bytes += 24 * 4 + 24 + 4;
+                                        to_probe = true; push_probe = true; n_bytes += 24 + 4;
                                     }
                                 }
                             }

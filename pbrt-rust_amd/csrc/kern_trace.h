@@ -185,6 +185,9 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
     // PROBE: chain state of the lane. A chain with more than kProbeRing matches after the selected one is walked a second time
     // ("rewalk") up to match number `selected`; the rewalk's work is not counted (the reference indexes its Vec instead).
     uint32_t nfound = 0, seen = 0; bool rewalk = false;
+    // the chain's target, the BSSRDF's material and the selection number u1: read ONCE, with the ray record at the refill (one 32-byte probe record, kernels.h: BssSoA), and kept
+    // in registers across the chain's segments (until round 6 five dword gathers at every retired segment; the kernel runs three waves per SIMD with registers to spare)
+    V3 pr_target(0.0f, 0.0f, 0.0f); uint32_t pr_mat = PT_NONE; float pr_u1n = 0.0f;
     // the medium the chain's current probe ray travels in (volpath only reads it): every hit's MediumInterface is the primitive's own when it is a
     // transition, else this medium on both sides (primitive.rs:139-145); the next probe ray takes its medium from that interface (interaction.rs:38-43);
     // the first ray starts from an interaction without one (bssrdf.rs:362-366). Packed as inside | outside << 16, 0xffff = none.
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
             bool retire = state == ST_DONE;
             if constexpr (PROBE) {
                 if (retire) {   // one step of the chain loop of bssrdf.rs:373-395, in world space (every instance marker is popped)
-                    const V3 target(job.bs.target_x[pid], job.bs.target_y[pid], job.bs.target_z[pid]);
+                    const V3 target = pr_target;
                     bool finish = false, next_seg = false, chain_end = false;
                     if (hit_pkt != PT_NONE) {
                         SurfaceInteraction si;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                         const uint32_t hprim = s.leaf[hit_pkt].prim;
                         const MedIface hif = surface_iface(s, hprim, cur_med);
                         const uint32_t hif_packed = (hif.inside & 0xffffu) | (hif.outside << 16);
-                        if (packet_material(s, pfl, hprim) == job.bs.mat[pid]) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
+                        if (packet_material(s, pfl, hprim) == pr_mat) {   // Arc::ptr_eq(material), bssrdf.rs:385-391
                             if (!rewalk) {
                                 const uint32_t k = nfound % (uint32_t)kProbeRing;
                                 ring[(3 * k + 0) * 64] = make_uint4(hit_pkt, hit_inst, __float_as_uint(hb0), __float_as_uint(hb1));
@@ -255,8 +258,8 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                                 ring[(3 * k + 2) * 64] = make_uint4(__float_as_uint(rd.x), __float_as_uint(rd.y), __float_as_uint(rd.z), hif_packed);
                                 if (nfound == 0xffffffffu) atomicMax(job.error, (uint32_t)PT_ERR_PROBE_CHAIN); else nfound++;
                             } else {
-                                const uint32_t selected = min(f2u32_sat(job.bs.u1n[pid] * (float)nfound), nfound - 1u);
-                                if (seen == selected) { finish = true; job.bs.iface[pid] = hif_packed; }
+                                const uint32_t selected = min(f2u32_sat(pr_u1n * (float)nfound), nfound - 1u);
+                                if (seen == selected) { finish = true; job.bs.iface(pid) = hif_packed; }
                                 seen++;
                             }
                         }
@@ -269,19 +272,19 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                     if (chain_end) {
                         if (!rewalk && nfound > 0u) {
                             // bssrdf.rs:398: selected = clamp((u1 * nfound) as usize, 0, nfound - 1)
-                            const uint32_t selected = min(f2u32_sat(job.bs.u1n[pid] * (float)nfound), nfound - 1u);
+                            const uint32_t selected = min(f2u32_sat(pr_u1n * (float)nfound), nfound - 1u);
                             if (nfound - selected <= (uint32_t)kProbeRing) {
                                 const uint32_t k = selected % (uint32_t)kProbeRing;
                                 const uint4 e0 = ring[(3 * k + 0) * 64], e1 = ring[(3 * k + 1) * 64], e2 = ring[(3 * k + 2) * 64];
                                 hit_pkt = e0.x; hit_inst = e0.y; hb0 = __uint_as_float(e0.z); hb1 = __uint_as_float(e0.w); hb2 = __uint_as_float(e1.x);
                                 ro = V3(__uint_as_float(e1.y), __uint_as_float(e1.z), __uint_as_float(e1.w));
                                 rd = V3(__uint_as_float(e2.x), __uint_as_float(e2.y), __uint_as_float(e2.z));
-                                job.bs.iface[pid] = e2.w;
+                                job.bs.iface(pid) = e2.w;
                                 finish = true;
                             } else {   // the selected intersection has left the ring: walk again from the start, uncounted
                                 rewalk = true; seen = 0u; cur_med = PT_NONE;
                                 sv_nodes = n_nodes; sv_tris = n_tris; sv_rays = n_rays; sv_sph = n_sph;
-                                ro = V3(job.bs.start_x[pid], job.bs.start_y[pid], job.bs.start_z[pid]); rd = target - ro;
+                                { const float4 st = job.bs.probe[(size_t)pid * BssSoA::kProbeQuads]; ro = V3(st.x, st.y, st.z); } rd = target - ro;
                                 next_seg = true;
                             }
                         } else { hit_pkt = PT_NONE; finish = true; }   // nfound == 0: S = 0 (bssrdf.rs:397); a rewalk cannot end before `selected`
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                         }
                     } else {
                         if (rewalk) { n_nodes = sv_nodes; n_tris = sv_tris; n_rays = sv_rays; n_sph = sv_sph; }
-                        job.bs.cnt[pid] = nfound;
+                        job.bs.nfound(pid) = nfound;
                     }
                 }
             }
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
             const float r_t = (INST || PROBE) ? hit_t : (hit_pkt != PT_NONE ? t_max : 0.0f);
             if (retire) state = ST_IDLE;
             // (B)
-            bool get = false; v4f_ rr0 = {0.0f, 0.0f, 0.0f, 0.0f}, rr1 = rr0; bool per_ray_tmax = PT_SUB(per_ray_tmax) != 0u; float scalar_tmax = PT_SUB(scalar_tmax);
+            bool get = false; v4f_ rr0 = {0.0f, 0.0f, 0.0f, 0.0f}, rr1 = rr0, pb0 = rr0, pb1 = rr0; bool per_ray_tmax = PT_SUB(per_ray_tmax) != 0u; float scalar_tmax = PT_SUB(scalar_tmax);
             // the wave's queue window: lane l holds the path id of queue entry win_base + l
             auto load_window = [&](uint32_t base, uint32_t left) {
                 const uint32_t qi = base + lane; uint32_t w = 0u;
@@ -383,12 +386,14 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                     }
                     gcf4 *const rp = rays + (size_t)pid * ray_stride;
                     rr0 = rp[0]; rr1 = rp[1];   // one 32-byte record
+                    if constexpr (PROBE) { gcf4 *const pp = (gcf4 *)job.bs.probe + (size_t)pid * BssSoA::kProbeQuads; pb0 = pp[0]; pb1 = pp[1]; }   // ... and the chain's 32-byte probe record with it
                 }
             }
             // (every lane consumes what (A) and (B) requested, here, once: consumed only inside the conditional blocks below, the loads stay "possibly pending" on the
             //  paths around those blocks as far as the compiler's wait-count bookkeeping can tell, and it then waits for EVERYTHING -- the prefetch of (E) included --
             //  at the first reuse of one of their registers in the record step)
             asm volatile("" :: "v"(hit_prim), "v"(hit_fl), "v"(rr0), "v"(rr1));
+            if constexpr (PROBE) asm volatile("" :: "v"(pb0), "v"(pb1));
             // (C)
             if (retire) {
                 gf4 *o_hit = (gf4 *)PT_SUB(out_hit), *o_hit2 = (gf4 *)PT_SUB(out_hit2); gu32 *o_word = (gu32 *)PT_SUB(out_word); gf32 *o_t = (gf32 *)PT_SUB(out_t);
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(kTraceBlock, (MODE == 0 && !PROBE) ? ((QUADK != 0) 
                 sp = 0; pending = 0;
                 hit_pkt = PT_NONE; hit_t = 0.0f; hb0 = hb1 = hb2 = 0.0f;
                 in_inst = PT_NONE; hit_inst = PT_NONE; inst_hit = false;
-                if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; cur_med = PT_NONE; }
+                if (PROBE) { nfound = 0u; seen = 0u; rewalk = false; cur_med = PT_NONE; pr_u1n = pb0.w; pr_target = V3(pb1.x, pb1.y, pb1.z); pr_mat = __float_as_uint(pb1.w); }
                 n_rays++;
                 state = ST_DONE;
                 if (s.n_nodes > 0) {

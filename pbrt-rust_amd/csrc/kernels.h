@@ -49,6 +49,10 @@ constexpr int kLdsStackMinQuad = kLdsStackQuad < kLdsStackQuadInst ? kLdsStackQu
 constexpr int kSpillEntries = (kMaxStackQuad - kLdsStackMinQuad) > (kMaxStack - kLdsStackMinTwo) ? (kMaxStackQuad - kLdsStackMinQuad) : (kMaxStack - kLdsStackMinTwo);   // per-lane HBM stack entries behind the LDS ones
 constexpr int kSpillWords = 2 * kSpillEntries + 8;   // per lane in the HBM slab of a wave: the stack entries behind the LDS ones, then the world-space ray of a lane inside an instance (six words; the four-wide walk of instanced scenes keeps it here, kern_trace.h)
 constexpr int kTraceBlock = 256;
+#ifndef PT_FILM_LANES
+#define PT_FILM_LANES 1
+#endif
+constexpr uint32_t kFilmLanes = PT_FILM_LANES;   // threads per pixel slot of the film kernels (kern_film.h: film_slot); a power of two <= 64. 1: measured best (profiles/r6/NOTES.md section 4)
 constexpr int kProbeRing = 8;       // k_trace<.., PROBE>: matching intersections of a BSSRDF probe chain kept per lane (3 x uint4 each)
 
 // path flags (meta >> 24)
@@ -105,18 +109,25 @@ struct PathSoA {
 #undef PT_REC_U
 };
 constexpr int kPathBytes = 4 * (PathSoA::kCoreWords + PathSoA::kRayWords + PathSoA::kHitWords + PathSoA::kNeeWords + PathSoA::kMisWords);   // 256 B per path
-// Per-path subsurface probe state (allocated only for scenes with a subsurface material): the sampled probe segment of
-// TabulatedBSSRDF::sample_sp (bssrdf.rs:357-365), the outgoing point's frame, and the chain counters.
+// Per-path subsurface probe state (allocated only for scenes with a subsurface material), as 16-byte-quad RECORDS indexed by path id like PathSoA's (round 6; rounds 1-5
+// kept 25 arrays of 4-byte fields here: the probe kernel gathered five of them dword by dword at every retired segment, k_bssrdf seventeen, each a 64-byte sector
+// fetched for 4 bytes once the path ids of a queue were scattered -- k_bssrdf moved 5.5x its algorithmic bytes):
+//   probe  32 B  {start.xyz, u1n} {target.xyz, material id}           the sampled probe segment of TabulatedBSSRDF::sample_sp (bssrdf.rs:357-365): shade -> probe kernel,
+//                                                                      which reads it ONCE per chain (at the refill) and keeps target / material / u1n in registers
+//   frame  48 B  {po.xyz, nfound} {ns.xyz, iface} {ss.xyz, material}  the outgoing point and its frame (shade ->), the chain's count and the selected intersection's
+//                                                                      MediumInterface, inside | outside << 16, 0xffff = none (probe kernel ->): all k_bssrdf reads
+//   coef   32 B  {sigma_a.rgb, -} {sigma_s.rgb, -}                    sigma_a / sigma_s as evaluated at the entry point (subsurface.rs:100-101) -- written and read
+//                                                                      only where they are not the material's constants (bss_coef_stored: textured scenes, kdsubsurface)
 struct BssSoA {
-    float *start_x, *start_y, *start_z, *target_x, *target_y, *target_z;
-    float *po_x, *po_y, *po_z, *ns_x, *ns_y, *ns_z, *ss_x, *ss_y, *ss_z;
-    float *u1n;
-    float *sa_r, *sa_g, *sa_b, *sc_r, *sc_g, *sc_b;   // sigma_a / sigma_s as evaluated at the entry point (subsurface.rs:100-101: textures of the outgoing interaction)
-    uint32_t *mat;   // material id of the BSSRDF (Arc::ptr_eq test of the chain, bssrdf.rs:385-391)
-    uint32_t *cnt;   // nfound of the finished chain (written by k_trace<.., PROBE>, read by k_bssrdf)
-    uint32_t *iface; // volpath: the selected intersection's MediumInterface, inside | outside << 16 (0xffff = none), as the chain of probe rays handed it on
+    float4 *probe, *frame, *coef;
+    static constexpr int kProbeQuads = 2, kFrameQuads = 3, kCoefQuads = 2;
+    PT_HD uint32_t &nfound(size_t p) const { return reinterpret_cast<uint32_t *>(frame)[p * 12 + 3]; }
+    PT_HD uint32_t &iface(size_t p) const { return reinterpret_cast<uint32_t *>(frame)[p * 12 + 7]; }
 };
-constexpr int kBssSoAArrays = 25;
+constexpr int kBssBytes = 16 * (BssSoA::kProbeQuads + BssSoA::kFrameQuads + BssSoA::kCoefQuads);   // 112 B per path
+// sigma_a / sigma_s travel with the path when they are not a function of the material alone: any textured scene (the textures are evaluated at the entry point), and
+// kdsubsurface materials (their conversion, subsurface_from_diffuse, is a Catmull-Rom inversion nobody wants to run twice)
+PT_HD bool bss_coef_stored(uint32_t n_textures, const PtMaterial &m) { return n_textures > 0u || m.kd_subsurface != 0u; }
 
 struct QueueSet {
     uint32_t *ext[2];                 // pids with a continuation ray to trace (ping-pong)

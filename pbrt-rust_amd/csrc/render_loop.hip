@@ -85,15 +85,11 @@ int ensure_workspace(pt_scene *sc, size_t capacity, size_t film_px) {
         ps.ray = (float *)p; p += capacity * (size_t)PathSoA::kRayWords * 4;
         ps.hit = (float *)p; p += capacity * (size_t)PathSoA::kHitWords * 4;
         if (sc->has_bssrdf) {
-            e = hipMalloc(&sc->bss_slab, capacity * (size_t)kBssSoAArrays * 4);
+            e = hipMalloc(&sc->bss_slab, capacity * (size_t)kBssBytes);
             if (e != hipSuccess) { sc->bss_slab = nullptr; return oom("BSSRDF probe state", e); }
             BssSoA &bs = sc->bs;
-            float *bp = (float *)sc->bss_slab;
-            float **ba[] = {&bs.start_x, &bs.start_y, &bs.start_z, &bs.target_x, &bs.target_y, &bs.target_z, &bs.po_x, &bs.po_y, &bs.po_z,
-                            &bs.ns_x, &bs.ns_y, &bs.ns_z, &bs.ss_x, &bs.ss_y, &bs.ss_z, &bs.u1n, &bs.sa_r, &bs.sa_g, &bs.sa_b, &bs.sc_r, &bs.sc_g, &bs.sc_b};
-            for (float **f : ba) { *f = bp; bp += capacity; }
-            bs.mat = (uint32_t *)bp; bp += capacity; bs.cnt = (uint32_t *)bp; bp += capacity; bs.iface = (uint32_t *)bp;
-            static_assert(sizeof(ba) / sizeof(ba[0]) + 3 == kBssSoAArrays, "BssSoA layout");
+            float4 *bp = (float4 *)sc->bss_slab;
+            bs.probe = bp; bp += capacity * (size_t)BssSoA::kProbeQuads; bs.frame = bp; bp += capacity * (size_t)BssSoA::kFrameQuads; bs.coef = bp;
         }
         // queues: ext[2] + shade[2][classes] + shadow + mis (+ probe[2])
         size_t nq = 2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0);
@@ -297,7 +293,7 @@ constexpr double kPassMemFraction = 0.65;   // of the device's free memory
 uint32_t choose_pass_size(const pt_scene *sc, uint32_t n_pix_slots, uint32_t spp, uint32_t share, bool volpath) {
     // per path: the five state records, the queues, the probe state of scenes with subsurface materials and -- volpath through material-less shells -- the
     // 128-byte chain record (PathSoA::ext, allocated after the main slab: left out of this sum, a shell scene asked for ~1.4x its budget)
-    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? 4u * kBssSoAArrays : 0u)
+    const size_t per_path = (size_t)kPathBytes + 4u * (2 + 2 * n_class_queues(sc) + 2 + (sc->has_bssrdf ? 2 : 0)) + (sc->has_bssrdf ? (size_t)kBssBytes : 0u)
                             + ((volpath && sc->has_null_material) ? 4u * (size_t)PathSoA::kExtWords : 0u);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -588,9 +584,10 @@ int run_pass(pt_scene *sc, RenderConst &rc, const LightGrid &grid, bool rp_profi
     sc->begin("film", total);
     const bool fsph = sc->ds.n_spheres > 0 || sc->ds.n_instances > 0;
     sc->set_kernel(fin ? (fsph ? "k_film_final<true>" : "k_film_final<false>") : "k_film");
-    if (fin && fsph) hipLaunchKernelGGL((k_film_final<true>), dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
-    else if (fin) hipLaunchKernelGGL((k_film_final<false>), dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
-    else hipLaunchKernelGGL(k_film, dim3((rc.n_pix_slots + 255) / 256), dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    const dim3 fgrid((unsigned)(((size_t)rc.n_pix_slots * kFilmLanes + 255) / 256));   // kFilmLanes threads per pixel slot (kern_film.h)
+    if (fin && fsph) hipLaunchKernelGGL((k_film_final<true>), fgrid, dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    else if (fin) hipLaunchKernelGGL((k_film_final<false>), fgrid, dim3(256), 0, sc->stream, sc->ds, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
+    else hipLaunchKernelGGL(k_film, fgrid, dim3(256), 0, sc->stream, rc, sc->ps, sc->d_filter, sc->film_rgbw, sc->dc);
     sc->end();
     HIP_TRY(hipGetLastError());
     return PT_OK;

@@ -29,7 +29,7 @@ class Library:
     def __init__(self, path=LIB_PATH):
         if not os.path.exists(path):
             raise PtError(f"{path} not found: build it with __graft_entry__.build() (no CPU fallback exists)")
-        self.lib = A.bind(C.CDLL(path))
+        self.lib = A.bind(C.CDLL(path), strict=not os.environ.get("PT_LIB_PATH"))   # (PT_LIB_PATH: a kernel-variant library of an A/B run, possibly built from an older tree)
 
     def check(self, st, what=""):
         if st != A.PT_OK:
