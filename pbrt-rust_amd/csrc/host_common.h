@@ -178,7 +178,7 @@ struct pt_multi_scene {
 
 namespace pth {
 // scene_create.hip
-uint8_t material_class(const PtMaterial &m, bool specialise);
+uint8_t material_class(const PtMaterial &m, bool specialise, bool untextured);
 void dist1d(const std::vector<float> &func, std::vector<float> &cdf, float &func_int);
 // render_loop.hip
 int launch_trace(pt_scene *sc, int any, TraceJob job, uint32_t n_upper, bool probe = false);

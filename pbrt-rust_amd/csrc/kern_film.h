@@ -22,11 +22,77 @@ PT_DEV bool slot_to_pixel(const RenderConst &rc, uint32_t slot, int32_t &px, int
 // and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
 // kFilmLanes > 1 (-DPT_FILM_LANES=2|4|8|16, round 6's experiment for VERDICT r5 item 5): that many lanes share a pixel slot, lane j takes the samples j, j + kFilmLanes, ...
 // (their record loads and last path steps are independent) and each round's own-pixel terms are handed to the group's first lane with `__shfl` and added there IN ORDER, so the
-// film keeps its bits. Measured on C2 (profiles/r6/NOTES.md section 4): 1 lane 18.3 ms, 2: 19.6, 4: 20.0, 8: 21.1, 16: 24.3 -- the kernel is not short of independent chains, it
-// streams 102 GB at 5.6 TB/s, and a wave that reads four 1 KB runs instead of one 4 KB run does that worse. The default stays one lane.
+// film keeps its bits. Measured on C2 (profiles/r6/NOTES.md section 4): the one-thread loop below 18.3 ms; the lanes loop with 1 / 2 / 4 / 8 / 16 lanes 20.1 / 19.6 / 20.0 / 21.1 /
+// 24.3 -- the kernel is not short of independent chains, it streams 102 GB at 5.6 TB/s. The default stays one lane, in round 5's loop (film_slot_one).
 // `fin(pid, L)`: called for every sample before it is sanitised and splatted (k_film: nothing; k_film_final, kern_aux.h: the path's last step -- its pending
 // next-event estimate, the environment's Le -- where the plain path integrator has no k_shade_miss pass any more).
-template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA &ps, const float *filter_table, float *film_rgbw, DevCounters *counters, Fin fin) {
+// ---- one thread per pixel slot (rounds 1-6: the production form) ----
+template <class Fin> PT_DEV void film_slot_one(const RenderConst &rc, const PathSoA &ps, const float *filter_table, float *film_rgbw, DevCounters *counters, Fin fin) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long nan_c = 0, neg_c = 0, inf_c = 0, splats = 0;
+    int32_t px, py;
+    if (slot < rc.n_pix_slots && slot_to_pixel(rc, slot, px, py)) {
+        // tile pixel bounds (Film::get_film_tile, film.rs:125-140)
+        uint32_t tile_slot = slot >> 8;
+        uint32_t tile = rc.tile_rank + tile_slot * rc.tile_world;
+        int32_t tx0 = rc.sample_bounds[0] + (int32_t)((tile % rc.ntx) * 16u), ty0 = rc.sample_bounds[1] + (int32_t)((tile / rc.ntx) * 16u);
+        int32_t tx1 = min(tx0 + 16, rc.sample_bounds[2]), ty1 = min(ty0 + 16, rc.sample_bounds[3]);
+        int64_t tb0 = max(f2i_sat(ceilf((float)tx0 - 0.5f - rc.filter_radius[0])), (int64_t)rc.crop[0]);
+        int64_t tb1 = max(f2i_sat(ceilf((float)ty0 - 0.5f - rc.filter_radius[1])), (int64_t)rc.crop[1]);
+        int64_t tb2 = min(f2i_sat(floorf((float)tx1 - 0.5f + rc.filter_radius[0])) + 1, (int64_t)rc.crop[2]);
+        int64_t tb3 = min(f2i_sat(floorf((float)ty1 - 0.5f + rc.filter_radius[1])) + 1, (int64_t)rc.crop[3]);
+        const float invrx = 1.0f / rc.filter_radius[0], invry = 1.0f / rc.filter_radius[1];
+        // Splats onto this thread's own pixel are accumulated in registers, seeded with the pixel's current value, and written
+        // back once: the additions happen in sample order exactly as before (and as FilmTile::add_sample does), without one
+        // L2 atomic per channel per sample. Splats onto other pixels (wide filters; for the box filter only the pfilm == px
+        // edge case) still use atomics; should one of them land on this pixel meanwhile, the final compare-and-swap fails
+        // and the delta is added atomically instead (contribution preserved, order then unspecified as for any such splat).
+        const bool own_ok = px >= tb0 && px < tb2 && py >= tb1 && py < tb3;
+        float *own = film_rgbw + 4 * ((size_t)(py - rc.crop[1]) * rc.film_w + (size_t)(px - rc.crop[0]));
+        float seed[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (own_ok) for (int k = 0; k < 4; ++k) { seed[k] = __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); acc[k] = seed[k]; }
+        for (uint32_t sl = 0; sl < rc.s_count; ++sl) {
+            const uint32_t pid = sl * rc.n_pix_slots + slot;
+            const float4 c0 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid], c2 = reinterpret_cast<const float4 *>(ps.core)[4 * (size_t)pid + 2];
+            RGB L(c0.x, c0.y, c0.z);
+            fin(pid, L);
+            // integrator.rs:350-368
+            if (L.has_nans()) { L = RGB(0.0f); nan_c++; }
+            else if (L.y() < -1.0e-5f) { L = RGB(0.0f); neg_c++; }
+            else if (__builtin_isinf(L.y())) { L = RGB(0.0f); inf_c++; }
+            if (L.y() > rc.max_sample_luminance) L = L * RGB(rc.max_sample_luminance / L.y());
+            const float dx = c2.z - 0.5f, dy = c2.w - 0.5f;   // pfilm
+            int64_t p0x = max(f2i_sat(ceilf(dx - rc.filter_radius[0])), tb0), p0y = max(f2i_sat(ceilf(dy - rc.filter_radius[1])), tb1);
+            int64_t p1x = min(f2i_sat(floorf(dx + rc.filter_radius[0])) + 1, tb2), p1y = min(f2i_sat(floorf(dy + rc.filter_radius[1])) + 1, tb3);
+            for (int64_t y = p0y; y < p1y; ++y) {
+                const float fy = fabsf(((float)y - dy) * invry * 16.0f);
+                const uint32_t iy = min(f2u32_sat(floorf(fy)), 15u);
+                for (int64_t x = p0x; x < p1x; ++x) {
+                    const float fx = fabsf(((float)x - dx) * invrx * 16.0f);
+                    const uint32_t ix = min(f2u32_sat(floorf(fx)), 15u);
+                    const float fw = filter_table[iy * 16 + ix];
+                    const RGB c = L * RGB(1.0f) * RGB(fw);
+                    if (own_ok && x == (int64_t)px && y == (int64_t)py) { acc[0] += c.r; acc[1] += c.g; acc[2] += c.b; acc[3] += fw; }
+                    else {
+                        float *dst = film_rgbw + 4 * ((size_t)(y - rc.crop[1]) * rc.film_w + (size_t)(x - rc.crop[0]));
+                        atomicAdd(dst + 0, c.r); atomicAdd(dst + 1, c.g); atomicAdd(dst + 2, c.b); atomicAdd(dst + 3, fw);
+                    }
+                    splats++;
+                }
+            }
+        }
+        if (own_ok) for (int k = 0; k < 4; ++k) {
+            if (__float_as_uint(acc[k]) == __float_as_uint(seed[k])) continue;
+            const uint32_t old = atomicCAS((uint32_t *)(own + k), __float_as_uint(seed[k]), __float_as_uint(acc[k]));
+            if (old != __float_as_uint(seed[k])) atomicAdd(own + k, acc[k] - seed[k]);
+        }
+    }
+    counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
+    counter_add(&counters->san_inf, inf_c); counter_add(&counters->splats, splats);
+}
+
+// ---- kFilmLanes threads per pixel slot (round 6's experiment) ----
+template <class Fin> PT_DEV void film_slot_lanes(const RenderConst &rc, const PathSoA &ps, const float *filter_table, float *film_rgbw, DevCounters *counters, Fin fin) {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t slot = gtid / kFilmLanes, sub = gtid % kFilmLanes;
     const int lane0 = (int)(lane_id() & ~(kFilmLanes - 1u));   // the group's first lane: it owns the pixel's running sums
@@ -102,4 +168,10 @@ template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA 
     }
     counter_add(&counters->san_nan, nan_c); counter_add(&counters->san_neg, neg_c);
     counter_add(&counters->san_inf, inf_c); counter_add(&counters->splats, splats);
+}
+
+// the film kernels call this: one thread per pixel slot (the measured best), or the lanes-per-pixel experiment when built with -DPT_FILM_LANES > 1
+template <class Fin> PT_DEV void film_slot(const RenderConst &rc, const PathSoA &ps, const float *filter_table, float *film_rgbw, DevCounters *counters, Fin fin) {
+    if constexpr (kFilmLanes == 1u) film_slot_one(rc, ps, filter_table, film_rgbw, counters, fin);
+    else film_slot_lanes(rc, ps, filter_table, film_rgbw, counters, fin);
 }

@@ -16,8 +16,8 @@ constexpr int kNumClasses = 11;     // material-sorted shade queues, one per sha
 //       // and by lobe SET, the kernels specialised for one material's BxDFs (round 5: a class each, so that one substrate, rough glass or translucent
 //       // material in a scene no longer sends every metal / plastic / uber vertex back to the general kernel of its lobe count):
 //       // 7 metal (k_shade<1, ., 3>), 8 plastic-like: plastic and the opaque uber without specular terms (k_shade<2, ., 4>), 9 uber (k_shade<5, ., 5>),
-//       // 10 smooth subsurface (k_shade<1, ., 6>). The specialised forms exist for the untextured path integrator: material_class() (scene_create.hip)
-//       // hands these classes out only to scenes without textures, and the volumetric router folds them back (class_general).
+//       // 10 smooth subsurface (k_shade<1, ., 6>). Classes 7-9 are handed out in textured scenes too (round 6: a texture changes a material's parameters, not its lobe set),
+//       // class 10 in untextured scenes only (material_class(), scene_create.hip); the volumetric router folds all four back (class_general).
 constexpr int kMissClass = 4, kMediumClass = 5, kSpecClass = 6, kMetalClass = 7, kPlasticClass = 8, kUberClass = 9, kSssClass = 10;
 PT_HD uint32_t class_general(uint32_t c) { return c == (uint32_t)kMetalClass ? 1u : c == (uint32_t)kPlasticClass ? 2u : (c == (uint32_t)kUberClass || c == (uint32_t)kSssClass) ? 3u : c; }
 constexpr int kRouteSlots = 12;        // most staging queues a k_route block holds

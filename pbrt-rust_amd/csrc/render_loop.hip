@@ -272,10 +272,10 @@ template <int MAXL, int DIFF = 0> void launch_shade(pt_scene *sc, const RenderCo
 #endif
     const uint32_t blocks = std::min<uint32_t>((upper + 255) / 256, (uint32_t)g_num_cus * PT_SHADE_BLOCKS_PER_CU);  // persistent blocks: the LDS Sobol' table is staged once per block
     const int mode = rc.volpath ? 3 : sc->ds.n_textures > 0 ? 2 : (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) ? 1 : 0;
-    if (DIFF >= 3 && mode >= 2) { launch_shade<MAXL, 0>(sc, rc, grid, job, upper); return; }   // (the metal-only kernel exists for the untextured path integrator)
+    if (DIFF >= 3 && (mode == 3 || (DIFF == 6 && mode == 2))) { launch_shade<MAXL, 0>(sc, rc, grid, job, upper); return; }   // (volpath folds the lobe-set classes back; the smooth-subsurface form is untextured only)
     sc->set_kernel("k_shade<" + std::to_string(MAXL) + ", " + std::to_string(mode) + ", " + std::to_string(DIFF) + ">");
     if (rc.volpath) hipLaunchKernelGGL((k_shade<MAXL, 3, (DIFF >= 2) ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
-    else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF >= 3 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
+    else if (sc->ds.n_textures > 0) hipLaunchKernelGGL((k_shade<MAXL, 2, DIFF == 6 ? 0 : DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else if (sc->ds.n_spheres > 0 || sc->ds.n_instances > 0 || rc.halton.enabled) hipLaunchKernelGGL((k_shade<MAXL, 1, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
     else hipLaunchKernelGGL((k_shade<MAXL, 0, DIFF>), dim3(blocks), dim3(256), 0, sc->stream, sc->ds, rc, g_tabs, grid, sc->ps, job);
 }

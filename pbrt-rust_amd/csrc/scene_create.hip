@@ -4,8 +4,9 @@
 namespace pth {
 // Shade class of a material = the kernel its vertices are shaded by (kernels.h: kNumClasses): by the number of BxDFs the material
 // can produce, decided from its constant parameters (a textured parameter can take any value).
-uint8_t material_class(const PtMaterial &m, bool specialise) {
-    // `specialise`: hand out the classes of the lobe-SET kernels (metal, plastic-like, uber, smooth subsurface; kernels.h) -- untextured scenes only, PT_SHADE_SPECIALISE != 0
+uint8_t material_class(const PtMaterial &m, bool specialise, bool untextured) {
+    // `specialise`: hand out the classes of the lobe-SET kernels (metal, plastic-like, uber; kernels.h; PT_SHADE_SPECIALISE != 0) -- textured scenes too since round 6 (ADVICE r5:
+    // one texture anywhere used to send every metal / plastic / uber vertex of the scene to the general kernels); the smooth-subsurface class in untextured scenes only
     auto textured = [&](int slot) { return m.tex[slot] >= 0; };
     auto black = [](const float c[3]) { return !(c[0] > 0.0f) && !(c[1] > 0.0f) && !(c[2] > 0.0f); };   // .clamps(0, inf).is_black()
     switch (m.type) {
@@ -24,7 +25,7 @@ uint8_t material_class(const PtMaterial &m, bool specialise) {
         return specialise ? (uint8_t)kUberClass : 3;
     }
     case PT_MAT_SUBSURFACE:   // constant zero roughness: one FresnelSpecular lobe + the BSSRDF (subsurface.rs:84-109)
-        if (specialise && m.u_roughness == 0.0f && m.v_roughness == 0.0f && !textured(PT_MP_U_ROUGHNESS) && !textured(PT_MP_V_ROUGHNESS)) return (uint8_t)kSssClass;
+        if (specialise && untextured && m.u_roughness == 0.0f && m.v_roughness == 0.0f && !textured(PT_MP_U_ROUGHNESS) && !textured(PT_MP_V_ROUGHNESS)) return (uint8_t)kSssClass;
         return 3;
     default: return 3;
     }
@@ -368,10 +369,8 @@ int pt_scene_create(const PtSceneDesc *d, pt_scene **out) {
     if (d->env_texels) { sc->env_w = d->env_width; sc->env_h = d->env_height; for (int k = 0; k < 3; ++k) sc->env_texel0[k] = d->env_power_lookup[k]; }
     {
         std::vector<uint8_t> mc(std::max<uint32_t>(1, d->n_materials), 0);
-        // (the lobe-set kernels exist for the untextured path integrator: a textured scene keeps the general classes, and the volumetric router folds the
-        //  specialised ones back into them -- kern_aux.h: k_medium_route)
-        const bool specialise = g_shade_specialise && d->n_textures == 0;
-        for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i], specialise); sc->class_used[mc[i]] = true; }
+        // (the volumetric router folds the lobe-set classes back into the lobe-count ones -- kern_aux.h: k_medium_route)
+        for (uint32_t i = 0; i < d->n_materials; ++i) { mc[i] = material_class(d->materials[i], g_shade_specialise, d->n_textures == 0); sc->class_used[mc[i]] = true; }
         UP(mat_class, mc.data(), mc.size());
         std::vector<DevBssTable> bt(d->n_bssrdf_tables);
         for (uint32_t i = 0; i < d->n_bssrdf_tables; ++i) {

@@ -10,15 +10,18 @@ PT_INST_SHADE(1, PT_TU_MODE, 1) PT_INST_SHADE(1, PT_TU_MODE, 0)
 #if PT_TU_MODE != 3   // (the volumetric integrator has no specular-only class: it estimates direct light at every vertex)
 PT_INST_SHADE(1, PT_TU_MODE, 2)
 #endif
-#if PT_TU_MODE < 2     // class 1 of scenes whose one-lobe materials are all metals; class 3 of scenes whose many-lobe materials are all smooth subsurface materials
-PT_INST_SHADE(1, PT_TU_MODE, 3) PT_INST_SHADE(1, PT_TU_MODE, 6)
+#if PT_TU_MODE < 3     // the metal class (round 6: textured scenes too -- a texture changes a metal's parameters, not its lobe set)
+PT_INST_SHADE(1, PT_TU_MODE, 3)
+#endif
+#if PT_TU_MODE < 2     // the smooth-subsurface class: untextured scenes only (its kernel takes sigma_a / sigma_s from the material)
+PT_INST_SHADE(1, PT_TU_MODE, 6)
 #endif
 #else
 PT_INST_SHADE(PT_TU_MAXL, PT_TU_MODE, 0)
-#if PT_TU_MAXL == 5 && PT_TU_MODE < 2   // class 3 of scenes whose many-lobe materials are all ubers
+#if PT_TU_MAXL == 5 && PT_TU_MODE < 3   // the uber class
 PT_INST_SHADE(5, PT_TU_MODE, 5)
 #endif
-#if PT_TU_MAXL == 2 && PT_TU_MODE < 2   // class 2 of scenes whose two-lobe materials are all plastic-like (no rough glass)
+#if PT_TU_MAXL == 2 && PT_TU_MODE < 3   // the plastic-like class (plastic, opaque uber without specular terms)
 PT_INST_SHADE(2, PT_TU_MODE, 4)
 #endif
 #endif
