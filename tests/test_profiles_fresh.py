@@ -1,6 +1,7 @@
 """tools/check_profiles.py as a test: the round's committed profile record must belong to the code in the tree -- every file under
 profiles/r6/final/, every record of profiles/pmc_traffic.json and the numbers DESIGN.md section 7 quotes from them. A change to the device sources after the
 record was taken turns this test red until the record is re-taken (tools/r6_profiles.sh): stale evidence fails loudly instead of being quoted."""
+import json
 import os
 import subprocess
 import sys
@@ -19,7 +20,7 @@ def test_the_check_notices_a_foreign_file_and_a_changed_one(tmp_path):
     import check_profiles as cp
     d = tmp_path / "profiles" / "r6" / "final"; d.mkdir(parents=True)
     for n in ("a.txt", "b.csv", "bench.json"):
-        (d / n).write_text("{}" if n.endswith("json") else n)
+        (d / n).write_text(json.dumps({"code_hash": cp.code_hash(ROOT), "roofline": {"avg_launch_ms": 1.0, "kernel": "k"}}) if n.endswith("json") else n)
     cp.write_manifest(str(d))
     saved = cp.final_dir
     cp.final_dir = lambda rnd=cp.ROUND: str(d)
