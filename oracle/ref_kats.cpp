@@ -94,6 +94,37 @@ int orc_test_float_bits(int iters, int *n_tested) {
     return failures;
 }
 
+// tests/sampling.rs:24-53 scrambled_radical_inverse_test: for dim < n_dims (the reference: 128), RNG::new(dim), base = PRIMES[dim], the permutation base-1 .. 0 shuffled by
+// `shuffle(&mut perm, len, 1, &mut rng)` (sampling.rs:178-186), and the seven indices of the test. The Rust file compares scrambled_radical_inverse with a hand-rolled
+// digit loop through a `relative_eq!` whose result it DROPS -- and the hand-rolled loop is broken (`val *= ..` on a zero, `n *= inv_base as u32`): it computes no reference
+// value at all. The twin compares the oracle's scrambled_radical_inverse_base (ref_sampler.h, lowdiscrepancy.rs:469-484: what HaltonSampler::sample_dimension calls) with
+// the value the radical inverse HAS -- sum_i perm[d_i] b^-(i+1) over the index's digits plus perm[0] for every digit beyond them (perm[0] b^-k / (b - 1)), in exact
+// rational arithmetic carried in long double -- to the test's epsilon 1e-5 (relative). Returns the number of violations; *worst = largest relative deviation.
+int orc_test_scrambled_radical_inverse(int n_dims, double *worst) {
+    const HaltonTables &T = halton_tables();
+    static const uint32_t indices[7] = {0u, 1u, 2u, 1151u, 32351u, 4363211u, 681122u};
+    int failures = 0; double w = 0.0;
+    for (int dim = 0; dim < n_dims; ++dim) {
+        Rng rng((uint64_t)dim);
+        const uint32_t base = T.primes[dim];
+        std::vector<uint16_t> perm(base);
+        for (uint32_t i = 0; i < base; ++i) perm[i] = (uint16_t)(base - 1 - i);
+        for (uint32_t i = 0; i < base; ++i) { const uint32_t other = i + rng.below(base - i); std::swap(perm[i], perm[other]); }
+        for (uint32_t index : indices) {
+            long double val = 0.0L, scale = 1.0L / (long double)base; uint32_t n = index;
+            while (n > 0) { val += (long double)perm[n % base] * scale; scale /= (long double)base; n /= base; }
+            val += (long double)perm[0] * scale * (long double)base / ((long double)base - 1.0L);   // perm[0] * sum_{j >= k+1} b^-j
+            const double got = (double)scrambled_radical_inverse_base(base, perm.data(), index);
+            const double want = (double)(val < 0.99999994L ? val : 0.99999994L);   // min(.., ONE_MINUS_EPSILON) as the function clamps
+            const double rel = std::fabs(got - want) / std::fmax(std::fmax(std::fabs(got), std::fabs(want)), 1e-30);
+            if (rel > w) w = rel;
+            if (!(rel <= 1.0e-5)) ++failures;
+        }
+    }
+    if (worst) *worst = w;
+    return failures;
+}
+
 // tests/bitops.rs:7-64 on the oracle's log2_int / round_up_pow2_32 (ref_sampler.h: SobolSampler::new and the MIPMap resampler use
 // them); the i64 variants of the reference are the same bit tricks on 64 bits and are restated here only for the test.
 int orc_test_bitops(void) {

@@ -264,4 +264,44 @@ int orc_test_triangle_watertight(int n_seeds, int as_written, float *verts, uint
     }
     return failures;
 }
+
+// tests/shapes.rs:490-535 partial_sphere_normal: for i < n_seeds, RNG::new(i): a random partial sphere (pexp(rng, 4) radius, zmin / zmax / phimax each clipped with
+// probability 1/2), a ray from pexp(rng, 8)^3 to a random point of the shape's bounding box (normalised with probability 1/2); where Sphere::intersect finds a hit, the
+// interaction's normal must point along the hit point: dot(normalize(n), normalize(p)) = 1. The Rust file evaluates `relative_eq!(1.0, dot, epsilon = 1e-5)` and drops the
+// result; here it is an assertion. Returns the number of hits with |dot - 1| > 1e-5 (relative_eq's max(|a|, |b|) * epsilon form); *n_tested = hits found; *worst = max |dot - 1|.
+int orc_test_partial_sphere_normal(int n_seeds, int *n_tested, double *worst) {
+    auto pexp = [](RNG &rng, float e) { const float logu = lerp(rng.uniform_float(), -e, e); return std::pow(10.0f, logu); };
+    int failures = 0, tested = 0; double w = 0.0;
+    for (int i = 0; i < n_seeds; ++i) {
+        RNG rng((uint64_t)i);
+        const float radius = pexp(rng, 4.0f);
+        const float zmin = (rng.uniform_float() < 0.5f) ? -radius : lerp(rng.uniform_float(), -radius, radius);
+        const float zmax = (rng.uniform_float() < 0.5f) ? radius : lerp(rng.uniform_float(), -radius, radius);
+        const float phimax = (rng.uniform_float() < 0.5f) ? 360.0f : rng.uniform_float() * 360.0f;
+        PtSphere S; std::memset(&S, 0, sizeof S);   // Sphere::new (sphere.rs:31-50)
+        for (int k = 0; k < 4; ++k) S.object_to_world[5 * k] = S.world_to_object[5 * k] = 1.0f;
+        S.radius = radius;
+        S.z_min = clampv(std::fmin(zmin, zmax), -radius, radius); S.z_max = clampv(std::fmax(zmin, zmax), -radius, radius);
+        S.theta_min = std::acos(clampv(std::fmin(zmin, zmax) / radius, -1.0f, 1.0f));
+        S.theta_max = std::acos(clampv(std::fmax(zmin, zmax) / radius, -1.0f, 1.0f));
+        S.phi_max = (PI / 180.0f) * clampv(phimax, 0.0f, 360.0f);
+        Scene s; s.spheres.push_back(S);
+        V3 o; o.x = pexp(rng, 8.0f); o.y = pexp(rng, 8.0f); o.z = pexp(rng, 8.0f);
+        const Bounds3 bbox = s.sphere_world_bound(0);
+        V3 t; t.x = rng.uniform_float(); t.y = rng.uniform_float(); t.z = rng.uniform_float();
+        const V3 p2 = bbox.lerp3(t);
+        Ray r(o, p2 - o, INF, 0.0f);
+        if (rng.uniform_float() < 0.5f) r.d = normalize(r.d);
+        SurfaceInteraction isect; Float thit;
+        if (!s.sphere_intersect(0, r, thit, isect, true)) continue;
+        ++tested;
+        const Float d = dot(normalize(isect.n), normalize(isect.p));
+        const double err = std::fabs((double)d - 1.0);
+        if (err > w) w = err;
+        if (!(err <= 1.0e-5 * std::fmax(1.0, std::fabs((double)d)))) ++failures;
+    }
+    if (n_tested) *n_tested = tested;
+    if (worst) *worst = w;
+    return failures;
+}
 }  // extern "C"

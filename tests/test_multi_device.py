@@ -97,6 +97,18 @@ def test_eight_replicas_and_two_film_sizes_on_one_multiscene(pkg, gpu):
 
 
 @pytest.mark.gpu
+def test_a_replica_that_cannot_be_created_fails_the_call_and_leaks_nothing(pkg, gpu):
+    """Round 6: replicas 1.. are created concurrently on host threads of their own; one that fails (here: a device ordinal that does not exist) must fail
+    pt_multi_scene_create with ITS error text handed back to the caller's thread, tear the finished replicas down, and leave the library usable."""
+    sd, rp = pkg.scenes.ganesha_scale(n=16, xres=64, yres=48, spp=2).world_end()
+    with pytest.raises(Exception, match=r"replica 2 \(device 99\).*out of range"):
+        pkg.MultiScene(gpu, sd, [0, 0, 99, 0])
+    ref = pkg.Scene(gpu, sd).render(rp)
+    film = pkg.MultiScene(gpu, sd, [0, 0]).render(rp)
+    assert np.array_equal(film[..., 3], ref[..., 3])
+
+
+@pytest.mark.gpu
 def test_distinct_devices_equal_the_plain_render(pkg, gpu):
     """Needs two or more visible GPUs (skipped on the one-GPU test box): peer access, hipMemcpyPeerAsync into the landing buffers and
     the per-thread device binding, on really different devices."""

@@ -786,3 +786,21 @@ def test_distribution1d_continuous_twin(oracle, pkg):
     dist1d_continuous_checks(sample)
     # count() == 5 (:263): the discrete pdfs of the same distribution sum to one over its five entries
     assert abs(sum(oracle.lib.orc_dist1d_discrete_pdf(func.ctypes.data_as(A.fp), 5, i) for i in range(5)) - 1.0) < 1e-6
+
+
+def test_scrambled_radical_inverse_twin(oracle):
+    """tests/sampling.rs:24-53 scrambled_radical_inverse_test (the Halton sampler's dimensions >= 2): 128 bases, RNG::new(dim)-shuffled permutations, the test's seven indices.
+    The Rust test drops its `relative_eq!` and its hand-rolled expectation is broken (oracle/ref_kats.cpp); the twin asserts the function against the exact digit sum."""
+    worst = C.c_double()
+    oracle.lib.orc_test_scrambled_radical_inverse.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_scrambled_radical_inverse(128, C.byref(worst)) == 0
+    assert worst.value < 1.0e-6
+
+
+def test_partial_sphere_normal_twin(oracle):
+    """tests/shapes.rs:490-535 partial_sphere_normal: 10 000 seeds of random partial spheres; at every hit Sphere::intersect finds, the normal points along the hit point
+    (the Rust file's dropped `relative_eq!(1.0, dot, epsilon = 1e-5)` as an assertion)."""
+    n = C.c_int(); worst = C.c_double()
+    oracle.lib.orc_test_partial_sphere_normal.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert oracle.lib.orc_test_partial_sphere_normal(10000, C.byref(n), C.byref(worst)) == 0
+    assert n.value > 3000 and worst.value <= 1.0e-5
