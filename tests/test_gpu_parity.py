@@ -716,15 +716,16 @@ def test_records_and_packets_beyond_four_gigabytes(pkg, gpu, oracle, tmp_path, t
     np.testing.assert_allclose(g["film"][..., :3], ref[..., :3], rtol=3e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("as_written", [0, 1])
-def test_triangle_watertight_twin_through_the_hip_path(pkg, gpu, oracle, as_written):
+@pytest.mark.parametrize("as_written,split", [(0, "sah"), (1, "sah"), (0, "hlbvh")])
+def test_triangle_watertight_twin_through_the_hip_path(pkg, gpu, oracle, as_written, split):
     """tests/shapes.rs:36-146 triangle_watertight through pt_trace_closest: the reference's mesh (RNG::new(12111), 16 x 16) as a scene, the 200 000 rays of its
-    100 000 seeds (oracle/ref_kats_shapes.cpp generates both from the same PCG32 streams). Every ray must hit (closed mesh; on the mesh as the Rust file
+    100 000 seeds (oracle/ref_kats_shapes.cpp generates both from the same PCG32 streams); under the reference's SAH tree and under the GPU-built HLBVH. Every ray must hit (closed mesh; on the mesh as the Rust file
     writes it, which is open along phi = 0 -- tests/test_oracle_kats.py -- exactly the rays that hit no triangle one by one must miss), and (prim, t, b) must be
     the oracle's BVHAccel::intersect over the same scene, bit for bit."""
     from test_oracle_kats import _watertight
     failures, v, idx, ro, rd, nh = _watertight(oracle, 100000, as_written)
     b = pkg.host.SceneBuilder()
+    b.split_method = split    # "hlbvh": the GPU-built tree (multi-triangle leaves, another visiting order): the vertex rays' near-ties resolve by THAT tree's order, on device as in the oracle
     b.trianglemesh(v, idx)
     sd, _ = b.world_end()
     g = pkg.Scene(gpu, sd); orc = oracle.scene(sd)
