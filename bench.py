@@ -124,7 +124,8 @@ def build_roofline(kstats, config, eff_spp_per_pass, workload_key):
                                  "the memory system's loaded latency (profiles/r4/tcp_counters_*.txt; DESIGN.md section 7)" % (None if hbm_frac is None else round(hbm_frac, 3), valu_busy),
                "unknown": "no committed counter record of this kernel from these sources (profiles/pmc_traffic.json: traffic_code_match)"}[bound]
     return dict(
-        bound=bound, kernel=name, launch_kinds=g["kinds"], unit="GB/s", peak=HBM_PEAK_GBS,
+        bound=bound, roof="hbm",   # `roof`: the roofline `achieved` / `peak` / `frac` / `traffic` are stated against (HBM, never MFMA -- no dense contraction on this path); `bound`: what the kernel's own counters show limits it
+        kernel=name, launch_kinds=g["kinds"], unit="GB/s", peak=HBM_PEAK_GBS,
         achieved=round(achieved, 2),
         achieved_kind="ALGORITHMIC bytes / launch time (cache-inclusive: mostly L1/L2-served, can exceed the HBM peak)",
         algorithmic_over_hbm_peak=round(achieved / HBM_PEAK_GBS, 5),
