@@ -1,5 +1,5 @@
 """The N > 1 path: 16x16 sample tiles dealt round-robin to ranks, per-rank films summed with one reduce.
-Runs with world_size 2 on CPU (gloo). The per-rank compute here is the CPU oracle (tile_rank / tile_world have
+Runs with world_size 2 and 8 on CPU (gloo). The per-rank compute here is the CPU oracle (tile_rank / tile_world have
 the same meaning in PtRenderParams for both back ends); on the GPU box the same plumbing runs over RCCL in bench.py."""
 import os
 import socket
@@ -35,19 +35,25 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_tile_sharding_world2_gloo(tmp_path, pkg, oracle):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tile_sharding_gloo(tmp_path, pkg, oracle, world):
+    """world 2, and 8 -- the world size of the driver's SCALE run -- as gloo processes on the CPU: every pixel owned by exactly one rank, ownership = tile index % world, the
+    reduced film bit-identical to one render (box filter: tiles map to disjoint pixels)."""
     out = str(tmp_path / "film.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r = np.load(out)
     sd, rp = pkg.scenes.ganesha_scale(n=12, xres=80, yres=48, spp=4).world_end()
     full = oracle.scene(sd).render(rp, nthreads=1)
-    masks = r["masks"]
-    assert not (masks[0] & masks[1]).any()              # box filter: tiles map to disjoint pixels
-    assert (masks[0] | masks[1]).all()
-    # tile t belongs to rank t % 2 (tiles are 16x16, 5 per row here)
+    masks = r["masks"].astype(np.int64)
+    assert (masks.sum(axis=0) == 1).all()               # disjoint and complete
+    # tile t belongs to rank t % world (tiles are 16x16, 5 per row here: 15 tiles)
     owner = np.zeros((48, 80), np.int64)
     for ty in range(3):
         for tx in range(5):
-            owner[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = (ty * 5 + tx) % 2
-    assert np.array_equal(masks[1].astype(np.int64), owner)
+            owner[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = (ty * 5 + tx) % world
+    for rk in range(world):
+        assert np.array_equal(masks[rk], (owner == rk).astype(np.int64)), rk
     assert np.array_equal(r["film"], full)              # disjoint pixels: the sum is bit-identical to one render
